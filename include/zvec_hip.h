@@ -1,0 +1,181 @@
+/*
+ * zvec_hip.h — C ABI of the MI355X (gfx950) flat / IVF-Flat distance-scan core for zvec.
+ *
+ * This is the drop-in boundary: plain C, opaque handles, plain pointers and sizes, `int` status
+ * (0 = success, negative = the reference's IndexError value, src/include/zvec/core/framework/
+ * index_error.h:39-62 / src/core/framework/index_error.cc:20-71).  The reference has no FFI for this
+ * path (it is in-process C++); every entry point below states the reference C++ operator it stands
+ * behind, so that the C++ subclasses a maintainer registers with INDEX_FACTORY_REGISTER_STREAMER /
+ * _SEARCHER are one-line forwards.
+ *
+ * Scores are the reference's metric-kernel ("boundary B") scores, smaller = better:
+ *   L2 -> squared Euclidean, IP -> MINUS inner product, COSINE -> 1 - ip on normalised rows.
+ * `core_interface::Index::_dense_search` (src/core/interface/index.cc:624-649) applies
+ * metric->normalize() above this boundary (IP: negate) and keeps doing so unchanged.
+ *
+ * Pointers named d_* are DEVICE pointers on the handle's GPU; all others are host pointers.
+ * *_dev entry points are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ * context's own stream); the host-pointer forms copy in/out and return after completion.
+ */
+#ifndef ZVEC_HIP_H_
+#define ZVEC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZVEC_HIP_ABI_VERSION 1
+
+/* IndexMeta::DataType subset (src/include/zvec/core/framework/index_meta.h:27-50) */
+enum { ZVEC_HIP_DT_FP32 = 0, ZVEC_HIP_DT_FP16 = 1 };
+
+/* IndexMetric names served: "SquaredEuclidean" (src/core/metric/euclidean_metric.cc:743),
+ * "InnerProduct" (inner_product_metric.cc:256), "Cosine" (cosine_metric.cc:141). */
+enum { ZVEC_HIP_METRIC_L2 = 0, ZVEC_HIP_METRIC_IP = 1, ZVEC_HIP_METRIC_COSINE = 2 };
+
+/* IndexError values used (index_error.cc:20-71) */
+enum {
+  ZVEC_HIP_OK = 0,
+  ZVEC_HIP_ERR_RUNTIME = -1,           /* IndexError_Runtime (a HIP call failed) */
+  ZVEC_HIP_ERR_UNSUPPORTED = -12,      /* IndexError_Unsupported */
+  ZVEC_HIP_ERR_OUT_OF_RANGE = -17,     /* IndexError_OutOfRange */
+  ZVEC_HIP_ERR_NO_MEMORY = -19,        /* IndexError_NoMemory (device or host allocation failed) */
+  ZVEC_HIP_ERR_NO_READY = -21,         /* IndexError_NoReady */
+  ZVEC_HIP_ERR_NO_EXIST = -22,         /* IndexError_NoExist (position / key not found) */
+  ZVEC_HIP_ERR_MISMATCH = -24,         /* IndexError_Mismatch (dim / dtype / metric mismatch) */
+  ZVEC_HIP_ERR_INVALID_ARGUMENT = -31, /* IndexError_InvalidArgument */
+  ZVEC_HIP_ERR_NO_INDEX_LOADED = -204, /* IndexError_NoIndexLoaded */
+  ZVEC_HIP_ERR_NO_TRAINED = -205       /* IndexError_NoTrained */
+};
+
+typedef struct zvec_hip_flat_s *zvec_hip_flat_t;
+typedef struct zvec_hip_ivf_s *zvec_hip_ivf_t;
+typedef struct zvec_hip_ctx_s *zvec_hip_ctx_t;
+
+/* library / device ------------------------------------------------------------------------- */
+int zvec_hip_abi_version(void);
+int zvec_hip_device_count(int *count);
+const char *zvec_hip_error_string(int code); /* IndexError::What analogue */
+
+/* search context: IndexRunner::create_context() (index_runner.h:400-470).  One per caller thread;
+ * owns a HIP stream and the scan workspace.  Passing NULL to a search uses the handle's built-in
+ * context under a mutex. */
+int zvec_hip_ctx_create(int device, zvec_hip_ctx_t *out);
+int zvec_hip_ctx_destroy(zvec_hip_ctx_t ctx);
+int zvec_hip_ctx_synchronize(zvec_hip_ctx_t ctx);
+/* bind the context to a caller-owned hipStream_t (e.g. torch's current stream); NULL restores its own */
+int zvec_hip_ctx_set_stream(zvec_hip_ctx_t ctx, void *stream);
+
+/* ---- flat (brute force) -------------------------------------------------------------------
+ * stands behind FlatStreamer<32> / FlatSearcher<32>
+ *   (src/core/algorithm/flat/flat_streamer.cc:304-389, flat_searcher.cc:162-211).
+ * `dim` is the element dimension of IndexMeta (for COSINE: d+1, the trailing float is the stored
+ * norm written by CosineConverter, cosine_converter.cc:112-127; it is not scanned). */
+int zvec_hip_flat_create(uint32_t dim, int dtype, int metric, int device, zvec_hip_flat_t *out);
+int zvec_hip_flat_destroy(zvec_hip_flat_t h);
+int zvec_hip_flat_reserve(zvec_hip_flat_t h, uint64_t capacity);
+/* IndexStreamer::add_impl / add_with_id_impl (index_runner.h:476-487), FlatBuilder::build
+ * (flat_builder.cc:188-276): append n rows (dim elements each) in storage order.
+ * keys == NULL -> key = storage position. */
+int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const uint64_t *keys);
+int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n,
+                             const uint64_t *d_keys, void *stream);
+int zvec_hip_flat_count(zvec_hip_flat_t h, uint64_t *count);
+/* IndexRunner::get_vector_by_id (index_runner.h:450-453): copy row `pos` (dim elements) to out. */
+int zvec_hip_flat_get_vector(zvec_hip_flat_t h, uint64_t pos, void *out);
+/* search_impl / search_bf_impl(query, qmeta, count, ctx) (index_runner.h:490-531).
+ * exclude_bitset: nullable, 1 bit per storage position (bit i of word i/64), set = filter(key)
+ * returned true = excluded (IndexFilter, index_filter.h:48-50).
+ * threshold: IndexContext::threshold() RNN radius, FLT_MAX = none (index_document.h:250-261).
+ * outputs: [count][topk] keys / scores ascending by score, out_counts[q] valid entries. */
+int zvec_hip_flat_search(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *queries,
+                         uint32_t count, uint32_t topk, float threshold,
+                         const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
+                         uint32_t *out_counts);
+int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *d_queries,
+                             uint32_t count, uint32_t topk, float threshold,
+                             const uint64_t *d_exclude_bitset, uint64_t *d_out_keys,
+                             float *d_out_scores, uint32_t *d_out_counts, void *stream);
+
+/* ---- IVF-Flat -----------------------------------------------------------------------------
+ * stands behind IVFStreamer / IVFSearcher (src/core/algorithm/ivf/ivf_streamer.cc:183-250,
+ * ivf_searcher.cc:183-250) with IVFCentroidIndex (ivf_centroid_index.cc:273-297) and
+ * IVFEntity::search (ivf_entity.cc:587-716). */
+int zvec_hip_ivf_create(uint32_t dim, int dtype, int metric, int device, zvec_hip_ivf_t *out);
+int zvec_hip_ivf_destroy(zvec_hip_ivf_t h);
+/* load a trained index (what IVFSearcher::load reads from the ivf.* segments,
+ * ivf_index_format.h:26-60,152-164): centroids [nlist][dim]; rows in inverted-list order, list l
+ * owning rows [list_offsets[l], list_offsets[l+1]); keys per row (NULL -> row number). */
+int zvec_hip_ivf_load(zvec_hip_ivf_t h, const void *centroids, uint32_t nlist,
+                      const uint64_t *list_offsets, const void *vecs, const uint64_t *keys);
+/* IVFBuilder::train + build on the GPU (ivf_builder.cc:212-403): k-means over a sample, nearest-
+ * centroid labelling, list packing.  d_vecs: [n][dim] row-major DEVICE rows; keys: host, nullable.
+ * The trained structure can be read back with zvec_hip_ivf_export so that a CPU reference can
+ * search the very same index. */
+int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, const uint64_t *keys,
+                           uint32_t nlist, uint32_t kmeans_iters, uint32_t sample_per_list,
+                           uint64_t seed, void *stream);
+int zvec_hip_ivf_build(zvec_hip_ivf_t h, const void *vecs, uint64_t n, const uint64_t *keys,
+                       uint32_t nlist, uint32_t kmeans_iters, uint32_t sample_per_list,
+                       uint64_t seed);
+int zvec_hip_ivf_info(zvec_hip_ivf_t h, uint64_t *count, uint32_t *nlist);
+/* read back: centroids [nlist][dim], list_offsets [nlist+1], row_ids [count] = original row number
+ * (build) / load-order row (load) of each list-order position; any pointer may be NULL. */
+int zvec_hip_ivf_export(zvec_hip_ivf_t h, void *centroids, uint64_t *list_offsets,
+                        uint64_t *row_ids);
+int zvec_hip_ivf_get_vector(zvec_hip_ivf_t h, uint64_t list_pos, void *out);
+/* IVFSearcher::search_impl(query, qmeta, count, ctx):
+ *   nprobe         = max(round(nlist*scan_ratio),1)          ivf_searcher_context.h:70-74
+ *   max_scan_count = max(bf_threshold, ceil(N*scan_ratio))    ivf_searcher_context.h:75-78
+ * lists are probed in coarse-score order while the running scanned count < max_scan_count
+ * (ivf_searcher.cc:217-237).  exclude_bitset is over list-order positions. */
+int zvec_hip_ivf_search(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count,
+                        uint32_t topk, float threshold, uint32_t nprobe, uint32_t max_scan_count,
+                        const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
+                        uint32_t *out_counts);
+int zvec_hip_ivf_search_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries,
+                            uint32_t count, uint32_t topk, float threshold, uint32_t nprobe,
+                            uint32_t max_scan_count, const uint64_t *d_exclude_bitset,
+                            uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts,
+                            void *stream);
+/* IVFSearcher::search_bf_impl: every list in list-id order (ivf_entity.cc:719-745). */
+int zvec_hip_ivf_search_bf(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries,
+                           uint32_t count, uint32_t topk, float threshold,
+                           const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
+                           uint32_t *out_counts);
+/* shard: keep only the lists l with l % nshards == shard (centroids stay replicated), the
+ * multi-GPU partition of SURVEY §8(e).  Call after load/build, before searching. */
+int zvec_hip_ivf_keep_shard(zvec_hip_ivf_t h, uint32_t shard, uint32_t nshards);
+/* per-query statistics of the last search on ctx (IndexContext::Stats, index_context.h:67-111):
+ * scanned[q] = total_scan_count, probes[q] = lists actually probed.  Host arrays, nullable. */
+int zvec_hip_ivf_last_stats(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, uint32_t count,
+                            uint32_t *scanned, uint32_t *probes);
+
+/* ---- partial top-k merge ------------------------------------------------------------------
+ * CombinedVectorColumnIndexer::Search concat + sort + truncate
+ * (src/db/index/column/vector_column/combined_vector_column_indexer.cc:91-232); also the merge
+ * after the RCCL all-gather of per-GPU candidate lists.
+ * inputs [nparts][count][topk] keys/scores + [nparts][count] counts; ties keep part order. */
+int zvec_hip_merge_topk(zvec_hip_ctx_t ctx, const uint64_t *keys, const float *scores,
+                        const uint32_t *counts, uint32_t nparts, uint32_t count, uint32_t topk,
+                        uint64_t *out_keys, float *out_scores, uint32_t *out_counts);
+int zvec_hip_merge_topk_dev(zvec_hip_ctx_t ctx, const uint64_t *d_keys, const float *d_scores,
+                            const uint32_t *d_counts, uint32_t nparts, uint32_t count,
+                            uint32_t topk, uint64_t *d_out_keys, float *d_out_scores,
+                            uint32_t *d_out_counts, void *stream);
+
+/* ---- measurement hook ---------------------------------------------------------------------
+ * Records HIP events around the dominant scan kernel of each search on ctx (on the stream the
+ * kernel is launched on) and returns the accumulated launch count / milliseconds since the last
+ * reset.  Used by bench.py for the roofline line. */
+int zvec_hip_ctx_profile(zvec_hip_ctx_t ctx, int enable);
+int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *scan_ms,
+                              double *algorithmic_bytes, double *algorithmic_flops, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZVEC_HIP_H_ */

@@ -1,0 +1,245 @@
+"""ctypes door onto the CPU oracle (oracle/liboracle.so) and, when present, the compiled reference
+kernels (oracle/_ref/libzvec_ref.so).
+
+TEST INFRASTRUCTURE ONLY — may be imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by the product package (zvec_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
+FLT_MAX = float(np.finfo(np.float32).max)
+
+_f32p = C.POINTER(C.c_float)
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref when /root/reference exists)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "zvec_oracle.c")
+    stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    ref_so = os.path.join(_HERE, "_ref", "libzvec_ref.so")
+    if os.path.isdir("/root/reference/src/ailego/math") and (force or not os.path.exists(ref_so)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def _ptr(a, ty):
+    return None if a is None else a.ctypes.data_as(ty)
+
+
+class Oracle:
+    def __init__(self):
+        build()
+        self.lib = L = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        for name in ("zo_sqeuclid_f32", "zo_ip_f32", "zo_minus_ip_f32", "zo_cosine_f32"):
+            f = getattr(L, name)
+            f.restype = C.c_float
+            f.argtypes = [_f32p, _f32p, C.c_size_t]
+        L.zo_norm2_f32.restype = C.c_float
+        L.zo_norm2_f32.argtypes = [_f32p, C.c_size_t]
+        L.zo_normalize_l2_f32.restype = None
+        L.zo_normalize_l2_f32.argtypes = [_f32p, C.c_size_t, _f32p]
+        L.zo_cosine_transform_f32.restype = None
+        L.zo_cosine_transform_f32.argtypes = [_f32p, C.c_size_t, _f32p]
+        L.zo_heap_replay.restype = C.c_size_t
+        L.zo_heap_replay.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_float, _u32p, _f32p]
+        L.zo_set_distance_override.restype = None
+        L.zo_set_distance_override.argtypes = [C.c_int, C.c_void_p]
+        L.zo_flat_search_mt.restype = C.c_int
+        L.zo_flat_search_mt.argtypes = [_f32p, _u64p, C.c_uint64, C.c_uint32, C.c_int, _f32p,
+                                        C.c_uint32, C.c_uint32, C.c_float, _u64p, _u64p, _f32p,
+                                        _u32p, _u32p, C.c_int]
+        L.zo_ivf_search.restype = C.c_int
+        L.zo_ivf_search.argtypes = [_f32p, C.c_uint32, _u64p, _f32p, _u64p, C.c_uint32, C.c_int,
+                                    _f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32,
+                                    C.c_uint32, C.c_int, _u64p, _u64p, _f32p, _u32p, _u32p, _u32p,
+                                    _u32p]
+        L.zo_ivf_search_mt.restype = C.c_int
+        L.zo_ivf_search_mt.argtypes = [_f32p, C.c_uint32, _u64p, _f32p, _u64p, C.c_uint32, C.c_int,
+                                       _f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32,
+                                       C.c_uint32, C.c_int, _u64p, _u64p, _f32p, _u32p, _u32p,
+                                       _u32p, C.c_int]
+        L.zo_merge_topk.restype = C.c_int
+        L.zo_merge_topk.argtypes = [_u64p, _f32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, _u64p,
+                                    _f32p, _u32p]
+        self.ref = None
+        ref_so = os.path.join(_HERE, "_ref", "libzvec_ref.so")
+        if os.path.exists(ref_so) and _cpu_has("avx512f"):
+            self.ref = R = C.CDLL(ref_so)
+            for name in ("zref_sqeuclid_f32", "zref_ip_f32", "zref_minus_ip_f32",
+                         "zref_cosine_f32"):
+                f = getattr(R, name)
+                f.restype = C.c_float
+                f.argtypes = [_f32p, _f32p, C.c_size_t]
+            R.zref_norm2_f32.restype = C.c_float
+            R.zref_norm2_f32.argtypes = [_f32p, C.c_size_t]
+            R.zref_normalize_l2_f32.restype = None
+            R.zref_normalize_l2_f32.argtypes = [_f32p, C.c_size_t, _f32p]
+            R.zref_heap_replay.restype = C.c_size_t
+            R.zref_heap_replay.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_float, _u32p, _f32p]
+
+    # -- kernels -------------------------------------------------------------------------------
+    def dist(self, metric, m, q, use_ref=False):
+        m = np.ascontiguousarray(m, np.float32)
+        q = np.ascontiguousarray(q, np.float32)
+        lib, pre = (self.ref, "zref_") if use_ref else (self.lib, "zo_")
+        fn = {METRIC_L2: "sqeuclid_f32", METRIC_IP: "minus_ip_f32", METRIC_COSINE: "cosine_f32"}[metric]
+        return float(getattr(lib, pre + fn)(_ptr(m, _f32p), _ptr(q, _f32p), m.size))
+
+    def ip(self, m, q, use_ref=False):
+        m = np.ascontiguousarray(m, np.float32)
+        q = np.ascontiguousarray(q, np.float32)
+        lib, pre = (self.ref, "zref_") if use_ref else (self.lib, "zo_")
+        return float(getattr(lib, pre + "ip_f32")(_ptr(m, _f32p), _ptr(q, _f32p), m.size))
+
+    def norm2(self, m, use_ref=False):
+        m = np.ascontiguousarray(m, np.float32)
+        lib, pre = (self.ref, "zref_") if use_ref else (self.lib, "zo_")
+        return float(getattr(lib, pre + "norm2_f32")(_ptr(m, _f32p), m.size))
+
+    def normalize_l2(self, v, use_ref=False):
+        v = np.array(v, np.float32, copy=True)
+        n = C.c_float(0)
+        lib, pre = (self.ref, "zref_") if use_ref else (self.lib, "zo_")
+        getattr(lib, pre + "normalize_l2_f32")(_ptr(v, _f32p), v.size, C.byref(n))
+        return v, float(n.value)
+
+    def cosine_transform(self, x):
+        """rows of d floats -> rows of d+1 floats (normalised + norm), CosineConverter/Reformer."""
+        x = np.ascontiguousarray(np.atleast_2d(x), np.float32)
+        out = np.empty((x.shape[0], x.shape[1] + 1), np.float32)
+        for i in range(x.shape[0]):
+            self.lib.zo_cosine_transform_f32(_ptr(x[i], _f32p), x.shape[1], _ptr(out[i], _f32p))
+        return out
+
+    def heap_replay(self, scores, limit, threshold=FLT_MAX, use_ref=False):
+        s = np.ascontiguousarray(scores, np.float32)
+        oi = np.zeros(max(limit, 1), np.uint32)
+        os_ = np.zeros(max(limit, 1), np.float32)
+        fn = self.ref.zref_heap_replay if use_ref else self.lib.zo_heap_replay
+        n = fn(_ptr(s, _f32p), s.size, limit, threshold, _ptr(oi, _u32p), _ptr(os_, _f32p))
+        return oi[:n].copy(), os_[:n].copy()
+
+    def use_reference_kernels(self, on=True):
+        """Route the scan loops' 1x1 distance through the reference's SIMD kernels (CPU baseline)."""
+        names = {METRIC_L2: "zref_sqeuclid_f32", METRIC_IP: "zref_minus_ip_f32",
+                 METRIC_COSINE: "zref_cosine_f32"}
+        for m, nm in names.items():
+            addr = C.cast(getattr(self.ref, nm), C.c_void_p) if (on and self.ref) else None
+            self.lib.zo_set_distance_override(m, addr)
+        return bool(on and self.ref)
+
+    # -- scans ---------------------------------------------------------------------------------
+    def flat_search(self, base, queries, topk, metric=METRIC_L2, keys=None, threshold=FLT_MAX,
+                    exclude_bits=None, threads=1):
+        base = np.ascontiguousarray(base, np.float32)
+        queries = np.ascontiguousarray(np.atleast_2d(queries), np.float32)
+        n, dim = base.shape
+        nq = queries.shape[0]
+        keys = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        ex = None if exclude_bits is None else np.ascontiguousarray(exclude_bits, np.uint64)
+        ok = np.zeros((nq, topk), np.uint64)
+        os_ = np.full((nq, topk), np.inf, np.float32)
+        oi = np.zeros((nq, topk), np.uint32)
+        oc = np.zeros(nq, np.uint32)
+        rc = self.lib.zo_flat_search_mt(_ptr(base, _f32p), _ptr(keys, _u64p), n, dim, metric,
+                                        _ptr(queries, _f32p), nq, topk, threshold, _ptr(ex, _u64p),
+                                        _ptr(ok, _u64p), _ptr(os_, _f32p), _ptr(oi, _u32p),
+                                        _ptr(oc, _u32p), threads)
+        if rc != 0:
+            raise RuntimeError("zo_flat_search rc=%d" % rc)
+        return ok, os_, oi, oc
+
+    def ivf_search(self, centroids, list_offsets, vecs, queries, topk, nprobe, max_scan_count,
+                   metric=METRIC_L2, keys=None, threshold=FLT_MAX, brute_force=False,
+                   exclude_bits=None, threads=1, want_probes=False):
+        centroids = np.ascontiguousarray(centroids, np.float32)
+        vecs = np.ascontiguousarray(vecs, np.float32)
+        queries = np.ascontiguousarray(np.atleast_2d(queries), np.float32)
+        lo = np.ascontiguousarray(list_offsets, np.uint64)
+        nlist, dim = centroids.shape
+        nq = queries.shape[0]
+        keys = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        ex = None if exclude_bits is None else np.ascontiguousarray(exclude_bits, np.uint64)
+        ok = np.zeros((nq, topk), np.uint64)
+        os_ = np.full((nq, topk), np.inf, np.float32)
+        oi = np.zeros((nq, topk), np.uint32)
+        oc = np.zeros(nq, np.uint32)
+        osc = np.zeros(nq, np.uint32)
+        npb = max(1, min(nprobe, nlist))
+        if want_probes:
+            op = np.zeros((nq, npb), np.uint32)
+            rc = self.lib.zo_ivf_search(_ptr(centroids, _f32p), nlist, _ptr(lo, _u64p),
+                                        _ptr(vecs, _f32p), _ptr(keys, _u64p), dim, metric,
+                                        _ptr(queries, _f32p), nq, topk, threshold, nprobe,
+                                        max_scan_count, int(brute_force), _ptr(ex, _u64p),
+                                        _ptr(ok, _u64p), _ptr(os_, _f32p), _ptr(oi, _u32p),
+                                        _ptr(oc, _u32p), _ptr(osc, _u32p), _ptr(op, _u32p))
+        else:
+            op = None
+            rc = self.lib.zo_ivf_search_mt(_ptr(centroids, _f32p), nlist, _ptr(lo, _u64p),
+                                           _ptr(vecs, _f32p), _ptr(keys, _u64p), dim, metric,
+                                           _ptr(queries, _f32p), nq, topk, threshold, nprobe,
+                                           max_scan_count, int(brute_force), _ptr(ex, _u64p),
+                                           _ptr(ok, _u64p), _ptr(os_, _f32p), _ptr(oi, _u32p),
+                                           _ptr(oc, _u32p), _ptr(osc, _u32p), threads)
+        if rc != 0:
+            raise RuntimeError("zo_ivf_search rc=%d" % rc)
+        if want_probes:
+            return ok, os_, oi, oc, osc, op
+        return ok, os_, oi, oc, osc
+
+    def merge_topk(self, keys, scores, counts, topk):
+        """keys/scores [nparts][nq][topk], counts [nparts][nq]."""
+        keys = np.ascontiguousarray(keys, np.uint64)
+        scores = np.ascontiguousarray(scores, np.float32)
+        counts = np.ascontiguousarray(counts, np.uint32)
+        nparts, nq = counts.shape
+        ok = np.zeros((nq, topk), np.uint64)
+        os_ = np.full((nq, topk), np.inf, np.float32)
+        oc = np.zeros(nq, np.uint32)
+        rc = self.lib.zo_merge_topk(_ptr(keys, _u64p), _ptr(scores, _f32p), _ptr(counts, _u32p),
+                                    nparts, nq, topk, _ptr(ok, _u64p), _ptr(os_, _f32p),
+                                    _ptr(oc, _u32p))
+        if rc != 0:
+            raise RuntimeError("zo_merge_topk rc=%d" % rc)
+        return ok, os_, oc
+
+
+def _cpu_has(flag):
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return flag in line.split()
+    except OSError:
+        pass
+    return False
+
+
+_ORACLE = None
+
+
+def get():
+    global _ORACLE
+    if _ORACLE is None:
+        _ORACLE = Oracle()
+    return _ORACLE
+
+
+def pack_bits(mask):
+    """bool[n] (True = excluded) -> uint64 words, bit i of word i//64."""
+    mask = np.asarray(mask, bool)
+    n = mask.size
+    words = np.zeros((n + 63) // 64, np.uint64)
+    idx = np.nonzero(mask)[0]
+    np.bitwise_or.at(words, idx // 64, np.uint64(1) << (idx % 64).astype(np.uint64))
+    return words

@@ -1,0 +1,83 @@
+// ref_shim.cc — thin extern "C" door onto the REFERENCE's own arithmetic kernels and heap, compiled
+// in place from /root/reference by oracle/Makefile into oracle/_ref/libzvec_ref.so.
+// TEST INFRASTRUCTURE ONLY.  This file is ours; it includes the reference's headers by path and
+// copies none of its source.  Reference entry points used:
+//   ailego::SquaredEuclideanDistanceMatrix<float,1,1>::Compute  src/ailego/math/euclidean_distance_matrix_fp32.cc:287
+//   ailego::InnerProductMatrix<float,1,1>::Compute              src/ailego/math/inner_product_matrix_fp32.cc:588
+//   ailego::MinusInnerProductMatrix<float,1,1>::Compute         src/ailego/math/inner_product_matrix_fp32.cc:870
+//   ailego::CosineDistanceMatrix<float,1,1>::Compute            src/ailego/math/cosine_distance_matrix.h:32
+//   ailego::Norm2Matrix<float,1>::Compute                       src/ailego/math/norm2_matrix_fp32.cc:47
+//   ailego::Normalizer<float>::L2                               src/ailego/math/normalizer.h:46
+//   ailego::Heap<T>                                             src/include/zvec/ailego/container/heap.h
+#include <cstddef>
+#include <cstdint>
+#include <limits>
+#include <ailego/math/cosine_distance_matrix.h>
+#include <ailego/math/euclidean_distance_matrix.h>
+#include <ailego/math/inner_product_matrix.h>
+#include <ailego/math/norm2_matrix.h>
+#include <ailego/math/normalizer.h>
+#include <zvec/ailego/container/heap.h>
+
+using namespace zvec::ailego;
+
+namespace {
+// Same ordering rule as core::IndexDocument (index_document.h:143: operator< on score only) and the
+// same RNN gate as IndexDocumentHeap::emplace (index_document.h:250-261).
+struct Doc {
+  uint64_t key;
+  float score;
+  uint32_t index;
+  Doc() : key(0), score(0), index(0) {}
+  Doc(uint64_t k, float s, uint32_t i) : key(k), score(s), index(i) {}
+  bool operator<(const Doc &rhs) const { return score < rhs.score; }
+};
+}  // namespace
+
+extern "C" {
+
+float zref_sqeuclid_f32(const float *m, const float *q, size_t dim) {
+  float out;
+  SquaredEuclideanDistanceMatrix<float, 1, 1>::Compute(m, q, dim, &out);
+  return out;
+}
+float zref_ip_f32(const float *m, const float *q, size_t dim) {
+  float out;
+  InnerProductMatrix<float, 1, 1>::Compute(m, q, dim, &out);
+  return out;
+}
+float zref_minus_ip_f32(const float *m, const float *q, size_t dim) {
+  float out;
+  MinusInnerProductMatrix<float, 1, 1>::Compute(m, q, dim, &out);
+  return out;
+}
+float zref_cosine_f32(const float *m, const float *q, size_t dim_with_norm) {
+  float out;
+  CosineDistanceMatrix<float, 1, 1>::Compute(m, q, dim_with_norm, &out);
+  return out;
+}
+float zref_norm2_f32(const float *m, size_t dim) {
+  float out;
+  Norm2Matrix<float, 1>::Compute(m, dim, &out);
+  return out;
+}
+void zref_normalize_l2_f32(float *arr, size_t dim, float *norm) {
+  Normalizer<float>::L2(arr, dim, norm);
+}
+
+// Replays n emplace() calls through the reference Heap and returns the heap array as laid out.
+size_t zref_heap_replay(const float *scores, size_t n, size_t limit, float threshold,
+                        uint32_t *out_index, float *out_score) {
+  Heap<Doc> heap;
+  heap.limit(limit);
+  for (size_t i = 0; i < n; ++i) {
+    if (scores[i] <= threshold) heap.emplace((uint64_t)i, scores[i], (uint32_t)i);
+  }
+  for (size_t i = 0; i < heap.size(); ++i) {
+    out_index[i] = heap[i].index;
+    out_score[i] = heap[i].score;
+  }
+  return heap.size();
+}
+
+}  // extern "C"

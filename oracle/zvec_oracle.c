@@ -1,0 +1,548 @@
+/*
+ * zvec_oracle.c — CPU restatement of the zvec flat / IVF-Flat scan path.  TEST INFRASTRUCTURE ONLY
+ * (see zvec_oracle.h).  Plain C99; compile with -ffp-contract=off so that every fused
+ * multiply-add below is an explicit fmaf() and nothing else is contracted.
+ *
+ * All file:line references are to /root/reference (sudo-flow/zvec @ 2026-03-20).
+ */
+#include "zvec_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ======================================================================================== *
+ * 1x1 distance kernels.
+ *
+ * The reference dispatches at run time (x86 build with AVX-512 enabled):
+ *     dim > 15 -> *AVX512 ; dim > 7 -> *AVX ; else *SSE
+ *   SquaredEuclideanDistanceMatrix<float,1,1>::Compute  euclidean_distance_matrix_fp32.cc:287-320
+ *   InnerProductMatrix<float,1,1>::Compute              inner_product_matrix_fp32.cc:588-615
+ * Each body keeps TWO vector accumulators of W lanes (W = 16/8/4), strides 2W, folds one more
+ * W-chunk into accumulator 0 if it fits, adds the accumulators lane-wise, handles the tail
+ * (AVX-512: one masked FMA into the combined vector, then the horizontal add;
+ *  AVX/SSE: horizontal add first, then scalar `sum += x*x` steps from the LAST tail element
+ *  down to the first — the switch falls through from case 7/3 to case 1), and reduces
+ * horizontally as  ((v0+v1)+(v2+v3)) + ((v4+v5)+(v6+v7))  after adding the upper half onto the
+ * lower half (matrix_utility.i:36-47,143-149,239-244).
+ * The model below reproduces that order exactly in scalar code.
+ * ======================================================================================== */
+
+typedef float (*zo_step_fn)(float m, float q, float acc);
+
+static inline float step_ssd(float m, float q, float acc) {
+  float x = m - q; /* _mm*_sub_ps */
+  return fmaf(x, x, acc);
+}
+static inline float step_fma(float m, float q, float acc) {
+  return fmaf(m, q, acc);
+}
+
+/* horizontal add of W lanes in the reference's order */
+static inline float hadd_lanes(const float *v, int w) {
+  if (w == 16) {
+    float t[8];
+    for (int i = 0; i < 8; ++i) t[i] = v[i] + v[i + 8]; /* low256 + high256 */
+    return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  }
+  if (w == 8) {
+    return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  /* w == 4: hadd(v,v) twice */
+  return (v[0] + v[1]) + (v[2] + v[3]);
+}
+
+#define ZO_DEFINE_LANE_KERNEL(NAME, STEP)                                                    \
+  static float NAME(const float *lhs, const float *rhs, size_t size) {                       \
+    int w = (size > 15) ? 16 : (size > 7 ? 8 : 4);                                           \
+    float s0[16], s1[16];                                                                    \
+    for (int i = 0; i < 16; ++i) s0[i] = s1[i] = 0.0f;                                       \
+    size_t aligned = (size / (size_t)(2 * w)) * (size_t)(2 * w);                             \
+    size_t p = 0;                                                                            \
+    for (; p != aligned; p += (size_t)(2 * w)) {                                             \
+      for (int i = 0; i < w; ++i) s0[i] = STEP(lhs[p + i], rhs[p + i], s0[i]);               \
+      for (int i = 0; i < w; ++i) s1[i] = STEP(lhs[p + w + i], rhs[p + w + i], s1[i]);       \
+    }                                                                                        \
+    if (size >= aligned + (size_t)w) {                                                       \
+      for (int i = 0; i < w; ++i) s0[i] = STEP(lhs[p + i], rhs[p + i], s0[i]);               \
+      p += (size_t)w;                                                                        \
+    }                                                                                        \
+    for (int i = 0; i < w; ++i) s0[i] = s0[i] + s1[i];                                       \
+    if (w == 16) {                                                                           \
+      size_t left = size - p; /* masked fma into the combined accumulator */                 \
+      for (size_t i = 0; i < left; ++i) s0[i] = STEP(lhs[p + i], rhs[p + i], s0[i]);         \
+      return hadd_lanes(s0, 16);                                                             \
+    }                                                                                        \
+    float result = hadd_lanes(s0, w);                                                        \
+    for (size_t i = size; i > p; --i) /* case N: ... case 1: fall-through order */           \
+      result = STEP(lhs[i - 1], rhs[i - 1], result);                                         \
+    return result;                                                                           \
+  }
+
+ZO_DEFINE_LANE_KERNEL(lane_ssd, step_ssd)
+ZO_DEFINE_LANE_KERNEL(lane_ip, step_fma)
+
+static zo_dist_fn g_override[3] = {NULL, NULL, NULL};
+
+void zo_set_distance_override(int metric, zo_dist_fn fn) {
+  if (metric >= 0 && metric < 3) g_override[metric] = fn;
+}
+
+float zo_sqeuclid_f32(const float *m, const float *q, size_t dim) {
+  return lane_ssd(m, q, dim);
+}
+float zo_ip_f32(const float *m, const float *q, size_t dim) {
+  return lane_ip(m, q, dim);
+}
+/* MinusInnerProductMatrix<float,1,1>::Compute  inner_product_matrix_fp32.cc:870-895 */
+float zo_minus_ip_f32(const float *m, const float *q, size_t dim) {
+  return -lane_ip(m, q, dim);
+}
+/* CosineDistanceMatrix<float,1,1>::Compute  cosine_distance_matrix.h:32-50 */
+float zo_cosine_f32(const float *m, const float *q, size_t dim_with_norm) {
+  size_t d = dim_with_norm - 1; /* extra_dim = sizeof(float)/sizeof(float) */
+  return 1 - lane_ip(m, q, d);
+}
+
+/* Norm2Matrix<float,1>::Compute, AVX-512 build: NORM_FP32_1_AVX512 (norm_matrix_fp32.i:120-157)
+ * two 16-lane accumulators, one extra 16-chunk and the masked tail both go to accumulator 0,
+ * then add + horizontal add + sqrt.  (With AVX512F compiled in, this macro is used for every dim.) */
+float zo_norm2_f32(const float *m, size_t dim) {
+  float s0[16], s1[16];
+  for (int i = 0; i < 16; ++i) s0[i] = s1[i] = 0.0f;
+  size_t aligned = (dim >> 5) << 5, p = 0;
+  for (; p != aligned; p += 32) {
+    for (int i = 0; i < 16; ++i) s0[i] = fmaf(m[p + i], m[p + i], s0[i]);
+    for (int i = 0; i < 16; ++i) s1[i] = fmaf(m[p + 16 + i], m[p + 16 + i], s1[i]);
+  }
+  if (dim >= aligned + 16) {
+    for (int i = 0; i < 16; ++i) s0[i] = fmaf(m[p + i], m[p + i], s0[i]);
+    p += 16;
+  }
+  for (size_t i = 0; p + i < dim; ++i) s0[i] = fmaf(m[p + i], m[p + i], s0[i]);
+  for (int i = 0; i < 16; ++i) s0[i] = s0[i] + s1[i];
+  return sqrtf(hadd_lanes(s0, 16));
+}
+
+/* Normalizer<float>::L2  normalizer.h:46-51 (+ NormalizeAVX512: element-wise IEEE division) */
+void zo_normalize_l2_f32(float *arr, size_t dim, float *norm) {
+  float n = zo_norm2_f32(arr, dim);
+  *norm = n;
+  if (n > 0.0f) {
+    for (size_t i = 0; i < dim; ++i) arr[i] = arr[i] / n;
+  }
+}
+
+/* CosineConverter (fp32 -> fp32) cosine_converter.cc:112-127 and
+ * CosineReformer::transform cosine_reformer.cc:66-101: normalised copy + trailing norm. */
+void zo_cosine_transform_f32(const float *in, size_t dim, float *out) {
+  memcpy(out, in, dim * sizeof(float));
+  float norm = 0.0f;
+  zo_normalize_l2_f32(out, dim, &norm);
+  out[dim] = norm;
+}
+
+float zo_distance(int metric, const float *m, const float *q, size_t dim) {
+  if (g_override[metric]) return g_override[metric](m, q, dim);
+  switch (metric) {
+    case ZO_METRIC_L2:
+      return zo_sqeuclid_f32(m, q, dim);
+    case ZO_METRIC_IP:
+      return zo_minus_ip_f32(m, q, dim);
+    default:
+      return zo_cosine_f32(m, q, dim);
+  }
+}
+
+/* ======================================================================================== *
+ * Bounded heap: ailego::Heap<IndexDocument> (heap.h) with std::less on score
+ * (IndexDocument::operator< compares score only, index_document.h:143), plus the RNN gate of
+ * IndexDocumentHeap::emplace (index_document.h:250-261).
+ * ======================================================================================== */
+
+void zo_heap_init(zo_heap *h, zo_doc *storage, size_t limit, float threshold) {
+  h->a = storage;
+  h->n = 0;
+  h->limit = limit < 1 ? 1 : limit; /* Heap::limit(): max(max,1) heap.h:155-158 */
+  h->threshold = threshold;
+}
+
+/* std::__push_heap (libstdc++ bits/stl_heap.h): sift the new last element up while
+ * parent < value. */
+static void push_heap_up(zo_doc *a, size_t hole, zo_doc value) {
+  while (hole > 0) {
+    size_t parent = (hole - 1) / 2;
+    if (!(a[parent].score < value.score)) break;
+    a[hole] = a[parent];
+    hole = parent;
+  }
+  a[hole] = value;
+}
+
+/* Heap::replace_heap  heap.h:180-205 */
+static void replace_heap_top(zo_doc *a, size_t count, zo_doc val) {
+  size_t hole = 0;
+  if (count > 1) {
+    size_t child = 1;
+    while (child < count) {
+      size_t right = child + 1;
+      if (right < count && a[child].score < a[right].score) child = right;
+      if (!(val.score < a[child].score)) break;
+      a[hole] = a[child];
+      hole = child;
+      child = (hole << 1) + 1;
+    }
+  }
+  a[hole] = val;
+}
+
+/* IndexDocumentHeap::emplace + Heap::emplace  heap.h:103-114 */
+void zo_heap_emplace(zo_heap *h, uint64_t key, float score, uint32_t index) {
+  if (!(score <= h->threshold)) return;
+  zo_doc v;
+  v.key = key;
+  v.score = score;
+  v.index = index;
+  if (h->n == h->limit) {
+    if (v.score < h->a[0].score) replace_heap_top(h->a, h->n, v);
+  } else {
+    h->n += 1;
+    push_heap_up(h->a, h->n - 1, v);
+  }
+}
+
+static int doc_cmp(const void *pa, const void *pb) {
+  const zo_doc *a = (const zo_doc *)pa, *b = (const zo_doc *)pb;
+  if (a->score < b->score) return -1;
+  if (a->score > b->score) return 1;
+  if (a->index < b->index) return -1;
+  if (a->index > b->index) return 1;
+  return 0;
+}
+
+void zo_heap_sort(zo_heap *h) {
+  qsort(h->a, h->n, sizeof(zo_doc), doc_cmp);
+}
+
+size_t zo_heap_replay(const float *scores, size_t n, size_t limit, float threshold,
+                      uint32_t *out_index, float *out_score) {
+  zo_doc *st = (zo_doc *)malloc(sizeof(zo_doc) * (limit ? limit : 1));
+  zo_heap h;
+  zo_heap_init(&h, st, limit, threshold);
+  for (size_t i = 0; i < n; ++i) zo_heap_emplace(&h, i, scores[i], (uint32_t)i);
+  for (size_t i = 0; i < h.n; ++i) {
+    out_index[i] = h.a[i].index;
+    out_score[i] = h.a[i].score;
+  }
+  size_t r = h.n;
+  free(st);
+  return r;
+}
+
+static inline int bit_set(const uint64_t *bits, uint64_t pos) {
+  return bits && ((bits[pos >> 6] >> (pos & 63)) & 1u);
+}
+
+/* ======================================================================================== *
+ * Flat scan.  FlatSearcherContext::batch_search_row_nofilter / _filter
+ * (flat_searcher_context.h:846-1003): for every stored vector in storage order, for every query:
+ * 1x1 distance, heap.emplace(key, score, index); afterwards keys are mapped and the heap sorted.
+ * A vector whose key the filter rejects is skipped for all queries (:949-963).
+ * (The single-query loops :420-560 and FlatStreamerEntity::search flat_streamer_entity.cc:212-316
+ * visit vectors in the same storage order, so the same restatement covers them.)
+ * ======================================================================================== */
+static int flat_search_range(const float *base, const uint64_t *keys, uint64_t n, uint32_t dim,
+                             int metric, const float *queries, uint32_t q0, uint32_t q1,
+                             uint32_t topk, float threshold, const uint64_t *exclude_bits,
+                             uint64_t *out_keys, float *out_scores, uint32_t *out_index,
+                             uint32_t *out_counts) {
+  if (topk == 0) return -31; /* IndexError_InvalidArgument */
+  zo_doc *st = (zo_doc *)malloc(sizeof(zo_doc) * topk);
+  if (!st) return -2;
+  for (uint32_t q = q0; q < q1; ++q) {
+    zo_heap h;
+    zo_heap_init(&h, st, topk, threshold);
+    const float *qv = queries + (size_t)q * dim;
+    for (uint64_t i = 0; i < n; ++i) {
+      if (bit_set(exclude_bits, i)) continue;
+      float s = zo_distance(metric, base + (size_t)i * dim, qv, dim);
+      zo_heap_emplace(&h, keys ? keys[i] : i, s, (uint32_t)i);
+    }
+    zo_heap_sort(&h);
+    for (size_t j = 0; j < h.n; ++j) {
+      out_keys[(size_t)q * topk + j] = h.a[j].key;
+      out_scores[(size_t)q * topk + j] = h.a[j].score;
+      if (out_index) out_index[(size_t)q * topk + j] = h.a[j].index;
+    }
+    out_counts[q] = (uint32_t)h.n;
+  }
+  free(st);
+  return 0;
+}
+
+int zo_flat_search(const float *base, const uint64_t *keys, uint64_t n, uint32_t dim, int metric,
+                   const float *queries, uint32_t nq, uint32_t topk, float threshold,
+                   const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores,
+                   uint32_t *out_index, uint32_t *out_counts) {
+  return flat_search_range(base, keys, n, dim, metric, queries, 0, nq, topk, threshold,
+                           exclude_bits, out_keys, out_scores, out_index, out_counts);
+}
+
+/* ======================================================================================== *
+ * IVF-Flat.
+ *  coarse:   IVFCentroidIndex::search = FlatSearcher over the centroids, topk = nprobe
+ *            (ivf_centroid_index.cc:273-297, ivf_searcher_context.h:70-74); result sorted by score.
+ *  probing:  IVFSearcher::search_impl driver loop (ivf_searcher.cc:217-247):
+ *              for i in centroids while total_scan_count < max_scan_count: scan list i;
+ *              total_scan_count += list.vector_count   (the whole list, filtered or not :651,:715)
+ *  list scan: IVFEntity::search (ivf_entity.cc:587-716): vectors in list order,
+ *              heap->emplace(key, distance * norm_val, local_id); norm_val == 1 for fp32 lists;
+ *              filtered keys are skipped (keeps mask :627-640).
+ *  brute force: IVFSearcher::search_bf_impl -> IVFEntity::search(query, heap) scans every list
+ *              in list-id order (ivf_entity.cc:719-745).
+ *  final:    heap.sort(); topk_to_result truncates at score > threshold (ivf_searcher_context.h:184-208).
+ * ======================================================================================== */
+static int ivf_search_range(const float *centroids, uint32_t nlist, const uint64_t *list_offsets,
+                            const float *vecs, const uint64_t *keys, uint32_t dim, int metric,
+                            const float *queries, uint32_t q0, uint32_t q1, uint32_t topk,
+                            float threshold, uint32_t nprobe, uint32_t max_scan_count,
+                            int brute_force, const uint64_t *exclude_bits, uint64_t *out_keys,
+                            float *out_scores, uint32_t *out_index, uint32_t *out_counts,
+                            uint32_t *out_scanned, uint32_t *out_probes) {
+  if (topk == 0) return -31;
+  if (nprobe < 1) nprobe = 1;
+  if (nprobe > nlist) nprobe = nlist;
+  zo_doc *st = (zo_doc *)malloc(sizeof(zo_doc) * topk);
+  zo_doc *cst = (zo_doc *)malloc(sizeof(zo_doc) * nprobe);
+  if (!st || !cst) return -2;
+  for (uint32_t q = q0; q < q1; ++q) {
+    const float *qv = queries + (size_t)q * dim;
+    zo_heap h;
+    zo_heap_init(&h, st, topk, threshold);
+    uint32_t total_scan = 0;
+    if (out_probes)
+      for (uint32_t i = 0; i < nprobe; ++i) out_probes[(size_t)q * nprobe + i] = ~0u;
+    if (brute_force) {
+      for (uint32_t l = 0; l < nlist; ++l) {
+        for (uint64_t p = list_offsets[l]; p < list_offsets[l + 1]; ++p) {
+          if (bit_set(exclude_bits, p)) continue;
+          float s = zo_distance(metric, vecs + (size_t)p * dim, qv, dim);
+          zo_heap_emplace(&h, keys ? keys[p] : p, s, (uint32_t)p);
+        }
+        total_scan += (uint32_t)(list_offsets[l + 1] - list_offsets[l]);
+      }
+    } else {
+      zo_heap ch;
+      zo_heap_init(&ch, cst, nprobe, FLT_MAX);
+      for (uint32_t c = 0; c < nlist; ++c) {
+        float s = zo_distance(metric, centroids + (size_t)c * dim, qv, dim);
+        zo_heap_emplace(&ch, c, s, c);
+      }
+      zo_heap_sort(&ch);
+      for (size_t i = 0; i < ch.n && total_scan < max_scan_count; ++i) {
+        uint32_t l = (uint32_t)ch.a[i].key;
+        if (out_probes) out_probes[(size_t)q * nprobe + i] = l;
+        for (uint64_t p = list_offsets[l]; p < list_offsets[l + 1]; ++p) {
+          if (bit_set(exclude_bits, p)) continue;
+          float s = zo_distance(metric, vecs + (size_t)p * dim, qv, dim);
+          zo_heap_emplace(&h, keys ? keys[p] : p, s, (uint32_t)p);
+        }
+        total_scan += (uint32_t)(list_offsets[l + 1] - list_offsets[l]);
+      }
+    }
+    zo_heap_sort(&h);
+    size_t cnt = 0;
+    for (size_t j = 0; j < h.n; ++j) {
+      if (h.a[j].score > threshold) break;
+      out_keys[(size_t)q * topk + j] = h.a[j].key;
+      out_scores[(size_t)q * topk + j] = h.a[j].score;
+      if (out_index) out_index[(size_t)q * topk + j] = h.a[j].index;
+      ++cnt;
+    }
+    out_counts[q] = (uint32_t)cnt;
+    if (out_scanned) out_scanned[q] = total_scan;
+  }
+  free(st);
+  free(cst);
+  return 0;
+}
+
+int zo_ivf_search(const float *centroids, uint32_t nlist, const uint64_t *list_offsets,
+                  const float *vecs, const uint64_t *keys, uint32_t dim, int metric,
+                  const float *queries, uint32_t nq, uint32_t topk, float threshold,
+                  uint32_t nprobe, uint32_t max_scan_count, int brute_force,
+                  const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores,
+                  uint32_t *out_index, uint32_t *out_counts, uint32_t *out_scanned,
+                  uint32_t *out_probes) {
+  return ivf_search_range(centroids, nlist, list_offsets, vecs, keys, dim, metric, queries, 0, nq,
+                          topk, threshold, nprobe, max_scan_count, brute_force, exclude_bits,
+                          out_keys, out_scores, out_index, out_counts, out_scanned, out_probes);
+}
+
+/* ---- thread fan-out across queries (tools/core/bench.cc:145-245: T workers, one context each,
+ * shared index; one query is always scanned by a single thread). */
+typedef struct {
+  int kind; /* 0 flat, 1 ivf */
+  const float *centroids;
+  uint32_t nlist;
+  const uint64_t *list_offsets;
+  const float *base;
+  const uint64_t *keys;
+  uint64_t n;
+  uint32_t dim;
+  int metric;
+  const float *queries;
+  uint32_t q0, q1, topk;
+  float threshold;
+  uint32_t nprobe, max_scan;
+  int brute_force;
+  const uint64_t *exclude_bits;
+  uint64_t *out_keys;
+  float *out_scores;
+  uint32_t *out_index, *out_counts, *out_scanned;
+  int rc;
+} zo_job;
+
+static void *zo_worker(void *arg) {
+  zo_job *j = (zo_job *)arg;
+  if (j->kind == 0)
+    j->rc = flat_search_range(j->base, j->keys, j->n, j->dim, j->metric, j->queries, j->q0, j->q1,
+                              j->topk, j->threshold, j->exclude_bits, j->out_keys, j->out_scores,
+                              j->out_index, j->out_counts);
+  else
+    j->rc = ivf_search_range(j->centroids, j->nlist, j->list_offsets, j->base, j->keys, j->dim,
+                             j->metric, j->queries, j->q0, j->q1, j->topk, j->threshold,
+                             j->nprobe, j->max_scan, j->brute_force, j->exclude_bits, j->out_keys,
+                             j->out_scores, j->out_index, j->out_counts, j->out_scanned, NULL);
+  return NULL;
+}
+
+static int run_jobs(zo_job proto, uint32_t nq, int threads) {
+  if (threads < 1) threads = 1;
+  if ((uint32_t)threads > nq) threads = (int)(nq ? nq : 1);
+  zo_job *jobs = (zo_job *)malloc(sizeof(zo_job) * (size_t)threads);
+  pthread_t *tids = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+  int rc = 0;
+  for (int t = 0; t < threads; ++t) {
+    jobs[t] = proto;
+    jobs[t].q0 = (uint32_t)(((uint64_t)nq * (uint64_t)t) / (uint64_t)threads);
+    jobs[t].q1 = (uint32_t)(((uint64_t)nq * (uint64_t)(t + 1)) / (uint64_t)threads);
+    jobs[t].rc = 0;
+    pthread_create(&tids[t], NULL, zo_worker, &jobs[t]);
+  }
+  for (int t = 0; t < threads; ++t) {
+    pthread_join(tids[t], NULL);
+    if (jobs[t].rc != 0) rc = jobs[t].rc;
+  }
+  free(jobs);
+  free(tids);
+  return rc;
+}
+
+int zo_flat_search_mt(const float *base, const uint64_t *keys, uint64_t n, uint32_t dim,
+                      int metric, const float *queries, uint32_t nq, uint32_t topk,
+                      float threshold, const uint64_t *exclude_bits, uint64_t *out_keys,
+                      float *out_scores, uint32_t *out_index, uint32_t *out_counts, int threads) {
+  zo_job p;
+  memset(&p, 0, sizeof(p));
+  p.kind = 0;
+  p.base = base;
+  p.keys = keys;
+  p.n = n;
+  p.dim = dim;
+  p.metric = metric;
+  p.queries = queries;
+  p.topk = topk;
+  p.threshold = threshold;
+  p.exclude_bits = exclude_bits;
+  p.out_keys = out_keys;
+  p.out_scores = out_scores;
+  p.out_index = out_index;
+  p.out_counts = out_counts;
+  return run_jobs(p, nq, threads);
+}
+
+int zo_ivf_search_mt(const float *centroids, uint32_t nlist, const uint64_t *list_offsets,
+                     const float *vecs, const uint64_t *keys, uint32_t dim, int metric,
+                     const float *queries, uint32_t nq, uint32_t topk, float threshold,
+                     uint32_t nprobe, uint32_t max_scan_count, int brute_force,
+                     const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores,
+                     uint32_t *out_index, uint32_t *out_counts, uint32_t *out_scanned,
+                     int threads) {
+  zo_job p;
+  memset(&p, 0, sizeof(p));
+  p.kind = 1;
+  p.centroids = centroids;
+  p.nlist = nlist;
+  p.list_offsets = list_offsets;
+  p.base = vecs;
+  p.keys = keys;
+  p.dim = dim;
+  p.metric = metric;
+  p.queries = queries;
+  p.topk = topk;
+  p.threshold = threshold;
+  p.nprobe = nprobe;
+  p.max_scan = max_scan_count;
+  p.brute_force = brute_force;
+  p.exclude_bits = exclude_bits;
+  p.out_keys = out_keys;
+  p.out_scores = out_scores;
+  p.out_index = out_index;
+  p.out_counts = out_counts;
+  p.out_scanned = out_scanned;
+  return run_jobs(p, nq, threads);
+}
+
+/* ======================================================================================== *
+ * Partial-result merge: CombinedVectorColumnIndexer::Search
+ * (combined_vector_column_indexer.cc:91-232): concatenate the per-block lists (block order),
+ * sort by score, truncate to topk.  Scores here are boundary-B scores (smaller is better for
+ * every metric), so the sort is ascending; ties keep concatenation order (the reference's
+ * std::sort leaves them unspecified).
+ * ======================================================================================== */
+typedef struct {
+  uint64_t key;
+  float score;
+  uint32_t ord;
+} zo_mrec;
+
+static int mrec_cmp(const void *pa, const void *pb) {
+  const zo_mrec *a = (const zo_mrec *)pa, *b = (const zo_mrec *)pb;
+  if (a->score < b->score) return -1;
+  if (a->score > b->score) return 1;
+  if (a->ord < b->ord) return -1;
+  if (a->ord > b->ord) return 1;
+  return 0;
+}
+
+int zo_merge_topk(const uint64_t *keys, const float *scores, const uint32_t *counts,
+                  uint32_t nparts, uint32_t nq, uint32_t topk, uint64_t *out_keys,
+                  float *out_scores, uint32_t *out_counts) {
+  zo_mrec *buf = (zo_mrec *)malloc(sizeof(zo_mrec) * (size_t)nparts * topk);
+  if (!buf) return -2;
+  for (uint32_t q = 0; q < nq; ++q) {
+    size_t m = 0;
+    for (uint32_t p = 0; p < nparts; ++p) {
+      uint32_t c = counts[(size_t)p * nq + q];
+      for (uint32_t j = 0; j < c; ++j) {
+        size_t off = ((size_t)p * nq + q) * topk + j;
+        buf[m].key = keys[off];
+        buf[m].score = scores[off];
+        buf[m].ord = (uint32_t)m;
+        ++m;
+      }
+    }
+    qsort(buf, m, sizeof(zo_mrec), mrec_cmp);
+    size_t c = m < topk ? m : topk;
+    for (size_t j = 0; j < c; ++j) {
+      out_keys[(size_t)q * topk + j] = buf[j].key;
+      out_scores[(size_t)q * topk + j] = buf[j].score;
+    }
+    out_counts[q] = (uint32_t)c;
+  }
+  free(buf);
+  return 0;
+}

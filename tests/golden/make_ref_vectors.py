@@ -1,0 +1,63 @@
+"""Generates tests/golden/ref_kernel_vectors.npz from the REFERENCE's own kernels.
+
+Needs oracle/_ref/libzvec_ref.so, i.e. /root/reference compiled in place by oracle/Makefile (the
+reference's ailego math kernels and ailego::Heap, -march=skylake-avx512 so its run-time dispatch is
+AVX512 > AVX > SSE).  Output = seeded inputs + the reference's outputs; it lets the oracle be pinned
+where neither /root/reference nor _ref exists.  Run:  python tests/golden/make_ref_vectors.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+o = O.get()
+assert o.ref is not None, "oracle/_ref/libzvec_ref.so missing (run `make -C oracle`)"
+rng = np.random.default_rng(20260320)
+dims = list(range(1, 41)) + [63, 64, 65, 100, 127, 128, 129, 255, 256, 768, 769]
+out = {}
+A, B, L2, IP, MIP, COS, NRM, NV = [], [], [], [], [], [], [], []
+for d in dims:
+    a = rng.standard_normal(d).astype(np.float32)
+    b = (rng.standard_normal(d) * 2 + 0.5).astype(np.float32)
+    A.append(a)
+    B.append(b)
+    L2.append(o.dist(O.METRIC_L2, a, b, use_ref=True))
+    MIP.append(o.dist(O.METRIC_IP, a, b, use_ref=True))
+    IP.append(o.ip(a, b, use_ref=True))
+    NRM.append(o.norm2(a, use_ref=True))
+    v, n = o.normalize_l2(a, use_ref=True)
+    NV.append(v)
+    if d >= 2:
+        a1 = np.append(*o.normalize_l2(a, use_ref=True)).astype(np.float32)
+        b1 = np.append(*o.normalize_l2(b, use_ref=True)).astype(np.float32)
+        COS.append(o.dist(O.METRIC_COSINE, a1, b1, use_ref=True))
+    else:
+        COS.append(np.nan)
+out["dims"] = np.array(dims, np.int32)
+out["a"] = np.concatenate(A)
+out["b"] = np.concatenate(B)
+out["normalized_a"] = np.concatenate(NV)
+for k, v in (("l2", L2), ("ip", IP), ("minus_ip", MIP), ("cosine", COS), ("norm2", NRM)):
+    out[k] = np.array(v, np.float32)
+# heap replays: sequences with many ties; expected = the reference heap's memory image
+hs, hl, hi, hv, hoff = [], [], [], [], [0]
+for t in range(64):
+    n = int(rng.integers(1, 300))
+    k = int(rng.integers(1, 50))
+    s = rng.integers(0, 20, n).astype(np.float32)
+    idx, sc = o.heap_replay(s, k, use_ref=True)
+    hs.append(s)
+    hl.append((n, k, len(idx)))
+    hi.append(idx)
+    hv.append(sc)
+out["heap_scores"] = np.concatenate(hs)
+out["heap_meta"] = np.array(hl, np.int32)
+out["heap_index"] = np.concatenate(hi)
+out["heap_kept_scores"] = np.concatenate(hv)
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_kernel_vectors.npz")
+np.savez_compressed(path, **out)
+print("wrote", path, os.path.getsize(path), "bytes")

@@ -1,0 +1,205 @@
+"""GPU parity of the flat scan, through the C ABI (include/zvec_hip.h) — run with -m gpu.
+
+Oracle = oracle/zvec_oracle.c (restated reference loops, pinned in test_oracle_cpu.py).
+Bars: integer-valued data => bit-exact scores and ids (outside exact boundary ties);
+      real-valued data  => fp32 tolerance stated per metric below.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import tie_tolerant_compare
+
+pytestmark = pytest.mark.gpu
+
+# fp32 tolerances: the GPU accumulates q.b as an fp32 FMA chain on the matrix core
+# and forms L2 as |q|^2 + |b|^2 - 2 q.b; the reference sums (q-b)^2 in 32 SIMD lanes.  Both are plain
+# fp32, so the difference is bounded by a few ulp of the largest term: 4e-6 * (|q|^2+|b|^2) for L2,
+# 4e-6 * |q||b| for IP / cosine.
+L2_RTOL = 4e-6
+IP_RTOL = 4e-6
+
+
+@pytest.fixture(scope="module")
+def zv():
+    import zvec_amd
+    return zvec_amd
+
+
+def _ramp(n, dim):
+    return np.repeat(np.arange(n, dtype=np.float32)[:, None], dim, 1)
+
+
+def _search(idx, q, k, ctx=None, **kw):
+    ctx = ctx or idx.create_context()
+    ctx.set_topk(k)
+    for name, v in kw.items():
+        getattr(ctx, name)(v)
+    assert idx.search_impl(q, q.shape[0], ctx) == 0
+    return ctx.keys, ctx.scores, ctx.counts, ctx
+
+
+def test_flat_linear_search_reference_expectations(zv, golden_dir):
+    """flat_streamer_test.cc:104-178 (TestLinearSearch), through HipFlatStreamer."""
+    g = json.load(open(os.path.join(golden_dir, "scan_known_answers.json")))["flat_linear"]
+    n, dim = g["n"], g["dim"]
+    st = zv.HipFlatStreamer(dim, "SquaredEuclidean")
+    base = _ramp(n, dim)
+    for i in range(0, 10):                       # add_impl one by one, then the rest in bulk
+        assert st.add_impl(i, base[i]) == 0
+    assert st.add_batch(base[10:], np.arange(10, n, dtype=np.uint64)) == 0
+    assert st.count() == n
+    ctx = st.create_context()
+    ctx.set_topk(3)
+    q = _ramp(n, dim)
+    assert st.search_impl(q, n, ctx) == 0                       # batch of 1000 queries
+    assert np.array_equal(ctx.keys[:, 0], np.arange(n, dtype=np.uint64))
+    assert not ctx.scores[:, 0].any()
+    assert st.search_impl(q + np.float32(0.1), n, ctx) == 0
+    last = n - 1
+    for i in range(n):
+        r = ctx.result(i)
+        assert len(r) == 3
+        assert r[0].key() == i
+        assert r[1].key() == (i - 1 if i == last else i + 1)
+        assert r[2].key() == (2 if i == 0 else (i - 2 if i == last else i - 1))
+    ctx.set_topk(100)
+    assert st.search_bf_impl(np.full((1, dim), 10.1, np.float32), 1, ctx) == 0
+    res = ctx.result(0)
+    assert len(res) == 100
+    for rank, key in g["query_10p1_top100_ranks"].items():
+        assert res[int(rank)].key() == key
+    # get_vector_by_id (provider->get_vector in TestAddVector :69-101)
+    for i in (0, 1, 127, 128, 999):
+        assert np.array_equal(st.get_vector_by_id(i), base[i])
+
+
+def test_flat_filter_reference_expectations(zv, golden_dir):
+    """flat_streamer_test.cc:731-801 (TestFilter) + filter-all of flat_searcher_test.cpp:93-209."""
+    g = json.load(open(os.path.join(golden_dir, "scan_known_answers.json")))["flat_filter"]
+    st = zv.HipFlatStreamer(g["dim"], "SquaredEuclidean")
+    assert st.add_batch(_ramp(g["n"], g["dim"])) == 0
+    q = np.full((1, g["dim"]), g["query"], np.float32)
+    ctx = st.create_context()
+    ctx.set_topk(g["topk"])
+    assert st.search_impl(q, 1, ctx) == 0
+    assert [d.key() for d in ctx.result(0)[:3]] == g["top3_nofilter"] and len(ctx.result(0)) == 10
+    ctx.set_filter(lambda key: key in (100, 101))
+    assert st.search_impl(q, 1, ctx) == 0
+    assert [d.key() for d in ctx.result(0)[:3]] == g["top3_filtered"] and len(ctx.result(0)) == 10
+    assert st.search_bf_impl(q, 1, ctx) == 0
+    assert [d.key() for d in ctx.result(0)[:3]] == g["top3_filtered"]
+    ctx.set_filter(lambda key: True)
+    assert st.search_impl(q, 1, ctx) == 0
+    assert len(ctx.result(0)) == 0
+
+
+def test_error_codes(zv):
+    st = zv.HipFlatStreamer(16, "SquaredEuclidean")
+    ctx = st.create_context()
+    q = np.zeros((1, 16), np.float32)
+    assert st.search_impl(q, 1, ctx) == zv.IndexError_.InvalidArgument      # topk not set (flat_searcher.cc:194)
+    ctx.set_topk(5)
+    assert st.search_impl(q, 1, ctx) == 0 and len(ctx.result(0)) == 0       # empty index -> empty result
+    assert st.add_batch(np.zeros((2, 15), np.float32)) == zv.IndexError_.InvalidArgument
+    assert st.get_vector_by_id(0) is None
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(1, 8, 1, 1), (5, 3, 2, 10), (127, 16, 3, 7), (128, 32, 33, 1),
+                                        (129, 33, 64, 10), (1000, 128, 65, 10), (4097, 96, 129, 32),
+                                        (3000, 768, 7, 10), (2500, 100, 130, 100), (700, 24, 5, 300)])
+def test_flat_integer_data_bit_exact(zv, oracle, n, dim, nq, k):
+    """integer-valued vectors => every distance is exact in fp32 => scores and ids must be identical."""
+    rng = np.random.default_rng(n * 7 + dim)
+    hi = 256 if dim <= 128 else 16                      # keep |q|^2+|b|^2 < 2^24
+    base = rng.integers(0, hi, (n, dim)).astype(np.float32)
+    q = rng.integers(0, hi, (nq, dim)).astype(np.float32)
+    keys = rng.permutation(10 * n)[:n].astype(np.uint64)
+    for metric, name in ((O.METRIC_L2, "SquaredEuclidean"), (O.METRIC_IP, "InnerProduct")):
+        se = zv.HipFlatSearcher(dim, name)
+        assert se.load(base, keys) == 0
+        gk, gs, gc, _ = _search(se, q, k)
+        ok, os_, _, oc = oracle.flat_search(base, q, k, metric, keys=keys)
+        tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="%s n=%d d=%d" % (name, n, dim))
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(2000, 128, 40, 10), (5000, 768, 16, 10), (1500, 20, 200, 5)])
+def test_flat_gaussian_tolerance(zv, oracle, n, dim, nq, k):
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    qn = (q.astype(np.float64) ** 2).sum(1)
+    bn = (base.astype(np.float64) ** 2).sum(1).max()
+    se = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert se.load(base) == 0
+    gk, gs, gc, _ = _search(se, q, k)
+    ok, os_, _, oc = oracle.flat_search(base, q, k, O.METRIC_L2)
+    tie_tolerant_compare(gk, gs, gc, ok, os_, oc, rtol=L2_RTOL, scale=qn + bn, what="L2 gaussian")
+    se = zv.HipFlatSearcher(dim, "InnerProduct")
+    assert se.load(base) == 0
+    gk, gs, gc, _ = _search(se, q, k)
+    ok, os_, _, oc = oracle.flat_search(base, q, k, O.METRIC_IP)
+    tie_tolerant_compare(gk, gs, gc, ok, os_, oc, rtol=IP_RTOL, scale=np.sqrt(qn * bn), what="IP gaussian")
+    # cosine: rows = CosineConverter output (normalised + norm), query = CosineReformer output
+    cb, cq = oracle.cosine_transform(base), oracle.cosine_transform(q)
+    se = zv.HipFlatSearcher(dim + 1, "Cosine")
+    assert se.load(cb) == 0
+    gk, gs, gc, _ = _search(se, cq, k)
+    ok, os_, _, oc = oracle.flat_search(cb, cq, k, O.METRIC_COSINE)
+    tie_tolerant_compare(gk, gs, gc, ok, os_, oc, atol=IP_RTOL, what="cosine gaussian")
+    assert np.array_equal(se.get_vector_by_id(3), cb[3])          # the stored norm column comes back
+
+
+def test_flat_threshold_and_bitmap(zv, oracle):
+    rng = np.random.default_rng(13)
+    n, dim, nq, k = 3000, 32, 50, 20
+    base = rng.integers(0, 64, (n, dim)).astype(np.float32)
+    q = rng.integers(0, 64, (nq, dim)).astype(np.float32)
+    se = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert se.load(base) == 0
+    for p in (0.5, 0.9, 0.999):
+        mask = rng.random(n) < p                                    # True = excluded
+        words = O.pack_bits(mask)
+        gk, gs, gc, _ = _search(se, q, k, set_exclude_bitset=words)
+        ok, os_, _, oc = oracle.flat_search(base, q, k, exclude_bits=words)
+        tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="bitmap p=%g" % p)
+        assert not mask[gk[gc[:, None] > np.arange(k)[None, :]].astype(np.int64)].any()
+    thr = float(np.median(oracle.flat_search(base, q, k)[1][:, k // 2]))
+    gk, gs, gc, _ = _search(se, q, k, set_threshold=thr)
+    ok, os_, _, oc = oracle.flat_search(base, q, k, threshold=thr)
+    tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="rnn threshold")
+    assert (gc < k).any() and (gc > 0).any()
+
+
+def test_flat_incremental_append_and_growth(zv, oracle):
+    rng = np.random.default_rng(17)
+    dim, k = 48, 10
+    st = zv.HipFlatStreamer(dim, "SquaredEuclidean")
+    chunks = [rng.integers(0, 100, (m, dim)).astype(np.float32) for m in (1, 63, 64, 300, 1000, 7)]
+    q = rng.integers(0, 100, (9, dim)).astype(np.float32)
+    have = np.zeros((0, dim), np.float32)
+    for c in chunks:
+        assert st.add_batch(c) == 0
+        have = np.concatenate([have, c])
+        gk, gs, gc, _ = _search(st, q, k)
+        ok, os_, _, oc = oracle.flat_search(have, q, k)
+        tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="append n=%d" % len(have))
+
+
+def test_merge_topk_matches_oracle(zv, oracle):
+    from zvec_amd.index import merge_topk, IndexContext
+    rng = np.random.default_rng(19)
+    nparts, nq, k = 8, 40, 10
+    scores = np.sort(rng.integers(0, 1000, (nparts, nq, k)).astype(np.float32), -1)
+    keys = rng.integers(0, 10 ** 9, (nparts, nq, k)).astype(np.uint64)
+    counts = rng.integers(0, k + 1, (nparts, nq)).astype(np.uint32)
+    ctx = IndexContext(0)
+    gk, gs, gc = merge_topk(ctx, keys, scores, counts, k)
+    ok, os_, oc = oracle.merge_topk(keys, scores, counts, k)
+    assert np.array_equal(gc, oc)
+    for q in range(nq):
+        assert np.array_equal(gs[q, :oc[q]], os_[q, :oc[q]])
+        assert np.array_equal(gk[q, :oc[q]], ok[q, :oc[q]])

@@ -1,0 +1,181 @@
+"""GPU parity of the IVF-Flat path through the C ABI — run with -m gpu.
+Both sides search THE SAME index (same centroids, same list order): zvec_hip_ivf_load of a host-built
+structure, or the oracle reading back zvec_hip_ivf_export after a GPU build."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import tie_tolerant_compare, kmeans_lists, exact_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zv():
+    import zvec_amd
+    return zvec_amd
+
+
+def _ramp(n, dim):
+    return np.repeat(np.arange(n, dtype=np.float32)[:, None], dim, 1)
+
+
+def test_ivf_simple_reference_expectations(zv, golden_dir):
+    """ivf_searcher_test.cc:200-321 (TestSimple): 33 rows, 1 centroid, scan_ratio 1, bf_threshold 1."""
+    g = json.load(open(os.path.join(golden_dir, "scan_known_answers.json")))["ivf_simple"]
+    n, dim = g["n"], g["dim"]
+    base = _ramp(n, dim)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=g["scan_ratio"],
+                           brute_force_threshold=g["brute_force_threshold"])
+    assert se.load(base.mean(0, keepdims=True), np.array([0, n], np.uint64), base) == 0
+    ctx = se.create_context()
+    q = np.full((1, dim), g["single_query"], np.float32)
+    qb = _ramp(33, dim)
+    for fn in (se.search_bf_impl, se.search_impl):
+        ctx.set_topk(33)
+        assert fn(q, 1, ctx) == 0
+        r = ctx.result(0)
+        assert len(r) == 33
+        for i in range(33):
+            assert r[i].key() == 32 - i and r[i].score() == float(i * i * dim)
+        ctx.set_topk(1)
+        assert fn(qb, 33, ctx) == 0
+        for qi in range(33):
+            assert len(ctx.result(qi)) == 1
+            assert ctx.result(qi)[0].key() == qi and ctx.result(qi)[0].score() == 0.0
+    for i in (0, 5, 32):
+        assert np.array_equal(se.get_vector_by_id(i), base[i])
+
+
+def test_ivf_errors(zv):
+    se = zv.HipIVFSearcher(8)
+    ctx = se.create_context()
+    ctx.set_topk(3)
+    se.brute_force_threshold = 0
+    se.total_count = 10
+    assert se.search_impl(np.zeros((1, 8), np.float32), 1, ctx) == zv.IndexError_.NoIndexLoaded
+    ctx.set_topk(0)
+    assert se.search_impl(np.zeros((1, 8), np.float32), 1, ctx) == zv.IndexError_.InvalidArgument
+
+
+@pytest.mark.parametrize("n,dim,nlist,nq,k,ratio", [(600, 8, 12, 5, 7, 0.34), (5000, 64, 50, 70, 10, 0.1),
+                                                     (20000, 128, 128, 130, 10, 1 / 32.), (3000, 768, 40, 33, 10, 0.2),
+                                                     (4000, 32, 64, 200, 50, 0.25)])
+def test_ivf_integer_data_bit_exact(zv, oracle, n, dim, nlist, nq, k, ratio):
+    rng = np.random.default_rng(n + dim)
+    hi = 64 if dim <= 128 else 16
+    base = rng.integers(0, hi, (n, dim)).astype(np.float32)
+    q = rng.integers(0, hi, (nq, dim)).astype(np.float32)
+    cent, offs, order = kmeans_lists(rng, base, nlist)
+    cent = np.round(cent)                     # integer centroids: coarse distances exact as well
+    vecs = base[order]
+    keys = order.astype(np.uint64)            # key = original row
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=ratio, brute_force_threshold=100)
+    assert se.load(cent, offs, vecs, keys) == 0
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, osc = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys)
+    # coarse ties (equal centroid distances) make the probe set itself ambiguous in the reference
+    # (unstable std::sort, heap.h:173-175): only compare queries whose nprobe-th and (nprobe+1)-th coarse
+    # distances differ
+    cd = np.sort(exact_l2(cent, q), 1)
+    clean = np.ones(nq, bool) if nprobe >= nlist else cd[:, nprobe - 1] != cd[:, nprobe]
+    assert clean.sum() >= nq * 0.8
+    sel = np.nonzero(clean)[0]
+    tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel], what="ivf int")
+    scanned, probes = se.last_stats(ctx, nq)
+    assert np.array_equal(scanned[sel], osc[sel])          # IndexContext::Stats parity (scan volume)
+    # brute force over the lists == exact flat top-k
+    assert se.search_bf_impl(q, nq, ctx) == 0
+    fk, fs, _, fc = oracle.flat_search(base, q, k)
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, fk, fs, fc, what="ivf bf")
+
+
+def test_ivf_max_scan_count_rule(zv, oracle):
+    """probing stops once the running scanned count reaches max_scan_count (ivf_searcher.cc:223-237)."""
+    rng = np.random.default_rng(23)
+    n, dim, nlist, nq, k = 6000, 16, 60, 90, 10
+    base = rng.integers(0, 100, (n, dim)).astype(np.float32)
+    q = rng.integers(0, 100, (nq, dim)).astype(np.float32)
+    cent, offs, order = kmeans_lists(rng, base, nlist)
+    cent = np.round(cent)
+    vecs, keys = base[order], order.astype(np.uint64)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=0.05, brute_force_threshold=100)
+    assert se.load(cent, offs, vecs, keys) == 0
+    nprobe, max_scan = se.probe_params()
+    assert nprobe == 3 and max_scan == 300
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, osc, opr = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys, want_probes=True)
+    cd = np.sort(exact_l2(cent, q), 1)
+    clean = (np.diff(cd[:, :nprobe + 1], axis=1) != 0).all(1)
+    sel = np.nonzero(clean)[0]
+    scanned, probes = se.last_stats(ctx, nq)
+    assert np.array_equal(scanned[sel], osc[sel])
+    assert np.array_equal(probes[sel], (opr[sel] != 0xffffffff).sum(1))
+    assert (probes < nprobe).any()            # the rule actually cut some probe lists short
+    tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel], what="max_scan")
+
+
+def test_ivf_filter_and_threshold(zv, oracle):
+    rng = np.random.default_rng(29)
+    n, dim, nlist, nq, k = 5000, 24, 32, 40, 10
+    base = rng.integers(0, 80, (n, dim)).astype(np.float32)
+    q = rng.integers(0, 80, (nq, dim)).astype(np.float32)
+    cent, offs, order = kmeans_lists(rng, base, nlist)
+    cent = np.round(cent)
+    vecs, keys = base[order], order.astype(np.uint64)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=1.0, brute_force_threshold=100)
+    assert se.load(cent, offs, vecs, keys) == 0
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    ctx.set_filter(lambda key: key % 3 == 0)                # true = exclude (index_filter.h:48-50)
+    assert se.search_impl(q, nq, ctx) == 0
+    mask = (keys % 3 == 0)
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys,
+                                          exclude_bits=O.pack_bits(mask))
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="ivf filter")
+    assert (ctx.keys[ctx.counts[:, None] > np.arange(k)[None, :]] % 3 != 0).all()
+    ctx.reset_filter()
+    ctx.set_threshold(float(np.median(os_)))
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys, threshold=ctx.threshold())
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="ivf rnn")
+    assert (ctx.counts < k).any()
+
+
+def test_ivf_gpu_build_then_same_index_on_oracle(zv, oracle):
+    """k-means build on the GPU; the oracle searches the exported structure."""
+    rng = np.random.default_rng(31)
+    n, dim, nlist, nq, k = 30000, 64, 64, 100, 10
+    means = rng.standard_normal((256, dim)) * 3
+    base = (means[rng.integers(0, 256, n)] + rng.standard_normal((n, dim))).astype(np.float32)
+    q = (base[rng.choice(n, nq, replace=False)] + 0.1 * rng.standard_normal((nq, dim))).astype(np.float32)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=8 / 64., brute_force_threshold=n - 1)
+    assert se.build(base, nlist, kmeans_iters=8, sample_per_list=128) == 0
+    cent, offs, rows = se.export()
+    assert offs[-1] == n and sorted(rows.tolist()) == list(range(n))
+    sizes = np.diff(offs.astype(np.int64))
+    assert sizes.min() > 0 and sizes.max() < 8 * n / nlist        # k-means did balance the lists
+    for p in (0, 77, n - 1):
+        assert np.array_equal(se.get_vector_by_id(p), base[rows[p]])
+    vecs = base[rows.astype(np.int64)]
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, osc = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=rows)
+    qn = (q.astype(np.float64) ** 2).sum(1)
+    bn = (base.astype(np.float64) ** 2).sum(1).max()
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, rtol=4e-6, scale=qn + bn, what="ivf built")
+    # recall@10 against the exact flat answer
+    fk, _, _, _ = oracle.flat_search(base, q, k)
+    recall = np.mean([len(set(ctx.keys[i].tolist()) & set(fk[i].tolist())) / k for i in range(nq)])
+    assert recall >= 0.95, recall

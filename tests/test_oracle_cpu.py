@@ -1,0 +1,203 @@
+"""Pins the CPU oracle (oracle/zvec_oracle.c) — no GPU needed.
+
+ 1. against the known-answer values of the reference's unit tests (tests/golden/kernel_known_answers.json)
+ 2. bit-for-bit against outputs of the reference's own kernels/heap on seeded inputs
+    (tests/golden/ref_kernel_vectors.npz, made by tests/golden/make_ref_vectors.py from oracle/_ref)
+ 3. live against oracle/_ref when that library is present (it is wherever /root/reference was compiled)
+ 4. the scan loops against the reference's structured-data expectations (scan_known_answers.json)
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def _ulp_close(a, b, ulps=4):
+    a32, b32 = np.float32(a), np.float32(b)
+    if a32 == b32:
+        return True
+    return abs(float(a32) - float(b32)) <= ulps * float(np.spacing(np.float32(max(abs(a32), abs(b32)))))
+
+
+def test_kernel_known_answers(oracle, golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "kernel_known_answers.json")))["cases"]
+    assert len(cases) >= 40
+    for c in cases:
+        a, b = np.array(c["a"], np.float32), np.array(c["b"], np.float32)
+        kind = c["kind"]
+        if kind == "euclidean":
+            got = math.sqrt(oracle.dist(O.METRIC_L2, a, b))      # Distance::Euclidean = sqrt(squared)
+        elif kind == "sqeuclidean":
+            got = oracle.dist(O.METRIC_L2, a, b)
+        elif kind == "inner_product":
+            got = oracle.ip(a, b)
+        elif kind == "minus_inner_product":
+            got = oracle.dist(O.METRIC_IP, a, b)
+        elif kind == "cosine":
+            got = oracle.dist(O.METRIC_COSINE, oracle.cosine_transform(a)[0], oracle.cosine_transform(b)[0])
+        else:
+            raise AssertionError(kind)
+        if c["tol"] == "4ulp":
+            assert _ulp_close(got, c["expect"]), (c["src"], got, c["expect"])
+        else:
+            assert abs(got - c["expect"]) <= float(c["tol"]), (c["src"], got, c["expect"])
+
+
+def test_bit_exact_vs_reference_vectors(oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "ref_kernel_vectors.npz"))
+    off = 0
+    for i, d in enumerate(z["dims"]):
+        a, b = z["a"][off:off + d], z["b"][off:off + d]
+        assert np.float32(oracle.dist(O.METRIC_L2, a, b)) == z["l2"][i], d
+        assert np.float32(oracle.ip(a, b)) == z["ip"][i], d
+        assert np.float32(oracle.dist(O.METRIC_IP, a, b)) == z["minus_ip"][i], d
+        assert np.float32(oracle.norm2(a)) == z["norm2"][i], d
+        v, _ = oracle.normalize_l2(a)
+        assert np.array_equal(v, z["normalized_a"][off:off + d]), d
+        if d >= 2:
+            a1 = oracle.cosine_transform(a)[0]
+            b1 = oracle.cosine_transform(b)[0]
+            assert np.float32(oracle.dist(O.METRIC_COSINE, a1, b1)) == z["cosine"][i], d
+        off += d
+    so = io = 0
+    for n, k, kept in z["heap_meta"]:
+        s = z["heap_scores"][so:so + n]
+        idx, sc = oracle.heap_replay(s, int(k))
+        assert np.array_equal(idx, z["heap_index"][io:io + kept])
+        assert np.array_equal(sc, z["heap_kept_scores"][io:io + kept])
+        so += n
+        io += kept
+
+
+def test_live_vs_compiled_reference(oracle):
+    if oracle.ref is None:
+        pytest.skip("oracle/_ref/libzvec_ref.so not present (or CPU lacks AVX-512)")
+    rng = np.random.default_rng(7)
+    for d in list(range(1, 70)) + [127, 128, 700, 768]:
+        for _ in range(5):
+            a = rng.standard_normal(d).astype(np.float32)
+            b = rng.standard_normal(d).astype(np.float32)
+            for m in (O.METRIC_L2, O.METRIC_IP):
+                assert oracle.dist(m, a, b) == oracle.dist(m, a, b, use_ref=True), (d, m)
+            assert oracle.norm2(a) == oracle.norm2(a, use_ref=True)
+    for _ in range(100):
+        n, k = int(rng.integers(1, 400)), int(rng.integers(1, 64))
+        s = rng.integers(0, 9, n).astype(np.float32)
+        thr = float(rng.integers(2, 9))
+        for t in (O.FLT_MAX, thr):
+            i1, s1 = oracle.heap_replay(s, k, t)
+            i2, s2 = oracle.heap_replay(s, k, t, use_ref=True)
+            assert np.array_equal(i1, i2) and np.array_equal(s1, s2)
+
+
+def _ramp(n, dim):
+    return np.repeat(np.arange(n, dtype=np.float32)[:, None], dim, 1)
+
+
+def test_flat_linear_known_answers(oracle, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "scan_known_answers.json")))["flat_linear"]
+    n, dim = g["n"], g["dim"]
+    base = _ramp(n, dim)
+    q = np.arange(0, n, 37, dtype=np.float32)
+    keys, scores, _, cnt = oracle.flat_search(base, np.repeat(q[:, None], dim, 1), 3)
+    assert np.array_equal(keys[:, 0], q.astype(np.uint64))
+    keys, _, _, _ = oracle.flat_search(base, np.repeat((q + np.float32(0.1))[:, None], dim, 1), 3)
+    for j, i in enumerate(q.astype(int)):
+        last = n - 1
+        assert keys[j, 0] == i
+        assert keys[j, 1] == (i - 1 if i == last else i + 1)
+        assert keys[j, 2] == (2 if i == 0 else (i - 2 if i == last else i - 1))
+    keys, _, _, cnt = oracle.flat_search(base, np.full((1, dim), 10.1, np.float32), 100)
+    assert cnt[0] == 100
+    for rank, key in g["query_10p1_top100_ranks"].items():
+        assert keys[0, int(rank)] == key
+
+
+def test_flat_filter_known_answers(oracle, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "scan_known_answers.json")))["flat_filter"]
+    base = _ramp(g["n"], g["dim"])
+    q = np.full((1, g["dim"]), g["query"], np.float32)
+    keys, _, _, cnt = oracle.flat_search(base, q, g["topk"])
+    assert cnt[0] == 10 and keys[0, :3].tolist() == g["top3_nofilter"]
+    mask = np.zeros(g["n"], bool)
+    mask[g["excluded_keys"]] = True
+    keys, _, _, cnt = oracle.flat_search(base, q, g["topk"], exclude_bits=O.pack_bits(mask))
+    assert cnt[0] == 10 and keys[0, :3].tolist() == g["top3_filtered"]
+    # filter everything => no result (flat_searcher_test.cpp:93-209)
+    keys, _, _, cnt = oracle.flat_search(base, q, g["topk"], exclude_bits=O.pack_bits(np.ones(g["n"], bool)))
+    assert cnt[0] == 0
+
+
+def test_ivf_simple_known_answers(oracle, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "scan_known_answers.json")))["ivf_simple"]
+    n, dim = g["n"], g["dim"]
+    base = _ramp(n, dim)
+    cent = base.mean(0, keepdims=True).astype(np.float32)
+    offs = np.array([0, n], np.uint64)
+    q = np.full((1, dim), g["single_query"], np.float32)
+    for bf in (True, False):
+        keys, scores, _, cnt, scanned = oracle.ivf_search(cent, offs, base, q, g["single_topk"], nprobe=1,
+                                                          max_scan_count=n, brute_force=bf)
+        assert cnt[0] == 33 and scanned[0] == 33
+        assert keys[0].tolist() == [32 - i for i in range(33)]
+        assert scores[0].tolist() == [float(i * i * dim) for i in range(33)]
+        qb = _ramp(33, dim)
+        keys, scores, _, cnt, _ = oracle.ivf_search(cent, offs, base, qb, 1, 1, n, brute_force=bf)
+        assert keys[:, 0].tolist() == list(range(33)) and not scores.any()
+
+
+def test_ivf_probe_rule_and_threshold(oracle):
+    # driver loop of ivf_searcher.cc:217-237: probe in coarse order while scanned < max_scan_count
+    rng = np.random.default_rng(3)
+    from tests.util import kmeans_lists, exact_l2
+    base = rng.integers(0, 50, (600, 8)).astype(np.float32)
+    cent, offs, order = kmeans_lists(rng, base, 12)
+    vecs = base[order]
+    q = rng.integers(0, 50, (5, 8)).astype(np.float32)
+    sizes = np.diff(offs.astype(np.int64))
+    keys, scores, idx, cnt, scanned, probes = oracle.ivf_search(cent, offs, vecs, q, 7, nprobe=4, max_scan_count=120,
+                                                                keys=order.astype(np.uint64), want_probes=True)
+    for qi in range(5):
+        tot = 0
+        for r in range(4):
+            if probes[qi, r] == 0xffffffff:
+                assert tot >= 120
+                break
+            tot += sizes[probes[qi, r]]
+        assert scanned[qi] == tot
+    # RNN radius (index_document.h:250-261, ivf_searcher_context.h:184-208)
+    k2, s2, _, c2, _ = oracle.ivf_search(cent, offs, vecs, q, 50, 12, 10 ** 6, keys=order.astype(np.uint64),
+                                         threshold=300.0)
+    assert all(s2[i, :c2[i]].max(initial=0) <= 300.0 for i in range(5))
+    # brute force == exact top-k
+    kb, sb, _, cb, _ = oracle.ivf_search(cent, offs, vecs, q, 5, 1, 1, keys=order.astype(np.uint64), brute_force=True)
+    d = exact_l2(base, q)
+    assert np.allclose(np.sort(d, 1)[:, :5], sb)
+
+
+def test_merge_matches_concat_sort_truncate(oracle):
+    rng = np.random.default_rng(5)
+    nparts, nq, k = 4, 6, 5
+    scores = np.sort(rng.integers(0, 30, (nparts, nq, k)).astype(np.float32), -1)
+    keys = rng.integers(0, 10 ** 6, (nparts, nq, k)).astype(np.uint64)
+    counts = rng.integers(0, k + 1, (nparts, nq)).astype(np.uint32)
+    ok, os_, oc = oracle.merge_topk(keys, scores, counts, k)
+    for q in range(nq):
+        allv = [(scores[p, q, j], p * k + j, keys[p, q, j]) for p in range(nparts) for j in range(counts[p, q])]
+        allv.sort(key=lambda t: (t[0], t[1]))
+        exp = allv[:k]
+        assert oc[q] == len(exp)
+        assert [e[2] for e in exp] == ok[q, :oc[q]].tolist()
+
+
+def test_multithreaded_matches_single(oracle):
+    rng = np.random.default_rng(9)
+    base = rng.standard_normal((500, 24)).astype(np.float32)
+    q = rng.standard_normal((17, 24)).astype(np.float32)
+    a = oracle.flat_search(base, q, 10, O.METRIC_IP)
+    b = oracle.flat_search(base, q, 10, O.METRIC_IP, threads=4)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))

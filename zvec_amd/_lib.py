@@ -1,0 +1,96 @@
+"""ctypes binding of include/zvec_hip.h (the C ABI of the gfx950 scan core).
+
+There is no CPU fallback: if the shared library cannot be loaded, or no HIP device is present when
+an index is created, the call raises.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_f32p = C.c_void_p
+_u64p = C.c_void_p
+_u32p = C.c_void_p
+_h = C.c_void_p
+
+# every symbol include/zvec_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "zvec_hip_abi_version": (C.c_int, []),
+    "zvec_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "zvec_hip_error_string": (C.c_char_p, [C.c_int]),
+    "zvec_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_h)]),
+    "zvec_hip_ctx_destroy": (C.c_int, [_h]),
+    "zvec_hip_ctx_synchronize": (C.c_int, [_h]),
+    "zvec_hip_ctx_set_stream": (C.c_int, [_h, C.c_void_p]),
+    "zvec_hip_flat_create": (C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_h)]),
+    "zvec_hip_flat_destroy": (C.c_int, [_h]),
+    "zvec_hip_flat_reserve": (C.c_int, [_h, C.c_uint64]),
+    "zvec_hip_flat_append": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p]),
+    "zvec_hip_flat_append_dev": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p, C.c_void_p]),
+    "zvec_hip_flat_count": (C.c_int, [_h, C.POINTER(C.c_uint64)]),
+    "zvec_hip_flat_get_vector": (C.c_int, [_h, C.c_uint64, C.c_void_p]),
+    "zvec_hip_flat_search": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, _u64p,
+                                       _u64p, _f32p, _u32p]),
+    "zvec_hip_flat_search_dev": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float,
+                                           _u64p, _u64p, _f32p, _u32p, C.c_void_p]),
+    "zvec_hip_ivf_create": (C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_h)]),
+    "zvec_hip_ivf_destroy": (C.c_int, [_h]),
+    "zvec_hip_ivf_load": (C.c_int, [_h, C.c_void_p, C.c_uint32, _u64p, C.c_void_p, _u64p]),
+    "zvec_hip_ivf_build_dev": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_uint64, C.c_void_p]),
+    "zvec_hip_ivf_build": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p, C.c_uint32, C.c_uint32,
+                                     C.c_uint32, C.c_uint64]),
+    "zvec_hip_ivf_info": (C.c_int, [_h, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "zvec_hip_ivf_export": (C.c_int, [_h, C.c_void_p, _u64p, _u64p]),
+    "zvec_hip_ivf_get_vector": (C.c_int, [_h, C.c_uint64, C.c_void_p]),
+    "zvec_hip_ivf_search": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float,
+                                      C.c_uint32, C.c_uint32, _u64p, _u64p, _f32p, _u32p]),
+    "zvec_hip_ivf_search_dev": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float,
+                                          C.c_uint32, C.c_uint32, _u64p, _u64p, _f32p, _u32p,
+                                          C.c_void_p]),
+    "zvec_hip_ivf_search_bf": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, _u64p,
+                                         _u64p, _f32p, _u32p]),
+    "zvec_hip_ivf_keep_shard": (C.c_int, [_h, C.c_uint32, C.c_uint32]),
+    "zvec_hip_ivf_last_stats": (C.c_int, [_h, _h, C.c_uint32, _u32p, _u32p]),
+    "zvec_hip_merge_topk": (C.c_int, [_h, _u64p, _f32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      _u64p, _f32p, _u32p]),
+    "zvec_hip_merge_topk_dev": (C.c_int, [_h, _u64p, _f32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          _u64p, _f32p, _u32p, C.c_void_p]),
+    "zvec_hip_ctx_profile": (C.c_int, [_h, C.c_int]),
+    "zvec_hip_ctx_profile_read": (C.c_int, [_h, C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
+}
+
+_LIB = None
+
+
+class ZvecHipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().zvec_hip_error_string(code)
+        super().__init__("%s failed: %d (%s)" % (where, code, msg.decode() if msg else "?"))
+
+
+def library_path():
+    return _build.OUT
+
+
+def lib():
+    """Load (building first if the sources are newer) the HIP shared library. Raises if absent."""
+    global _LIB
+    if _LIB is None:
+        path = _build.build()
+        if not os.path.exists(path):
+            raise RuntimeError("zvec_amd: %s missing — the HIP extension is required (no CPU fallback)" % path)
+        L = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)   # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(code, where):
+    if code != 0:
+        raise ZvecHipError(code, where)

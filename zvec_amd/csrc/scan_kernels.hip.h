@@ -1,0 +1,778 @@
+// scan_kernels.hip.h — gfx950 (CDNA4, wave64) device code of the zvec flat / IVF-Flat scan core.
+//
+// One kernel does the whole hot path of SURVEY §8(a) rows 1-4, 6-11: the batched query x base
+// distance matrix on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, so the
+// scores are fp32-faithful like the reference's AVX kernels, euclidean_distance_matrix_fp32.cc:229-320,
+// inner_product_matrix_fp32.cc:509-556) fused with the per-query bounded top-k
+// (ailego::Heap semantics, heap.h:103-114: keep the k smallest, first-seen wins ties).
+//
+// HBM layout ("blocked"): base rows are stored in tiles of 128 rows; inside a tile the K dimension
+// is cut in steps of 32 floats, and each (tile, k-step) slab is 128 rows x 128 B = 16 KiB contiguous,
+// already XOR-swizzled the way the LDS image wants it.  A work-group therefore streams a list as
+// a sequence of contiguous 16 KiB slabs (perfectly coalesced, DRAM-page friendly) and the slab is
+// copied to LDS verbatim.
+//
+//   float offset of (pos, kcol), row stride dpad (multiple of 32):
+//     tile = pos / 128, r = pos % 128, ks = kcol / 32, c = (kcol % 32) / 4, e = kcol % 4
+//     off  = tile*128*dpad + ks*4096 + (r*8 + (c ^ ((r >> 1) & 7)))*4 + e
+//
+// The swizzle makes the ds_read_b128 operand fetch conflict free: lanes 0..31 of a wave read 32
+// different rows at the same 16-byte chunk; (r&1)*8 + (c ^ ((r>>1)&7)) is a bijection onto the 16
+// 16-byte slots of a 256 B bank row for each of the instruction's 16-lane groups.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zvk {
+
+constexpr int TILE_N = 128;   // base rows per tile (4 waves x 32 MFMA columns)
+constexpr int TILE_K = 32;    // floats per k-step (one 128 B line per row)
+constexpr int QGROUP = 32;    // query rows per MFMA row block
+constexpr int SLAB = TILE_N * TILE_K;  // floats per (tile, k-step) slab
+constexpr uint32_t IDX_NONE = 0xffffffffu;
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+enum { METRIC_L2 = 0, METRIC_IP = 1, METRIC_COSINE = 2 };
+
+__host__ __device__ inline size_t blocked_offset(uint64_t pos, uint32_t kcol, uint32_t dpad) {
+  uint64_t tile = pos >> 7;
+  uint32_t r = (uint32_t)(pos & 127);
+  uint32_t ks = kcol >> 5, c = (kcol & 31) >> 2, e = kcol & 3;
+  return (size_t)tile * TILE_N * dpad + (size_t)ks * SLAB + (size_t)((r * 8 + (c ^ ((r >> 1) & 7))) * 4 + e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan kernel arguments
+// ---------------------------------------------------------------------------------------------
+struct ScanArgs {
+  const float *base;        // blocked rows
+  const float *bnorm;       // [padded positions] squared norms (L2 only)
+  const uint32_t *exclude;  // nullable bitset over DENSE positions (32-bit words), set = skip
+  const float *queries;     // [nq][dpad] row-major, zero padded
+  const float *qnorm;       // [nq] squared norms (L2 only)
+  uint32_t dpad;
+  uint32_t nks;             // dpad / 32
+  int metric;
+  uint32_t k;
+  float threshold;
+  int mode;                 // 0 flat, 1 ivf
+  // flat decomposition: item = chunk * nqtiles + qtile
+  uint32_t nq;
+  uint64_t n;               // rows in the flat store
+  uint32_t tiles_per_chunk;
+  uint32_t nchunks;
+  uint32_t nqtiles;
+  // ivf decomposition (built on device by the plan kernels)
+  const uint32_t *total_items;  // [1]
+  const uint32_t *item_off;     // [nlist+1] exclusive prefix of work items per list
+  const uint32_t *list_tile0;   // [nlist] first tile of the list in the blocked store
+  const uint32_t *list_size;    // [nlist] rows stored in the list (this shard)
+  const uint64_t *list_dense0;  // [nlist] dense (unpadded) position of the list's first row
+  const uint32_t *list_qoff;    // [nlist+1] CSR offsets: queries probing the list
+  const uint32_t *csr_q;        // query row
+  const uint32_t *csr_slot;     // output slot of (query, probe rank), chunk 0
+  uint32_t nlist;
+  // outputs: per-(slot) partial lists
+  float *part_s;                // [slots][k]
+  uint32_t *part_i;             // [slots][k] padded position, IDX_NONE = empty
+};
+
+// LDS footprint in bytes for a given NG / k (host mirrors this)
+__host__ __device__ inline size_t scan_lds_bytes(int ng, uint32_t k) {
+  size_t rows = (size_t)ng * QGROUP;
+  return (2 * rows * TILE_K + 2 * (size_t)SLAB + 7 * rows + 2 * rows * k) * 4;
+}
+
+struct RowState {
+  float *tau;        // admission bound per row: threshold until the list is full, then its max score
+  uint32_t *taui;    // position of the max element (tie order)
+  uint32_t *cnt;
+  uint32_t *mpos;    // slot of the max element in the list
+  float *Ls;         // [rows][k]
+  uint32_t *Li;
+  uint32_t k;
+};
+
+// (score, position) lexicographic "a is worse (later in the final order) than b"
+__device__ __forceinline__ bool worse(float as, uint32_t ai, float bs, uint32_t bi) {
+  return as > bs || (as == bs && ai > bi);
+}
+
+// Whole-wave recomputation of the list maximum of `row` (the heap top of heap.h).
+__device__ __forceinline__ void recompute_max(const RowState &st, int row, int lane) {
+  float bs = -__builtin_inff();
+  uint32_t bi = 0, bp = 0;
+  const uint32_t k = st.k;
+  bool has = false;
+  for (uint32_t j = lane; j < k; j += 64) {
+    float v = st.Ls[(size_t)row * k + j];
+    uint32_t vi = st.Li[(size_t)row * k + j];
+    if (!has || worse(v, vi, bs, bi)) { bs = v; bi = vi; bp = j; has = true; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    float os = __shfl_xor(bs, off);
+    uint32_t oi = __shfl_xor(bi, off);
+    uint32_t op = __shfl_xor(bp, off);
+    bool ohas = __shfl_xor((int)has, off) != 0;
+    if (ohas && (!has || worse(os, oi, bs, bi))) { bs = os; bi = oi; bp = op; has = true; }
+  }
+  if (lane == 0) {
+    st.tau[row] = bs;
+    st.taui[row] = bi;
+    st.mpos[row] = bp;
+  }
+}
+
+// Whole-wave insertion of one candidate into the bounded list of `row`.  A row's list is only ever
+// touched by its owner wave (rows are dealt to waves in the epilogue), so no locking is needed.
+// Kept set = the k smallest under (score, position): exactly what a sequential scan with
+// `if (score < heap.top) replace` (heap.h:103-114) keeps when no two scores tie at the boundary.
+__device__ __forceinline__ void wave_insert(const RowState &st, int row, float s, uint32_t idx, int lane) {
+  const uint32_t k = st.k;
+  const uint32_t c = st.cnt[row];
+  if (c < k) {
+    if (lane == 0) {
+      st.Ls[(size_t)row * k + c] = s;
+      st.Li[(size_t)row * k + c] = idx;
+      st.cnt[row] = c + 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (c + 1 == k) recompute_max(st, row, lane);
+  } else {
+    const float t = st.tau[row];
+    const uint32_t ti = st.taui[row];
+    if (worse(t, ti, s, idx)) {
+      if (lane == 0) {
+        const uint32_t p = st.mpos[row];
+        st.Ls[(size_t)row * k + p] = s;
+        st.Li[(size_t)row * k + p] = idx;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      recompute_max(st, row, lane);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Owner-wave admission of one row of the score tile: lane holds the scores of columns 2*lane and
+// 2*lane+1 (s0, s1); pos0 = padded position of column 0 of the tile.
+__device__ __forceinline__ void owner_row(const RowState &st, int row, float s0, float s1, uint32_t pos0, int lane) {
+  float t = st.tau[row];
+  uint64_t m0 = __ballot(s0 <= t);
+  uint64_t m1 = __ballot(s1 <= t);
+  while ((m0 | m1) != 0) {
+    int l;
+    float cs;
+    uint32_t ci;
+    if (m0 != 0) {
+      l = __builtin_ctzll(m0);
+      cs = __shfl(s0, l);
+      ci = pos0 + 2u * (uint32_t)l;
+      m0 &= m0 - 1;
+    } else {
+      l = __builtin_ctzll(m1);
+      cs = __shfl(s1, l);
+      ci = pos0 + 2u * (uint32_t)l + 1u;
+      m1 &= m1 - 1;
+    }
+    wave_insert(st, row, cs, ci, lane);
+    t = st.tau[row];
+    m0 &= __ballot(s0 <= t);
+    m1 &= __ballot(s1 <= t);
+  }
+}
+
+// register staging of one k-step: 4 x 16 B of the base slab and NG x 16 B of the query rows per thread
+template <int NG>
+struct StageRegs {
+  f32x4 b0, b1, b2, b3;
+  f32x4 q[NG];
+};
+
+template <int NG>
+__device__ __forceinline__ void stage_load(StageRegs<NG> &sr, const float *base, const float *queries,
+                                           const uint32_t (&qoff)[NG], uint32_t tile, uint32_t ks, uint32_t dpad,
+                                           int tid) {
+  const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(base + (size_t)tile * TILE_N * dpad + (size_t)ks * SLAB) + tid;
+  sr.b0 = bsrc[0];
+  sr.b1 = bsrc[256];
+  sr.b2 = bsrc[512];
+  sr.b3 = bsrc[768];
+#pragma unroll
+  for (int i = 0; i < NG; ++i)
+    sr.q[i] = *reinterpret_cast<const f32x4 *>(queries + (size_t)(qoff[i] + ks * TILE_K));
+}
+
+template <int NG>
+__device__ __forceinline__ void stage_store(const StageRegs<NG> &sr, float *Bb, float *Qb, int srow, int sswz,
+                                            int tid) {
+  f32x4 *bdst = reinterpret_cast<f32x4 *>(Bb) + tid;
+  bdst[0] = sr.b0;
+  bdst[256] = sr.b1;
+  bdst[512] = sr.b2;
+  bdst[768] = sr.b3;
+#pragma unroll
+  for (int i = 0; i < NG; ++i)
+    *reinterpret_cast<f32x4 *>(Qb + ((srow + 32 * i) * 8 + sswz) * 4) = sr.q[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The scan kernel.  256 threads = 4 waves; wave w owns tile columns [32w, 32w+32); all waves share
+// the NG*32 query rows.  Persistent grid-stride loop over work items (every wave reaches the loop
+// exit: `item` is uniform in the work-group and bounded by a value read once).
+// ---------------------------------------------------------------------------------------------
+template <int NG>
+__global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
+  constexpr int ROWS = NG * QGROUP;
+  extern __shared__ f32x4 zvk_smem4[];
+  float *smem = reinterpret_cast<float *>(zvk_smem4);
+  float *Qs = smem;                      // [2][ROWS*32]
+  float *Bs = Qs + 2 * ROWS * TILE_K;    // [2][SLAB]
+  float *qn_s = Bs + 2 * SLAB;           // [ROWS]
+  RowState st;
+  st.tau = qn_s + ROWS;
+  st.taui = reinterpret_cast<uint32_t *>(st.tau + ROWS);
+  st.cnt = st.taui + ROWS;
+  st.mpos = st.cnt + ROWS;
+  uint32_t *qrow_s = st.mpos + ROWS;
+  uint32_t *slot_s = qrow_s + ROWS;
+  st.k = a.k;
+  st.Ls = reinterpret_cast<float *>(slot_s + ROWS);
+  st.Li = reinterpret_cast<uint32_t *>(st.Ls + (size_t)ROWS * a.k);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int srow = tid >> 3, schunk = tid & 7;           // staging coordinates
+  const int sswz = schunk ^ ((srow >> 1) & 7);            // swizzled chunk for the Q image
+  const uint32_t dpad = a.dpad, nks = a.nks, k = a.k;
+
+  uint32_t total;
+  if (a.mode == 0) total = a.nchunks * a.nqtiles;
+  else total = *a.total_items;
+
+  for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+    // ---- decode the work item (uniform) ----
+    uint32_t tile_begin, tile_end, nrows, rows_valid_total;
+    uint64_t dense0 = 0;  // dense position of padded position tile0*128
+    uint32_t tile0 = 0;   // first tile of the row range the dense mapping refers to
+    uint32_t li = 0, r0 = 0, chunk = 0;
+    if (a.mode == 0) {
+      uint32_t qtile = item % a.nqtiles;
+      chunk = item / a.nqtiles;
+      uint32_t ntiles_total = (uint32_t)((a.n + TILE_N - 1) / TILE_N);
+      tile_begin = chunk * a.tiles_per_chunk;
+      tile_end = min(tile_begin + a.tiles_per_chunk, ntiles_total);
+      r0 = qtile * ROWS;
+      nrows = min((uint32_t)ROWS, a.nq - r0);
+      rows_valid_total = (uint32_t)min((uint64_t)0xffffffffu, a.n);  // rows valid from tile 0
+    } else {
+      // binary search: item_off[li] <= item < item_off[li+1]
+      uint32_t lo = 0, hi = a.nlist;
+      while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (a.item_off[mid] <= item) lo = mid; else hi = mid;
+      }
+      li = lo;
+      uint32_t within = item - a.item_off[li];
+      uint32_t qcnt = a.list_qoff[li + 1] - a.list_qoff[li];
+      uint32_t ngroups = (qcnt + ROWS - 1) / ROWS;
+      chunk = within / ngroups;
+      uint32_t group = within % ngroups;
+      uint32_t lsize = a.list_size[li];
+      uint32_t ltiles = (lsize + TILE_N - 1) / TILE_N;
+      tile0 = a.list_tile0[li];
+      tile_begin = tile0 + chunk * a.tiles_per_chunk;
+      tile_end = tile0 + min((chunk + 1) * a.tiles_per_chunk, ltiles);
+      r0 = group * ROWS;
+      nrows = min((uint32_t)ROWS, qcnt - r0);
+      rows_valid_total = lsize;
+      dense0 = a.list_dense0[li];
+    }
+
+    // ---- per-item LDS state ----
+    for (int j = tid; j < ROWS; j += 256) {
+      uint32_t qrow, slot;
+      if ((uint32_t)j < nrows) {
+        if (a.mode == 0) {
+          qrow = r0 + j;
+          slot = qrow * a.nchunks + chunk;
+        } else {
+          uint32_t e = a.list_qoff[li] + r0 + j;
+          qrow = a.csr_q[e];
+          slot = a.csr_slot[e] + chunk;
+        }
+      } else {
+        qrow = (a.mode == 0) ? r0 : a.csr_q[a.list_qoff[li] + r0];  // any valid row; results unused
+        slot = IDX_NONE;
+      }
+      qrow_s[j] = qrow;
+      slot_s[j] = slot;
+      qn_s[j] = (a.metric == METRIC_L2) ? a.qnorm[qrow] : 0.f;
+      st.tau[j] = a.threshold;
+      st.taui[j] = IDX_NONE;
+      st.cnt[j] = 0;
+      st.mpos[j] = 0;
+    }
+    __syncthreads();
+
+    // staging sources
+    uint32_t qoff[NG];   // float offsets into the padded query matrix (host guarantees nq*dpad < 2^32)
+#pragma unroll
+    for (int i = 0; i < NG; ++i) qoff[i] = qrow_s[srow + 32 * i] * dpad + (uint32_t)schunk * 4u;
+
+    const uint32_t ntiles = tile_end - tile_begin;
+    const uint32_t nsteps = ntiles * nks;
+
+    StageRegs<NG> sr;
+    floatx16 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+
+    uint32_t tile = tile_begin, ks = 0;
+    if (nsteps > 0) {
+      stage_load<NG>(sr, a.base, a.queries, qoff, tile, 0, dpad, tid);
+      stage_store<NG>(sr, Bs, Qs, srow, sswz, tid);
+    }
+    __syncthreads();
+
+    for (uint32_t s = 0; s < nsteps; ++s) {
+      const int buf = s & 1;
+      uint32_t ntile = tile, nk = ks + 1;
+      if (nk == nks) { nk = 0; ntile = tile + 1; }
+      const bool has_next = (s + 1 < nsteps);
+      if (has_next) stage_load<NG>(sr, a.base, a.queries, qoff, ntile, nk, dpad, tid);
+
+      // ---- MFMA over this 32-float k-step ----
+      {
+        const float *Qb = Qs + buf * ROWS * TILE_K;
+        const float *Bb = Bs + buf * SLAB;
+        const int brow = wave * 32 + r;
+        const int swz = (r >> 1) & 7;
+        constexpr int KK_UNROLL = (NG >= 4) ? 1 : 4;   // keep the A-fragment live range short when NG is large
+#pragma unroll KK_UNROLL
+        for (int kk = 0; kk < 4; ++kk) {
+          const int c = (2 * kk + h) ^ swz;
+          const f32x4 bf = *reinterpret_cast<const f32x4 *>(Bb + (brow * 8 + c) * 4);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const f32x4 af = *reinterpret_cast<const f32x4 *>(Qb + ((g * 32 + r) * 8 + c) * 4);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[g], 0, 0, 0);
+          }
+        }
+      }
+
+      // ---- tile epilogue: metric fix-up, then bounded top-k admission ----
+      // The MFMA C layout spreads one query row over 32 lanes of a wave and the 4 waves hold
+      // different columns of it, so the scores of 32 rows x 128 columns are transposed through the
+      // staging buffer that is idle during this step (16 KiB) and every row is then admitted by
+      // ONE owner wave (rows 8w..8w+7 of the group belong to wave w): no locks, no atomics.
+      if (ks == nks - 1) {
+        float *Sc = Bs + (buf ^ 1) * SLAB;                                  // [32 rows][128 cols]
+        const uint32_t local = (tile - tile0) * TILE_N + wave * 32 + r;     // row index inside list/store
+        bool colvalid = local < rows_valid_total;
+        if (a.exclude != nullptr && colvalid) {
+          uint64_t dpos = dense0 + local;
+          colvalid = ((a.exclude[dpos >> 5] >> (dpos & 31)) & 1u) == 0;
+        }
+        const uint32_t pos0 = tile * TILE_N;                                // padded position of column 0
+        float bn = 0.f;
+        if (a.metric == METRIC_L2 && colvalid) bn = a.bnorm[(size_t)pos0 + wave * 32 + r];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row_l = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float dot = acc[g][e];
+            float sc;
+            if (a.metric == METRIC_L2) sc = fmaxf(fmaf(-2.f, dot, qn_s[g * 32 + row_l] + bn), 0.f);
+            else if (a.metric == METRIC_IP) sc = -dot;
+            else sc = 1.f - dot;
+            Sc[row_l * TILE_N + wave * 32 + r] = colvalid ? sc : __builtin_inff();
+            acc[g][e] = 0.f;
+          }
+          __syncthreads();
+#pragma unroll 1
+          for (int i = 0; i < 8; ++i) {
+            const int row_l = wave * 8 + i;
+            const int row = g * 32 + row_l;
+            if ((uint32_t)row < nrows) {
+              const f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + row_l * TILE_N + 2 * lane);
+              owner_row(st, row, v.x, v.y, pos0, lane);
+            }
+          }
+          __syncthreads();
+        }
+      }
+
+      if (has_next) stage_store<NG>(sr, Bs + (buf ^ 1) * SLAB, Qs + (buf ^ 1) * ROWS * TILE_K, srow, sswz, tid);
+      __syncthreads();
+      tile = ntile;
+      ks = nk;
+    }
+
+    // ---- write the partial lists ----
+    for (uint32_t j = tid; j < nrows * k; j += 256) {
+      uint32_t row = j / k, t = j - row * k;
+      uint32_t c = st.cnt[row];
+      size_t o = (size_t)slot_s[row] * k + t;
+      a.part_s[o] = (t < c) ? st.Ls[(size_t)row * k + t] : __builtin_inff();
+      a.part_i[o] = (t < c) ? st.Li[(size_t)row * k + t] : IDX_NONE;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// merge kernel: one wave per query; merges the query's slots (scan order = slot order, then
+// position) into the final sorted top-k.  Also used for the shard merge after the all-gather.
+// ---------------------------------------------------------------------------------------------
+struct MergeArgs {
+  const float *part_s;
+  const uint32_t *part_i;        // positions (nullptr when part_keys is used)
+  const uint64_t *part_keys;     // alternative candidate keys (shard merge); nullptr otherwise
+  const uint32_t *slot_begin;    // [nq+1] or nullptr => q*slots_per_q
+  uint32_t slots_per_q;
+  // candidate e of slot j lives at ((slot_base + j*slot_stride) * k + e)
+  uint32_t slot_stride;          // 1 for scan partials; nq for [part][q][k] shard layout
+  const uint32_t *part_counts;   // optional [slots] valid entries per slot (shard merge)
+  uint32_t k;
+  float threshold;
+  const uint64_t *keymap;        // position -> key (nullable => key = position)
+  uint64_t *out_keys;            // [nq][k]
+  float *out_scores;             // [nq][k]
+  uint32_t *out_idx;             // optional [nq][k] positions
+  uint32_t *out_counts;          // [nq]
+};
+
+__global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
+  extern __shared__ f32x4 zvk_smem4[];
+  const uint32_t k = a.k;
+  float *Ls = reinterpret_cast<float *>(zvk_smem4);          // [k]
+  uint32_t *Lo = reinterpret_cast<uint32_t *>(Ls + k);       // [k] order (slot)
+  uint32_t *Li = Lo + k;                                      // [k] idx / candidate ordinal
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  uint32_t sb, nslots;
+  if (a.slot_begin) { sb = a.slot_begin[q]; nslots = a.slot_begin[q + 1] - sb; }
+  else if (a.slot_stride == 1) { sb = q * a.slots_per_q; nslots = a.slots_per_q; }
+  else { sb = q; nslots = a.slots_per_q; }
+
+  uint32_t cnt = 0;            // uniform
+  float tau = a.threshold;     // uniform: admission bound
+  uint32_t tauo = IDX_NONE, taui = IDX_NONE, mpos = 0;
+  const uint64_t total = (uint64_t)nslots * k;
+
+  auto recompute = [&]() {
+    float bs = -__builtin_inff(); uint32_t bo = 0, bi = 0, bp = 0; bool has = false;
+    for (uint32_t j = lane; j < k; j += 64) {
+      float v = Ls[j]; uint32_t vo = Lo[j], vi = Li[j];
+      if (!has || v > bs || (v == bs && (vo > bo || (vo == bo && vi > bi)))) { bs = v; bo = vo; bi = vi; bp = j; has = true; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      float os = __shfl_xor(bs, off); uint32_t oo = __shfl_xor(bo, off), oi = __shfl_xor(bi, off), op = __shfl_xor(bp, off);
+      bool oh = __shfl_xor((int)has, off) != 0;
+      if (oh && (!has || os > bs || (os == bs && (oo > bo || (oo == bo && oi > bi))))) { bs = os; bo = oo; bi = oi; bp = op; has = true; }
+    }
+    tau = __shfl(bs, 0); tauo = __shfl(bo, 0); taui = __shfl(bi, 0); mpos = __shfl(bp, 0);
+  };
+
+  for (uint64_t base = 0; base < total; base += 64) {
+    uint64_t e = base + lane;
+    bool valid = e < total;
+    uint32_t j = valid ? (uint32_t)(e / k) : 0, t = valid ? (uint32_t)(e - (uint64_t)j * k) : 0;
+    size_t o = ((size_t)sb + (size_t)j * a.slot_stride) * k + t;
+    float s = __builtin_inff();
+    uint32_t idx = IDX_NONE;
+    if (valid) {
+      if (a.part_counts) valid = t < a.part_counts[sb + (size_t)j * a.slot_stride];
+      if (valid) {
+        s = a.part_s[o];
+        idx = a.part_i ? a.part_i[o] : t;
+        if (a.part_i && idx == IDX_NONE) valid = false;
+      }
+    }
+    auto passes = [&]() {
+      if (!valid) return false;
+      if (cnt < k) return s <= tau;
+      return s < tau || (s == tau && (j < tauo || (j == tauo && idx < taui)));
+    };
+    uint64_t m = __ballot(passes());
+    while (m) {
+      int l = __builtin_ctzll(m);
+      float cs = __shfl(s, l); uint32_t co = __shfl(j, l), ci = __shfl(idx, l);
+      if (cnt < k) {
+        if (lane == 0) { Ls[cnt] = cs; Lo[cnt] = co; Li[cnt] = ci; }
+        cnt += 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (cnt == k) recompute();
+      } else {
+        if (lane == 0) { Ls[mpos] = cs; Lo[mpos] = co; Li[mpos] = ci; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        recompute();
+      }
+      m &= m - 1;
+      m &= __ballot(passes());
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  // rank-by-counting sort of the cnt kept entries, ascending (score, slot, idx)
+  for (uint32_t j = lane; j < k; j += 64) {
+    if (j < cnt) {
+      float v = Ls[j]; uint32_t vo = Lo[j], vi = Li[j];
+      uint32_t rank = 0;
+      for (uint32_t u = 0; u < cnt; ++u) {
+        float w = Ls[u]; uint32_t wo = Lo[u], wi = Li[u];
+        rank += (w < v || (w == v && (wo < vo || (wo == vo && wi < vi)))) ? 1u : 0u;
+      }
+      size_t o = (size_t)q * k + rank;
+      uint64_t key;
+      if (a.part_keys) key = a.part_keys[((size_t)sb + (size_t)vo * a.slot_stride) * k + vi];
+      else key = a.keymap ? a.keymap[vi] : (uint64_t)vi;
+      a.out_keys[o] = key;
+      a.out_scores[o] = v;
+      if (a.out_idx) a.out_idx[o] = vi;
+    } else {
+      size_t o = (size_t)q * k + j;
+      a.out_keys[o] = ~0ull;
+      a.out_scores[o] = __builtin_inff();
+      if (a.out_idx) a.out_idx[o] = IDX_NONE;
+    }
+  }
+  if (lane == 0) a.out_counts[q] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// data-movement kernels
+// ---------------------------------------------------------------------------------------------
+// one wave per row: rows [n][dim_in] (row-major, fp32) -> blocked store at positions pos0 + i
+// (or dst_pos[i]); writes the squared norm of the scanned dims; zero-fills the k padding.
+__global__ void __launch_bounds__(256) pack_rows_kernel(const float *src, uint64_t n, uint32_t dim_in,
+                                                        uint32_t dscan, uint32_t dpad,
+                                                        const uint64_t *src_row,   // nullable gather
+                                                        uint64_t pos0, const uint64_t *dst_pos,
+                                                        float *base, float *bnorm, float *extra /*cosine norm*/) {
+  const int lane = threadIdx.x & 63;
+  uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  uint64_t sr = src_row ? src_row[i] : i;
+  uint64_t pos = dst_pos ? dst_pos[i] : pos0 + i;
+  const float *row = src + (size_t)sr * dim_in;
+  float acc = 0.f;
+  for (uint32_t c = lane; c < dpad; c += 64) {
+    float v = (c < dscan) ? row[c] : 0.f;
+    base[blocked_offset(pos, c, dpad)] = v;
+    acc = fmaf(v, v, acc);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) {
+    if (bnorm) bnorm[pos] = acc;
+    if (extra) extra[pos] = (dim_in > dscan) ? row[dscan] : 0.f;
+  }
+}
+
+// zero-fill padded rows [pos_begin, pos_end) of the blocked store (list tails)
+__global__ void __launch_bounds__(256) zero_rows_kernel(float *base, float *bnorm, uint32_t dpad,
+                                                        const uint64_t *pos_list, uint64_t count) {
+  const int lane = threadIdx.x & 63;
+  uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= count) return;
+  uint64_t pos = pos_list[i];
+  for (uint32_t c = lane; c < dpad; c += 64) base[blocked_offset(pos, c, dpad)] = 0.f;
+  if (lane == 0 && bnorm) bnorm[pos] = 0.f;
+}
+
+// queries [nq][dim_in] -> padded row-major [nq][dpad] + squared norms
+__global__ void __launch_bounds__(256) prep_queries_kernel(const float *src, uint32_t nq, uint32_t dim_in,
+                                                           uint32_t dscan, uint32_t dpad, float *dst,
+                                                           float *qnorm) {
+  const int lane = threadIdx.x & 63;
+  uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= nq) return;
+  const float *row = src + (size_t)i * dim_in;
+  float acc = 0.f;
+  for (uint32_t c = lane; c < dpad; c += 64) {
+    float v = (c < dscan) ? row[c] : 0.f;
+    dst[(size_t)i * dpad + c] = v;
+    acc = fmaf(v, v, acc);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) qnorm[i] = acc;
+}
+
+// blocked row -> plain row (get_vector_by_id)
+__global__ void unpack_row_kernel(const float *base, const float *extra, uint64_t pos, uint32_t dscan,
+                                  uint32_t dim_out, uint32_t dpad, float *out) {
+  for (uint32_t c = threadIdx.x; c < dim_out; c += blockDim.x) {
+    out[c] = (c < dscan) ? base[blocked_offset(pos, c, dpad)] : (extra ? extra[pos] : 0.f);
+  }
+}
+
+__global__ void fill_keys_kernel(uint64_t *keys, uint64_t pos0, uint64_t n, const uint64_t *src) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[pos0 + i] = src ? src[i] : pos0 + i;
+}
+
+// bitset widening is not needed: the API bitset is uint64 words, bit i of word i/64 == bit (i&31) of
+// 32-bit word i/32 on a little-endian host/device, so the kernel reads it as uint32 words directly.
+
+// ---------------------------------------------------------------------------------------------
+// IVF plan kernels: turn the per-query probe lists into list-major work.
+// ---------------------------------------------------------------------------------------------
+struct PlanArgs {
+  const uint32_t *coarse_idx;     // [nq][nprobe] list ids in probe order (IDX_NONE = none)
+  const uint32_t *coarse_cnt;     // [nq]
+  uint32_t nq, nprobe, nlist;
+  uint32_t max_scan_count;
+  int brute_force;                // probe every list in id order
+  const uint32_t *list_size;      // stored rows (this shard)
+  const uint32_t *list_size_global;  // rows of the whole index (scan-count rule)
+  uint32_t tiles_per_chunk;
+  uint32_t rows_per_group;        // NG*32 of the scan kernel
+  // outputs
+  uint32_t *q_nprobe;             // [nq] lists actually probed (IndexContext::Stats)
+  uint32_t *q_scanned;            // [nq] total_scan_count
+  uint32_t *q_nslots;             // [nq]
+  uint32_t *slot_begin;           // [nq+1]
+  uint32_t *list_count;           // [nlist] queries probing the list (zeroed before)
+  uint32_t *list_fill;            // [nlist] fill cursors (zeroed before)
+  uint32_t *list_qoff;            // [nlist+1]
+  uint32_t *item_off;             // [nlist+1]
+  uint32_t *total_items;          // [1]
+  uint32_t *csr_q, *csr_slot;
+};
+
+__device__ __forceinline__ uint32_t list_chunks(uint32_t size, uint32_t tiles_per_chunk) {
+  uint32_t tiles = (size + TILE_N - 1) / TILE_N;
+  return (tiles + tiles_per_chunk - 1) / tiles_per_chunk;
+}
+
+// probe rule of IVFSearcher::search_impl (ivf_searcher.cc:223-237): walk the coarse result in
+// order while total_scan_count < max_scan_count; every probed list adds its full vector_count.
+__device__ __forceinline__ uint32_t probe_list(const PlanArgs &p, uint32_t q, uint32_t rank) {
+  return p.brute_force ? rank : p.coarse_idx[(size_t)q * p.nprobe + rank];
+}
+
+__global__ void plan_count_kernel(const PlanArgs p) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= p.nq) return;
+  uint32_t np = p.brute_force ? p.nlist : min(p.coarse_cnt[q], p.nprobe);
+  uint32_t scanned = 0, probes = 0, slots = 0;
+  for (uint32_t rnk = 0; rnk < np && (p.brute_force || scanned < p.max_scan_count); ++rnk) {
+    uint32_t l = probe_list(p, q, rnk);
+    scanned += p.list_size_global[l];
+    probes += 1;
+    uint32_t sz = p.list_size[l];
+    if (sz > 0) {
+      slots += list_chunks(sz, p.tiles_per_chunk);
+      atomicAdd(&p.list_count[l], 1u);
+    }
+  }
+  p.q_nprobe[q] = probes;
+  p.q_scanned[q] = scanned;
+  p.q_nslots[q] = slots;
+}
+
+// single work-group exclusive scans: slot_begin over queries, list_qoff / item_off over lists
+__global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x;
+  auto block_scan = [&](auto getv, auto putv, uint32_t n, uint32_t *total_out) {
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+      uint32_t i = base + tid;
+      uint32_t v = (i < n) ? getv(i) : 0;
+      sh[tid] = v;
+      __syncthreads();
+      for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t t = (tid >= off) ? sh[tid - off] : 0;
+        __syncthreads();
+        sh[tid] += t;
+        __syncthreads();
+      }
+      uint32_t incl = sh[tid];
+      uint32_t c = carry;
+      if (i < n) putv(i, c + incl - v);
+      __syncthreads();
+      if (tid == 1023) carry = c + incl;
+      __syncthreads();
+    }
+    if (tid == 0) *total_out = carry;
+    __syncthreads();
+  };
+  block_scan([&](uint32_t i) { return p.q_nslots[i]; }, [&](uint32_t i, uint32_t v) { p.slot_begin[i] = v; },
+             p.nq, &p.slot_begin[p.nq]);
+  block_scan([&](uint32_t i) { return p.list_count[i]; }, [&](uint32_t i, uint32_t v) { p.list_qoff[i] = v; },
+             p.nlist, &p.list_qoff[p.nlist]);
+  block_scan(
+      [&](uint32_t i) {
+        uint32_t c = p.list_count[i];
+        uint32_t groups = (c + p.rows_per_group - 1) / p.rows_per_group;
+        return groups * list_chunks(p.list_size[i], p.tiles_per_chunk);
+      },
+      [&](uint32_t i, uint32_t v) { p.item_off[i] = v; }, p.nlist, &p.item_off[p.nlist]);
+  if (tid == 0) *p.total_items = p.item_off[p.nlist];
+}
+
+__global__ void plan_fill_kernel(const PlanArgs p) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= p.nq) return;
+  uint32_t np = p.q_nprobe[q];
+  uint32_t slot = p.slot_begin[q];
+  for (uint32_t rnk = 0; rnk < np; ++rnk) {
+    uint32_t l = probe_list(p, q, rnk);
+    uint32_t sz = p.list_size[l];
+    if (sz == 0) continue;
+    uint32_t e = p.list_qoff[l] + atomicAdd(&p.list_fill[l], 1u);
+    p.csr_q[e] = q;
+    p.csr_slot[e] = slot;
+    slot += list_chunks(sz, p.tiles_per_chunk);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-means helpers (IVF build): mean of member rows per cluster, members given as CSR of row ids.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) centroid_mean_kernel(const float *rows, uint32_t dim,
+                                                            const uint64_t *member_off,
+                                                            const uint64_t *members, float *centroids) {
+  const uint32_t c = blockIdx.x;
+  const uint64_t b = member_off[c], e = member_off[c + 1];
+  if (e == b) return;  // empty cluster keeps its previous centroid
+  const float inv = 1.0f / (float)(e - b);
+  for (uint32_t col = threadIdx.x; col < dim; col += blockDim.x) {
+    float acc = 0.f;
+    for (uint64_t m = b; m < e; ++m) acc += rows[(size_t)members[m] * dim + col];
+    centroids[(size_t)c * dim + col] = acc * inv;
+  }
+}
+
+__global__ void gather_rows_kernel(const float *rows, uint32_t dim, const uint64_t *ids, uint64_t n, float *out) {
+  uint64_t i = blockIdx.x;
+  if (i >= n) return;
+  for (uint32_t c = threadIdx.x; c < dim; c += blockDim.x) out[(size_t)i * dim + c] = rows[(size_t)ids[i] * dim + c];
+}
+
+}  // namespace zvk

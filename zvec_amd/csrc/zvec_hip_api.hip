@@ -1,0 +1,1122 @@
+// zvec_hip_api.hip — host side of the C ABI in include/zvec_hip.h: HBM-resident stores, search
+// orchestration (prep -> [coarse -> plan] -> scan -> merge), IVF build, and the measurement hook.
+// gfx950 only; no CPU fallback exists anywhere in this file: if HIP is unavailable the calls fail.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/zvec_hip.h"
+#include "scan_kernels.hip.h"
+
+using namespace zvk;
+
+#define ZCHK(expr)                                                                               \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      fprintf(stderr, "[zvec_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e),        \
+              __FILE__, __LINE__);                                                               \
+      return (_e == hipErrorOutOfMemory) ? ZVEC_HIP_ERR_NO_MEMORY : ZVEC_HIP_ERR_RUNTIME;        \
+    }                                                                                            \
+  } while (0)
+
+#define ZRET(expr)            \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != 0) return _r;   \
+  } while (0)
+
+namespace {
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+constexpr uint32_t IVF_TILES_PER_CHUNK = 8;
+constexpr int PROFILE_MAX = 8192;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    ZCHK(hipMalloc(&p, want));
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// a blocked, HBM-resident set of rows (flat store, IVF centroids, IVF inverted lists)
+struct Store {
+  uint32_t dim_in = 0;   // element dimension at the ABI (cosine: d+1)
+  uint32_t dscan = 0;    // scanned dims
+  uint32_t dpad = 0;     // multiple of 32
+  int metric = 0;
+  uint64_t n = 0;        // padded positions in use
+  uint64_t cap_tiles = 0;
+  float *base = nullptr;
+  float *bnorm = nullptr;
+  float *extra = nullptr;   // cosine: stored norm column
+  uint64_t *keys = nullptr;
+
+  void configure(uint32_t dim, int met) {
+    dim_in = dim;
+    metric = met;
+    dscan = (met == ZVEC_HIP_METRIC_COSINE) ? dim - 1 : dim;
+    dpad = (dscan + TILE_K - 1) / TILE_K * TILE_K;
+  }
+  int reserve(uint64_t rows, hipStream_t stream) {
+    uint64_t tiles = (rows + TILE_N - 1) / TILE_N;
+    if (tiles <= cap_tiles) return 0;
+    uint64_t nt = std::max<uint64_t>(tiles, cap_tiles + cap_tiles / 2 + 1);
+    float *nb = nullptr, *nn = nullptr, *ne = nullptr;
+    uint64_t *nk = nullptr;
+    ZCHK(hipMalloc(&nb, (size_t)nt * TILE_N * dpad * sizeof(float)));
+    ZCHK(hipMalloc(&nn, (size_t)nt * TILE_N * sizeof(float)));
+    ZCHK(hipMalloc(&nk, (size_t)nt * TILE_N * sizeof(uint64_t)));
+    if (metric == ZVEC_HIP_METRIC_COSINE) ZCHK(hipMalloc(&ne, (size_t)nt * TILE_N * sizeof(float)));
+    uint64_t used_tiles = (n + TILE_N - 1) / TILE_N;
+    if (used_tiles) {
+      ZCHK(hipMemcpyAsync(nb, base, (size_t)used_tiles * TILE_N * dpad * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      ZCHK(hipMemcpyAsync(nn, bnorm, (size_t)used_tiles * TILE_N * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      ZCHK(hipMemcpyAsync(nk, keys, (size_t)used_tiles * TILE_N * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
+      if (ne) ZCHK(hipMemcpyAsync(ne, extra, (size_t)used_tiles * TILE_N * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      ZCHK(hipStreamSynchronize(stream));
+    }
+    release();
+    base = nb; bnorm = nn; keys = nk; extra = ne; cap_tiles = nt;
+    return 0;
+  }
+  void release() {
+    if (base) (void)hipFree(base);
+    if (bnorm) (void)hipFree(bnorm);
+    if (extra) (void)hipFree(extra);
+    if (keys) (void)hipFree(keys);
+    base = bnorm = extra = nullptr; keys = nullptr; cap_tiles = 0;
+  }
+};
+
+}  // namespace
+
+struct zvec_hip_ctx_s {
+  int device = 0;
+  hipStream_t own = nullptr;
+  hipStream_t cur = nullptr;
+  std::mutex mu;
+  // workspace
+  DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
+  DevBuf plan;        // all u32 plan arrays
+  DevBuf io_q, io_ex, io_keys, io_scores, io_counts;   // staging for host-pointer entry points
+  DevBuf stats;       // per-launch {distinct_rows, pair_rows} u64 x PROFILE_MAX
+  uint32_t *q_scanned = nullptr, *q_nprobe = nullptr;  // inside plan
+  uint32_t *last_list_count = nullptr;                 // inside plan
+  uint32_t last_count = 0;
+  // profiling
+  bool profile = false;
+  std::vector<hipEvent_t> ev0, ev1;
+  std::vector<double> host_bytes, host_flops;   // flat launches: known on the host
+  std::vector<int> launch_is_ivf;
+  std::vector<uint32_t> prof_dscan;
+  int nprof = 0;
+  int cus = 0;
+};
+
+struct zvec_hip_flat_s {
+  int device = 0;
+  int dtype = 0;
+  Store st;
+  zvec_hip_ctx_s *defctx = nullptr;
+  std::mutex mu;
+};
+
+struct zvec_hip_ivf_s {
+  int device = 0;
+  int dtype = 0;
+  uint32_t dim = 0;
+  int metric = 0;
+  uint32_t nlist = 0;
+  uint32_t shard = 0, nshards = 1;
+  bool loaded = false;
+  Store cent;     // centroids as a flat store
+  Store lists;    // inverted lists, each padded to whole tiles
+  uint64_t count_local = 0, count_global = 0;
+  std::vector<uint32_t> h_size, h_size_global, h_tile0;
+  std::vector<uint64_t> h_dense0;      // local dense offsets (nlist+1)
+  std::vector<uint64_t> h_row_ids;     // local dense position -> original row
+  std::vector<float> h_centroids;      // [nlist][dim]
+  uint32_t *d_size = nullptr, *d_size_global = nullptr, *d_tile0 = nullptr;
+  uint64_t *d_dense0 = nullptr;
+  zvec_hip_ctx_s *defctx = nullptr;
+  std::mutex mu;
+};
+
+namespace {
+
+struct KernelInfo {
+  bool init = false;
+  int cus = 0;
+};
+KernelInfo g_info[16];
+std::mutex g_info_mu;
+
+template <int NG>
+int launch_scan(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
+  static bool attr_set[16] = {false};
+  size_t lds = scan_lds_bytes(NG, a.k);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set[dev & 15]) {
+    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<NG>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    attr_set[dev & 15] = true;
+  }
+  int occ = 0;
+  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<NG>, 256, lds));
+  if (occ < 1) occ = 1;
+  uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)max_items, (uint64_t)cus * (uint64_t)occ);
+  if (grid == 0) return 0;
+  hipLaunchKernelGGL(scan_kernel<NG>, dim3(grid), dim3(256), lds, stream, a);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int launch_scan_ng(int ng, const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
+  switch (ng) {
+    case 1: return launch_scan<1>(a, max_items, cus, stream);
+    case 2: return launch_scan<2>(a, max_items, cus, stream);
+    case 4: return launch_scan<4>(a, max_items, cus, stream);
+  }
+  return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+}
+
+int pick_ng(uint32_t rows_wanted, uint32_t k) {
+  int ng = 4;   // 128 query rows per work-group is the largest tile whose accumulators + staging fit 512 registers
+  while (ng > 1 && (uint32_t)(ng / 2) * QGROUP >= rows_wanted) ng /= 2;
+  while (ng >= 1 && scan_lds_bytes(ng, k) > LDS_LIMIT - 1024) ng /= 2;
+  return ng;  // 0 => k too large for the LDS-resident lists
+}
+
+int device_cus(zvec_hip_ctx_s *ctx) {
+  if (ctx->cus == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
+    if (ctx->cus <= 0) ctx->cus = 256;
+  }
+  return ctx->cus;
+}
+
+int prof_begin(zvec_hip_ctx_s *ctx, hipStream_t stream, double bytes, double flops, int is_ivf) {
+  if (!ctx->profile || ctx->nprof >= PROFILE_MAX) return -1;
+  int i = ctx->nprof;
+  if ((int)ctx->ev0.size() <= i) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+    ctx->ev0.push_back(a);
+    ctx->ev1.push_back(b);
+    ctx->host_bytes.push_back(0);
+    ctx->host_flops.push_back(0);
+    ctx->launch_is_ivf.push_back(0);
+    ctx->prof_dscan.push_back(0);
+  }
+  ctx->host_bytes[i] = bytes;
+  ctx->host_flops[i] = flops;
+  ctx->launch_is_ivf[i] = is_ivf;
+  (void)hipEventRecord(ctx->ev0[i], stream);
+  return i;
+}
+void prof_end(zvec_hip_ctx_s *ctx, hipStream_t stream, int i) {
+  if (i < 0) return;
+  (void)hipEventRecord(ctx->ev1[i], stream);
+  ctx->nprof = i + 1;
+}
+
+// Outputs of a search on the device
+struct SearchOut {
+  uint64_t *keys;
+  float *scores;
+  uint32_t *idx;     // optional positions
+  uint32_t *counts;
+};
+
+// flat scan of `st` for `count` prepared queries (ctx->qpad / qnorm already filled)
+int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold,
+                       const uint64_t *d_exclude, const SearchOut &out, hipStream_t stream, bool profile_it) {
+  if (st.n == 0) {
+    // no rows: empty results
+    MergeArgs m{};
+    ZCHK(hipMemsetAsync(out.counts, 0, sizeof(uint32_t) * count, stream));
+    ZCHK(hipMemsetAsync(out.keys, 0xff, sizeof(uint64_t) * (size_t)count * topk, stream));
+    return 0;
+  }
+  int ng = pick_ng(count, topk);
+  if (ng < 1) return ZVEC_HIP_ERR_UNSUPPORTED;
+  const int cus = device_cus(ctx);
+  const uint32_t rows = ng * QGROUP;
+  const uint32_t nqtiles = (count + rows - 1) / rows;
+  const uint64_t ntiles = (st.n + TILE_N - 1) / TILE_N;
+  // aim at ~2 items per resident work-group, each chunk >= 1 tile
+  uint64_t resident = (uint64_t)cus * (ng >= 4 ? 1 : (ng == 2 ? 2 : 3));
+  uint64_t want_chunks = std::max<uint64_t>(1, (2 * resident + nqtiles - 1) / nqtiles);
+  uint64_t tpc = std::max<uint64_t>(1, (ntiles + want_chunks - 1) / want_chunks);
+  uint32_t nchunks = (uint32_t)((ntiles + tpc - 1) / tpc);
+  uint64_t slots = (uint64_t)count * nchunks;
+  ZRET(ctx->part_s.ensure(slots * topk * sizeof(float)));
+  ZRET(ctx->part_i.ensure(slots * topk * sizeof(uint32_t)));
+
+  ScanArgs a{};
+  a.base = st.base; a.bnorm = st.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
+  a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
+  a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = topk; a.threshold = threshold;
+  a.mode = 0; a.nq = count; a.n = st.n; a.tiles_per_chunk = (uint32_t)tpc; a.nchunks = nchunks; a.nqtiles = nqtiles;
+  a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
+  int pi = -1;
+  if (profile_it) {
+    double bytes = (double)st.n * st.dscan * 4.0 + (double)count * st.dscan * 4.0 + (double)count * topk * 12.0;
+    double flops = 2.0 * (double)count * (double)st.n * st.dscan;
+    pi = prof_begin(ctx, stream, bytes, flops, 0);
+  }
+  ZRET(launch_scan_ng(ng, a, nchunks * nqtiles, cus, stream));
+  prof_end(ctx, stream, pi);
+
+  MergeArgs m{};
+  m.part_s = a.part_s; m.part_i = a.part_i; m.part_keys = nullptr; m.slot_begin = nullptr;
+  m.slots_per_q = nchunks; m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.threshold = threshold;
+  m.keymap = st.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int prep_queries(zvec_hip_ctx_s *ctx, const Store &st, const float *d_queries, uint32_t count, hipStream_t stream) {
+  ZRET(ctx->qpad.ensure((size_t)count * st.dpad * sizeof(float)));
+  ZRET(ctx->qnorm.ensure((size_t)count * sizeof(float)));
+  hipLaunchKernelGGL(prep_queries_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, d_queries, count,
+                     st.dim_in, st.dscan, st.dpad, ctx->qpad.as<float>(), ctx->qnorm.as<float>());
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int store_append_dev(Store &st, const float *d_vecs, uint64_t n, const uint64_t *d_keys, hipStream_t stream) {
+  if (n == 0) return 0;
+  ZRET(st.reserve(st.n + n, stream));
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_vecs, n, st.dim_in,
+                     st.dscan, st.dpad, (const uint64_t *)nullptr, st.n, (const uint64_t *)nullptr, st.base,
+                     st.bnorm, st.extra);
+  ZCHK(hipGetLastError());
+  hipLaunchKernelGGL(fill_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st.keys, st.n, n, d_keys);
+  ZCHK(hipGetLastError());
+  st.n += n;
+  return 0;
+}
+
+hipStream_t pick_stream(zvec_hip_ctx_s *ctx, void *stream) {
+  return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->cur;
+}
+
+int ctx_new(int device, zvec_hip_ctx_s **out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fprintf(stderr, "[zvec_hip] no HIP device available: the zvec_hip core has no CPU fallback\n");
+    return ZVEC_HIP_ERR_RUNTIME;
+  }
+  if (device < 0 || device >= ndev) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  ZCHK(hipSetDevice(device));
+  zvec_hip_ctx_s *c = new (std::nothrow) zvec_hip_ctx_s();
+  if (!c) return ZVEC_HIP_ERR_NO_MEMORY;
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking) != hipSuccess) { delete c; return ZVEC_HIP_ERR_RUNTIME; }
+  c->cur = c->own;
+  *out = c;
+  return 0;
+}
+
+void ctx_free(zvec_hip_ctx_s *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own) (void)hipStreamSynchronize(c->own);
+  c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
+  c->coarse_keys.release(); c->coarse_scores.release(); c->coarse_idx.release(); c->coarse_cnt.release();
+  c->plan.release(); c->io_q.release(); c->io_ex.release(); c->io_keys.release(); c->io_scores.release();
+  c->io_counts.release(); c->stats.release();
+  for (auto e : c->ev0) (void)hipEventDestroy(e);
+  for (auto e : c->ev1) (void)hipEventDestroy(e);
+  if (c->own) (void)hipStreamDestroy(c->own);
+  delete c;
+}
+
+// ---- IVF search core (device pointers) ------------------------------------------------------
+int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queries, uint32_t count, uint32_t topk,
+                    float threshold, uint32_t nprobe, uint32_t max_scan_count, int brute_force,
+                    const uint64_t *d_exclude, const SearchOut &out, hipStream_t stream) {
+  const int cus = device_cus(ctx);
+  const uint32_t nlist = h->nlist;
+  if (nprobe < 1) nprobe = 1;
+  if (nprobe > nlist) nprobe = nlist;
+  ZRET(prep_queries(ctx, h->lists, d_queries, count, stream));
+
+  // 1. coarse assign: flat scan over the centroids, k = nprobe (IVFCentroidIndex::search)
+  if (!brute_force) {
+    ZRET(ctx->coarse_keys.ensure((size_t)count * nprobe * sizeof(uint64_t)));
+    ZRET(ctx->coarse_scores.ensure((size_t)count * nprobe * sizeof(float)));
+    ZRET(ctx->coarse_idx.ensure((size_t)count * nprobe * sizeof(uint32_t)));
+    ZRET(ctx->coarse_cnt.ensure((size_t)count * sizeof(uint32_t)));
+    SearchOut co{ctx->coarse_keys.as<uint64_t>(), ctx->coarse_scores.as<float>(), ctx->coarse_idx.as<uint32_t>(),
+                 ctx->coarse_cnt.as<uint32_t>()};
+    ZRET(flat_scan_prepared(ctx, h->cent, count, nprobe, FLT_MAX, nullptr, co, stream, false));
+  }
+
+  // 2. plan: list-major work items
+  const int ng = 1;
+  if (scan_lds_bytes(ng, topk) > LDS_LIMIT - 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
+  const uint32_t rows_per_group = ng * QGROUP;
+  const uint64_t npairs = (uint64_t)count * (brute_force ? nlist : nprobe);
+  // layout of the plan buffer (u32 words)
+  size_t off = 0;
+  auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
+  size_t o_qnprobe = take(count), o_qscanned = take(count), o_qnslots = take(count), o_slotbegin = take(count + 1);
+  size_t o_lcount = take(nlist), o_lfill = take(nlist), o_lqoff = take(nlist + 1), o_itemoff = take(nlist + 1);
+  size_t o_total = take(4), o_csrq = take(npairs), o_csrslot = take(npairs);
+  ZRET(ctx->plan.ensure(off * sizeof(uint32_t)));
+  uint32_t *pb = ctx->plan.as<uint32_t>();
+  ZCHK(hipMemsetAsync(pb + o_lcount, 0, (o_lqoff - o_lcount) * sizeof(uint32_t), stream));  // list_count + list_fill
+  PlanArgs p{};
+  p.coarse_idx = ctx->coarse_idx.as<uint32_t>(); p.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
+  p.nq = count; p.nprobe = nprobe; p.nlist = nlist; p.max_scan_count = max_scan_count; p.brute_force = brute_force;
+  p.list_size = h->d_size; p.list_size_global = h->d_size_global; p.tiles_per_chunk = IVF_TILES_PER_CHUNK;
+  p.rows_per_group = rows_per_group;
+  p.q_nprobe = pb + o_qnprobe; p.q_scanned = pb + o_qscanned; p.q_nslots = pb + o_qnslots; p.slot_begin = pb + o_slotbegin;
+  p.list_count = pb + o_lcount; p.list_fill = pb + o_lfill; p.list_qoff = pb + o_lqoff; p.item_off = pb + o_itemoff;
+  p.total_items = pb + o_total; p.csr_q = pb + o_csrq; p.csr_slot = pb + o_csrslot;
+  ctx->q_nprobe = p.q_nprobe; ctx->q_scanned = p.q_scanned; ctx->last_count = count;
+  ctx->last_list_count = p.list_count;
+  hipLaunchKernelGGL(plan_count_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+  hipLaunchKernelGGL(plan_fill_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, p);
+  ZCHK(hipGetLastError());
+
+  // 3. scan.  Upper bound of slots: every probed list contributes ceil(size/chunk_rows) chunks;
+  //    bound it by pairs * max chunks per list.
+  uint32_t max_list = 0;
+  for (uint32_t l = 0; l < nlist; ++l) max_list = std::max(max_list, h->h_size[l]);
+  uint32_t max_chunks = std::max<uint32_t>(1, ((max_list + TILE_N - 1) / TILE_N + IVF_TILES_PER_CHUNK - 1) / IVF_TILES_PER_CHUNK);
+  // exact worst case: each query probes its lists; bounded by the nprobe largest lists
+  std::vector<uint32_t> &sz = h->h_size;
+  uint64_t slots_bound;
+  {
+    std::vector<uint32_t> chunks(nlist);
+    for (uint32_t l = 0; l < nlist; ++l)
+      chunks[l] = sz[l] ? (((sz[l] + TILE_N - 1) / TILE_N + IVF_TILES_PER_CHUNK - 1) / IVF_TILES_PER_CHUNK) : 0;
+    uint32_t np = brute_force ? nlist : nprobe;
+    std::partial_sort(chunks.begin(), chunks.begin() + np, chunks.end(), std::greater<uint32_t>());
+    uint64_t s = 0;
+    for (uint32_t i = 0; i < np; ++i) s += chunks[i];
+    slots_bound = s * count;
+  }
+  (void)max_chunks;
+  if (slots_bound == 0) slots_bound = 1;
+  ZRET(ctx->part_s.ensure(slots_bound * topk * sizeof(float)));
+  ZRET(ctx->part_i.ensure(slots_bound * topk * sizeof(uint32_t)));
+
+  ScanArgs a{};
+  a.base = h->lists.base; a.bnorm = h->lists.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
+  a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
+  a.dpad = h->lists.dpad; a.nks = h->lists.dpad / TILE_K; a.metric = h->metric; a.k = topk; a.threshold = threshold;
+  a.mode = 1; a.nq = count; a.n = h->lists.n; a.tiles_per_chunk = IVF_TILES_PER_CHUNK;
+  a.total_items = p.total_items; a.item_off = p.item_off; a.list_tile0 = h->d_tile0; a.list_size = h->d_size;
+  a.list_dense0 = h->d_dense0; a.list_qoff = p.list_qoff; a.csr_q = p.csr_q; a.csr_slot = p.csr_slot; a.nlist = nlist;
+  a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
+  // algorithmic bytes of the list scan = rows of the DISTINCT probed lists (counted on device from
+  // the plan, see ivf_work_stats_kernel) + the query rows + the result lists
+  int pi = prof_begin(ctx, stream, (double)count * h->lists.dscan * 4.0 + (double)count * topk * 12.0, 0, 1);
+  if (pi >= 0) ctx->prof_dscan[pi] = h->lists.dscan;
+  ZRET(launch_scan_ng(ng, a, 0x7fffffffu, cus, stream));
+  prof_end(ctx, stream, pi);
+
+  // 4. merge the per-(query, probe, chunk) partial lists in probe order
+  MergeArgs m{};
+  m.part_s = a.part_s; m.part_i = a.part_i; m.part_keys = nullptr; m.slot_begin = p.slot_begin; m.slots_per_q = 0;
+  m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.threshold = threshold; m.keymap = h->lists.keys;
+  m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+// work statistics of an IVF launch (for the roofline line): distinct probed rows & pair rows
+__global__ void ivf_work_stats_kernel(const uint32_t *list_count, const uint32_t *list_size, uint32_t nlist,
+                                      unsigned long long *out2) {
+  unsigned long long rows = 0, pairs = 0;
+  for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
+    uint32_t c = list_count[l];
+    if (c) { rows += list_size[l]; pairs += (unsigned long long)c * list_size[l]; }
+  }
+  atomicAdd(&out2[0], rows);
+  atomicAdd(&out2[1], pairs);
+}
+
+int host_search_wrap_begin(zvec_hip_ctx_s *ctx, const void *queries, size_t qbytes, const uint64_t *exclude,
+                           uint64_t nbits, uint32_t count, uint32_t topk, hipStream_t stream) {
+  ZRET(ctx->io_q.ensure(qbytes));
+  ZCHK(hipMemcpyAsync(ctx->io_q.p, queries, qbytes, hipMemcpyHostToDevice, stream));
+  if (exclude) {
+    size_t words = (size_t)((nbits + 63) / 64);
+    ZRET(ctx->io_ex.ensure(words * 8 + 8));
+    ZCHK(hipMemcpyAsync(ctx->io_ex.p, exclude, words * 8, hipMemcpyHostToDevice, stream));
+  }
+  ZRET(ctx->io_keys.ensure((size_t)count * topk * sizeof(uint64_t)));
+  ZRET(ctx->io_scores.ensure((size_t)count * topk * sizeof(float)));
+  ZRET(ctx->io_counts.ensure((size_t)count * sizeof(uint32_t)));
+  return 0;
+}
+
+int host_search_wrap_end(zvec_hip_ctx_s *ctx, uint32_t count, uint32_t topk, uint64_t *out_keys, float *out_scores,
+                         uint32_t *out_counts, hipStream_t stream) {
+  ZCHK(hipMemcpyAsync(out_keys, ctx->io_keys.p, (size_t)count * topk * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  ZCHK(hipMemcpyAsync(out_scores, ctx->io_scores.p, (size_t)count * topk * sizeof(float), hipMemcpyDeviceToHost, stream));
+  ZCHK(hipMemcpyAsync(out_counts, ctx->io_counts.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  ZCHK(hipStreamSynchronize(stream));
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int zvec_hip_abi_version(void) { return ZVEC_HIP_ABI_VERSION; }
+
+int zvec_hip_device_count(int *count) {
+  if (!count) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return ZVEC_HIP_ERR_RUNTIME; }
+  *count = n;
+  return 0;
+}
+
+const char *zvec_hip_error_string(int code) {
+  switch (code) {
+    case ZVEC_HIP_OK: return "Success";
+    case ZVEC_HIP_ERR_RUNTIME: return "Runtime error";
+    case ZVEC_HIP_ERR_UNSUPPORTED: return "Unsupported";
+    case ZVEC_HIP_ERR_OUT_OF_RANGE: return "Out of range";
+    case ZVEC_HIP_ERR_NO_MEMORY: return "Not enough space";
+    case ZVEC_HIP_ERR_NO_READY: return "No ready";
+    case ZVEC_HIP_ERR_NO_EXIST: return "No exist";
+    case ZVEC_HIP_ERR_MISMATCH: return "Mismatch";
+    case ZVEC_HIP_ERR_INVALID_ARGUMENT: return "Invalid argument";
+    case ZVEC_HIP_ERR_NO_INDEX_LOADED: return "No index loaded";
+    case ZVEC_HIP_ERR_NO_TRAINED: return "No trained";
+  }
+  return "Unknown error";
+}
+
+int zvec_hip_ctx_create(int device, zvec_hip_ctx_t *out) {
+  if (!out) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  return ctx_new(device, out);
+}
+int zvec_hip_ctx_destroy(zvec_hip_ctx_t ctx) { ctx_free(ctx); return 0; }
+int zvec_hip_ctx_synchronize(zvec_hip_ctx_t ctx) {
+  if (!ctx) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  ZCHK(hipSetDevice(ctx->device));
+  ZCHK(hipStreamSynchronize(ctx->cur));
+  return 0;
+}
+int zvec_hip_ctx_set_stream(zvec_hip_ctx_t ctx, void *stream) {
+  if (!ctx) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  ctx->cur = stream ? reinterpret_cast<hipStream_t>(stream) : ctx->own;
+  return 0;
+}
+
+// ---- flat -----------------------------------------------------------------------------------
+int zvec_hip_flat_create(uint32_t dim, int dtype, int metric, int device, zvec_hip_flat_t *out) {
+  if (!out || dim == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (dtype != ZVEC_HIP_DT_FP32) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (metric < 0 || metric > 2) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (metric == ZVEC_HIP_METRIC_COSINE && dim < 2) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  zvec_hip_ctx_s *c = nullptr;
+  ZRET(ctx_new(device, &c));
+  zvec_hip_flat_s *h = new (std::nothrow) zvec_hip_flat_s();
+  if (!h) { ctx_free(c); return ZVEC_HIP_ERR_NO_MEMORY; }
+  h->device = device; h->dtype = dtype; h->defctx = c;
+  h->st.configure(dim, metric);
+  *out = h;
+  return 0;
+}
+
+int zvec_hip_flat_destroy(zvec_hip_flat_t h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  h->st.release();
+  ctx_free(h->defctx);
+  delete h;
+  return 0;
+}
+
+int zvec_hip_flat_reserve(zvec_hip_flat_t h, uint64_t capacity) {
+  if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  return h->st.reserve(capacity, h->defctx->own);
+}
+
+int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n, const uint64_t *d_keys, void *stream) {
+  if (!h || (!d_vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = pick_stream(h->defctx, stream);
+  return store_append_dev(h->st, reinterpret_cast<const float *>(d_vecs), n, d_keys, s);
+}
+
+int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const uint64_t *keys) {
+  if (!h || (!vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = h->defctx->own;
+  // stage through the device in slices of <= 1 GiB
+  const uint64_t rows_per = std::max<uint64_t>(1, ((uint64_t)1 << 30) / ((uint64_t)h->st.dim_in * 4));
+  DevBuf tmp, tk;
+  for (uint64_t o = 0; o < n; o += rows_per) {
+    uint64_t m = std::min(rows_per, n - o);
+    int rc = tmp.ensure((size_t)m * h->st.dim_in * 4);
+    if (rc == 0 && keys) rc = tk.ensure((size_t)m * 8);
+    if (rc != 0) { tmp.release(); tk.release(); return rc; }
+    ZCHK(hipMemcpyAsync(tmp.p, reinterpret_cast<const float *>(vecs) + (size_t)o * h->st.dim_in,
+                        (size_t)m * h->st.dim_in * 4, hipMemcpyHostToDevice, s));
+    if (keys) ZCHK(hipMemcpyAsync(tk.p, keys + o, (size_t)m * 8, hipMemcpyHostToDevice, s));
+    rc = store_append_dev(h->st, tmp.as<float>(), m, keys ? tk.as<uint64_t>() : nullptr, s);
+    if (rc != 0) { tmp.release(); tk.release(); return rc; }
+    ZCHK(hipStreamSynchronize(s));
+  }
+  tmp.release(); tk.release();
+  return 0;
+}
+
+int zvec_hip_flat_count(zvec_hip_flat_t h, uint64_t *count) {
+  if (!h || !count) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  *count = h->st.n;
+  return 0;
+}
+
+int zvec_hip_flat_get_vector(zvec_hip_flat_t h, uint64_t pos, void *out) {
+  if (!h || !out) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  if (pos >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
+  ZCHK(hipSetDevice(h->device));
+  zvec_hip_ctx_s *c = h->defctx;
+  ZRET(c->io_q.ensure((size_t)h->st.dim_in * 4));
+  hipLaunchKernelGGL(unpack_row_kernel, dim3(1), dim3(256), 0, c->own, h->st.base, h->st.extra, pos, h->st.dscan,
+                     h->st.dim_in, h->st.dpad, c->io_q.as<float>());
+  ZCHK(hipMemcpyAsync(out, c->io_q.p, (size_t)h->st.dim_in * 4, hipMemcpyDeviceToHost, c->own));
+  ZCHK(hipStreamSynchronize(c->own));
+  return 0;
+}
+
+int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count,
+                             uint32_t topk, float threshold, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys,
+                             float *d_out_scores, uint32_t *d_out_counts, void *stream) {
+  if (!h || !d_queries || !d_out_keys || !d_out_scores || !d_out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;   // "Invalid context or topk not set yet" flat_searcher.cc:194
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = pick_stream(c, stream);
+  ZRET(prep_queries(c, h->st, reinterpret_cast<const float *>(d_queries), count, s));
+  SearchOut out{d_out_keys, d_out_scores, nullptr, d_out_counts};
+  return flat_scan_prepared(c, h->st, count, topk, threshold, d_exclude_bitset, out, s, true);
+}
+
+int zvec_hip_flat_search(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count, uint32_t topk,
+                         float threshold, const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
+                         uint32_t *out_counts) {
+  if (!h || !queries || !out_keys || !out_scores || !out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    ZCHK(hipSetDevice(h->device));
+    ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->st.dim_in * 4, exclude_bitset, h->st.n, count, topk, c->cur));
+  }
+  ZRET(zvec_hip_flat_search_dev(h, c, c->io_q.p, count, topk, threshold, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr,
+                                c->io_keys.as<uint64_t>(), c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
+  std::lock_guard<std::mutex> g(c->mu);
+  return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, c->cur);
+}
+
+// ---- IVF ------------------------------------------------------------------------------------
+int zvec_hip_ivf_create(uint32_t dim, int dtype, int metric, int device, zvec_hip_ivf_t *out) {
+  if (!out || dim == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (dtype != ZVEC_HIP_DT_FP32) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (metric < 0 || metric > 2) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (metric == ZVEC_HIP_METRIC_COSINE && dim < 2) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  zvec_hip_ctx_s *c = nullptr;
+  ZRET(ctx_new(device, &c));
+  zvec_hip_ivf_s *h = new (std::nothrow) zvec_hip_ivf_s();
+  if (!h) { ctx_free(c); return ZVEC_HIP_ERR_NO_MEMORY; }
+  h->device = device; h->dtype = dtype; h->dim = dim; h->metric = metric; h->defctx = c;
+  h->cent.configure(dim, metric);
+  h->lists.configure(dim, metric);
+  *out = h;
+  return 0;
+}
+
+static void ivf_release(zvec_hip_ivf_s *h) {
+  h->cent.release(); h->lists.release();
+  h->cent.n = 0; h->lists.n = 0;
+  if (h->d_size) (void)hipFree(h->d_size);
+  if (h->d_size_global) (void)hipFree(h->d_size_global);
+  if (h->d_tile0) (void)hipFree(h->d_tile0);
+  if (h->d_dense0) (void)hipFree(h->d_dense0);
+  h->d_size = h->d_size_global = h->d_tile0 = nullptr; h->d_dense0 = nullptr;
+  h->loaded = false;
+}
+
+int zvec_hip_ivf_destroy(zvec_hip_ivf_t h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  ivf_release(h);
+  ctx_free(h->defctx);
+  delete h;
+  return 0;
+}
+
+int zvec_hip_ivf_keep_shard(zvec_hip_ivf_t h, uint32_t shard, uint32_t nshards) {
+  if (!h || nshards == 0 || shard >= nshards) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (h->loaded) return ZVEC_HIP_ERR_NO_READY;   // must be set before load/build
+  h->shard = shard; h->nshards = nshards;
+  return 0;
+}
+
+// pack rows (device, row-major [n][dim]) given per-row labels (host) into the inverted-list store
+static int ivf_pack(zvec_hip_ivf_s *h, const float *d_rows, uint64_t n, const uint64_t *keys,
+                    const std::vector<uint32_t> &labels, const float *h_centroids, uint32_t nlist, hipStream_t s) {
+  h->nlist = nlist;
+  h->h_centroids.assign(h_centroids, h_centroids + (size_t)nlist * h->dim);
+  h->h_size_global.assign(nlist, 0);
+  for (uint64_t i = 0; i < n; ++i) h->h_size_global[labels[i]] += 1;
+  h->h_size.assign(nlist, 0);
+  for (uint32_t l = 0; l < nlist; ++l)
+    if (l % h->nshards == h->shard) h->h_size[l] = h->h_size_global[l];
+  h->h_tile0.assign(nlist, 0);
+  h->h_dense0.assign(nlist + 1, 0);
+  uint64_t tiles = 0, dense = 0;
+  for (uint32_t l = 0; l < nlist; ++l) {
+    h->h_tile0[l] = (uint32_t)tiles;
+    h->h_dense0[l] = dense;
+    tiles += (h->h_size[l] + TILE_N - 1) / TILE_N;
+    dense += h->h_size[l];
+  }
+  h->h_dense0[nlist] = dense;
+  h->count_local = dense;
+  h->count_global = n;
+  if (tiles * TILE_N >= 0xffffffffull) return ZVEC_HIP_ERR_OUT_OF_RANGE;
+  // stable counting sort of the owned rows into list order
+  std::vector<uint64_t> cursor(nlist);
+  for (uint32_t l = 0; l < nlist; ++l) cursor[l] = h->h_dense0[l];
+  h->h_row_ids.assign(dense, 0);
+  for (uint64_t i = 0; i < n; ++i) {
+    uint32_t l = labels[i];
+    if (l % h->nshards == h->shard) h->h_row_ids[cursor[l]++] = i;
+  }
+  std::vector<uint64_t> dst(dense), hkeys((size_t)tiles * TILE_N, ~0ull);
+  for (uint32_t l = 0; l < nlist; ++l) {
+    uint64_t pos0 = (uint64_t)h->h_tile0[l] * TILE_N;
+    for (uint64_t j = 0; j < h->h_size[l]; ++j) {
+      uint64_t d = h->h_dense0[l] + j;
+      dst[d] = pos0 + j;
+      hkeys[pos0 + j] = keys ? keys[h->h_row_ids[d]] : h->h_row_ids[d];
+    }
+  }
+  // device side
+  h->lists.n = 0;
+  ZRET(h->lists.reserve(std::max<uint64_t>(tiles * TILE_N, 1), s));
+  h->lists.n = tiles * TILE_N;
+  if (dense) {
+    uint64_t *d_src = nullptr, *d_dst = nullptr;
+    ZCHK(hipMalloc(&d_src, dense * 8));
+    ZCHK(hipMalloc(&d_dst, dense * 8));
+    ZCHK(hipMemcpyAsync(d_src, h->h_row_ids.data(), dense * 8, hipMemcpyHostToDevice, s));
+    ZCHK(hipMemcpyAsync(d_dst, dst.data(), dense * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((dense + 3) / 4)), dim3(256), 0, s, d_rows, dense, h->dim,
+                       h->lists.dscan, h->lists.dpad, d_src, (uint64_t)0, d_dst, h->lists.base, h->lists.bnorm,
+                       h->lists.extra);
+    ZCHK(hipGetLastError());
+    ZCHK(hipMemcpyAsync(h->lists.keys, hkeys.data(), hkeys.size() * 8, hipMemcpyHostToDevice, s));
+    ZCHK(hipStreamSynchronize(s));
+    (void)hipFree(d_src);
+    (void)hipFree(d_dst);
+  }
+  // centroids as a flat store
+  h->cent.n = 0;
+  {
+    float *d_c = nullptr;
+    ZCHK(hipMalloc(&d_c, (size_t)nlist * h->dim * 4));
+    ZCHK(hipMemcpyAsync(d_c, h_centroids, (size_t)nlist * h->dim * 4, hipMemcpyHostToDevice, s));
+    int rc = store_append_dev(h->cent, d_c, nlist, nullptr, s);
+    ZCHK(hipStreamSynchronize(s));
+    (void)hipFree(d_c);
+    if (rc != 0) return rc;
+  }
+  // list tables
+  if (h->d_size) { (void)hipFree(h->d_size); (void)hipFree(h->d_size_global); (void)hipFree(h->d_tile0); (void)hipFree(h->d_dense0); }
+  ZCHK(hipMalloc(&h->d_size, nlist * 4));
+  ZCHK(hipMalloc(&h->d_size_global, nlist * 4));
+  ZCHK(hipMalloc(&h->d_tile0, nlist * 4));
+  ZCHK(hipMalloc(&h->d_dense0, (nlist + 1) * 8));
+  ZCHK(hipMemcpy(h->d_size, h->h_size.data(), nlist * 4, hipMemcpyHostToDevice));
+  ZCHK(hipMemcpy(h->d_size_global, h->h_size_global.data(), nlist * 4, hipMemcpyHostToDevice));
+  ZCHK(hipMemcpy(h->d_tile0, h->h_tile0.data(), nlist * 4, hipMemcpyHostToDevice));
+  ZCHK(hipMemcpy(h->d_dense0, h->h_dense0.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
+  h->loaded = true;
+  return 0;
+}
+
+int zvec_hip_ivf_load(zvec_hip_ivf_t h, const void *centroids, uint32_t nlist, const uint64_t *list_offsets,
+                      const void *vecs, const uint64_t *keys) {
+  if (!h || !centroids || nlist == 0 || !list_offsets) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = h->defctx->own;
+  uint64_t n = list_offsets[nlist];
+  if (n && !vecs) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::vector<uint32_t> labels(n);
+  for (uint32_t l = 0; l < nlist; ++l) {
+    if (list_offsets[l + 1] < list_offsets[l]) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+    for (uint64_t i = list_offsets[l]; i < list_offsets[l + 1]; ++i) labels[i] = l;
+  }
+  float *d_rows = nullptr;
+  if (n) {
+    ZCHK(hipMalloc(&d_rows, (size_t)n * h->dim * 4));
+    ZCHK(hipMemcpyAsync(d_rows, vecs, (size_t)n * h->dim * 4, hipMemcpyHostToDevice, s));
+  }
+  bool was_loaded = h->loaded;
+  if (was_loaded) ivf_release(h);
+  int rc = ivf_pack(h, d_rows, n, keys, labels, reinterpret_cast<const float *>(centroids), nlist, s);
+  if (d_rows) (void)hipFree(d_rows);
+  return rc;
+}
+
+int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, const uint64_t *keys, uint32_t nlist,
+                           uint32_t kmeans_iters, uint32_t sample_per_list, uint64_t seed, void *stream) {
+  if (!h || !d_vecs || n == 0 || nlist == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (nlist > n) nlist = (uint32_t)n;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  zvec_hip_ctx_s *c = h->defctx;
+  hipStream_t s = pick_stream(c, stream);
+  const float *rows = reinterpret_cast<const float *>(d_vecs);
+  const uint32_t dim = h->dim;
+  if (sample_per_list == 0) sample_per_list = 256;
+  if (h->loaded) ivf_release(h);
+
+  // ---- sample (deterministic stride) ----
+  uint64_t S = std::min<uint64_t>(n, (uint64_t)sample_per_list * nlist);
+  std::vector<uint64_t> sample_ids(S);
+  for (uint64_t i = 0; i < S; ++i) sample_ids[i] = (uint64_t)(((unsigned __int128)i * n) / S);
+  uint64_t *d_ids = nullptr;
+  float *d_sample = nullptr, *d_cent = nullptr;
+  ZCHK(hipMalloc(&d_ids, S * 8));
+  ZCHK(hipMalloc(&d_sample, (size_t)S * dim * 4));
+  ZCHK(hipMalloc(&d_cent, (size_t)nlist * dim * 4));
+  ZCHK(hipMemcpyAsync(d_ids, sample_ids.data(), S * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)S), dim3(256), 0, s, rows, dim, d_ids, S, d_sample);
+  ZCHK(hipGetLastError());
+  // ---- initial centroids: nlist distinct sample rows picked by a seeded partial shuffle ----
+  {
+    std::vector<uint64_t> perm(S);
+    for (uint64_t i = 0; i < S; ++i) perm[i] = i;
+    uint64_t x = seed * 6364136223846793005ull + 1442695040888963407ull;
+    for (uint32_t i = 0; i < nlist; ++i) {
+      x = x * 6364136223846793005ull + 1442695040888963407ull;
+      uint64_t j = i + (x >> 33) % (S - i);
+      std::swap(perm[i], perm[j]);
+    }
+    ZCHK(hipMemcpyAsync(d_ids, perm.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nlist), dim3(256), 0, s, d_sample, dim, d_ids, (uint64_t)nlist, d_cent);
+    ZCHK(hipGetLastError());
+    ZCHK(hipStreamSynchronize(s));
+  }
+  // ---- Lloyd iterations on the sample ----
+  Store cs;
+  cs.configure(dim, h->metric);
+  uint64_t *d_lab_keys = nullptr; float *d_lab_scores = nullptr; uint32_t *d_lab_idx = nullptr, *d_lab_cnt = nullptr;
+  const uint64_t BATCH = 1u << 18;
+  uint64_t maxq = std::max<uint64_t>(std::min<uint64_t>(S, BATCH), std::min<uint64_t>(n, BATCH));
+  ZCHK(hipMalloc(&d_lab_keys, maxq * 8));
+  ZCHK(hipMalloc(&d_lab_scores, maxq * 4));
+  ZCHK(hipMalloc(&d_lab_idx, maxq * 4));
+  ZCHK(hipMalloc(&d_lab_cnt, maxq * 4));
+  uint64_t *d_moff = nullptr, *d_members = nullptr;
+  ZCHK(hipMalloc(&d_moff, ((size_t)nlist + 1) * 8));
+  ZCHK(hipMalloc(&d_members, S * 8));
+  std::vector<uint32_t> lab(std::max<uint64_t>(S, n));
+  auto assign = [&](const float *q, uint64_t nq, uint32_t *host_labels) -> int {
+    for (uint64_t o = 0; o < nq; o += BATCH) {
+      uint32_t m = (uint32_t)std::min<uint64_t>(BATCH, nq - o);
+      ZRET(prep_queries(c, cs, q + (size_t)o * dim, m, s));
+      SearchOut out{d_lab_keys, d_lab_scores, d_lab_idx, d_lab_cnt};
+      ZRET(flat_scan_prepared(c, cs, m, 1, FLT_MAX, nullptr, out, s, false));
+      ZCHK(hipMemcpyAsync(host_labels + o, d_lab_idx, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+      ZCHK(hipStreamSynchronize(s));
+    }
+    return 0;
+  };
+  for (uint32_t it = 0; it < kmeans_iters; ++it) {
+    cs.n = 0;
+    ZRET(store_append_dev(cs, d_cent, nlist, nullptr, s));
+    ZRET(assign(d_sample, S, lab.data()));
+    std::vector<uint64_t> moff(nlist + 1, 0), members(S);
+    for (uint64_t i = 0; i < S; ++i) moff[(lab[i] < nlist ? lab[i] : 0) + 1] += 1;
+    for (uint32_t l = 0; l < nlist; ++l) moff[l + 1] += moff[l];
+    std::vector<uint64_t> cur(moff.begin(), moff.end() - 1);
+    for (uint64_t i = 0; i < S; ++i) members[cur[lab[i] < nlist ? lab[i] : 0]++] = i;
+    ZCHK(hipMemcpyAsync(d_moff, moff.data(), moff.size() * 8, hipMemcpyHostToDevice, s));
+    ZCHK(hipMemcpyAsync(d_members, members.data(), S * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(centroid_mean_kernel, dim3(nlist), dim3(256), 0, s, d_sample, dim, d_moff, d_members, d_cent);
+    ZCHK(hipGetLastError());
+    ZCHK(hipStreamSynchronize(s));
+  }
+  // ---- label every row with its nearest centroid (ivf_builder.h:253-274) ----
+  cs.n = 0;
+  ZRET(store_append_dev(cs, d_cent, nlist, nullptr, s));
+  ZRET(assign(rows, n, lab.data()));
+  std::vector<float> hc((size_t)nlist * dim);
+  ZCHK(hipMemcpy(hc.data(), d_cent, hc.size() * 4, hipMemcpyDeviceToHost));
+  cs.release();
+  (void)hipFree(d_ids); (void)hipFree(d_sample); (void)hipFree(d_cent); (void)hipFree(d_lab_keys);
+  (void)hipFree(d_lab_scores); (void)hipFree(d_lab_idx); (void)hipFree(d_lab_cnt); (void)hipFree(d_moff); (void)hipFree(d_members);
+  lab.resize(n);
+  for (uint64_t i = 0; i < n; ++i) if (lab[i] >= nlist) lab[i] = 0;
+  return ivf_pack(h, rows, n, keys, lab, hc.data(), nlist, s);
+}
+
+int zvec_hip_ivf_build(zvec_hip_ivf_t h, const void *vecs, uint64_t n, const uint64_t *keys, uint32_t nlist,
+                       uint32_t kmeans_iters, uint32_t sample_per_list, uint64_t seed) {
+  if (!h || !vecs || n == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  ZCHK(hipSetDevice(h->device));
+  float *d_rows = nullptr;
+  ZCHK(hipMalloc(&d_rows, (size_t)n * h->dim * 4));
+  ZCHK(hipMemcpy(d_rows, vecs, (size_t)n * h->dim * 4, hipMemcpyHostToDevice));
+  int rc = zvec_hip_ivf_build_dev(h, d_rows, n, keys, nlist, kmeans_iters, sample_per_list, seed, nullptr);
+  (void)hipFree(d_rows);
+  return rc;
+}
+
+int zvec_hip_ivf_info(zvec_hip_ivf_t h, uint64_t *count, uint32_t *nlist) {
+  if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count) *count = h->count_local;
+  if (nlist) *nlist = h->nlist;
+  return 0;
+}
+
+int zvec_hip_ivf_export(zvec_hip_ivf_t h, void *centroids, uint64_t *list_offsets, uint64_t *row_ids) {
+  if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  if (centroids) memcpy(centroids, h->h_centroids.data(), h->h_centroids.size() * 4);
+  if (list_offsets) memcpy(list_offsets, h->h_dense0.data(), h->h_dense0.size() * 8);
+  if (row_ids) memcpy(row_ids, h->h_row_ids.data(), h->h_row_ids.size() * 8);
+  return 0;
+}
+
+int zvec_hip_ivf_get_vector(zvec_hip_ivf_t h, uint64_t list_pos, void *out) {
+  if (!h || !out) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  if (list_pos >= h->count_local) return ZVEC_HIP_ERR_NO_EXIST;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  uint32_t l = (uint32_t)(std::upper_bound(h->h_dense0.begin(), h->h_dense0.end(), list_pos) - h->h_dense0.begin()) - 1;
+  uint64_t pos = (uint64_t)h->h_tile0[l] * TILE_N + (list_pos - h->h_dense0[l]);
+  zvec_hip_ctx_s *c = h->defctx;
+  ZRET(c->io_q.ensure((size_t)h->dim * 4));
+  hipLaunchKernelGGL(unpack_row_kernel, dim3(1), dim3(256), 0, c->own, h->lists.base, h->lists.extra, pos,
+                     h->lists.dscan, h->dim, h->lists.dpad, c->io_q.as<float>());
+  ZCHK(hipMemcpyAsync(out, c->io_q.p, (size_t)h->dim * 4, hipMemcpyDeviceToHost, c->own));
+  ZCHK(hipStreamSynchronize(c->own));
+  return 0;
+}
+
+static int ivf_search_dev_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count,
+                               uint32_t topk, float threshold, uint32_t nprobe, uint32_t max_scan_count,
+                               int brute_force, const uint64_t *d_exclude, uint64_t *d_out_keys, float *d_out_scores,
+                               uint32_t *d_out_counts, void *stream) {
+  if (!h || !d_queries || !d_out_keys || !d_out_scores || !d_out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  if (count == 0) return 0;
+  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;   // ivf_searcher.cc:197-200
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = pick_stream(c, stream);
+  SearchOut out{d_out_keys, d_out_scores, nullptr, d_out_counts};
+  int rc = ivf_search_core(h, c, reinterpret_cast<const float *>(d_queries), count, topk, threshold, nprobe,
+                           max_scan_count, brute_force, d_exclude, out, s);
+  if (rc == 0 && c->profile && c->nprof > 0 && c->nprof <= PROFILE_MAX && c->stats.p) {
+    int i = c->nprof - 1;
+    if (c->launch_is_ivf[i]) {
+      unsigned long long *st = c->stats.as<unsigned long long>() + 2 * (size_t)i;
+      ZCHK(hipMemsetAsync(st, 0, 16, s));
+      hipLaunchKernelGGL(ivf_work_stats_kernel, dim3(16), dim3(256), 0, s, c->last_list_count, h->d_size, h->nlist, st);
+      ZCHK(hipGetLastError());
+    }
+  }
+  return rc;
+}
+
+int zvec_hip_ivf_search_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,
+                            float threshold, uint32_t nprobe, uint32_t max_scan_count, const uint64_t *d_exclude_bitset,
+                            uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts, void *stream) {
+  return ivf_search_dev_impl(h, ctx, d_queries, count, topk, threshold, nprobe, max_scan_count, 0, d_exclude_bitset,
+                             d_out_keys, d_out_scores, d_out_counts, stream);
+}
+
+static int ivf_search_host_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count, uint32_t topk,
+                                float threshold, uint32_t nprobe, uint32_t max_scan_count, int brute_force,
+                                const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
+                                uint32_t *out_counts) {
+  if (!h || !queries || !out_keys || !out_scores || !out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  if (count == 0) return 0;
+  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    ZCHK(hipSetDevice(h->device));
+    ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->dim * 4, exclude_bitset, h->count_local, count, topk, c->cur));
+  }
+  ZRET(ivf_search_dev_impl(h, c, c->io_q.p, count, topk, threshold, nprobe, max_scan_count, brute_force,
+                           exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr, c->io_keys.as<uint64_t>(),
+                           c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
+  std::lock_guard<std::mutex> g(c->mu);
+  return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, c->cur);
+}
+
+int zvec_hip_ivf_search(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count, uint32_t topk,
+                        float threshold, uint32_t nprobe, uint32_t max_scan_count, const uint64_t *exclude_bitset,
+                        uint64_t *out_keys, float *out_scores, uint32_t *out_counts) {
+  return ivf_search_host_impl(h, ctx, queries, count, topk, threshold, nprobe, max_scan_count, 0, exclude_bitset,
+                              out_keys, out_scores, out_counts);
+}
+
+int zvec_hip_ivf_search_bf(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count, uint32_t topk,
+                           float threshold, const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
+                           uint32_t *out_counts) {
+  return ivf_search_host_impl(h, ctx, queries, count, topk, threshold, 1, 0xffffffffu, 1, exclude_bitset, out_keys,
+                              out_scores, out_counts);
+}
+
+int zvec_hip_ivf_last_stats(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, uint32_t count, uint32_t *scanned, uint32_t *probes) {
+  if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  if (!c->q_scanned || count > c->last_count) return ZVEC_HIP_ERR_NO_READY;
+  ZCHK(hipSetDevice(h->device));
+  ZCHK(hipStreamSynchronize(c->cur));
+  if (scanned) ZCHK(hipMemcpy(scanned, c->q_scanned, (size_t)count * 4, hipMemcpyDeviceToHost));
+  if (probes) ZCHK(hipMemcpy(probes, c->q_nprobe, (size_t)count * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- merge ----------------------------------------------------------------------------------
+int zvec_hip_merge_topk_dev(zvec_hip_ctx_t ctx, const uint64_t *d_keys, const float *d_scores, const uint32_t *d_counts,
+                            uint32_t nparts, uint32_t count, uint32_t topk, uint64_t *d_out_keys, float *d_out_scores,
+                            uint32_t *d_out_counts, void *stream) {
+  if (!ctx || !d_keys || !d_scores || !d_counts || !d_out_keys || !d_out_scores || !d_out_counts)
+    return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (topk == 0 || nparts == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if ((size_t)topk * 12 + 16 > 64 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ZCHK(hipSetDevice(ctx->device));
+  hipStream_t s = pick_stream(ctx, stream);
+  MergeArgs m{};
+  m.part_s = d_scores; m.part_i = nullptr; m.part_keys = d_keys; m.slot_begin = nullptr; m.slots_per_q = nparts;
+  m.slot_stride = count; m.part_counts = d_counts; m.k = topk; m.threshold = FLT_MAX; m.keymap = nullptr;
+  m.out_keys = d_out_keys; m.out_scores = d_out_scores; m.out_idx = nullptr; m.out_counts = d_out_counts;
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, s, m);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int zvec_hip_merge_topk(zvec_hip_ctx_t ctx, const uint64_t *keys, const float *scores, const uint32_t *counts,
+                        uint32_t nparts, uint32_t count, uint32_t topk, uint64_t *out_keys, float *out_scores,
+                        uint32_t *out_counts) {
+  if (!ctx || !keys || !scores || !counts || !out_keys || !out_scores || !out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  ZCHK(hipSetDevice(ctx->device));
+  size_t ne = (size_t)nparts * count * topk;
+  uint64_t *dk = nullptr, *dok = nullptr; float *ds = nullptr, *dos = nullptr; uint32_t *dc = nullptr, *doc = nullptr;
+  ZCHK(hipMalloc(&dk, ne * 8)); ZCHK(hipMalloc(&ds, ne * 4)); ZCHK(hipMalloc(&dc, (size_t)nparts * count * 4));
+  ZCHK(hipMalloc(&dok, (size_t)count * topk * 8)); ZCHK(hipMalloc(&dos, (size_t)count * topk * 4)); ZCHK(hipMalloc(&doc, (size_t)count * 4));
+  ZCHK(hipMemcpy(dk, keys, ne * 8, hipMemcpyHostToDevice));
+  ZCHK(hipMemcpy(ds, scores, ne * 4, hipMemcpyHostToDevice));
+  ZCHK(hipMemcpy(dc, counts, (size_t)nparts * count * 4, hipMemcpyHostToDevice));
+  int rc = zvec_hip_merge_topk_dev(ctx, dk, ds, dc, nparts, count, topk, dok, dos, doc, nullptr);
+  if (rc == 0) {
+    ZCHK(hipStreamSynchronize(ctx->cur));
+    ZCHK(hipMemcpy(out_keys, dok, (size_t)count * topk * 8, hipMemcpyDeviceToHost));
+    ZCHK(hipMemcpy(out_scores, dos, (size_t)count * topk * 4, hipMemcpyDeviceToHost));
+    ZCHK(hipMemcpy(out_counts, doc, (size_t)count * 4, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(dk); (void)hipFree(ds); (void)hipFree(dc); (void)hipFree(dok); (void)hipFree(dos); (void)hipFree(doc);
+  return rc;
+}
+
+// ---- measurement hook -----------------------------------------------------------------------
+int zvec_hip_ctx_profile(zvec_hip_ctx_t ctx, int enable) {
+  if (!ctx) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->profile = enable != 0;
+  if (ctx->profile) {
+    ZCHK(hipSetDevice(ctx->device));
+    ZRET(ctx->stats.ensure(sizeof(uint64_t) * 2 * PROFILE_MAX));
+  }
+  return 0;
+}
+
+int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *scan_ms, double *algorithmic_bytes,
+                              double *algorithmic_flops, int reset) {
+  if (!ctx) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ZCHK(hipSetDevice(ctx->device));
+  ZCHK(hipStreamSynchronize(ctx->cur));
+  double ms = 0, bytes = 0, flops = 0;
+  std::vector<unsigned long long> st;
+  if (ctx->nprof > 0 && ctx->stats.p) {
+    st.resize((size_t)2 * ctx->nprof);
+    ZCHK(hipMemcpy(st.data(), ctx->stats.p, st.size() * 8, hipMemcpyDeviceToHost));
+  }
+  for (int i = 0; i < ctx->nprof; ++i) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, ctx->ev0[i], ctx->ev1[i]) == hipSuccess) ms += t;
+    bytes += ctx->host_bytes[i];
+    flops += ctx->host_flops[i];
+  }
+  for (int i = 0; i < ctx->nprof && !st.empty(); ++i) {
+    if (!ctx->launch_is_ivf[i]) continue;
+    bytes += (double)st[2 * (size_t)i] * ctx->prof_dscan[i] * 4.0;          // distinct probed rows
+    flops += (double)st[2 * (size_t)i + 1] * ctx->prof_dscan[i] * 2.0;      // (query, row) pairs
+  }
+  if (launches) *launches = (uint64_t)ctx->nprof;
+  if (scan_ms) *scan_ms = ms;
+  if (algorithmic_bytes) *algorithmic_bytes = bytes;
+  if (algorithmic_flops) *algorithmic_flops = flops;
+  if (reset) ctx->nprof = 0;
+  return 0;
+}
+
+}  // extern "C"

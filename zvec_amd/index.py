@@ -1,0 +1,453 @@
+"""Python plumbing over the C ABI (include/zvec_hip.h), shaped like the reference's index operators.
+
+The C++ host mirror of the reference interface lives in zvec_amd/csrc/host/ (hip_index.h); this module
+is the same surface for Python callers (pytest, bench.py): `search_impl(query, count, ctx)` fills
+`ctx.result(i)` with IndexDocument(key, score) lists exactly like
+IndexSearcher::search_impl(query, qmeta, count, context) (src/include/zvec/core/framework/
+index_runner.h:490-500) and returns 0 or a negative IndexError value (index_error.cc:20-71).
+No exceptions cross `search_impl` for argument errors — same contract as the reference — but a
+missing HIP library / device raises at construction: there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
+DT_FP32 = 0
+FLT_MAX = float(np.finfo(np.float32).max)
+
+_METRIC_NAMES = {
+    "SquaredEuclidean": METRIC_L2,   # src/core/metric/euclidean_metric.cc:743
+    "InnerProduct": METRIC_IP,       # src/core/metric/inner_product_metric.cc:256
+    "Cosine": METRIC_COSINE,         # src/core/metric/cosine_metric.cc:141
+}
+
+
+def metric_from_name(name):
+    return _METRIC_NAMES[name]
+
+
+class IndexError_:
+    """Negative IndexError values used on this path (index_error.cc:20-71)."""
+    Success = 0
+    Runtime = -1
+    Unsupported = -12
+    OutOfRange = -17
+    NoMemory = -19
+    NoReady = -21
+    NoExist = -22
+    Mismatch = -24
+    InvalidArgument = -31
+    NoIndexLoaded = -204
+    NoTrained = -205
+
+
+class IndexDocument:
+    """key / score / index triple (index_document.h:69-218)."""
+    __slots__ = ("_key", "_score")
+
+    def __init__(self, key, score):
+        self._key = int(key)
+        self._score = float(score)
+
+    def key(self):
+        return self._key
+
+    def score(self):
+        return self._score
+
+    def __repr__(self):
+        return "IndexDocument(key=%d, score=%r)" % (self._key, self._score)
+
+
+class IndexContext:
+    """IndexContext subset used by the scan path (index_context.h:123-195): topk, filter, threshold,
+    per-query result lists.  Owns one HIP stream + workspace (zvec_hip_ctx_t)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().zvec_hip_ctx_create(device, C.byref(self._h)), "zvec_hip_ctx_create")
+        self._topk = 0
+        self._threshold = FLT_MAX
+        self._exclude = None      # numpy uint64 words (host) — materialised IndexFilter
+        self._filter_fn = None
+        self._results = []
+        self.keys = None
+        self.scores = None
+        self.counts = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().zvec_hip_ctx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- reference surface -------------------------------------------------------------------------
+    def set_topk(self, topk):
+        self._topk = int(topk)
+
+    def topk(self):
+        return self._topk
+
+    def set_threshold(self, val):
+        self._threshold = float(val)
+
+    def threshold(self):
+        return self._threshold
+
+    def set_filter(self, fn):
+        """IndexFilter: callable(key) -> True means EXCLUDE (index_filter.h:48-50).  It is swept once
+        over the index keys on the host into a bitset at the next search."""
+        self._filter_fn = fn
+        self._exclude = None
+
+    def set_exclude_bitset(self, words):
+        """side channel: an already materialised predicate, 1 bit per storage position."""
+        self._exclude = None if words is None else np.ascontiguousarray(words, np.uint64)
+        self._filter_fn = None
+
+    def reset_filter(self):
+        self._filter_fn = None
+        self._exclude = None
+
+    def result(self, index=0):
+        return self._results[index]
+
+    def results(self):
+        return self._results
+
+    # -- plumbing ----------------------------------------------------------------------------------
+    def _exclude_for(self, keys_of_positions):
+        if self._exclude is not None:
+            return self._exclude
+        if self._filter_fn is None:
+            return None
+        n = len(keys_of_positions)
+        mask = np.fromiter((bool(self._filter_fn(int(k))) for k in keys_of_positions), bool, n)
+        words = np.zeros((n + 63) // 64, np.uint64)
+        idx = np.nonzero(mask)[0]
+        np.bitwise_or.at(words, idx // 64, np.uint64(1) << (idx % 64).astype(np.uint64))
+        return words
+
+    def _set_results(self, keys, scores, counts):
+        self.keys, self.scores, self.counts = keys, scores, counts
+        self._results = [
+            [IndexDocument(keys[q, j], scores[q, j]) for j in range(int(counts[q]))]
+            for q in range(keys.shape[0])
+        ]
+
+    def synchronize(self):
+        _lib.check(_lib.lib().zvec_hip_ctx_synchronize(self._h), "zvec_hip_ctx_synchronize")
+
+    def set_stream(self, stream_ptr):
+        _lib.check(_lib.lib().zvec_hip_ctx_set_stream(self._h, C.c_void_p(stream_ptr)), "ctx_set_stream")
+
+    def profile(self, enable=True):
+        _lib.check(_lib.lib().zvec_hip_ctx_profile(self._h, int(enable)), "zvec_hip_ctx_profile")
+
+    def profile_read(self, reset=True):
+        n = C.c_uint64(0)
+        ms, b, f = C.c_double(0), C.c_double(0), C.c_double(0)
+        _lib.check(_lib.lib().zvec_hip_ctx_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(b),
+                                                        C.byref(f), int(reset)), "profile_read")
+        return {"launches": int(n.value), "scan_ms": ms.value, "bytes": b.value, "flops": f.value}
+
+
+def _np_ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class _FlatBase:
+    """Common body of HipFlatStreamer / HipFlatSearcher: one HBM-resident blocked store."""
+
+    def __init__(self, dim, metric=METRIC_L2, device=0):
+        if isinstance(metric, str):
+            metric = metric_from_name(metric)
+        self.dim = int(dim)
+        self.metric = metric
+        self.device = device
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().zvec_hip_flat_create(self.dim, DT_FP32, metric, device, C.byref(self._h)),
+                   "zvec_hip_flat_create")
+        self._keys_host = []      # for IndexFilter sweeps
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().zvec_hip_flat_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def create_context(self):
+        return IndexContext(self.device)
+
+    def count(self):
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().zvec_hip_flat_count(self._h, C.byref(n)), "zvec_hip_flat_count")
+        return int(n.value)
+
+    def reserve(self, n):
+        return _lib.lib().zvec_hip_flat_reserve(self._h, int(n))
+
+    def add_batch(self, vecs, keys=None):
+        vecs = np.ascontiguousarray(vecs, np.float32)
+        if vecs.ndim != 2 or vecs.shape[1] != self.dim:
+            return IndexError_.InvalidArgument
+        n0 = self.count()
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        rc = _lib.lib().zvec_hip_flat_append(self._h, _np_ptr(vecs), vecs.shape[0], _np_ptr(k))
+        if rc == 0:
+            self._keys_host.append(np.arange(n0, n0 + vecs.shape[0], dtype=np.uint64) if k is None else k.copy())
+        return rc
+
+    def add_batch_dev(self, d_ptr, n, d_keys_ptr=None, stream=None):
+        """append rows already resident in HBM (device pointer, [n][dim] fp32 row-major)."""
+        n0 = self.count()
+        rc = _lib.lib().zvec_hip_flat_append_dev(self._h, C.c_void_p(d_ptr), int(n),
+                                                 C.c_void_p(d_keys_ptr) if d_keys_ptr else None,
+                                                 C.c_void_p(stream) if stream else None)
+        if rc == 0 and d_keys_ptr is None:
+            self._keys_host.append(("range", n0, n0 + int(n)))
+        return rc
+
+    def _all_keys(self):
+        parts = []
+        for p in self._keys_host:
+            if isinstance(p, tuple):
+                parts.append(np.arange(p[1], p[2], dtype=np.uint64))
+            else:
+                parts.append(p)
+        return np.concatenate(parts) if parts else np.zeros(0, np.uint64)
+
+    def get_vector_by_id(self, pos):
+        out = np.zeros(self.dim, np.float32)
+        rc = _lib.lib().zvec_hip_flat_get_vector(self._h, int(pos), _np_ptr(out))
+        return out if rc == 0 else None
+
+    def search_impl(self, query, count, ctx):
+        """IndexRunner::search_impl(query, qmeta, count, context); query: [count][dim] fp32."""
+        if ctx is None or ctx.topk() == 0:
+            return IndexError_.InvalidArgument      # flat_searcher.cc:194-198
+        q = np.ascontiguousarray(query, np.float32).reshape(-1)
+        if q.size != int(count) * self.dim:
+            return IndexError_.InvalidArgument
+        k = ctx.topk()
+        keys = np.zeros((count, k), np.uint64)
+        scores = np.zeros((count, k), np.float32)
+        counts = np.zeros(count, np.uint32)
+        ex = ctx._exclude_for(self._all_keys()) if (ctx._filter_fn or ctx._exclude is not None) else None
+        rc = _lib.lib().zvec_hip_flat_search(self._h, ctx._h, _np_ptr(q), count, k, ctx.threshold(),
+                                             _np_ptr(ex), _np_ptr(keys), _np_ptr(scores), _np_ptr(counts))
+        if rc == 0:
+            ctx._set_results(keys, scores, counts)
+        return rc
+
+    # brute force == the flat scan itself (flat_streamer.cc:304-344)
+    search_bf_impl = search_impl
+
+    def search_dev(self, d_queries, count, topk, d_out_keys, d_out_scores, d_out_counts, ctx,
+                   threshold=FLT_MAX, d_exclude=None, stream=None):
+        """device-pointer form (async): all arguments are raw device pointers (ints)."""
+        return _lib.lib().zvec_hip_flat_search_dev(
+            self._h, ctx._h, C.c_void_p(d_queries), count, topk, threshold,
+            C.c_void_p(d_exclude) if d_exclude else None, C.c_void_p(d_out_keys),
+            C.c_void_p(d_out_scores), C.c_void_p(d_out_counts), C.c_void_p(stream) if stream else None)
+
+
+class HipFlatStreamer(_FlatBase):
+    """stands where "FlatStreamer" is registered (flat_streamer.cc:486-489): mutable, add + search."""
+
+    def add_impl(self, key, vec, ctx=None):
+        return self.add_batch(np.asarray(vec, np.float32).reshape(1, -1), np.array([key], np.uint64))
+
+
+class HipFlatSearcher(_FlatBase):
+    """stands where "FlatSearcher" is registered (flat_searcher.cc:247-250): load once, search."""
+
+    def load(self, vecs, keys=None):
+        return self.add_batch(vecs, keys)
+
+
+class HipIVFSearcher:
+    """stands where "IVFSearcher"/"IVFStreamer" are registered (ivf_searcher.cc:183-250)."""
+
+    def __init__(self, dim, metric=METRIC_L2, device=0, scan_ratio=0.1, brute_force_threshold=1000):
+        if isinstance(metric, str):
+            metric = metric_from_name(metric)
+        self.dim = int(dim)
+        self.metric = metric
+        self.device = device
+        # IVFSearcherContext defaults (ivf_searcher_context.h:211-213)
+        self.scan_ratio = float(scan_ratio)
+        self.brute_force_threshold = int(brute_force_threshold)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().zvec_hip_ivf_create(self.dim, DT_FP32, metric, device, C.byref(self._h)),
+                   "zvec_hip_ivf_create")
+        self._list_keys = None    # keys in list order (filter sweeps)
+        self._orig_keys = None    # keys per original row (build)
+        self.total_count = 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().zvec_hip_ivf_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def create_context(self):
+        return IndexContext(self.device)
+
+    def set_shard(self, shard, nshards):
+        return _lib.lib().zvec_hip_ivf_keep_shard(self._h, shard, nshards)
+
+    def load(self, centroids, list_offsets, vecs, keys=None):
+        centroids = np.ascontiguousarray(centroids, np.float32)
+        lo = np.ascontiguousarray(list_offsets, np.uint64)
+        vecs = np.ascontiguousarray(vecs, np.float32)
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        rc = _lib.lib().zvec_hip_ivf_load(self._h, _np_ptr(centroids), centroids.shape[0], _np_ptr(lo),
+                                          _np_ptr(vecs), _np_ptr(k))
+        if rc == 0:
+            self.total_count = int(lo[-1])
+            self._orig_keys = k
+            self._list_keys = None
+        return rc
+
+    def build(self, vecs, nlist, keys=None, kmeans_iters=10, sample_per_list=256, seed=20260320):
+        vecs = np.ascontiguousarray(vecs, np.float32)
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        rc = _lib.lib().zvec_hip_ivf_build(self._h, _np_ptr(vecs), vecs.shape[0], _np_ptr(k), nlist,
+                                           kmeans_iters, sample_per_list, seed)
+        if rc == 0:
+            self.total_count = vecs.shape[0]
+            self._orig_keys = k
+            self._list_keys = None
+        return rc
+
+    def build_dev(self, d_vecs, n, nlist, keys=None, kmeans_iters=10, sample_per_list=256, seed=20260320,
+                  stream=None):
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        rc = _lib.lib().zvec_hip_ivf_build_dev(self._h, C.c_void_p(d_vecs), int(n), _np_ptr(k), nlist,
+                                               kmeans_iters, sample_per_list, seed,
+                                               C.c_void_p(stream) if stream else None)
+        if rc == 0:
+            self.total_count = int(n)
+            self._orig_keys = k
+            self._list_keys = None
+        return rc
+
+    def info(self):
+        n = C.c_uint64(0)
+        nl = C.c_uint32(0)
+        _lib.check(_lib.lib().zvec_hip_ivf_info(self._h, C.byref(n), C.byref(nl)), "zvec_hip_ivf_info")
+        return int(n.value), int(nl.value)
+
+    def export(self):
+        n, nlist = self.info()
+        cent = np.zeros((nlist, self.dim), np.float32)
+        lo = np.zeros(nlist + 1, np.uint64)
+        rows = np.zeros(n, np.uint64)
+        _lib.check(_lib.lib().zvec_hip_ivf_export(self._h, _np_ptr(cent), _np_ptr(lo), _np_ptr(rows)),
+                   "zvec_hip_ivf_export")
+        return cent, lo, rows
+
+    def get_vector_by_id(self, list_pos):
+        out = np.zeros(self.dim, np.float32)
+        rc = _lib.lib().zvec_hip_ivf_get_vector(self._h, int(list_pos), _np_ptr(out))
+        return out if rc == 0 else None
+
+    # IVFSearcherContext::update (ivf_searcher_context.h:61-79)
+    def probe_params(self):
+        n, nlist = self.total_count, self.info()[1]
+        # float arithmetic and std::round (half away from zero) as in the reference
+        nprobe = max(int(np.floor(np.float32(np.float32(nlist) * np.float32(self.scan_ratio)) + np.float32(0.5))), 1)
+        max_scan = int(np.ceil(np.float32(np.float32(n) * np.float32(self.scan_ratio))))
+        max_scan = max(self.brute_force_threshold, max_scan)
+        return nprobe, max_scan
+
+    def keys_in_list_order(self):
+        """key of every dense list-order position (what IVFEntity::get_keys reads, ivf_entity.cc:612)."""
+        if self._list_keys is None:
+            _, _, rows = self.export()
+            self._list_keys = rows if self._orig_keys is None else self._orig_keys[rows.astype(np.int64)]
+        return self._list_keys
+
+    def _exclude(self, ctx):
+        if ctx._exclude is not None:
+            return ctx._exclude
+        if ctx._filter_fn is None:
+            return None
+        return ctx._exclude_for(self.keys_in_list_order())
+
+    def search_impl(self, query, count, ctx):
+        if ctx is None or ctx.topk() == 0:
+            return IndexError_.InvalidArgument      # ivf_searcher.cc:197-200
+        if self.total_count <= self.brute_force_threshold:
+            return self.search_bf_impl(query, count, ctx)   # ivf_searcher.cc:188-190
+        q = np.ascontiguousarray(query, np.float32).reshape(-1)
+        if q.size != int(count) * self.dim:
+            return IndexError_.InvalidArgument
+        k = ctx.topk()
+        nprobe, max_scan = self.probe_params()
+        keys = np.zeros((count, k), np.uint64)
+        scores = np.zeros((count, k), np.float32)
+        counts = np.zeros(count, np.uint32)
+        ex = self._exclude(ctx)
+        rc = _lib.lib().zvec_hip_ivf_search(self._h, ctx._h, _np_ptr(q), count, k, ctx.threshold(), nprobe,
+                                            max_scan, _np_ptr(ex), _np_ptr(keys), _np_ptr(scores),
+                                            _np_ptr(counts))
+        if rc == 0:
+            ctx._set_results(keys, scores, counts)
+        return rc
+
+    def search_bf_impl(self, query, count, ctx):
+        if ctx is None or ctx.topk() == 0:
+            return IndexError_.InvalidArgument
+        q = np.ascontiguousarray(query, np.float32).reshape(-1)
+        if q.size != int(count) * self.dim:
+            return IndexError_.InvalidArgument
+        k = ctx.topk()
+        keys = np.zeros((count, k), np.uint64)
+        scores = np.zeros((count, k), np.float32)
+        counts = np.zeros(count, np.uint32)
+        ex = self._exclude(ctx)
+        rc = _lib.lib().zvec_hip_ivf_search_bf(self._h, ctx._h, _np_ptr(q), count, k, ctx.threshold(),
+                                               _np_ptr(ex), _np_ptr(keys), _np_ptr(scores), _np_ptr(counts))
+        if rc == 0:
+            ctx._set_results(keys, scores, counts)
+        return rc
+
+    def search_dev(self, d_queries, count, topk, nprobe, max_scan, d_out_keys, d_out_scores, d_out_counts,
+                   ctx, threshold=FLT_MAX, d_exclude=None, stream=None):
+        return _lib.lib().zvec_hip_ivf_search_dev(
+            self._h, ctx._h, C.c_void_p(d_queries), count, topk, threshold, nprobe, max_scan,
+            C.c_void_p(d_exclude) if d_exclude else None, C.c_void_p(d_out_keys), C.c_void_p(d_out_scores),
+            C.c_void_p(d_out_counts), C.c_void_p(stream) if stream else None)
+
+    def last_stats(self, ctx, count):
+        scanned = np.zeros(count, np.uint32)
+        probes = np.zeros(count, np.uint32)
+        _lib.check(_lib.lib().zvec_hip_ivf_last_stats(self._h, ctx._h, count, _np_ptr(scanned), _np_ptr(probes)),
+                   "zvec_hip_ivf_last_stats")
+        return scanned, probes
+
+
+def merge_topk(ctx, keys, scores, counts, topk):
+    """host form of the shard merge: inputs [nparts][count][topk] / [nparts][count]."""
+    keys = np.ascontiguousarray(keys, np.uint64)
+    scores = np.ascontiguousarray(scores, np.float32)
+    counts = np.ascontiguousarray(counts, np.uint32)
+    nparts, count = counts.shape
+    ok = np.zeros((count, topk), np.uint64)
+    os_ = np.zeros((count, topk), np.float32)
+    oc = np.zeros(count, np.uint32)
+    _lib.check(_lib.lib().zvec_hip_merge_topk(ctx._h, _np_ptr(keys), _np_ptr(scores), _np_ptr(counts), nparts,
+                                              count, topk, _np_ptr(ok), _np_ptr(os_), _np_ptr(oc)),
+               "zvec_hip_merge_topk")
+    return ok, os_, oc
