@@ -890,6 +890,26 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
     hipLaunchKernelGGL(centroid_mean_kernel, dim3(nlist), dim3(256), 0, s, d_sample, dim, d_moff, d_members, d_cent);
     ZCHK(hipGetLastError());
     ZCHK(hipStreamSynchronize(s));
+    // empty clusters: split the currently largest one (tiny symmetric perturbation), as k-means trainers do
+    std::vector<uint32_t> empties;
+    std::vector<uint64_t> sizes(nlist);
+    for (uint32_t l = 0; l < nlist; ++l) { sizes[l] = moff[l + 1] - moff[l]; if (sizes[l] == 0) empties.push_back(l); }
+    if (!empties.empty() && it + 1 < kmeans_iters) {
+      std::vector<float> hc((size_t)nlist * dim);
+      ZCHK(hipMemcpy(hc.data(), d_cent, hc.size() * 4, hipMemcpyDeviceToHost));
+      for (uint32_t e : empties) {
+        uint32_t b = (uint32_t)(std::max_element(sizes.begin(), sizes.end()) - sizes.begin());
+        if (sizes[b] < 2) break;
+        for (uint32_t c = 0; c < dim; ++c) {
+          float v = hc[(size_t)b * dim + c];
+          hc[(size_t)e * dim + c] = v * (1.0f + 1.0f / 1024.0f);
+          hc[(size_t)b * dim + c] = v * (1.0f - 1.0f / 1024.0f);
+        }
+        sizes[e] = sizes[b] / 2;
+        sizes[b] -= sizes[e];
+      }
+      ZCHK(hipMemcpy(d_cent, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+    }
   }
   // ---- label every row with its nearest centroid (ivf_builder.h:253-274) ----
   cs.n = 0;

@@ -1,0 +1,86 @@
+"""One-process-per-GPU sharding of the IVF scan + the candidate-list exchange.
+
+The index shards by inverted list (list l lives on rank l % world; centroids are replicated), every
+rank sees the whole query batch, scans only the probed lists it owns and produces a partial top-k per
+query.  The only exchange on the path is ONE all-gather of the small candidate lists
+([count][topk] keys u64 + scores f32 + counts u32 per rank; 1024x10 => 124 KiB per rank) over RCCL
+(`torch.distributed` backend "nccl" on ROCm), followed by a local k-way merge with the same order rule
+as CombinedVectorColumnIndexer::Search (combined_vector_column_indexer.cc:172-232): concatenate in
+part order, sort by score, truncate.  No all-reduce anywhere; the collective is latency-bound.
+
+`torch` is used for device buffers and the collective only.
+"""
+import torch
+import torch.distributed as dist
+
+
+def packed_bytes(count, topk):
+    return count * topk * 8 + count * topk * 4 + count * 4
+
+
+def pack_candidates(keys, scores, counts):
+    """keys int64 [count][topk], scores f32 [count][topk], counts int32 [count] -> one uint8 buffer."""
+    return torch.cat([keys.reshape(-1).view(torch.uint8), scores.reshape(-1).view(torch.uint8),
+                      counts.reshape(-1).view(torch.uint8)])
+
+
+def unpack_candidates(gathered, world, count, topk):
+    """gathered uint8 [world][packed_bytes] -> (keys [world][count][topk] i64, scores f32, counts i32)."""
+    kb, sb = count * topk * 8, count * topk * 4
+    g = gathered.view(world, -1)
+    keys = g[:, :kb].contiguous().view(torch.int64).view(world, count, topk)
+    scores = g[:, kb:kb + sb].contiguous().view(torch.float32).view(world, count, topk)
+    counts = g[:, kb + sb:].contiguous().view(torch.int32).view(world, count)
+    return keys, scores, counts
+
+
+def all_gather_candidates(keys, scores, counts, group=None):
+    """the one collective of the path.  Works on any backend (RCCL on GPUs, gloo in the CPU tests)."""
+    world = dist.get_world_size(group)
+    count, topk = keys.shape
+    mine = pack_candidates(keys, scores, counts)
+    out = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return unpack_candidates(out, world, count, topk)
+
+
+class ShardedIVF:
+    """rank-local shard of an IVF index + the exchange/merge step."""
+
+    def __init__(self, searcher, ctx, rank, world, group=None):
+        self.searcher = searcher
+        self.ctx = ctx
+        self.rank, self.world, self.group = rank, world, group
+        self._buf = {}
+
+    def _buffers(self, count, topk, device):
+        key = (count, topk)
+        if key not in self._buf:
+            self._buf[key] = dict(
+                keys=torch.empty((count, topk), dtype=torch.int64, device=device),
+                scores=torch.empty((count, topk), dtype=torch.float32, device=device),
+                counts=torch.empty((count,), dtype=torch.int32, device=device),
+                okeys=torch.empty((count, topk), dtype=torch.int64, device=device),
+                oscores=torch.empty((count, topk), dtype=torch.float32, device=device),
+                ocounts=torch.empty((count,), dtype=torch.int32, device=device))
+        return self._buf[key]
+
+    def search(self, d_queries, topk, nprobe, max_scan, stream_ptr):
+        """d_queries: torch float32 [count][dim] on this rank's GPU.  Returns (keys, scores, counts)
+        tensors of the GLOBAL top-k (identical on every rank)."""
+        from . import _lib
+        import ctypes as C
+        count = d_queries.shape[0]
+        b = self._buffers(count, topk, d_queries.device)
+        rc = self.searcher.search_dev(d_queries.data_ptr(), count, topk, nprobe, max_scan, b["keys"].data_ptr(),
+                                      b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx, stream=stream_ptr)
+        _lib.check(rc, "zvec_hip_ivf_search_dev")
+        if self.world == 1:
+            return b["keys"], b["scores"], b["counts"]
+        gk, gs, gc = all_gather_candidates(b["keys"], b["scores"], b["counts"], self.group)
+        rc = _lib.lib().zvec_hip_merge_topk_dev(self.ctx._h, C.c_void_p(gk.data_ptr()), C.c_void_p(gs.data_ptr()),
+                                                C.c_void_p(gc.data_ptr()), self.world, count, topk,
+                                                C.c_void_p(b["okeys"].data_ptr()), C.c_void_p(b["oscores"].data_ptr()),
+                                                C.c_void_p(b["ocounts"].data_ptr()), C.c_void_p(stream_ptr))
+        _lib.check(rc, "zvec_hip_merge_topk_dev")
+        return b["okeys"], b["oscores"], b["ocounts"]
