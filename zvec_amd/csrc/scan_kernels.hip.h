@@ -67,7 +67,9 @@ struct ScanArgs {
   uint32_t nqtiles;
   // ivf decomposition (built on device by the plan kernels)
   const uint32_t *total_items;  // [1]
-  const uint32_t *item_off;     // [nlist+1] exclusive prefix of work items per list
+  uint32_t *queue;              // [1] work-queue head (zeroed per search): items are dealt dynamically
+  const uint32_t *list_order;   // [nlist] lists sorted by stored size, largest first (LPT dealing)
+  const uint32_t *item_off;     // [nlist+1] exclusive prefix of work items over list_order positions
   const uint32_t *list_tile0;   // [nlist] first tile of the list in the blocked store
   const uint32_t *list_size;    // [nlist] rows stored in the list (this shard)
   const uint64_t *list_dense0;  // [nlist] dense (unpadded) position of the list's first row
@@ -83,82 +85,95 @@ struct ScanArgs {
 // LDS footprint in bytes for a given NG / k (host mirrors this)
 __host__ __device__ inline size_t scan_lds_bytes(int ng, uint32_t k) {
   size_t rows = (size_t)ng * QGROUP;
-  return (2 * rows * TILE_K + 2 * (size_t)SLAB + 7 * rows + 2 * rows * k) * 4;
+  return (2 * rows * TILE_K + 2 * (size_t)SLAB + 5 * rows + 4 + 2 * rows * k) * 4;
 }
 
 struct RowState {
-  float *tau;        // admission bound per row: threshold until the list is full, then its max score
-  uint32_t *taui;    // position of the max element (tie order)
+  float *tau;        // admission bound per row: threshold until the list is full, then its k-th score
   uint32_t *cnt;
-  uint32_t *mpos;    // slot of the max element in the list
-  float *Ls;         // [rows][k]
-  uint32_t *Li;
+  float *Ls;         // [rows][k] scores, ascending (score, position)
+  uint32_t *Li;      // [rows][k] positions
   uint32_t k;
 };
 
-// (score, position) lexicographic "a is worse (later in the final order) than b"
-__device__ __forceinline__ bool worse(float as, uint32_t ai, float bs, uint32_t bi) {
-  return as > bs || (as == bs && ai > bi);
-}
-
-// Whole-wave recomputation of the list maximum of `row` (the heap top of heap.h).
-__device__ __forceinline__ void recompute_max(const RowState &st, int row, int lane) {
-  float bs = -__builtin_inff();
-  uint32_t bi = 0, bp = 0;
-  const uint32_t k = st.k;
-  bool has = false;
-  for (uint32_t j = lane; j < k; j += 64) {
-    float v = st.Ls[(size_t)row * k + j];
-    uint32_t vi = st.Li[(size_t)row * k + j];
-    if (!has || worse(v, vi, bs, bi)) { bs = v; bi = vi; bp = j; has = true; }
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    float os = __shfl_xor(bs, off);
-    uint32_t oi = __shfl_xor(bi, off);
-    uint32_t op = __shfl_xor(bp, off);
-    bool ohas = __shfl_xor((int)has, off) != 0;
-    if (ohas && (!has || worse(os, oi, bs, bi))) { bs = os; bi = oi; bp = op; has = true; }
-  }
-  if (lane == 0) {
-    st.tau[row] = bs;
-    st.taui[row] = bi;
-    st.mpos[row] = bp;
-  }
-}
-
-// Whole-wave insertion of one candidate into the bounded list of `row`.  A row's list is only ever
-// touched by its owner wave (rows are dealt to waves in the epilogue), so no locking is needed.
-// Kept set = the k smallest under (score, position): exactly what a sequential scan with
-// `if (score < heap.top) replace` (heap.h:103-114) keeps when no two scores tie at the boundary.
-__device__ __forceinline__ void wave_insert(const RowState &st, int row, float s, uint32_t idx, int lane) {
-  const uint32_t k = st.k;
-  const uint32_t c = st.cnt[row];
-  if (c < k) {
-    if (lane == 0) {
-      st.Ls[(size_t)row * k + c] = s;
-      st.Li[(size_t)row * k + c] = idx;
-      st.cnt[row] = c + 1;
+// Whole-wave insertion of candidate (s, o, i) into a bounded list kept SORTED ascending by
+// (score, order, index) in LDS: count the entries that precede it (one ballot per 64 entries), shift
+// the tail up by one, drop it in.  No reduction, no atomics.  Returns false when the candidate does
+// not make the list.  The kept set is the k smallest under (score, scan order): exactly what the
+// reference's sequential `if (score < heap.top) replace` (heap.h:103-114) keeps whenever no two
+// scores tie at the k-th place.  `c` (entries in the list) and `tau` (admission bound) are wave-uniform
+// values the caller keeps in registers.
+template <bool HAS_ORD>
+__device__ __forceinline__ bool sorted_insert(float *L, uint32_t *O, uint32_t *I, uint32_t k, uint32_t &c, float s,
+                                              uint32_t o, uint32_t i, int lane, float &tau) {
+  if (k <= 64) {
+    // fast path: one entry per lane
+    float es = 0.f;
+    uint32_t eo = 0, ei = 0;
+    bool less = false;
+    const uint32_t j = (uint32_t)lane;
+    if (j < c) {
+      es = L[j];
+      ei = I[j];
+      if (HAS_ORD) eo = O[j];
+      less = es < s || (es == s && (eo < o || (eo == o && ei < i)));
     }
+    const uint32_t p = (uint32_t)__popcll(__ballot(less));
+    if (p >= k) return false;
+    const uint32_t hi = min(c, k - 1);                 // entries [p, hi) move up by one
+    if (j >= p && j < hi) {
+      L[j + 1] = es;
+      I[j + 1] = ei;
+      if (HAS_ORD) O[j + 1] = eo;
+    }
+    if (lane == 0) {
+      L[p] = s;
+      I[p] = i;
+      if (HAS_ORD) O[p] = o;
+    }
+    c = min(c + 1, k);
+    if (c == k) tau = (p == k - 1) ? s : __shfl(es, (int)k - 2);   // new k-th = candidate or the old (k-1)-th
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (c + 1 == k) recompute_max(st, row, lane);
-  } else {
-    const float t = st.tau[row];
-    const uint32_t ti = st.taui[row];
-    if (worse(t, ti, s, idx)) {
-      if (lane == 0) {
-        const uint32_t p = st.mpos[row];
-        st.Ls[(size_t)row * k + p] = s;
-        st.Li[(size_t)row * k + p] = idx;
-      }
+    return true;
+  }
+  uint32_t p = 0;
+  for (uint32_t j0 = 0; j0 < c; j0 += 64) {
+    const uint32_t j = j0 + lane;
+    bool less = false;
+    if (j < c) {
+      const float es = L[j];
+      const uint32_t ei = I[j];
+      const uint32_t eo = HAS_ORD ? O[j] : 0u;
+      less = es < s || (es == s && (eo < o || (eo == o && ei < i)));
+    }
+    p += (uint32_t)__popcll(__ballot(less));
+  }
+  if (p >= k) return false;
+  const uint32_t hi = min(c, k - 1);
+  if (hi > p) {
+    for (int m = (int)((hi - 1) >> 6); m >= (int)(p >> 6); --m) {   // top chunk first: never overwrites unread data
+      const uint32_t j = (uint32_t)m * 64u + lane;
+      const bool mv = j >= p && j < hi;
+      float es = 0.f;
+      uint32_t eo = 0, ei = 0;
+      if (mv) { es = L[j]; ei = I[j]; if (HAS_ORD) eo = O[j]; }
+      __builtin_amdgcn_wave_barrier();
+      if (mv) { L[j + 1] = es; I[j + 1] = ei; if (HAS_ORD) O[j + 1] = eo; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      recompute_max(st, row, lane);
     }
   }
+  if (lane == 0) {
+    L[p] = s;
+    I[p] = i;
+    if (HAS_ORD) O[p] = o;
+  }
+  c = min(c + 1, k);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
+  if (c == k) tau = L[k - 1];
+  return true;
 }
 
 // Owner-wave admission of one row of the score tile: lane holds the scores of columns 2*lane and
@@ -167,6 +182,11 @@ __device__ __forceinline__ void owner_row(const RowState &st, int row, float s0,
   float t = st.tau[row];
   uint64_t m0 = __ballot(s0 <= t);
   uint64_t m1 = __ballot(s1 <= t);
+  if ((m0 | m1) == 0) return;
+  const uint32_t k = st.k;
+  uint32_t c = st.cnt[row];
+  float *L = st.Ls + (size_t)row * k;
+  uint32_t *I = st.Li + (size_t)row * k;
   while ((m0 | m1) != 0) {
     int l;
     float cs;
@@ -182,10 +202,14 @@ __device__ __forceinline__ void owner_row(const RowState &st, int row, float s0,
       ci = pos0 + 2u * (uint32_t)l + 1u;
       m1 &= m1 - 1;
     }
-    wave_insert(st, row, cs, ci, lane);
-    t = st.tau[row];
-    m0 &= __ballot(s0 <= t);
-    m1 &= __ballot(s1 <= t);
+    if (sorted_insert<false>(L, nullptr, I, k, c, cs, 0u, ci, lane, t)) {
+      m0 &= __ballot(s0 <= t);
+      m1 &= __ballot(s1 <= t);
+    }
+  }
+  if (lane == 0) {
+    st.cnt[row] = c;
+    st.tau[row] = t;
   }
 }
 
@@ -238,13 +262,12 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
   float *qn_s = Bs + 2 * SLAB;           // [ROWS]
   RowState st;
   st.tau = qn_s + ROWS;
-  st.taui = reinterpret_cast<uint32_t *>(st.tau + ROWS);
-  st.cnt = st.taui + ROWS;
-  st.mpos = st.cnt + ROWS;
-  uint32_t *qrow_s = st.mpos + ROWS;
+  st.cnt = reinterpret_cast<uint32_t *>(st.tau + ROWS);
+  uint32_t *qrow_s = st.cnt + ROWS;
   uint32_t *slot_s = qrow_s + ROWS;
+  uint32_t *item_s = slot_s + ROWS;          // [4] work-queue hand-off word
   st.k = a.k;
-  st.Ls = reinterpret_cast<float *>(slot_s + ROWS);
+  st.Ls = reinterpret_cast<float *>(item_s + 4);
   st.Li = reinterpret_cast<uint32_t *>(st.Ls + (size_t)ROWS * a.k);
 
   const int tid = threadIdx.x;
@@ -259,7 +282,17 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
   if (a.mode == 0) total = a.nchunks * a.nqtiles;
   else total = *a.total_items;
 
-  for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+  for (uint32_t iter = 0;; ++iter) {
+    uint32_t item;
+    if (a.mode == 0) {
+      item = blockIdx.x + iter * gridDim.x;
+    } else {
+      // dynamic dealing: one returning atomic per item (largest lists first => balanced tail)
+      if (tid == 0) item_s[0] = atomicAdd(a.queue, 1u);
+      __syncthreads();
+      item = item_s[0];
+    }
+    if (item >= total) break;   // uniform: every wave of the work-group leaves together
     // ---- decode the work item (uniform) ----
     uint32_t tile_begin, tile_end, nrows, rows_valid_total;
     uint64_t dense0 = 0;  // dense position of padded position tile0*128
@@ -281,8 +314,8 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
         uint32_t mid = (lo + hi) >> 1;
         if (a.item_off[mid] <= item) lo = mid; else hi = mid;
       }
-      li = lo;
-      uint32_t within = item - a.item_off[li];
+      uint32_t within = item - a.item_off[lo];
+      li = a.list_order[lo];
       uint32_t qcnt = a.list_qoff[li + 1] - a.list_qoff[li];
       uint32_t ngroups = (qcnt + ROWS - 1) / ROWS;
       chunk = within / ngroups;
@@ -318,9 +351,7 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
       slot_s[j] = slot;
       qn_s[j] = (a.metric == METRIC_L2) ? a.qnorm[qrow] : 0.f;
       st.tau[j] = a.threshold;
-      st.taui[j] = IDX_NONE;
       st.cnt[j] = 0;
-      st.mpos[j] = 0;
     }
     __syncthreads();
 
@@ -379,7 +410,7 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
       // The MFMA C layout spreads one query row over 32 lanes of a wave and the 4 waves hold
       // different columns of it, so the scores of 32 rows x 128 columns are transposed through the
       // staging buffer that is idle during this step (16 KiB) and every row is then admitted by
-      // ONE owner wave (rows 8w..8w+7 of the group belong to wave w): no locks, no atomics.
+      // ONE owner wave (row r of the group belongs to wave r % 4): no locks, no atomics.
       if (ks == nks - 1) {
         float *Sc = Bs + (buf ^ 1) * SLAB;                                  // [32 rows][128 cols]
         const uint32_t local = (tile - tile0) * TILE_N + wave * 32 + r;     // row index inside list/store
@@ -407,7 +438,7 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
           __syncthreads();
 #pragma unroll 1
           for (int i = 0; i < 8; ++i) {
-            const int row_l = wave * 8 + i;
+            const int row_l = i * 4 + wave;                  // rows dealt round-robin to the 4 waves
             const int row = g * 32 + row_l;
             if ((uint32_t)row < nrows) {
               const f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + row_l * TILE_N + 2 * lane);
@@ -472,30 +503,14 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
   else { sb = q; nslots = a.slots_per_q; }
 
   uint32_t cnt = 0;            // uniform
-  float tau = a.threshold;     // uniform: admission bound
-  uint32_t tauo = IDX_NONE, taui = IDX_NONE, mpos = 0;
+  float tau = a.threshold;     // uniform admission bound: threshold until the list is full, then its k-th score
   const uint64_t total = (uint64_t)nslots * k;
 
-  auto recompute = [&]() {
-    float bs = -__builtin_inff(); uint32_t bo = 0, bi = 0, bp = 0; bool has = false;
-    for (uint32_t j = lane; j < k; j += 64) {
-      float v = Ls[j]; uint32_t vo = Lo[j], vi = Li[j];
-      if (!has || v > bs || (v == bs && (vo > bo || (vo == bo && vi > bi)))) { bs = v; bo = vo; bi = vi; bp = j; has = true; }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      float os = __shfl_xor(bs, off); uint32_t oo = __shfl_xor(bo, off), oi = __shfl_xor(bi, off), op = __shfl_xor(bp, off);
-      bool oh = __shfl_xor((int)has, off) != 0;
-      if (oh && (!has || os > bs || (os == bs && (oo > bo || (oo == bo && oi > bi))))) { bs = os; bo = oo; bi = oi; bp = op; has = true; }
-    }
-    tau = __shfl(bs, 0); tauo = __shfl(bo, 0); taui = __shfl(bi, 0); mpos = __shfl(bp, 0);
-  };
-
   for (uint64_t base = 0; base < total; base += 64) {
-    uint64_t e = base + lane;
+    const uint64_t e = base + lane;
     bool valid = e < total;
-    uint32_t j = valid ? (uint32_t)(e / k) : 0, t = valid ? (uint32_t)(e - (uint64_t)j * k) : 0;
-    size_t o = ((size_t)sb + (size_t)j * a.slot_stride) * k + t;
+    const uint32_t j = valid ? (uint32_t)(e / k) : 0, t = valid ? (uint32_t)(e - (uint64_t)j * k) : 0;
+    const size_t o = ((size_t)sb + (size_t)j * a.slot_stride) * k + t;
     float s = __builtin_inff();
     uint32_t idx = IDX_NONE;
     if (valid) {
@@ -506,44 +521,25 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
         if (a.part_i && idx == IDX_NONE) valid = false;
       }
     }
-    auto passes = [&]() {
-      if (!valid) return false;
-      if (cnt < k) return s <= tau;
-      return s < tau || (s == tau && (j < tauo || (j == tauo && idx < taui)));
-    };
-    uint64_t m = __ballot(passes());
+    if (!valid) s = __builtin_inff();
+    uint64_t m = __ballot(valid && s <= tau);
     while (m) {
-      int l = __builtin_ctzll(m);
-      float cs = __shfl(s, l); uint32_t co = __shfl(j, l), ci = __shfl(idx, l);
-      if (cnt < k) {
-        if (lane == 0) { Ls[cnt] = cs; Lo[cnt] = co; Li[cnt] = ci; }
-        cnt += 1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (cnt == k) recompute();
-      } else {
-        if (lane == 0) { Ls[mpos] = cs; Lo[mpos] = co; Li[mpos] = ci; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        recompute();
-      }
+      const int l = __builtin_ctzll(m);
+      const float cs = __shfl(s, l);
+      const uint32_t co = __shfl(j, l), ci = __shfl(idx, l);
       m &= m - 1;
-      m &= __ballot(passes());
+      if (sorted_insert<true>(Ls, Lo, Li, k, cnt, cs, co, ci, lane, tau)) m &= __ballot(valid && s <= tau);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
 
-  // rank-by-counting sort of the cnt kept entries, ascending (score, slot, idx)
+  // the list is already sorted ascending by (score, slot, index) = the reference's result order
   for (uint32_t j = lane; j < k; j += 64) {
+    const size_t o = (size_t)q * k + j;
     if (j < cnt) {
-      float v = Ls[j]; uint32_t vo = Lo[j], vi = Li[j];
-      uint32_t rank = 0;
-      for (uint32_t u = 0; u < cnt; ++u) {
-        float w = Ls[u]; uint32_t wo = Lo[u], wi = Li[u];
-        rank += (w < v || (w == v && (wo < vo || (wo == vo && wi < vi)))) ? 1u : 0u;
-      }
-      size_t o = (size_t)q * k + rank;
+      const float v = Ls[j];
+      const uint32_t vo = Lo[j], vi = Li[j];
       uint64_t key;
       if (a.part_keys) key = a.part_keys[((size_t)sb + (size_t)vo * a.slot_stride) * k + vi];
       else key = a.keymap ? a.keymap[vi] : (uint64_t)vi;
@@ -551,7 +547,6 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
       a.out_scores[o] = v;
       if (a.out_idx) a.out_idx[o] = vi;
     } else {
-      size_t o = (size_t)q * k + j;
       a.out_keys[o] = ~0ull;
       a.out_scores[o] = __builtin_inff();
       if (a.out_idx) a.out_idx[o] = IDX_NONE;
@@ -647,6 +642,7 @@ struct PlanArgs {
   int brute_force;                // probe every list in id order
   const uint32_t *list_size;      // stored rows (this shard)
   const uint32_t *list_size_global;  // rows of the whole index (scan-count rule)
+  const uint32_t *list_order;        // [nlist] lists by stored size, largest first
   uint32_t tiles_per_chunk;
   uint32_t rows_per_group;        // NG*32 of the scan kernel
   // outputs
@@ -728,9 +724,10 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
              p.nlist, &p.list_qoff[p.nlist]);
   block_scan(
       [&](uint32_t i) {
-        uint32_t c = p.list_count[i];
+        const uint32_t l = p.list_order[i];
+        uint32_t c = p.list_count[l];
         uint32_t groups = (c + p.rows_per_group - 1) / p.rows_per_group;
-        return groups * list_chunks(p.list_size[i], p.tiles_per_chunk);
+        return groups * list_chunks(p.list_size[l], p.tiles_per_chunk);
       },
       [&](uint32_t i, uint32_t v) { p.item_off[i] = v; }, p.nlist, &p.item_off[p.nlist]);
   if (tid == 0) *p.total_items = p.item_off[p.nlist];

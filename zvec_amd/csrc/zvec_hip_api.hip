@@ -37,7 +37,6 @@ using namespace zvk;
 namespace {
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
-constexpr uint32_t IVF_TILES_PER_CHUNK = 8;
 constexpr int PROFILE_MAX = 8192;
 
 struct DevBuf {
@@ -153,7 +152,8 @@ struct zvec_hip_ivf_s {
   std::vector<uint64_t> h_dense0;      // local dense offsets (nlist+1)
   std::vector<uint64_t> h_row_ids;     // local dense position -> original row
   std::vector<float> h_centroids;      // [nlist][dim]
-  uint32_t *d_size = nullptr, *d_size_global = nullptr, *d_tile0 = nullptr;
+  uint32_t *d_size = nullptr, *d_size_global = nullptr, *d_tile0 = nullptr, *d_order = nullptr;
+  uint32_t tiles_per_chunk = 8;
   uint64_t *d_dense0 = nullptr;
   zvec_hip_ctx_s *defctx = nullptr;
   std::mutex mu;
@@ -258,6 +258,11 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     return 0;
   }
   int ng = pick_ng(count, topk);
+  // a base that stays in the 256 MiB Infinity Cache (IVF centroids, k-means codebooks) can be re-read by
+  // every query tile for free: prefer many small query tiles (more work-groups, each with a long run of
+  // tiles per top-k warm-up) over few large ones
+  const bool cache_resident = (double)st.n * st.dpad * 4.0 <= 64.0 * 1024 * 1024;
+  if (cache_resident && ng > 1) ng = 1;
   if (ng < 1) return ZVEC_HIP_ERR_UNSUPPORTED;
   const int cus = device_cus(ctx);
   const uint32_t rows = ng * QGROUP;
@@ -267,6 +272,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   uint64_t resident = (uint64_t)cus * (ng >= 4 ? 1 : (ng == 2 ? 2 : 3));
   uint64_t want_chunks = std::max<uint64_t>(1, (2 * resident + nqtiles - 1) / nqtiles);
   uint64_t tpc = std::max<uint64_t>(1, (ntiles + want_chunks - 1) / want_chunks);
+  tpc = std::max<uint64_t>(tpc, std::min<uint64_t>(ntiles, 4));   // >= 4 tiles per top-k warm-up
   uint32_t nchunks = (uint32_t)((ntiles + tpc - 1) / tpc);
   uint64_t slots = (uint64_t)count * nchunks;
   ZRET(ctx->part_s.ensure(slots * topk * sizeof(float)));
@@ -384,14 +390,17 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
   size_t o_qnprobe = take(count), o_qscanned = take(count), o_qnslots = take(count), o_slotbegin = take(count + 1);
   size_t o_lcount = take(nlist), o_lfill = take(nlist), o_lqoff = take(nlist + 1), o_itemoff = take(nlist + 1);
+  size_t o_queue = take(4);   // right after item_off; zeroed with list_count/list_fill? no: separate memset below
   size_t o_total = take(4), o_csrq = take(npairs), o_csrslot = take(npairs);
   ZRET(ctx->plan.ensure(off * sizeof(uint32_t)));
   uint32_t *pb = ctx->plan.as<uint32_t>();
   ZCHK(hipMemsetAsync(pb + o_lcount, 0, (o_lqoff - o_lcount) * sizeof(uint32_t), stream));  // list_count + list_fill
+  ZCHK(hipMemsetAsync(pb + o_queue, 0, 4 * sizeof(uint32_t), stream));                       // work-queue head
   PlanArgs p{};
   p.coarse_idx = ctx->coarse_idx.as<uint32_t>(); p.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
   p.nq = count; p.nprobe = nprobe; p.nlist = nlist; p.max_scan_count = max_scan_count; p.brute_force = brute_force;
-  p.list_size = h->d_size; p.list_size_global = h->d_size_global; p.tiles_per_chunk = IVF_TILES_PER_CHUNK;
+  p.list_size = h->d_size; p.list_size_global = h->d_size_global; p.list_order = h->d_order;
+  p.tiles_per_chunk = h->tiles_per_chunk;
   p.rows_per_group = rows_per_group;
   p.q_nprobe = pb + o_qnprobe; p.q_scanned = pb + o_qscanned; p.q_nslots = pb + o_qnslots; p.slot_begin = pb + o_slotbegin;
   p.list_count = pb + o_lcount; p.list_fill = pb + o_lfill; p.list_qoff = pb + o_lqoff; p.item_off = pb + o_itemoff;
@@ -403,18 +412,19 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   hipLaunchKernelGGL(plan_fill_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, p);
   ZCHK(hipGetLastError());
 
+  const uint32_t TPC = h->tiles_per_chunk;
   // 3. scan.  Upper bound of slots: every probed list contributes ceil(size/chunk_rows) chunks;
   //    bound it by pairs * max chunks per list.
   uint32_t max_list = 0;
   for (uint32_t l = 0; l < nlist; ++l) max_list = std::max(max_list, h->h_size[l]);
-  uint32_t max_chunks = std::max<uint32_t>(1, ((max_list + TILE_N - 1) / TILE_N + IVF_TILES_PER_CHUNK - 1) / IVF_TILES_PER_CHUNK);
+  uint32_t max_chunks = std::max<uint32_t>(1, ((max_list + TILE_N - 1) / TILE_N + TPC - 1) / TPC);
   // exact worst case: each query probes its lists; bounded by the nprobe largest lists
   std::vector<uint32_t> &sz = h->h_size;
   uint64_t slots_bound;
   {
     std::vector<uint32_t> chunks(nlist);
     for (uint32_t l = 0; l < nlist; ++l)
-      chunks[l] = sz[l] ? (((sz[l] + TILE_N - 1) / TILE_N + IVF_TILES_PER_CHUNK - 1) / IVF_TILES_PER_CHUNK) : 0;
+      chunks[l] = sz[l] ? (((sz[l] + TILE_N - 1) / TILE_N + TPC - 1) / TPC) : 0;
     uint32_t np = brute_force ? nlist : nprobe;
     std::partial_sort(chunks.begin(), chunks.begin() + np, chunks.end(), std::greater<uint32_t>());
     uint64_t s = 0;
@@ -430,8 +440,8 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   a.base = h->lists.base; a.bnorm = h->lists.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
   a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
   a.dpad = h->lists.dpad; a.nks = h->lists.dpad / TILE_K; a.metric = h->metric; a.k = topk; a.threshold = threshold;
-  a.mode = 1; a.nq = count; a.n = h->lists.n; a.tiles_per_chunk = IVF_TILES_PER_CHUNK;
-  a.total_items = p.total_items; a.item_off = p.item_off; a.list_tile0 = h->d_tile0; a.list_size = h->d_size;
+  a.mode = 1; a.nq = count; a.n = h->lists.n; a.tiles_per_chunk = TPC;
+  a.total_items = p.total_items; a.queue = pb + o_queue; a.list_order = h->d_order; a.item_off = p.item_off; a.list_tile0 = h->d_tile0; a.list_size = h->d_size;
   a.list_dense0 = h->d_dense0; a.list_qoff = p.list_qoff; a.csr_q = p.csr_q; a.csr_slot = p.csr_slot; a.nlist = nlist;
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
   // algorithmic bytes of the list scan = rows of the DISTINCT probed lists (counted on device from
@@ -680,8 +690,9 @@ static void ivf_release(zvec_hip_ivf_s *h) {
   if (h->d_size) (void)hipFree(h->d_size);
   if (h->d_size_global) (void)hipFree(h->d_size_global);
   if (h->d_tile0) (void)hipFree(h->d_tile0);
+  if (h->d_order) (void)hipFree(h->d_order);
   if (h->d_dense0) (void)hipFree(h->d_dense0);
-  h->d_size = h->d_size_global = h->d_tile0 = nullptr; h->d_dense0 = nullptr;
+  h->d_size = h->d_size_global = h->d_tile0 = h->d_order = nullptr; h->d_dense0 = nullptr;
   h->loaded = false;
 }
 
@@ -773,7 +784,18 @@ static int ivf_pack(zvec_hip_ivf_s *h, const float *d_rows, uint64_t n, const ui
     if (rc != 0) return rc;
   }
   // list tables
-  if (h->d_size) { (void)hipFree(h->d_size); (void)hipFree(h->d_size_global); (void)hipFree(h->d_tile0); (void)hipFree(h->d_dense0); }
+  if (h->d_size) { (void)hipFree(h->d_size); (void)hipFree(h->d_size_global); (void)hipFree(h->d_tile0); (void)hipFree(h->d_dense0); (void)hipFree(h->d_order); }
+  // largest lists are dealt first by the scan's work queue; chunk length adapts to the index size so
+  // that a search has a few items per resident work-group yet long runs per top-k warm-up
+  std::vector<uint32_t> order(nlist);
+  for (uint32_t l = 0; l < nlist; ++l) order[l] = l;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h->h_size[x] > h->h_size[y]; });
+  {
+    uint64_t tpc = tiles / (4ull * 256ull * 3ull);
+    h->tiles_per_chunk = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(4, tpc));
+  }
+  ZCHK(hipMalloc(&h->d_order, nlist * 4));
+  ZCHK(hipMemcpy(h->d_order, order.data(), nlist * 4, hipMemcpyHostToDevice));
   ZCHK(hipMalloc(&h->d_size, nlist * 4));
   ZCHK(hipMalloc(&h->d_size_global, nlist * 4));
   ZCHK(hipMalloc(&h->d_tile0, nlist * 4));
