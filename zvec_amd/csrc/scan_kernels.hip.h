@@ -77,14 +77,15 @@ struct ScanArgs {
   const uint32_t *csr_q;        // query row
   const uint32_t *csr_slot;     // output slot of (query, probe rank), chunk 0
   uint32_t nlist;
+  uint64_t ndense;              // number of dense positions (bits of `exclude`)
   // outputs: per-(slot) partial lists
   float *part_s;                // [slots][k]
   uint32_t *part_i;             // [slots][k] padded position, IDX_NONE = empty
 };
 
 // LDS footprint in bytes for a given NG / k (host mirrors this)
-__host__ __device__ inline size_t scan_lds_bytes(int ng, uint32_t k) {
-  size_t rows = (size_t)ng * QGROUP;
+__host__ __device__ inline size_t scan_lds_bytes(int ng, uint32_t k, bool m16 = false) {
+  size_t rows = m16 ? 16 : (size_t)ng * QGROUP;
   return (2 * rows * TILE_K + 2 * (size_t)SLAB + 5 * rows + 4 + 2 * rows * k) * 4;
 }
 
@@ -248,13 +249,29 @@ __device__ __forceinline__ void stage_store(const StageRegs<NG> &sr, float *Bb, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// The scan kernel.  256 threads = 4 waves; wave w owns tile columns [32w, 32w+32); all waves share
-// the NG*32 query rows.  Persistent grid-stride loop over work items (every wave reaches the loop
-// exit: `item` is uniform in the work-group and bounded by a value read once).
+// The scan kernel.  256 threads = 4 waves; wave w owns tile columns [32w, 32w+32); all waves share the
+// ROWS query rows of the work item.  Two matrix-core shapes:
+//   M16 = false : ROWS = NG*32, v_mfma_f32_32x32x2_f32   (flat scans, coarse assign: many queries per tile)
+//   M16 = true  : ROWS = 16,    v_mfma_f32_16x16x4_f32   (IVF list scan: a list is probed by ~10 queries
+//                 of the batch, so 16-row tiles waste half as many matrix-core cycles as 32-row ones)
+// EXCL selects the bitmap-gated variant (the filter word is fetched with the tile, unconditionally, so
+// the no-filter variant carries no extra load).
+// Persistent loop over work items: static grid-stride for flat, a device work queue for IVF (every
+// wave reaches the loop exit: `item` is uniform in the work-group and bounded by a value read once).
 // ---------------------------------------------------------------------------------------------
-template <int NG>
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int NG, bool M16>
+struct ScanShape {
+  static constexpr int ROWS = M16 ? 16 : NG * QGROUP;
+  static constexpr int QLOADS = M16 ? 1 : NG;           // 16-byte query loads per thread per k-step
+};
+
+template <int NG, bool M16, bool EXCL>
 __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
-  constexpr int ROWS = NG * QGROUP;
+  constexpr int ROWS = ScanShape<NG, M16>::ROWS;
+  constexpr int QL = ScanShape<NG, M16>::QLOADS;
+  constexpr int QROWMASK = M16 ? 15 : 31;
   extern __shared__ f32x4 zvk_smem4[];
   float *smem = reinterpret_cast<float *>(zvk_smem4);
   float *Qs = smem;                      // [2][ROWS*32]
@@ -273,8 +290,9 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int srow = tid >> 3, schunk = tid & 7;           // staging coordinates
+  const int r = lane & 31, h = lane >> 5;                 // 32x32x2 operand coordinates
+  const int r16 = lane & 15, kq = lane >> 4;              // 16x16x4 operand coordinates
+  const int srow = (tid >> 3) & QROWMASK, schunk = tid & 7;   // staging coordinates (M16: threads >= 128 duplicate)
   const int sswz = schunk ^ ((srow >> 1) & 7);            // swizzled chunk for the Q image
   const uint32_t dpad = a.dpad, nks = a.nks, k = a.k;
 
@@ -295,7 +313,7 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
     if (item >= total) break;   // uniform: every wave of the work-group leaves together
     // ---- decode the work item (uniform) ----
     uint32_t tile_begin, tile_end, nrows, rows_valid_total;
-    uint64_t dense0 = 0;  // dense position of padded position tile0*128
+    uint64_t dense0 = 0;  // dense position of the first row of the list / store
     uint32_t tile0 = 0;   // first tile of the row range the dense mapping refers to
     uint32_t li = 0, r0 = 0, chunk = 0;
     if (a.mode == 0) {
@@ -308,7 +326,7 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
       nrows = min((uint32_t)ROWS, a.nq - r0);
       rows_valid_total = (uint32_t)min((uint64_t)0xffffffffu, a.n);  // rows valid from tile 0
     } else {
-      // binary search: item_off[li] <= item < item_off[li+1]
+      // binary search: item_off[pos] <= item < item_off[pos+1]
       uint32_t lo = 0, hi = a.nlist;
       while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
@@ -356,103 +374,198 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
     __syncthreads();
 
     // staging sources
-    uint32_t qoff[NG];   // float offsets into the padded query matrix (host guarantees nq*dpad < 2^32)
+    uint32_t qoff[QL];   // float offsets into the padded query matrix (host guarantees nq*dpad < 2^32)
 #pragma unroll
-    for (int i = 0; i < NG; ++i) qoff[i] = qrow_s[srow + 32 * i] * dpad + (uint32_t)schunk * 4u;
+    for (int i = 0; i < QL; ++i) qoff[i] = qrow_s[srow + 32 * i] * dpad + (uint32_t)schunk * 4u;
 
     const uint32_t ntiles = tile_end - tile_begin;
     const uint32_t nsteps = ntiles * nks;
 
-    StageRegs<NG> sr;
-    floatx16 acc[NG];
+    // Software pipeline: the operands of step t travel HBM -> registers sr[t & 1] -> LDS buffer t & 1.
+    // PF steps are kept in flight in registers (2 for the HBM-bound small shapes: ~40 KB per
+    // work-group on the wire while the matrix cores chew the current step).
+    constexpr int PF = (NG <= 2) ? 2 : 1;
+    StageRegs<QL> sr[2];
+    floatx16 acc[M16 ? 1 : NG];
+    floatx4 acc16[2];
+    if constexpr (M16) {
+      acc16[0] = floatx4{0.f, 0.f, 0.f, 0.f};
+      acc16[1] = floatx4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+      for (int g = 0; g < NG; ++g)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+    }
 
-    uint32_t tile = tile_begin, ks = 0;
+    uint32_t tile = tile_begin, ks = 0;          // coordinates of the step being computed
+    uint32_t ptile = tile_begin, pks = 0;        // coordinates of the next step to fetch
+    uint32_t fetched = 0;
+    auto advance = [&](uint32_t &t_, uint32_t &k_) { if (++k_ == nks) { k_ = 0; ++t_; } };
     if (nsteps > 0) {
-      stage_load<NG>(sr, a.base, a.queries, qoff, tile, 0, dpad, tid);
-      stage_store<NG>(sr, Bs, Qs, srow, sswz, tid);
+      stage_load<QL>(sr[0], a.base, a.queries, qoff, ptile, pks, dpad, tid);
+      if (nsteps > 1) advance(ptile, pks);
+      fetched = 1;
+      stage_store<QL>(sr[0], Bs, Qs, srow, sswz, tid);
+      if (PF == 2) {
+        stage_load<QL>(sr[1], a.base, a.queries, qoff, ptile, pks, dpad, tid);
+        if (nsteps > 2) advance(ptile, pks);
+        fetched = 2;
+      }
     }
     __syncthreads();
 
-    for (uint32_t s = 0; s < nsteps; ++s) {
-      const int buf = s & 1;
-      uint32_t ntile = tile, nk = ks + 1;
-      if (nk == nks) { nk = 0; ntile = tile + 1; }
+    // per-tile column constants, fetched with every step (same address within a tile: L1/L2 hits) so that
+    // the loads in flight per step are the same on every path and the epilogue never drains the pipeline
+    float bn0 = 0.f, bn1 = 0.f;
+    uint32_t ex0 = 0, ex1 = 0;
+
+    for (uint32_t s0 = 0; s0 < nsteps; s0 += 2) {
+#pragma unroll
+     for (int u = 0; u < 2; ++u) {
+      const uint32_t s = s0 + u;
+      if (s >= nsteps) break;                      // uniform
+      const int buf = u;                            // == s & 1
+      // fetch step s + PF into sr[(s + PF) & 1].  Unconditional on purpose: a conditional load would
+      // give the compiler two paths with different numbers of loads in flight and it would then wait
+      // for the YOUNGEST set before the LDS store below (vmcnt merges conservatively); past the end
+      // the last step is simply fetched again and never used.
+      stage_load<QL>(sr[(u + PF) & 1], a.base, a.queries, qoff, ptile, pks, dpad, tid);
+      if (fetched + 1 < nsteps) advance(ptile, pks);
+      ++fetched;
+      {
+        const uint32_t pos0 = tile * TILE_N + wave * 32;
+        if constexpr (M16) {
+          bn0 = a.bnorm[(size_t)pos0 + r16];
+          bn1 = a.bnorm[(size_t)pos0 + 16 + r16];
+        } else {
+          bn0 = a.bnorm[(size_t)pos0 + r];
+        }
+        if constexpr (EXCL) {
+          // (positions in a list's tail padding are clamped: they are masked by rows_valid_total anyway)
+          const uint64_t dlast = a.ndense - 1;
+          const uint64_t d0 = min(dense0 + (uint64_t)(tile - tile0) * TILE_N + wave * 32 + (M16 ? r16 : r), dlast);
+          ex0 = (a.exclude[d0 >> 5] >> (d0 & 31)) & 1u;
+          if constexpr (M16) {
+            const uint64_t d1 = min(d0 + 16, dlast);
+            ex1 = (a.exclude[d1 >> 5] >> (d1 & 31)) & 1u;
+          }
+        }
+      }
       const bool has_next = (s + 1 < nsteps);
-      if (has_next) stage_load<NG>(sr, a.base, a.queries, qoff, ntile, nk, dpad, tid);
 
       // ---- MFMA over this 32-float k-step ----
       {
         const float *Qb = Qs + buf * ROWS * TILE_K;
         const float *Bb = Bs + buf * SLAB;
-        const int brow = wave * 32 + r;
-        const int swz = (r >> 1) & 7;
-        constexpr int KK_UNROLL = (NG >= 4) ? 1 : 4;   // keep the A-fragment live range short when NG is large
-#pragma unroll KK_UNROLL
-        for (int kk = 0; kk < 4; ++kk) {
-          const int c = (2 * kk + h) ^ swz;
-          const f32x4 bf = *reinterpret_cast<const f32x4 *>(Bb + (brow * 8 + c) * 4);
+        if constexpr (M16) {
+          const int swz = (r16 >> 1) & 7;
 #pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            const f32x4 af = *reinterpret_cast<const f32x4 *>(Qb + ((g * 32 + r) * 8 + c) * 4);
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[g], 0, 0, 0);
+          for (int kk2 = 0; kk2 < 2; ++kk2) {
+            const int c = (kq + 4 * kk2) ^ swz;
+            const f32x4 af = *reinterpret_cast<const f32x4 *>(Qb + (r16 * 8 + c) * 4);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              const int brow = wave * 32 + cb * 16 + r16;
+              const f32x4 bf = *reinterpret_cast<const f32x4 *>(Bb + (brow * 8 + c) * 4);
+              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc16[cb], 0, 0, 0);
+              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc16[cb], 0, 0, 0);
+              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc16[cb], 0, 0, 0);
+              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc16[cb], 0, 0, 0);
+            }
+          }
+        } else {
+          const int brow = wave * 32 + r;
+          const int swz = (r >> 1) & 7;
+          constexpr int KK_UNROLL = (NG >= 4) ? 1 : 4;   // keep the A-fragment live range short when NG is large
+#pragma unroll KK_UNROLL
+          for (int kk = 0; kk < 4; ++kk) {
+            const int c = (2 * kk + h) ^ swz;
+            const f32x4 bf = *reinterpret_cast<const f32x4 *>(Bb + (brow * 8 + c) * 4);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              const f32x4 af = *reinterpret_cast<const f32x4 *>(Qb + ((g * 32 + r) * 8 + c) * 4);
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[g], 0, 0, 0);
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[g], 0, 0, 0);
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[g], 0, 0, 0);
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[g], 0, 0, 0);
+            }
           }
         }
       }
 
       // ---- tile epilogue: metric fix-up, then bounded top-k admission ----
-      // The MFMA C layout spreads one query row over 32 lanes of a wave and the 4 waves hold
-      // different columns of it, so the scores of 32 rows x 128 columns are transposed through the
-      // staging buffer that is idle during this step (16 KiB) and every row is then admitted by
-      // ONE owner wave (row r of the group belongs to wave r % 4): no locks, no atomics.
+      // The MFMA C layout spreads one query row over the lanes of a wave and the 4 waves hold different
+      // columns of it, so the scores of one row group x 128 columns are transposed through the staging
+      // buffer that is idle during this step (16 KiB) and every row is then admitted by ONE owner wave
+      // (row i of the group belongs to wave i % 4): no locks, no atomics.
       if (ks == nks - 1) {
-        float *Sc = Bs + (buf ^ 1) * SLAB;                                  // [32 rows][128 cols]
-        const uint32_t local = (tile - tile0) * TILE_N + wave * 32 + r;     // row index inside list/store
-        bool colvalid = local < rows_valid_total;
-        if (a.exclude != nullptr && colvalid) {
-          uint64_t dpos = dense0 + local;
-          colvalid = ((a.exclude[dpos >> 5] >> (dpos & 31)) & 1u) == 0;
-        }
+        float *Sc = Bs + (buf ^ 1) * SLAB;                                  // [<=32 rows][128 cols]
+        const uint32_t local0 = (tile - tile0) * TILE_N + wave * 32;        // row index inside list/store, lane 0
         const uint32_t pos0 = tile * TILE_N;                                // padded position of column 0
-        float bn = 0.f;
-        if (a.metric == METRIC_L2 && colvalid) bn = a.bnorm[(size_t)pos0 + wave * 32 + r];
+        if constexpr (M16) {
+          const bool v0 = (local0 + r16 < rows_valid_total) && (ex0 == 0);
+          const bool v1 = (local0 + 16 + r16 < rows_valid_total) && (ex1 == 0);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
+          for (int cb = 0; cb < 2; ++cb) {
+            const float bn = cb ? bn1 : bn0;
+            const bool cv = cb ? v1 : v0;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int row_l = (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float dot = acc[g][e];
-            float sc;
-            if (a.metric == METRIC_L2) sc = fmaxf(fmaf(-2.f, dot, qn_s[g * 32 + row_l] + bn), 0.f);
-            else if (a.metric == METRIC_IP) sc = -dot;
-            else sc = 1.f - dot;
-            Sc[row_l * TILE_N + wave * 32 + r] = colvalid ? sc : __builtin_inff();
-            acc[g][e] = 0.f;
+            for (int e = 0; e < 4; ++e) {
+              const int row_l = kq * 4 + e;
+              const float dot = acc16[cb][e];
+              float sc;
+              if (a.metric == METRIC_L2) sc = fmaxf(fmaf(-2.f, dot, qn_s[row_l] + bn), 0.f);
+              else if (a.metric == METRIC_IP) sc = -dot;
+              else sc = 1.f - dot;
+              Sc[row_l * TILE_N + wave * 32 + cb * 16 + r16] = cv ? sc : __builtin_inff();
+              acc16[cb][e] = 0.f;
+            }
           }
           __syncthreads();
 #pragma unroll 1
-          for (int i = 0; i < 8; ++i) {
-            const int row_l = i * 4 + wave;                  // rows dealt round-robin to the 4 waves
-            const int row = g * 32 + row_l;
+          for (int i = 0; i < 4; ++i) {
+            const int row = i * 4 + wave;                    // rows dealt round-robin to the 4 waves
             if ((uint32_t)row < nrows) {
-              const f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + row_l * TILE_N + 2 * lane);
+              const f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + row * TILE_N + 2 * lane);
               owner_row(st, row, v.x, v.y, pos0, lane);
             }
           }
           __syncthreads();
+        } else {
+          const bool colvalid = (local0 + r < rows_valid_total) && (ex0 == 0);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row_l = (e & 3) + 8 * (e >> 2) + 4 * h;
+              const float dot = acc[g][e];
+              float sc;
+              if (a.metric == METRIC_L2) sc = fmaxf(fmaf(-2.f, dot, qn_s[g * 32 + row_l] + bn0), 0.f);
+              else if (a.metric == METRIC_IP) sc = -dot;
+              else sc = 1.f - dot;
+              Sc[row_l * TILE_N + wave * 32 + r] = colvalid ? sc : __builtin_inff();
+              acc[g][e] = 0.f;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int i = 0; i < 8; ++i) {
+              const int row_l = i * 4 + wave;                  // rows dealt round-robin to the 4 waves
+              const int row = g * 32 + row_l;
+              if ((uint32_t)row < nrows) {
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + row_l * TILE_N + 2 * lane);
+                owner_row(st, row, v.x, v.y, pos0, lane);
+              }
+            }
+            __syncthreads();
+          }
         }
       }
 
-      if (has_next) stage_store<NG>(sr, Bs + (buf ^ 1) * SLAB, Qs + (buf ^ 1) * ROWS * TILE_K, srow, sswz, tid);
+      if (has_next) stage_store<QL>(sr[u ^ 1], Bs + (buf ^ 1) * SLAB, Qs + (buf ^ 1) * ROWS * TILE_K, srow, sswz, tid);
       __syncthreads();
-      tile = ntile;
-      ks = nk;
+      advance(tile, ks);
+     }
     }
 
     // ---- write the partial lists ----

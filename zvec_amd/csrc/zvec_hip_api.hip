@@ -168,32 +168,40 @@ struct KernelInfo {
 KernelInfo g_info[16];
 std::mutex g_info_mu;
 
-template <int NG>
-int launch_scan(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
+template <int NG, bool M16, bool EXCL>
+int launch_scan_t(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
   static bool attr_set[16] = {false};
-  size_t lds = scan_lds_bytes(NG, a.k);
+  size_t lds = scan_lds_bytes(NG, a.k, M16);
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_set[dev & 15]) {
-    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<NG>),
+    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<NG, M16, EXCL>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     attr_set[dev & 15] = true;
   }
   int occ = 0;
-  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<NG>, 256, lds));
+  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<NG, M16, EXCL>, 256, lds));
   if (occ < 1) occ = 1;
   uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)max_items, (uint64_t)cus * (uint64_t)occ);
   if (grid == 0) return 0;
-  hipLaunchKernelGGL(scan_kernel<NG>, dim3(grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((scan_kernel<NG, M16, EXCL>), dim3(grid), dim3(256), lds, stream, a);
   ZCHK(hipGetLastError());
   return 0;
 }
 
+template <int NG, bool M16>
+int launch_scan(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
+  return a.exclude ? launch_scan_t<NG, M16, true>(a, max_items, cus, stream)
+                   : launch_scan_t<NG, M16, false>(a, max_items, cus, stream);
+}
+
+// ng == 0 selects the 16-row (16x16x4 MFMA) shape
 int launch_scan_ng(int ng, const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
   switch (ng) {
-    case 1: return launch_scan<1>(a, max_items, cus, stream);
-    case 2: return launch_scan<2>(a, max_items, cus, stream);
-    case 4: return launch_scan<4>(a, max_items, cus, stream);
+    case 0: return launch_scan<1, true>(a, max_items, cus, stream);
+    case 1: return launch_scan<1, false>(a, max_items, cus, stream);
+    case 2: return launch_scan<2, false>(a, max_items, cus, stream);
+    case 4: return launch_scan<4, false>(a, max_items, cus, stream);
   }
   return ZVEC_HIP_ERR_INVALID_ARGUMENT;
 }
@@ -282,7 +290,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   a.base = st.base; a.bnorm = st.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
   a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
   a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = topk; a.threshold = threshold;
-  a.mode = 0; a.nq = count; a.n = st.n; a.tiles_per_chunk = (uint32_t)tpc; a.nchunks = nchunks; a.nqtiles = nqtiles;
+  a.mode = 0; a.nq = count; a.n = st.n; a.ndense = st.n; a.tiles_per_chunk = (uint32_t)tpc; a.nchunks = nchunks; a.nqtiles = nqtiles;
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
   int pi = -1;
   if (profile_it) {
@@ -381,9 +389,11 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   }
 
   // 2. plan: list-major work items
-  const int ng = 1;
-  if (scan_lds_bytes(ng, topk) > LDS_LIMIT - 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
-  const uint32_t rows_per_group = ng * QGROUP;
+  // list scan shape: 16-row tiles (16x16x4 MFMA); a list probed by more than 16 queries of the batch is
+  // dealt as several 16-row groups (its slabs come back from L2 / Infinity Cache for the later groups)
+  const int ng = 0;
+  if (scan_lds_bytes(1, topk, true) > LDS_LIMIT - 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
+  const uint32_t rows_per_group = 16;
   const uint64_t npairs = (uint64_t)count * (brute_force ? nlist : nprobe);
   // layout of the plan buffer (u32 words)
   size_t off = 0;
@@ -440,7 +450,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   a.base = h->lists.base; a.bnorm = h->lists.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
   a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
   a.dpad = h->lists.dpad; a.nks = h->lists.dpad / TILE_K; a.metric = h->metric; a.k = topk; a.threshold = threshold;
-  a.mode = 1; a.nq = count; a.n = h->lists.n; a.tiles_per_chunk = TPC;
+  a.mode = 1; a.nq = count; a.n = h->lists.n; a.ndense = h->count_local; a.tiles_per_chunk = TPC;
   a.total_items = p.total_items; a.queue = pb + o_queue; a.list_order = h->d_order; a.item_off = p.item_off; a.list_tile0 = h->d_tile0; a.list_size = h->d_size;
   a.list_dense0 = h->d_dense0; a.list_qoff = p.list_qoff; a.csr_q = p.csr_q; a.csr_slot = p.csr_slot; a.nlist = nlist;
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
