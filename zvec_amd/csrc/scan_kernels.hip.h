@@ -78,6 +78,11 @@ struct ScanArgs {
   const uint32_t *csr_slot;     // output slot of (query, probe rank), chunk 0
   uint32_t nlist;
   uint64_t ndense;              // number of dense positions (bits of `exclude`)
+  // dense-score mode (small cache-resident bases, e.g. the IVF coarse step): instead of admitting
+  // into top-k lists the kernel writes every score to dump[query][padded position]; selection is then
+  // done by merge_kernel over whole rows (one wave per query)
+  float *dump;                  // nullable
+  uint32_t dump_stride;         // floats per query row (= tiles * 128)
   // outputs: per-(slot) partial lists
   float *part_s;                // [slots][k]
   uint32_t *part_i;             // [slots][k] padded position, IDX_NONE = empty
@@ -87,6 +92,14 @@ struct ScanArgs {
 __host__ __device__ inline size_t scan_lds_bytes(int ng, uint32_t k, bool m16 = false) {
   size_t rows = m16 ? 16 : (size_t)ng * QGROUP;
   return (2 * rows * TILE_K + 2 * (size_t)SLAB + 5 * rows + 4 + 2 * rows * k) * 4;
+}
+
+// broadcast of lane `l` (wave-uniform index) without touching the LDS crossbar: v_readlane_b32
+__device__ __forceinline__ float bcast_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ uint32_t bcast_u(uint32_t v, int l) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
 
 struct RowState {
@@ -133,7 +146,7 @@ __device__ __forceinline__ bool sorted_insert(float *L, uint32_t *O, uint32_t *I
       if (HAS_ORD) O[p] = o;
     }
     c = min(c + 1, k);
-    if (c == k) tau = (p == k - 1) ? s : __shfl(es, (int)k - 2);   // new k-th = candidate or the old (k-1)-th
+    if (c == k) tau = (p == k - 1) ? s : bcast_f(es, (int)k - 2);   // new k-th = candidate or the old (k-1)-th
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     return true;
@@ -194,12 +207,12 @@ __device__ __forceinline__ void owner_row(const RowState &st, int row, float s0,
     uint32_t ci;
     if (m0 != 0) {
       l = __builtin_ctzll(m0);
-      cs = __shfl(s0, l);
+      cs = bcast_f(s0, l);
       ci = pos0 + 2u * (uint32_t)l;
       m0 &= m0 - 1;
     } else {
       l = __builtin_ctzll(m1);
-      cs = __shfl(s1, l);
+      cs = bcast_f(s1, l);
       ci = pos0 + 2u * (uint32_t)l + 1u;
       m1 &= m1 - 1;
     }
@@ -528,7 +541,8 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
             const int row = i * 4 + wave;                    // rows dealt round-robin to the 4 waves
             if ((uint32_t)row < nrows) {
               const f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + row * TILE_N + 2 * lane);
-              owner_row(st, row, v.x, v.y, pos0, lane);
+              if (a.dump) *reinterpret_cast<f32x2 *>(a.dump + (size_t)qrow_s[row] * a.dump_stride + pos0 + 2 * lane) = v;
+              else owner_row(st, row, v.x, v.y, pos0, lane);
             }
           }
           __syncthreads();
@@ -554,7 +568,8 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
               const int row = g * 32 + row_l;
               if ((uint32_t)row < nrows) {
                 const f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + row_l * TILE_N + 2 * lane);
-                owner_row(st, row, v.x, v.y, pos0, lane);
+                if (a.dump) *reinterpret_cast<f32x2 *>(a.dump + (size_t)qrow_s[row] * a.dump_stride + pos0 + 2 * lane) = v;
+                else owner_row(st, row, v.x, v.y, pos0, lane);
               }
             }
             __syncthreads();
@@ -569,7 +584,7 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
     }
 
     // ---- write the partial lists ----
-    for (uint32_t j = tid; j < nrows * k; j += 256) {
+    for (uint32_t j = tid; a.dump == nullptr && j < nrows * k; j += 256) {
       uint32_t row = j / k, t = j - row * k;
       uint32_t c = st.cnt[row];
       size_t o = (size_t)slot_s[row] * k + t;
@@ -594,6 +609,7 @@ struct MergeArgs {
   uint32_t slot_stride;          // 1 for scan partials; nq for [part][q][k] shard layout
   const uint32_t *part_counts;   // optional [slots] valid entries per slot (shard merge)
   uint32_t k;
+  uint32_t slot_len;             // candidates per slot (k for partial lists; the row length for dense scores)
   float threshold;
   const uint64_t *keymap;        // position -> key (nullable => key = position)
   uint64_t *out_keys;            // [nq][k]
@@ -617,13 +633,14 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
 
   uint32_t cnt = 0;            // uniform
   float tau = a.threshold;     // uniform admission bound: threshold until the list is full, then its k-th score
-  const uint64_t total = (uint64_t)nslots * k;
+  const uint32_t sl = a.slot_len;
+  const uint64_t total = (uint64_t)nslots * sl;
 
   for (uint64_t base = 0; base < total; base += 64) {
     const uint64_t e = base + lane;
     bool valid = e < total;
-    const uint32_t j = valid ? (uint32_t)(e / k) : 0, t = valid ? (uint32_t)(e - (uint64_t)j * k) : 0;
-    const size_t o = ((size_t)sb + (size_t)j * a.slot_stride) * k + t;
+    const uint32_t j = valid ? (uint32_t)(e / sl) : 0, t = valid ? (uint32_t)(e - (uint64_t)j * sl) : 0;
+    const size_t o = ((size_t)sb + (size_t)j * a.slot_stride) * sl + t;
     float s = __builtin_inff();
     uint32_t idx = IDX_NONE;
     if (valid) {
@@ -638,8 +655,8 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
     uint64_t m = __ballot(valid && s <= tau);
     while (m) {
       const int l = __builtin_ctzll(m);
-      const float cs = __shfl(s, l);
-      const uint32_t co = __shfl(j, l), ci = __shfl(idx, l);
+      const float cs = bcast_f(s, l);
+      const uint32_t co = bcast_u(j, l), ci = bcast_u(idx, l);
       m &= m - 1;
       if (sorted_insert<true>(Ls, Lo, Li, k, cnt, cs, co, ci, lane, tau)) m &= __ballot(valid && s <= tau);
     }
@@ -654,7 +671,7 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
       const float v = Ls[j];
       const uint32_t vo = Lo[j], vi = Li[j];
       uint64_t key;
-      if (a.part_keys) key = a.part_keys[((size_t)sb + (size_t)vo * a.slot_stride) * k + vi];
+      if (a.part_keys) key = a.part_keys[((size_t)sb + (size_t)vo * a.slot_stride) * sl + vi];
       else key = a.keymap ? a.keymap[vi] : (uint64_t)vi;
       a.out_keys[o] = key;
       a.out_scores[o] = v;

@@ -265,6 +265,38 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     ZCHK(hipMemsetAsync(out.keys, 0xff, sizeof(uint64_t) * (size_t)count * topk, stream));
     return 0;
   }
+  // Dense-score path for small cache-resident bases searched by many queries with a large k (the IVF
+  // coarse step: 1024 x 4096 centroids, k = nprobe): the fused admission would spend longer warming up
+  // 1024 top-40 lists per tile run than the matrix cores need for the distances, so the scores are
+  // written once (16 MiB, stays in L2 / Infinity Cache) and each query row is selected by one wave.
+  {
+    const uint64_t ntiles_d = (st.n + TILE_N - 1) / TILE_N;
+    const double dump_bytes = (double)count * (double)ntiles_d * TILE_N * 4.0;
+    const bool small_base = (double)st.n * st.dpad * 4.0 <= 64.0 * 1024 * 1024;
+    if (small_base && d_exclude == nullptr && topk > 8 && count >= 64 && dump_bytes <= 128.0 * 1024 * 1024 &&
+        (size_t)topk * 12 + 16 <= 60 * 1024) {
+      const int cus_d = device_cus(ctx);
+      const int ngd = pick_ng(count, 1);
+      const uint32_t rows_d = ngd * QGROUP;
+      const uint32_t nqt = (count + rows_d - 1) / rows_d;
+      ZRET(ctx->part_s.ensure((size_t)dump_bytes));
+      ScanArgs a{};
+      a.base = st.base; a.bnorm = st.bnorm; a.exclude = nullptr;
+      a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
+      a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = 1; a.threshold = threshold;
+      a.mode = 0; a.nq = count; a.n = st.n; a.ndense = st.n; a.tiles_per_chunk = 1; a.nchunks = (uint32_t)ntiles_d; a.nqtiles = nqt;
+      a.dump = ctx->part_s.as<float>(); a.dump_stride = (uint32_t)(ntiles_d * TILE_N);
+      a.part_s = nullptr; a.part_i = nullptr;
+      ZRET(launch_scan_ng(ngd, a, (uint32_t)ntiles_d * nqt, cus_d, stream));
+      MergeArgs m{};
+      m.part_s = a.dump; m.part_i = nullptr; m.part_keys = nullptr; m.slot_begin = nullptr; m.slots_per_q = 1;
+      m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = a.dump_stride; m.threshold = threshold;
+      m.keymap = st.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
+      hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+      ZCHK(hipGetLastError());
+      return 0;
+    }
+  }
   int ng = pick_ng(count, topk);
   // a base that stays in the 256 MiB Infinity Cache (IVF centroids, k-means codebooks) can be re-read by
   // every query tile for free: prefer many small query tiles (more work-groups, each with a long run of
@@ -303,7 +335,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
 
   MergeArgs m{};
   m.part_s = a.part_s; m.part_i = a.part_i; m.part_keys = nullptr; m.slot_begin = nullptr;
-  m.slots_per_q = nchunks; m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.threshold = threshold;
+  m.slots_per_q = nchunks; m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = topk; m.threshold = threshold;
   m.keymap = st.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
   hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
   ZCHK(hipGetLastError());
@@ -464,7 +496,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   // 4. merge the per-(query, probe, chunk) partial lists in probe order
   MergeArgs m{};
   m.part_s = a.part_s; m.part_i = a.part_i; m.part_keys = nullptr; m.slot_begin = p.slot_begin; m.slots_per_q = 0;
-  m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.threshold = threshold; m.keymap = h->lists.keys;
+  m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = topk; m.threshold = threshold; m.keymap = h->lists.keys;
   m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
   hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
   ZCHK(hipGetLastError());
@@ -1097,7 +1129,7 @@ int zvec_hip_merge_topk_dev(zvec_hip_ctx_t ctx, const uint64_t *d_keys, const fl
   hipStream_t s = pick_stream(ctx, stream);
   MergeArgs m{};
   m.part_s = d_scores; m.part_i = nullptr; m.part_keys = d_keys; m.slot_begin = nullptr; m.slots_per_q = nparts;
-  m.slot_stride = count; m.part_counts = d_counts; m.k = topk; m.threshold = FLT_MAX; m.keymap = nullptr;
+  m.slot_stride = count; m.part_counts = d_counts; m.k = topk; m.slot_len = topk; m.threshold = FLT_MAX; m.keymap = nullptr;
   m.out_keys = d_out_keys; m.out_scores = d_out_scores; m.out_idx = nullptr; m.out_counts = d_out_counts;
   hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, s, m);
   ZCHK(hipGetLastError());
