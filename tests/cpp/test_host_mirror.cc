@@ -1,0 +1,179 @@
+// C++ parity test of the host mirror (zvec_amd/csrc/host/hip_index.h) over the C ABI, written like the
+// reference's own tests.  Expectations are those of
+//   tests/core/algorithm/flat/flat_streamer_test.cc:104-178 (TestLinearSearch), :731-801 (TestFilter)
+//   tests/core/algorithm/ivf/ivf_searcher_test.cc:200-321 (TestSimple), :2830-2886 (TestRnnSearch shape)
+// Needs a GPU.  Exit code 0 = all checks passed.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../zvec_amd/csrc/host/hip_index.h"
+
+using namespace zvec_hip_host;
+static int g_fail = 0;
+#define EXPECT(cond)                                                              \
+  do {                                                                            \
+    if (!(cond)) { printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); ++g_fail; } \
+  } while (0)
+#define ASSERT(cond)                                                              \
+  do {                                                                            \
+    if (!(cond)) { printf("FATAL %s:%d  %s\n", __FILE__, __LINE__, #cond); return 1; } \
+  } while (0)
+
+static int TestLinearSearch() {
+  constexpr size_t dim = 16;
+  IndexMeta meta(IndexMeta::DT_FP32, dim);
+  meta.set_metric("SquaredEuclidean");
+  HipFlatStreamer streamer;
+  ASSERT(0 == streamer.init(meta, Params()));
+  ASSERT(0 == streamer.open());
+  auto ctx = streamer.create_context();
+  ASSERT(!!ctx);
+  size_t cnt = 1000UL;
+  IndexQueryMeta qmeta(IndexMeta::DT_FP32, dim);
+  for (size_t i = 0; i < cnt; i++) {
+    std::vector<float> vec(dim, (float)i);
+    ASSERT(0 == streamer.add_impl(i, vec.data(), qmeta, ctx));
+  }
+  size_t topk = 3;
+  for (size_t i = 0; i < cnt; i += 7) {
+    std::vector<float> vec(dim, (float)i);
+    ctx->set_topk(topk);
+    ASSERT(0 == streamer.search_impl(vec.data(), qmeta, ctx));
+    auto &result1 = ctx->result();
+    ASSERT(topk == result1.size());
+    EXPECT(i == result1[0].key());
+    std::vector<float> got;
+    ASSERT(0 == streamer.get_vector_by_id((uint32_t)result1[0].key(), &got));
+    for (size_t j = 0; j < dim; ++j) EXPECT(got[j] == (float)i);
+    for (size_t j = 0; j < dim; ++j) vec[j] = i + 0.1f;
+    ASSERT(0 == streamer.search_impl(vec.data(), qmeta, ctx));
+    auto &result2 = ctx->result();
+    ASSERT(topk == result2.size());
+    EXPECT(i == result2[0].key());
+    EXPECT((i == cnt - 1 ? i - 1 : i + 1) == result2[1].key());
+    EXPECT((i == 0 ? 2 : (i == cnt - 1 ? i - 2 : i - 1)) == result2[2].key());
+  }
+  ctx->set_topk(100U);
+  std::vector<float> vec(dim, 10.1f);
+  ASSERT(0 == streamer.search_bf_impl(vec.data(), qmeta, ctx));
+  auto &result = ctx->result();
+  ASSERT(100U == result.size());
+  EXPECT(10 == result[0].key());
+  EXPECT(11 == result[1].key());
+  EXPECT(5 == result[10].key());
+  EXPECT(0 == result[20].key());
+  EXPECT(30 == result[30].key());
+  EXPECT(35 == result[35].key());
+  EXPECT(99 == result[99].key());
+  // error behaviour: topk not set -> InvalidArgument; wrong qmeta -> InvalidArgument
+  auto ctx2 = streamer.create_context();
+  EXPECT(IndexError_InvalidArgument == streamer.search_impl(vec.data(), qmeta, ctx2));
+  ctx2->set_topk(1);
+  IndexQueryMeta bad(IndexMeta::DT_FP32, dim + 1);
+  EXPECT(IndexError_InvalidArgument == streamer.search_impl(vec.data(), bad, ctx2));
+  return 0;
+}
+
+static int TestFilter() {
+  constexpr size_t dim = 16;
+  IndexMeta meta(IndexMeta::DT_FP32, dim);
+  meta.set_metric("SquaredEuclidean");
+  HipFlatStreamer streamer;
+  ASSERT(0 == streamer.init(meta, Params()));
+  ASSERT(0 == streamer.open());
+  auto ctx = streamer.create_context();
+  ASSERT(!!ctx);
+  ctx->set_topk(10U);
+  IndexQueryMeta qmeta(IndexMeta::DT_FP32, dim);
+  size_t cnt = 2000;
+  std::vector<float> all(cnt * dim);
+  for (size_t i = 0; i < cnt; i++) for (size_t j = 0; j < dim; ++j) all[i * dim + j] = (float)i;
+  ASSERT(0 == streamer.add_batch(all.data(), cnt, nullptr));
+  std::vector<float> vec(dim, 100.1f);
+  ASSERT(0 == streamer.search_impl(vec.data(), qmeta, ctx));
+  auto &results = ctx->result();
+  ASSERT(10 == results.size());
+  EXPECT(100 == results[0].key());
+  EXPECT(101 == results[1].key());
+  EXPECT(99 == results[2].key());
+  auto filterFunc = [](uint64_t key) { return key == 100UL || key == 101UL; };
+  ctx->set_filter(filterFunc);
+  ASSERT(0 == streamer.search_impl(vec.data(), qmeta, ctx));
+  auto &results1 = ctx->result();
+  ASSERT(10 == results1.size());
+  EXPECT(99 == results1[0].key());
+  EXPECT(102 == results1[1].key());
+  EXPECT(98 == results1[2].key());
+  ASSERT(0 == streamer.search_bf_impl(vec.data(), qmeta, ctx));
+  auto &results2 = ctx->result();
+  ASSERT(10 == results2.size());
+  EXPECT(99 == results2[0].key());
+  EXPECT(102 == results2[1].key());
+  EXPECT(98 == results2[2].key());
+  return 0;
+}
+
+static int TestIVFSimple() {
+  constexpr uint32_t dimension_ = 8;
+  IndexMeta meta(IndexMeta::DT_FP32, dimension_);
+  meta.set_metric("SquaredEuclidean");
+  const size_t n = 33;
+  std::vector<float> base(n * dimension_), centroid(dimension_, 16.0f);
+  std::vector<uint64_t> keys(n), offs = {0, n};
+  for (size_t i = 0; i < n; ++i) { keys[i] = i; for (size_t j = 0; j < dimension_; ++j) base[i * dimension_ + j] = 1.0f * i; }
+  HipIVFSearcher searcher;
+  Params params;
+  params.set(PARAM_IVF_SEARCHER_SCAN_RATIO, 1.0);
+  params.set(PARAM_IVF_SEARCHER_BRUTE_FORCE_THRESHOLD, 1);
+  ASSERT(0 == searcher.init(params));
+  EXPECT(nullptr == searcher.create_context());                  // not loaded yet
+  ASSERT(0 == searcher.load(meta, centroid.data(), 1, offs.data(), base.data(), keys.data()));
+  std::vector<float> query(dimension_, 32.0f);
+  size_t qnum = 33;
+  std::vector<float> query1;
+  for (size_t i = 0; i < dimension_ * qnum; ++i) query1.push_back((float)(i / dimension_));
+  auto context = searcher.create_context();
+  ASSERT(!!context);
+  IndexQueryMeta qmeta(IndexMeta::DT_FP32, dimension_);
+  for (int pass = 0; pass < 2; ++pass) {   // pass 0: bf search, pass 1: knn search
+    size_t topk = 33;
+    context->set_topk(topk);
+    int ret = pass == 0 ? searcher.search_bf_impl(query.data(), qmeta, context) : searcher.search_impl(query.data(), qmeta, context);
+    ASSERT(0 == ret);
+    const IndexDocumentList &result = context->result(0);
+    ASSERT(topk == result.size());
+    for (size_t i = 0; i < topk; ++i) {
+      EXPECT((uint64_t)32 - i == result[i].key());
+      EXPECT((float)i * i * dimension_ == result[i].score());
+    }
+    topk = 1;
+    context->set_topk(topk);
+    ret = pass == 0 ? searcher.search_bf_impl(query1.data(), qmeta, qnum, context) : searcher.search_impl(query1.data(), qmeta, qnum, context);
+    ASSERT(0 == ret);
+    for (size_t q = 0; q < qnum; ++q) {
+      const IndexDocumentList &r = context->result(q);
+      ASSERT(topk == r.size());
+      EXPECT((uint64_t)q == r[0].key());
+      EXPECT((float)0 == r[0].score());
+    }
+  }
+  // RNN radius (TestRnnSearch shape): fewer than topk, all within the radius
+  context->set_topk(33);
+  context->set_threshold(100.0f);
+  ASSERT(0 == searcher.search_impl(query.data(), qmeta, context));
+  EXPECT(context->result().size() < 33 && context->result().size() > 0);
+  for (auto &d : context->result()) EXPECT(d.score() <= 100.0f);
+  EXPECT(0 == searcher.unload());
+  return 0;
+}
+
+int main() {
+  int rc = 0;
+  rc |= TestLinearSearch();
+  rc |= TestFilter();
+  rc |= TestIVFSimple();
+  if (rc == 0 && g_fail == 0) { printf("host mirror: all tests passed\n"); return 0; }
+  printf("host mirror: %d failures (rc=%d)\n", g_fail, rc);
+  return 1;
+}

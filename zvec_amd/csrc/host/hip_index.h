@@ -1,0 +1,331 @@
+// hip_index.h — C++ host side above the C ABI (include/zvec_hip.h): the reference's index-operator
+// surface for the flat / IVF scan path, same names, argument meaning and error behaviour, so that
+// (a) tests read like the reference's own (tests/cpp/test_host_mirror.cc), and
+// (b) the real drop-in subclasses of core::IndexStreamer / core::IndexSearcher shown in INTEGRATION.md
+//     are line-for-line forwards of these bodies (they only swap these mirror types for the framework's).
+//
+// Mirrors (reference file:line):
+//   IndexMeta / IndexQueryMeta   src/include/zvec/core/framework/index_meta.h:27-50,525-580
+//   IndexDocument(+List)         src/include/zvec/core/framework/index_document.h:69-218,313
+//   IndexFilter                  src/include/zvec/core/framework/index_filter.h:22-71   (true = EXCLUDE)
+//   IndexContext                 src/include/zvec/core/framework/index_context.h:123-262
+//   IndexRunner operators        src/include/zvec/core/framework/index_runner.h:440-531
+//   FlatStreamer / FlatSearcher  src/core/algorithm/flat/flat_streamer.cc:304-389, flat_searcher.cc:162-211
+//   IVFSearcher (+Context)       src/core/algorithm/ivf/ivf_searcher.cc:183-250, ivf_searcher_context.h:61-79
+// Header-only, no framework dependency; link with -lzvec_hip.
+#pragma once
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/zvec_hip.h"
+
+namespace zvec_hip_host {
+
+// IndexError values (src/core/framework/index_error.cc:20-71)
+enum : int {
+  IndexError_Success = 0,
+  IndexError_Runtime = -1,
+  IndexError_Unsupported = -12,
+  IndexError_NoExist = -22,
+  IndexError_Mismatch = -24,
+  IndexError_InvalidArgument = -31,
+  IndexError_NoIndexLoaded = -204,
+};
+
+struct IndexMeta {
+  enum DataType { DT_UNDEFINED = 0, DT_FP32 = 1 };
+  IndexMeta() {}
+  IndexMeta(DataType t, uint32_t dim) : type_(t), dimension_(dim) {}
+  void set_metric(const std::string &name, uint32_t /*revision*/ = 0) { metric_ = name; }
+  const std::string &metric_name() const { return metric_; }
+  DataType data_type() const { return type_; }
+  uint32_t dimension() const { return dimension_; }
+  uint32_t element_size() const { return dimension_ * 4u; }
+  DataType type_{DT_FP32};
+  uint32_t dimension_{0};
+  std::string metric_{"SquaredEuclidean"};
+};
+
+struct IndexQueryMeta {
+  IndexQueryMeta() {}
+  IndexQueryMeta(IndexMeta::DataType t, uint32_t dim) : type_(t), dimension_(dim) {}
+  uint32_t dimension() const { return dimension_; }
+  uint32_t element_size() const { return dimension_ * 4u; }
+  IndexMeta::DataType data_type() const { return type_; }
+  IndexMeta::DataType type_{IndexMeta::DT_FP32};
+  uint32_t dimension_{0};
+};
+
+// string-keyed parameter bag (ailego::Params subset); keys as in ivf_params.h:25-78
+class Params {
+ public:
+  void set(const std::string &k, double v) { kv_[k] = v; }
+  bool get(const std::string &k, double *v) const {
+    auto it = kv_.find(k);
+    if (it == kv_.end()) return false;
+    *v = it->second;
+    return true;
+  }
+ private:
+  std::map<std::string, double> kv_;
+};
+static const char *const PARAM_IVF_SEARCHER_SCAN_RATIO = "proxima.ivf.searcher.scan_ratio";
+static const char *const PARAM_IVF_SEARCHER_BRUTE_FORCE_THRESHOLD = "proxima.ivf.searcher.brute_force_threshold";
+
+class IndexDocument {
+ public:
+  IndexDocument() {}
+  IndexDocument(uint64_t k, float s) : key_(k), score_(s) {}
+  uint64_t key() const { return key_; }
+  float score() const { return score_; }
+  bool operator<(const IndexDocument &rhs) const { return score_ < rhs.score_; }   // index_document.h:143
+ private:
+  uint64_t key_{0};
+  float score_{0.f};
+};
+using IndexDocumentList = std::vector<IndexDocument>;
+
+class IndexFilter {
+ public:
+  template <typename T> void set(T &&fn) { fn_ = std::forward<T>(fn); }
+  void reset() { fn_ = nullptr; }
+  bool is_valid() const { return (bool)fn_; }
+  bool operator()(uint64_t key) const { return fn_ ? fn_(key) : false; }   // true => filtered OUT
+ private:
+  std::function<bool(uint64_t)> fn_;
+};
+
+inline int metric_from_name(const std::string &name) {
+  if (name == "SquaredEuclidean") return ZVEC_HIP_METRIC_L2;
+  if (name == "InnerProduct") return ZVEC_HIP_METRIC_IP;
+  if (name == "Cosine") return ZVEC_HIP_METRIC_COSINE;
+  return -1;
+}
+
+// IndexContext for this path: topk, filter, RNN threshold, result lists, one HIP stream + workspace.
+class Context {
+ public:
+  using Pointer = std::unique_ptr<Context>;
+  explicit Context(int device, uint32_t magic) : magic_(magic) { rc_ = zvec_hip_ctx_create(device, &h_); }
+  ~Context() { if (h_) zvec_hip_ctx_destroy(h_); }
+  bool ok() const { return rc_ == 0; }
+  void set_topk(uint32_t k) { topk_ = k; }
+  uint32_t topk() const { return topk_; }
+  void set_threshold(float v) { threshold_ = v; }
+  float threshold() const { return threshold_; }
+  template <typename T> void set_filter(T &&fn) { filter_.set(std::forward<T>(fn)); }
+  void reset_filter() { filter_.reset(); }
+  const IndexFilter &filter() const { return filter_; }
+  // side channel of SURVEY H4: an already materialised predicate (1 bit per storage position)
+  void set_exclude_bitset(std::vector<uint64_t> words) { bits_ = std::move(words); has_bits_ = true; }
+  const IndexDocumentList &result() const { return results_.at(0); }
+  const IndexDocumentList &result(size_t i) const { return results_.at(i); }
+  IndexDocumentList *mutable_result(size_t i) { return &results_.at(i); }
+  uint32_t magic() const { return magic_; }
+  void set_magic(uint32_t m) { magic_ = m; }
+  zvec_hip_ctx_t handle() const { return h_; }
+
+  // host sweep of the callback over the keys of the storage positions -> bitset
+  const uint64_t *materialise(const std::vector<uint64_t> &keys_by_position) {
+    if (has_bits_) return bits_.data();
+    if (!filter_.is_valid()) return nullptr;
+    bits_.assign((keys_by_position.size() + 63) / 64, 0);
+    for (size_t i = 0; i < keys_by_position.size(); ++i)
+      if (filter_(keys_by_position[i])) bits_[i >> 6] |= (1ull << (i & 63));
+    return bits_.data();
+  }
+  void take(uint32_t count, uint32_t topk, const std::vector<uint64_t> &keys, const std::vector<float> &scores,
+            const std::vector<uint32_t> &counts) {
+    results_.assign(count, IndexDocumentList());
+    for (uint32_t q = 0; q < count; ++q) {
+      results_[q].reserve(counts[q]);
+      for (uint32_t j = 0; j < counts[q]; ++j) results_[q].emplace_back(keys[(size_t)q * topk + j], scores[(size_t)q * topk + j]);
+    }
+  }
+ private:
+  zvec_hip_ctx_t h_{nullptr};
+  int rc_{0};
+  uint32_t magic_{0};
+  uint32_t topk_{0};
+  float threshold_{FLT_MAX};
+  IndexFilter filter_;
+  std::vector<uint64_t> bits_;
+  bool has_bits_{false};
+  std::vector<IndexDocumentList> results_{1};
+};
+
+// ---- flat: one class body serves the "FlatStreamer" and "FlatSearcher" registrations -------------
+class HipFlatStreamer {
+ public:
+  ~HipFlatStreamer() { close(); }
+  int init(const IndexMeta &meta, const Params & /*params*/) {
+    meta_ = meta;
+    metric_ = metric_from_name(meta.metric_name());
+    if (metric_ < 0 || meta.data_type() != IndexMeta::DT_FP32) return IndexError_Unsupported;
+    return 0;
+  }
+  int open(int device = 0) {
+    device_ = device;
+    static uint32_t next_magic = 0x48495031u;
+    magic_ = next_magic++;
+    return zvec_hip_flat_create(meta_.dimension(), ZVEC_HIP_DT_FP32, metric_, device, &h_);
+  }
+  int close() { int rc = h_ ? zvec_hip_flat_destroy(h_) : 0; h_ = nullptr; return rc; }
+  const IndexMeta &meta() const { return meta_; }
+  uint32_t magic() const { return magic_; }
+  Context::Pointer create_context() const {
+    if (!h_) return nullptr;
+    Context::Pointer c(new Context(device_, magic_));
+    return c->ok() ? std::move(c) : nullptr;
+  }
+  //! Add a vector into index (index_runner.h:476-480)
+  int add_impl(uint64_t key, const void *query, const IndexQueryMeta &qmeta, Context::Pointer & /*context*/) {
+    if (!h_ || !query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
+    int rc = zvec_hip_flat_append(h_, query, 1, &key);
+    if (rc == 0) keys_.push_back(key);
+    return rc;
+  }
+  //! bulk form used by FlatBuilder::build / FlatSearcher::load (flat_builder.cc:188-276)
+  int add_batch(const void *vecs, uint64_t n, const uint64_t *keys) {
+    if (!h_) return IndexError_InvalidArgument;
+    int rc = zvec_hip_flat_append(h_, vecs, n, keys);
+    if (rc == 0) for (uint64_t i = 0; i < n; ++i) keys_.push_back(keys ? keys[i] : keys_.size());
+    return rc;
+  }
+  //! Similarity search (index_runner.h:490-500)
+  int search_impl(const void *query, const IndexQueryMeta &qmeta, Context::Pointer &context) const {
+    return search_impl(query, qmeta, 1, context);
+  }
+  int search_impl(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context) const {
+    if (!h_ || !query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
+    Context *ctx = context.get();
+    if (!ctx || ctx->topk() == 0) return IndexError_InvalidArgument;    // flat_searcher.cc:194-198
+    if (ctx->magic() != magic_) ctx->set_magic(magic_);                 // context made by another index: re-bind
+    const uint32_t k = ctx->topk();
+    std::vector<uint64_t> keys((size_t)count * k);
+    std::vector<float> scores((size_t)count * k);
+    std::vector<uint32_t> counts(count);
+    int rc = zvec_hip_flat_search(h_, ctx->handle(), query, count, k, ctx->threshold(), ctx->materialise(keys_),
+                                  keys.data(), scores.data(), counts.data());
+    if (rc != 0) return rc;
+    ctx->take(count, k, keys, scores, counts);
+    return 0;
+  }
+  //! Similarity brute force search (index_runner.h:520-531): the flat scan is the brute force
+  int search_bf_impl(const void *query, const IndexQueryMeta &qmeta, Context::Pointer &context) const {
+    return search_impl(query, qmeta, 1, context);
+  }
+  int search_bf_impl(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context) const {
+    return search_impl(query, qmeta, count, context);
+  }
+  //! Fetch vector by id (index_runner.h:445-453)
+  int get_vector_by_id(uint32_t id, std::vector<float> *out) const {
+    if (!h_) return IndexError_InvalidArgument;
+    out->resize(meta_.dimension());
+    return zvec_hip_flat_get_vector(h_, id, out->data());
+  }
+  uint64_t count() const { uint64_t n = 0; if (h_) zvec_hip_flat_count(h_, &n); return n; }
+ protected:
+  IndexMeta meta_;
+  int metric_{0};
+  int device_{0};
+  uint32_t magic_{0};
+  zvec_hip_flat_t h_{nullptr};
+  std::vector<uint64_t> keys_;
+};
+using HipFlatSearcher = HipFlatStreamer;
+
+// ---- IVF -----------------------------------------------------------------------------------------
+class HipIVFSearcher {
+ public:
+  ~HipIVFSearcher() { unload(); }
+  int init(const Params &params) {
+    double v;
+    if (params.get(PARAM_IVF_SEARCHER_SCAN_RATIO, &v)) scan_ratio_ = (float)v;
+    if (params.get(PARAM_IVF_SEARCHER_BRUTE_FORCE_THRESHOLD, &v)) bruteforce_threshold_ = (uint32_t)v;
+    if (scan_ratio_ <= 0.0f) return IndexError_InvalidArgument;   // ivf_searcher_context.h:65-69
+    return 0;
+  }
+  //! what IVFSearcher::load reads from the ivf.* segments (ivf_index_format.h:26-60,152-164)
+  int load(const IndexMeta &meta, const float *centroids, uint32_t nlist, const uint64_t *list_offsets,
+           const float *vecs, const uint64_t *keys, int device = 0) {
+    meta_ = meta;
+    int metric = metric_from_name(meta.metric_name());
+    if (metric < 0) return IndexError_Unsupported;
+    device_ = device;
+    static uint32_t next_magic = 0x49564631u;
+    magic_ = next_magic++;
+    int rc = zvec_hip_ivf_create(meta.dimension(), ZVEC_HIP_DT_FP32, metric, device, &h_);
+    if (rc != 0) return rc;
+    rc = zvec_hip_ivf_load(h_, centroids, nlist, list_offsets, vecs, keys);
+    if (rc != 0) return rc;
+    nlist_ = nlist;
+    count_ = list_offsets[nlist];
+    keys_.resize(count_);
+    for (uint64_t i = 0; i < count_; ++i) keys_[i] = keys ? keys[i] : i;
+    return 0;
+  }
+  int unload() { int rc = h_ ? zvec_hip_ivf_destroy(h_) : 0; h_ = nullptr; return rc; }
+  Context::Pointer create_context() const {
+    if (!h_) return nullptr;                                   // "Load the index first" ivf_searcher.cc:257-260
+    Context::Pointer c(new Context(device_, magic_));
+    return c->ok() ? std::move(c) : nullptr;
+  }
+  // IVFSearcherContext::update (ivf_searcher_context.h:61-79)
+  uint32_t nprobe() const { return std::max<uint32_t>((uint32_t)std::round((float)nlist_ * scan_ratio_), 1u); }
+  uint32_t max_scan_count() const {
+    uint32_t m = (uint32_t)std::ceil((float)count_ * scan_ratio_);
+    return std::max(bruteforce_threshold_, m);
+  }
+  int search_impl(const void *query, const IndexQueryMeta &qmeta, Context::Pointer &context) const {
+    return search_impl(query, qmeta, 1, context);
+  }
+  int search_impl(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context) const {
+    if (h_ && count_ <= bruteforce_threshold_) return search_bf_impl(query, qmeta, count, context);   // ivf_searcher.cc:188-190
+    return run(query, qmeta, count, context, false);
+  }
+  int search_bf_impl(const void *query, const IndexQueryMeta &qmeta, Context::Pointer &context) const {
+    return run(query, qmeta, 1, context, true);
+  }
+  int search_bf_impl(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context) const {
+    return run(query, qmeta, count, context, true);
+  }
+ private:
+  int run(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context, bool bf) const {
+    if (!h_) return IndexError_NoIndexLoaded;
+    if (!query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;   // ivf_searcher.cc:191-194
+    Context *ctx = context.get();
+    if (!ctx || ctx->topk() == 0) return IndexError_InvalidArgument;                                 // ivf_searcher.cc:197-200
+    if (ctx->magic() != magic_) ctx->set_magic(magic_);
+    const uint32_t k = ctx->topk();
+    std::vector<uint64_t> keys((size_t)count * k);
+    std::vector<float> scores((size_t)count * k);
+    std::vector<uint32_t> counts(count);
+    const uint64_t *bits = ctx->materialise(keys_);
+    int rc = bf ? zvec_hip_ivf_search_bf(h_, ctx->handle(), query, count, k, ctx->threshold(), bits, keys.data(),
+                                         scores.data(), counts.data())
+                : zvec_hip_ivf_search(h_, ctx->handle(), query, count, k, ctx->threshold(), nprobe(), max_scan_count(),
+                                      bits, keys.data(), scores.data(), counts.data());
+    if (rc != 0) return rc;
+    ctx->take(count, k, keys, scores, counts);
+    return 0;
+  }
+  IndexMeta meta_;
+  int device_{0};
+  uint32_t magic_{0};
+  zvec_hip_ivf_t h_{nullptr};
+  uint32_t nlist_{0};
+  uint64_t count_{0};
+  float scan_ratio_{0.1f};                 // kDefaultScanRatio  ivf_searcher_context.h:211
+  uint32_t bruteforce_threshold_{1000u};   // kDefaultBfThreshold ivf_searcher_context.h:212
+  std::vector<uint64_t> keys_;
+};
+
+}  // namespace zvec_hip_host
