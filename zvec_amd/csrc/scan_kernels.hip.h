@@ -78,6 +78,7 @@ struct ScanArgs {
   const uint32_t *csr_slot;     // output slot of (query, probe rank), chunk 0
   uint32_t nlist;
   uint64_t ndense;              // number of dense positions (bits of `exclude`)
+  uint32_t *gtau;               // [nq] query-wide admission bounds (keys, see fkey), initialised to fkey(threshold)
   // dense-score mode (small cache-resident bases, e.g. the IVF coarse step): instead of admitting
   // into top-k lists the kernel writes every score to dump[query][padded position]; selection is then
   // done by merge_kernel over whole rows (one wave per query)
@@ -91,7 +92,7 @@ struct ScanArgs {
 // LDS footprint in bytes for a given NG / k (host mirrors this)
 __host__ __device__ inline size_t scan_lds_bytes(int ng, uint32_t k, bool m16 = false) {
   size_t rows = m16 ? 16 : (size_t)ng * QGROUP;
-  return (2 * rows * TILE_K + 2 * (size_t)SLAB + 5 * rows + 4 + 2 * rows * k) * 4;
+  return (2 * rows * TILE_K + 2 * (size_t)SLAB + 6 * rows + 4 + 2 * rows * k) * 4;
 }
 
 // broadcast of lane `l` (wave-uniform index) without touching the LDS crossbar: v_readlane_b32
@@ -102,12 +103,25 @@ __device__ __forceinline__ uint32_t bcast_u(uint32_t v, int l) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
 
+// order-preserving float <-> uint32 map (so that atomicMin on the key is a float min, negative IP scores included)
+__device__ __forceinline__ uint32_t fkey(float f) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  const uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __builtin_bit_cast(float, b);
+}
+
 struct RowState {
   float *tau;        // admission bound per row: threshold until the list is full, then its k-th score
   uint32_t *cnt;
   float *Ls;         // [rows][k] scores, ascending (score, position)
   uint32_t *Li;      // [rows][k] positions
   uint32_t k;
+  float *gt;         // [rows] query-wide bound fetched from gtau at the start of the tile epilogue
+  uint32_t *gtau;    // global [nq] keys: min over all work-groups of a FULL local list's k-th score
+  const uint32_t *qrow;  // [rows] global query row of each local row
 };
 
 // Whole-wave insertion of candidate (s, o, i) into a bounded list kept SORTED ascending by
@@ -193,7 +207,12 @@ __device__ __forceinline__ bool sorted_insert(float *L, uint32_t *O, uint32_t *I
 // Owner-wave admission of one row of the score tile: lane holds the scores of columns 2*lane and
 // 2*lane+1 (s0, s1); pos0 = padded position of column 0 of the tile.
 __device__ __forceinline__ void owner_row(const RowState &st, int row, float s0, float s1, uint32_t pos0, int lane) {
-  float t = st.tau[row];
+  // admission bound = min(this list's k-th score, the query-wide bound shared by every work-group that
+  // scans for the same query).  A score above the shared bound cannot be in the final top-k: some
+  // work-group already holds k candidates at or below it.  Ties (==) are kept; the merge orders them.
+  float tl = st.tau[row];
+  const float tg = st.gt[row];
+  float t = fminf(tl, tg);
   uint64_t m0 = __ballot(s0 <= t);
   uint64_t m1 = __ballot(s1 <= t);
   if ((m0 | m1) == 0) return;
@@ -201,6 +220,7 @@ __device__ __forceinline__ void owner_row(const RowState &st, int row, float s0,
   uint32_t c = st.cnt[row];
   float *L = st.Ls + (size_t)row * k;
   uint32_t *I = st.Li + (size_t)row * k;
+  bool improved = false;
   while ((m0 | m1) != 0) {
     int l;
     float cs;
@@ -216,14 +236,17 @@ __device__ __forceinline__ void owner_row(const RowState &st, int row, float s0,
       ci = pos0 + 2u * (uint32_t)l + 1u;
       m1 &= m1 - 1;
     }
-    if (sorted_insert<false>(L, nullptr, I, k, c, cs, 0u, ci, lane, t)) {
+    if (sorted_insert<false>(L, nullptr, I, k, c, cs, 0u, ci, lane, tl)) {
+      improved = true;
+      t = fminf(tl, tg);
       m0 &= __ballot(s0 <= t);
       m1 &= __ballot(s1 <= t);
     }
   }
   if (lane == 0) {
     st.cnt[row] = c;
-    st.tau[row] = t;
+    st.tau[row] = tl;
+    if (improved && c == k && tl < tg) atomicMin(&st.gtau[st.qrow[row]], fkey(tl));
   }
 }
 
@@ -297,7 +320,10 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
   uint32_t *slot_s = qrow_s + ROWS;
   uint32_t *item_s = slot_s + ROWS;          // [4] work-queue hand-off word
   st.k = a.k;
-  st.Ls = reinterpret_cast<float *>(item_s + 4);
+  st.gt = reinterpret_cast<float *>(item_s + 4);
+  st.gtau = a.gtau;
+  st.qrow = qrow_s;
+  st.Ls = st.gt + ROWS;
   st.Li = reinterpret_cast<uint32_t *>(st.Ls + (size_t)ROWS * a.k);
 
   const int tid = threadIdx.x;
@@ -382,6 +408,7 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
       slot_s[j] = slot;
       qn_s[j] = (a.metric == METRIC_L2) ? a.qnorm[qrow] : 0.f;
       st.tau[j] = a.threshold;
+      st.gt[j] = a.threshold;
       st.cnt[j] = 0;
     }
     __syncthreads();
@@ -490,7 +517,7 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
         } else {
           const int brow = wave * 32 + r;
           const int swz = (r >> 1) & 7;
-          constexpr int KK_UNROLL = (NG >= 4) ? 1 : 4;   // keep the A-fragment live range short when NG is large
+          constexpr int KK_UNROLL = (NG >= 4) ? 2 : 4;   // keep the A-fragment live range short when NG is large
 #pragma unroll KK_UNROLL
           for (int kk = 0; kk < 4; ++kk) {
             const int c = (2 * kk + h) ^ swz;
@@ -513,6 +540,9 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
       // buffer that is idle during this step (16 KiB) and every row is then admitted by ONE owner wave
       // (row i of the group belongs to wave i % 4): no locks, no atomics.
       if (ks == nks - 1) {
+        if (a.dump == nullptr)
+          for (int j = tid; j < ROWS; j += 256)    // refresh the query-wide bounds (visible after the barrier below)
+            st.gt[j] = fkey_inv(__hip_atomic_load(&a.gtau[qrow_s[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         float *Sc = Bs + (buf ^ 1) * SLAB;                                  // [<=32 rows][128 cols]
         const uint32_t local0 = (tile - tile0) * TILE_N + wave * 32;        // row index inside list/store, lane 0
         const uint32_t pos0 = tile * TILE_N;                                // padded position of column 0
@@ -729,7 +759,7 @@ __global__ void __launch_bounds__(256) zero_rows_kernel(float *base, float *bnor
 // queries [nq][dim_in] -> padded row-major [nq][dpad] + squared norms
 __global__ void __launch_bounds__(256) prep_queries_kernel(const float *src, uint32_t nq, uint32_t dim_in,
                                                            uint32_t dscan, uint32_t dpad, float *dst,
-                                                           float *qnorm) {
+                                                           float *qnorm, uint32_t *gtau, float threshold) {
   const int lane = threadIdx.x & 63;
   uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= nq) return;
@@ -742,7 +772,10 @@ __global__ void __launch_bounds__(256) prep_queries_kernel(const float *src, uin
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if (lane == 0) qnorm[i] = acc;
+  if (lane == 0) {
+    qnorm[i] = acc;
+    gtau[i] = fkey(threshold);
+  }
 }
 
 // blocked row -> plain row (get_vector_by_id)
@@ -751,6 +784,11 @@ __global__ void unpack_row_kernel(const float *base, const float *extra, uint64_
   for (uint32_t c = threadIdx.x; c < dim_out; c += blockDim.x) {
     out[c] = (c < dscan) ? base[blocked_offset(pos, c, dpad)] : (extra ? extra[pos] : 0.f);
   }
+}
+
+__global__ void fill_gtau_kernel(uint32_t *gtau, uint32_t n, float threshold) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) gtau[i] = fkey(threshold);
 }
 
 __global__ void fill_keys_kernel(uint64_t *keys, uint64_t pos0, uint64_t n, const uint64_t *src) {

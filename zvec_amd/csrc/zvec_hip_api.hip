@@ -112,6 +112,7 @@ struct zvec_hip_ctx_s {
   hipStream_t cur = nullptr;
   std::mutex mu;
   // workspace
+  DevBuf gtau;
   DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
   DevBuf plan;        // all u32 plan arrays
   DevBuf io_q, io_ex, io_keys, io_scores, io_counts;   // staging for host-pointer entry points
@@ -285,6 +286,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
       a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
       a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = 1; a.threshold = threshold;
       a.mode = 0; a.nq = count; a.n = st.n; a.ndense = st.n; a.tiles_per_chunk = 1; a.nchunks = (uint32_t)ntiles_d; a.nqtiles = nqt;
+      a.gtau = ctx->gtau.as<uint32_t>();
       a.dump = ctx->part_s.as<float>(); a.dump_stride = (uint32_t)(ntiles_d * TILE_N);
       a.part_s = nullptr; a.part_i = nullptr;
       ZRET(launch_scan_ng(ngd, a, (uint32_t)ntiles_d * nqt, cus_d, stream));
@@ -322,6 +324,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   a.base = st.base; a.bnorm = st.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
   a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
   a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = topk; a.threshold = threshold;
+  a.gtau = ctx->gtau.as<uint32_t>();
   a.mode = 0; a.nq = count; a.n = st.n; a.ndense = st.n; a.tiles_per_chunk = (uint32_t)tpc; a.nchunks = nchunks; a.nqtiles = nqtiles;
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
   int pi = -1;
@@ -342,11 +345,21 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   return 0;
 }
 
-int prep_queries(zvec_hip_ctx_s *ctx, const Store &st, const float *d_queries, uint32_t count, hipStream_t stream) {
+int reset_gtau(zvec_hip_ctx_s *ctx, uint32_t count, float threshold, hipStream_t stream) {
+  ZRET(ctx->gtau.ensure((size_t)count * sizeof(uint32_t)));
+  hipLaunchKernelGGL(fill_gtau_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, ctx->gtau.as<uint32_t>(), count, threshold);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int prep_queries(zvec_hip_ctx_s *ctx, const Store &st, const float *d_queries, uint32_t count, float threshold,
+                 hipStream_t stream) {
   ZRET(ctx->qpad.ensure((size_t)count * st.dpad * sizeof(float)));
   ZRET(ctx->qnorm.ensure((size_t)count * sizeof(float)));
+  ZRET(ctx->gtau.ensure((size_t)count * sizeof(uint32_t)));
   hipLaunchKernelGGL(prep_queries_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, d_queries, count,
-                     st.dim_in, st.dscan, st.dpad, ctx->qpad.as<float>(), ctx->qnorm.as<float>());
+                     st.dim_in, st.dscan, st.dpad, ctx->qpad.as<float>(), ctx->qnorm.as<float>(),
+                     ctx->gtau.as<uint32_t>(), threshold);
   ZCHK(hipGetLastError());
   return 0;
 }
@@ -389,7 +402,7 @@ void ctx_free(zvec_hip_ctx_s *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own) (void)hipStreamSynchronize(c->own);
-  c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
+  c->gtau.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
   c->coarse_keys.release(); c->coarse_scores.release(); c->coarse_idx.release(); c->coarse_cnt.release();
   c->plan.release(); c->io_q.release(); c->io_ex.release(); c->io_keys.release(); c->io_scores.release();
   c->io_counts.release(); c->stats.release();
@@ -407,7 +420,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   const uint32_t nlist = h->nlist;
   if (nprobe < 1) nprobe = 1;
   if (nprobe > nlist) nprobe = nlist;
-  ZRET(prep_queries(ctx, h->lists, d_queries, count, stream));
+  ZRET(prep_queries(ctx, h->lists, d_queries, count, FLT_MAX, stream));   // coarse pass: no RNN radius
 
   // 1. coarse assign: flat scan over the centroids, k = nprobe (IVFCentroidIndex::search)
   if (!brute_force) {
@@ -482,6 +495,8 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   a.base = h->lists.base; a.bnorm = h->lists.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
   a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
   a.dpad = h->lists.dpad; a.nks = h->lists.dpad / TILE_K; a.metric = h->metric; a.k = topk; a.threshold = threshold;
+  ZRET(reset_gtau(ctx, count, threshold, stream));   // the coarse pass may have left centroid-score bounds behind
+  a.gtau = ctx->gtau.as<uint32_t>();
   a.mode = 1; a.nq = count; a.n = h->lists.n; a.ndense = h->count_local; a.tiles_per_chunk = TPC;
   a.total_items = p.total_items; a.queue = pb + o_queue; a.list_order = h->d_order; a.item_off = p.item_off; a.list_tile0 = h->d_tile0; a.list_size = h->d_size;
   a.list_dense0 = h->d_dense0; a.list_qoff = p.list_qoff; a.csr_q = p.csr_q; a.csr_slot = p.csr_slot; a.nlist = nlist;
@@ -686,7 +701,7 @@ int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *
   std::lock_guard<std::mutex> g(c->mu);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(c, stream);
-  ZRET(prep_queries(c, h->st, reinterpret_cast<const float *>(d_queries), count, s));
+  ZRET(prep_queries(c, h->st, reinterpret_cast<const float *>(d_queries), count, threshold, s));
   SearchOut out{d_out_keys, d_out_scores, nullptr, d_out_counts};
   return flat_scan_prepared(c, h->st, count, topk, threshold, d_exclude_bitset, out, s, true);
 }
@@ -932,7 +947,7 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
   auto assign = [&](const float *q, uint64_t nq, uint32_t *host_labels) -> int {
     for (uint64_t o = 0; o < nq; o += BATCH) {
       uint32_t m = (uint32_t)std::min<uint64_t>(BATCH, nq - o);
-      ZRET(prep_queries(c, cs, q + (size_t)o * dim, m, s));
+      ZRET(prep_queries(c, cs, q + (size_t)o * dim, m, FLT_MAX, s));
       SearchOut out{d_lab_keys, d_lab_scores, d_lab_idx, d_lab_cnt};
       ZRET(flat_scan_prepared(c, cs, m, 1, FLT_MAX, nullptr, out, s, false));
       ZCHK(hipMemcpyAsync(host_labels + o, d_lab_idx, (size_t)m * 4, hipMemcpyDeviceToHost, s));
