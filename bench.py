@@ -94,6 +94,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the scan core has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one explicit HIP stream for everything (torch ops, the scan library, RCCL): torch's legacy default
+    # stream has handle 0, which the C ABI would read as "the context's own stream"
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)

@@ -1,0 +1,76 @@
+"""Sharded IVF on the GPU, single process: the index is cut into `world` shards by inverted list
+(zvec_hip_ivf_keep_shard, the partition bench.py uses across ranks), every shard answers the whole
+batch, the candidate lists are merged with zvec_hip_merge_topk_dev — the result must equal the
+unsharded search and the oracle.  Covers everything of the N>1 path except the RCCL transport
+(which tests/test_dist_cpu.py covers over gloo)."""
+import numpy as np
+import pytest
+
+from tests.util import tie_tolerant_compare, kmeans_lists
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_search_equals_unsharded(oracle, world):
+    import zvec_amd
+    from zvec_amd.index import merge_topk
+    rng = np.random.default_rng(100 + world)
+    n, dim, nlist, nq, k = 20000, 64, 96, 150, 10
+    base = rng.integers(0, 64, (n, dim)).astype(np.float32)
+    q = rng.integers(0, 64, (nq, dim)).astype(np.float32)
+    cent, offs, order = kmeans_lists(rng, base, nlist)
+    cent = np.round(cent)
+    vecs, keys = base[order], order.astype(np.uint64)
+
+    def make(shard, nshards):
+        se = zvec_amd.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=12 / 96., brute_force_threshold=100)
+        assert se.set_shard(shard, nshards) == 0
+        assert se.load(cent, offs, vecs, keys) == 0
+        se.total_count = n                      # probe parameters come from the WHOLE index
+        return se
+
+    full = make(0, 1)
+    nprobe, max_scan = full.probe_params()
+    ctx = full.create_context()
+    ctx.set_topk(k)
+    assert full.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys)
+    parts_k, parts_s, parts_c = [], [], []
+    total_rows = 0
+    for r in range(world):
+        sh = make(r, world)
+        total_rows += sh.info()[0]
+        c = sh.create_context()
+        c.set_topk(k)
+        assert sh.search_impl(q, nq, c) == 0
+        parts_k.append(c.keys.copy()); parts_s.append(c.scores.copy()); parts_c.append(c.counts.copy())
+    assert total_rows == n                      # shards partition the rows
+    mk, ms, mc = merge_topk(ctx, np.stack(parts_k), np.stack(parts_s), np.stack(parts_c), k)
+    tie_tolerant_compare(mk, ms, mc, ctx.keys, ctx.scores, ctx.counts, what="sharded vs unsharded")
+    from tests.util import exact_l2
+    cd = np.sort(exact_l2(cent, q), 1)
+    sel = np.nonzero(cd[:, nprobe - 1] != cd[:, nprobe])[0]
+    tie_tolerant_compare(mk[sel], ms[sel], mc[sel], ok[sel], os_[sel], oc[sel], what="sharded vs oracle")
+
+
+def test_sharded_build_is_deterministic_across_shards():
+    """every rank builds from the same data + seed and keeps its own lists: the union must be the
+    whole index with identical centroids (bench.py relies on this for N>1)."""
+    import zvec_amd
+    rng = np.random.default_rng(7)
+    n, dim, nlist = 12000, 32, 48
+    base = (rng.standard_normal((n, 6)) @ rng.standard_normal((6, dim))).astype(np.float32)
+    cents, rows_all = [], []
+    for r in range(3):
+        se = zvec_amd.HipIVFSearcher(dim, "SquaredEuclidean")
+        assert se.set_shard(r, 3) == 0
+        assert se.build(base, nlist, kmeans_iters=5, sample_per_list=64, seed=5) == 0
+        c, offs, rows = se.export()
+        cents.append(c)
+        rows_all.append(rows)
+        sizes = np.diff(offs.astype(np.int64))
+        assert all(sizes[l] == 0 for l in range(nlist) if l % 3 != r)
+    assert np.array_equal(cents[0], cents[1]) and np.array_equal(cents[1], cents[2])
+    allrows = np.sort(np.concatenate(rows_all))
+    assert np.array_equal(allrows, np.arange(n, dtype=np.uint64))

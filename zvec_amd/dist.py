@@ -39,8 +39,15 @@ def all_gather_candidates(keys, scores, counts, group=None):
     world = dist.get_world_size(group)
     count, topk = keys.shape
     mine = pack_candidates(keys, scores, counts)
-    out = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
-    dist.all_gather_into_tensor(out, mine, group=group)
+    if mine.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the N>1 path on a box without RCCL peers: stage through the host
+        host = mine.cpu()
+        out = torch.empty(world * host.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, host, group=group)
+        out = out.to(mine.device)
+    else:
+        out = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
+        dist.all_gather_into_tensor(out, mine, group=group)
     return unpack_candidates(out, world, count, topk)
 
 
@@ -72,15 +79,27 @@ class ShardedIVF:
         import ctypes as C
         count = d_queries.shape[0]
         b = self._buffers(count, topk, d_queries.device)
+        # torch's legacy default stream has the handle 0, which the C ABI reads as "use the context's own
+        # stream": callers should run torch on an explicit stream (bench.py does); if they do not, order the
+        # two streams by hand so that torch never reads candidate buffers the scan is still writing
+        legacy = not stream_ptr
+        if legacy:
+            torch.cuda.current_stream().synchronize()
         rc = self.searcher.search_dev(d_queries.data_ptr(), count, topk, nprobe, max_scan, b["keys"].data_ptr(),
                                       b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx, stream=stream_ptr)
         _lib.check(rc, "zvec_hip_ivf_search_dev")
+        if legacy:
+            self.ctx.synchronize()
         if self.world == 1:
             return b["keys"], b["scores"], b["counts"]
         gk, gs, gc = all_gather_candidates(b["keys"], b["scores"], b["counts"], self.group)
+        if legacy:
+            torch.cuda.current_stream().synchronize()
         rc = _lib.lib().zvec_hip_merge_topk_dev(self.ctx._h, C.c_void_p(gk.data_ptr()), C.c_void_p(gs.data_ptr()),
                                                 C.c_void_p(gc.data_ptr()), self.world, count, topk,
                                                 C.c_void_p(b["okeys"].data_ptr()), C.c_void_p(b["oscores"].data_ptr()),
                                                 C.c_void_p(b["ocounts"].data_ptr()), C.c_void_p(stream_ptr))
         _lib.check(rc, "zvec_hip_merge_topk_dev")
+        if legacy:
+            self.ctx.synchronize()
         return b["okeys"], b["oscores"], b["ocounts"]
