@@ -665,30 +665,69 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
   float tau = a.threshold;     // uniform admission bound: threshold until the list is full, then its k-th score
   const uint32_t sl = a.slot_len;
   const uint64_t total = (uint64_t)nslots * sl;
+  constexpr int U = 4;           // candidate batches fetched together (hides the L2 latency of the stream)
 
-  for (uint64_t base = 0; base < total; base += 64) {
-    const uint64_t e = base + lane;
-    bool valid = e < total;
-    const uint32_t j = valid ? (uint32_t)(e / sl) : 0, t = valid ? (uint32_t)(e - (uint64_t)j * sl) : 0;
-    const size_t o = ((size_t)sb + (size_t)j * a.slot_stride) * sl + t;
-    float s = __builtin_inff();
-    uint32_t idx = IDX_NONE;
-    if (valid) {
-      if (a.part_counts) valid = t < a.part_counts[sb + (size_t)j * a.slot_stride];
+  // Dense rows (coarse step): a cheap, exact upper bound of the k-th score before any insertion — every
+  // lane takes the minimum of its own strided elements; those are 64 distinct candidates, so the k-th
+  // smallest of them is >= the k-th smallest of the whole row.  Cuts the insertions to the few elements
+  // at or below that bound.
+  if (a.part_i == nullptr && a.part_keys == nullptr && a.part_counts == nullptr && k <= 64 && total >= 64) {
+    float mn = __builtin_inff();
+    for (uint64_t base = 0; base < total; base += 64 * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t e = base + (uint64_t)u * 64 + lane;
+        v[u] = (e < total) ? a.part_s[(size_t)sb * sl + e] : __builtin_inff();
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) mn = fminf(mn, v[u]);
+    }
+    uint32_t rank = 0;
+    for (int m = 0; m < 64; ++m) {
+      const float o = bcast_f(mn, m);
+      rank += (o < mn || (o == mn && m < lane)) ? 1u : 0u;
+    }
+    const uint64_t hit = __ballot(rank == k - 1);
+    const float bound = bcast_f(mn, __builtin_ctzll(hit));
+    tau = fminf(tau, bound);
+  }
+
+  for (uint64_t base = 0; base < total; base += 64 * U) {
+    float sv[U];
+    uint32_t iv[U], jv[U];
+    bool vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t e = base + (uint64_t)u * 64 + lane;
+      bool valid = e < total;
+      const uint32_t j = valid ? (uint32_t)(e / sl) : 0, t = valid ? (uint32_t)(e - (uint64_t)j * sl) : 0;
+      const size_t o = ((size_t)sb + (size_t)j * a.slot_stride) * sl + t;
+      float s = __builtin_inff();
+      uint32_t idx = IDX_NONE;
+      if (valid && a.part_counts) valid = t < a.part_counts[sb + (size_t)j * a.slot_stride];
       if (valid) {
         s = a.part_s[o];
         idx = a.part_i ? a.part_i[o] : t;
         if (a.part_i && idx == IDX_NONE) valid = false;
       }
+      sv[u] = valid ? s : __builtin_inff();
+      iv[u] = idx;
+      jv[u] = j;
+      vv[u] = valid;
     }
-    if (!valid) s = __builtin_inff();
-    uint64_t m = __ballot(valid && s <= tau);
-    while (m) {
-      const int l = __builtin_ctzll(m);
-      const float cs = bcast_f(s, l);
-      const uint32_t co = bcast_u(j, l), ci = bcast_u(idx, l);
-      m &= m - 1;
-      if (sorted_insert<true>(Ls, Lo, Li, k, cnt, cs, co, ci, lane, tau)) m &= __ballot(valid && s <= tau);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float s = sv[u];
+      const bool valid = vv[u];
+      uint64_t m = __ballot(valid && s <= tau);
+      while (m) {
+        const int l = __builtin_ctzll(m);
+        const float cs = bcast_f(s, l);
+        const uint32_t co = bcast_u(jv[u], l), ci = bcast_u(iv[u], l);
+        m &= m - 1;
+        if (sorted_insert<true>(Ls, Lo, Li, k, cnt, cs, co, ci, lane, tau)) m &= __ballot(valid && s <= tau);
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -837,24 +876,61 @@ __device__ __forceinline__ uint32_t probe_list(const PlanArgs &p, uint32_t q, ui
   return p.brute_force ? rank : p.coarse_idx[(size_t)q * p.nprobe + rank];
 }
 
-__global__ void plan_count_kernel(const PlanArgs p) {
-  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= p.nq) return;
-  uint32_t np = p.brute_force ? p.nlist : min(p.coarse_cnt[q], p.nprobe);
-  uint32_t scanned = 0, probes = 0, slots = 0;
-  for (uint32_t rnk = 0; rnk < np && (p.brute_force || scanned < p.max_scan_count); ++rnk) {
-    uint32_t l = probe_list(p, q, rnk);
-    scanned += p.list_size_global[l];
-    probes += 1;
-    uint32_t sz = p.list_size[l];
-    if (sz > 0) {
-      slots += list_chunks(sz, p.tiles_per_chunk);
-      atomicAdd(&p.list_count[l], 1u);
-    }
+// wave-wide inclusive prefix sum (6 shuffle steps)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = __shfl_up(v, off);
+    if (lane >= off) v += t;
   }
-  p.q_nprobe[q] = probes;
-  p.q_scanned[q] = scanned;
-  p.q_nslots[q] = slots;
+  return v;
+}
+
+// One wave per query, one lane per probe rank (64 ranks per pass): evaluates the probe rule with a
+// prefix sum of the global list sizes instead of a serial walk.
+//   probed(rank)  <=>  sum of vector_count of the lists before it  <  max_scan_count
+// FILL = false: counts (q_nprobe, q_scanned, q_nslots, list_count); FILL = true: writes the CSR.
+template <bool FILL>
+__global__ void __launch_bounds__(256) plan_wave_kernel(const PlanArgs p) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= p.nq) return;
+  const uint32_t np = p.brute_force ? p.nlist : min(p.coarse_cnt[q], p.nprobe);
+  uint32_t scanned_before = 0;   // uniform carries across 64-rank passes
+  uint32_t slot_carry = FILL ? p.slot_begin[q] : 0;
+  uint32_t probes = 0, scanned = 0;
+  for (uint32_t r0 = 0; r0 < np; r0 += 64) {
+    const uint32_t rnk = r0 + lane;
+    const bool in = rnk < np;
+    const uint32_t l = in ? probe_list(p, q, rnk) : 0;
+    const uint32_t szg = in ? p.list_size_global[l] : 0;
+    const uint32_t incl = wave_incl_scan(szg, lane);
+    const uint32_t before = scanned_before + incl - szg;
+    const bool probed = in && (p.brute_force || before < p.max_scan_count);
+    const uint32_t szl = probed ? p.list_size[l] : 0;
+    const uint32_t ch = szl ? list_chunks(szl, p.tiles_per_chunk) : 0;
+    const uint32_t chincl = wave_incl_scan(ch, lane);
+    if (FILL) {
+      if (szl) {
+        const uint32_t e = p.list_qoff[l] + atomicAdd(&p.list_fill[l], 1u);
+        p.csr_q[e] = q;
+        p.csr_slot[e] = slot_carry + chincl - ch;
+      }
+    } else {
+      if (szl) atomicAdd(&p.list_count[l], 1u);
+      probes += (uint32_t)__popcll(__ballot(probed));
+      const uint32_t probed_sz = wave_incl_scan(probed ? szg : 0, lane);
+      scanned += __shfl(probed_sz, 63);
+    }
+    slot_carry += __shfl(chincl, 63);
+    scanned_before += __shfl(incl, 63);
+    if (!p.brute_force && scanned_before >= p.max_scan_count) break;   // uniform
+  }
+  if (!FILL && lane == 0) {
+    p.q_nprobe[q] = probes;
+    p.q_scanned[q] = scanned;
+    p.q_nslots[q] = slot_carry;
+  }
 }
 
 // single work-group exclusive scans: slot_begin over queries, list_qoff / item_off over lists
@@ -899,22 +975,6 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
       },
       [&](uint32_t i, uint32_t v) { p.item_off[i] = v; }, p.nlist, &p.item_off[p.nlist]);
   if (tid == 0) *p.total_items = p.item_off[p.nlist];
-}
-
-__global__ void plan_fill_kernel(const PlanArgs p) {
-  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= p.nq) return;
-  uint32_t np = p.q_nprobe[q];
-  uint32_t slot = p.slot_begin[q];
-  for (uint32_t rnk = 0; rnk < np; ++rnk) {
-    uint32_t l = probe_list(p, q, rnk);
-    uint32_t sz = p.list_size[l];
-    if (sz == 0) continue;
-    uint32_t e = p.list_qoff[l] + atomicAdd(&p.list_fill[l], 1u);
-    p.csr_q[e] = q;
-    p.csr_slot[e] = slot;
-    slot += list_chunks(sz, p.tiles_per_chunk);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -462,9 +462,9 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   p.total_items = pb + o_total; p.csr_q = pb + o_csrq; p.csr_slot = pb + o_csrslot;
   ctx->q_nprobe = p.q_nprobe; ctx->q_scanned = p.q_scanned; ctx->last_count = count;
   ctx->last_list_count = p.list_count;
-  hipLaunchKernelGGL(plan_count_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(plan_wave_kernel<false>, dim3((count + 3) / 4), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
-  hipLaunchKernelGGL(plan_fill_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(plan_wave_kernel<true>, dim3((count + 3) / 4), dim3(256), 0, stream, p);
   ZCHK(hipGetLastError());
 
   const uint32_t TPC = h->tiles_per_chunk;
