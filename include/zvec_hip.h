@@ -100,6 +100,15 @@ int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *
                              const uint64_t *d_exclude_bitset, uint64_t *d_out_keys,
                              float *d_out_scores, uint32_t *d_out_counts, void *stream);
 
+/* FlatStreamer::search_bf_by_p_keys_impl (flat_streamer.cc:346-389; index_runner.h:579-585): query q is
+ * compared only with the rows ids[offsets[q] .. offsets[q+1]) (storage positions; the host maps primary
+ * keys to positions and drops unknown keys, as get_vector_by_key != 0 -> continue does).  Same outputs and
+ * filter / threshold meaning as zvec_hip_flat_search. */
+int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *queries,
+                                uint32_t count, const uint32_t *ids, const uint32_t *offsets,
+                                uint32_t topk, float threshold, const uint64_t *exclude_bitset,
+                                uint64_t *out_keys, float *out_scores, uint32_t *out_counts);
+
 /* ---- IVF-Flat -----------------------------------------------------------------------------
  * stands behind IVFStreamer / IVFSearcher (src/core/algorithm/ivf/ivf_streamer.cc:183-250,
  * ivf_searcher.cc:183-250) with IVFCentroidIndex (ivf_centroid_index.cc:273-297) and

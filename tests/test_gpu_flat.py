@@ -203,3 +203,35 @@ def test_merge_topk_matches_oracle(zv, oracle):
     for q in range(nq):
         assert np.array_equal(gs[q, :oc[q]], os_[q, :oc[q]])
         assert np.array_equal(gk[q, :oc[q]], ok[q, :oc[q]])
+
+
+def test_search_bf_by_p_keys(zv, oracle):
+    """FlatStreamer::search_bf_by_p_keys_impl (flat_streamer.cc:346-389): only the listed keys compete;
+    the oracle answer is a flat scan with every other position excluded."""
+    rng = np.random.default_rng(37)
+    n, dim, nq, k = 4000, 40, 12, 10
+    base = rng.integers(0, 90, (n, dim)).astype(np.float32)
+    q = rng.integers(0, 90, (nq, dim)).astype(np.float32)
+    keys = (rng.permutation(5 * n)[:n] + 7).astype(np.uint64)
+    st = zv.HipFlatStreamer(dim, "SquaredEuclidean")
+    assert st.add_batch(base, keys) == 0
+    ctx = st.create_context()
+    ctx.set_topk(k)
+    p_keys = []
+    for i in range(nq):
+        m = int(rng.integers(0, 300))
+        sel = rng.choice(n, m, replace=False)
+        lst = keys[sel].tolist() + [10 ** 12 + i]           # plus one unknown key: skipped
+        p_keys.append(lst)
+    assert st.search_bf_by_p_keys_impl(q, p_keys, nq, ctx) == 0
+    key2pos = {int(kk): i for i, kk in enumerate(keys)}
+    for i in range(nq):
+        mask = np.ones(n, bool)
+        mask[[key2pos[kk] for kk in p_keys[i][:-1]]] = False
+        ok, os_, _, oc = oracle.flat_search(base, q[i:i + 1], k, keys=keys, exclude_bits=O.pack_bits(mask))
+        tie_tolerant_compare(ctx.keys[i:i + 1], ctx.scores[i:i + 1], ctx.counts[i:i + 1], ok, os_, oc, what="p_keys q%d" % i)
+    # with a filter on top (TestFilter's p_keys leg, flat_streamer_test.cc:752-760)
+    ctx.set_filter(lambda key: key % 2 == 0)
+    assert st.search_bf_by_p_keys_impl(q, p_keys, nq, ctx) == 0
+    for i in range(nq):
+        assert all(d.key() % 2 == 1 for d in ctx.result(i))

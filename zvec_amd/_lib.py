@@ -31,6 +31,8 @@ SYMBOLS = {
     "zvec_hip_flat_get_vector": (C.c_int, [_h, C.c_uint64, C.c_void_p]),
     "zvec_hip_flat_search": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, _u64p,
                                        _u64p, _f32p, _u32p]),
+    "zvec_hip_flat_search_by_ids": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, _u32p, _u32p, C.c_uint32, C.c_float,
+                                              _u64p, _u64p, _f32p, _u32p]),
     "zvec_hip_flat_search_dev": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float,
                                            _u64p, _u64p, _f32p, _u32p, C.c_void_p]),
     "zvec_hip_ivf_create": (C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_h)]),

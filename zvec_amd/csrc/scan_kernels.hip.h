@@ -839,6 +839,44 @@ __global__ void fill_keys_kernel(uint64_t *keys, uint64_t pos0, uint64_t n, cons
 // 32-bit word i/32 on a little-endian host/device, so the kernel reads it as uint32 words directly.
 
 // ---------------------------------------------------------------------------------------------
+// brute force by primary keys (FlatStreamer::search_bf_by_p_keys_impl, flat_streamer.cc:346-389): every
+// query comes with its own short list of storage positions; one wave scores one (query, position) pair
+// DIRECTLY (sum of (q-b)^2 / q.b over the row, no norm expansion) — the path is taken when a filter is so
+// selective that gathering beats scanning.  Scores land in a padded [nq][maxlen] matrix for merge_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pkeys_score_kernel(const float *base, const float *queries, uint32_t dpad,
+                                                          int metric, const uint32_t *pos, const uint32_t *off,
+                                                          uint32_t nq, uint32_t maxlen, float *out_s, uint32_t *out_i) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (uint64_t)nq * maxlen) return;
+  const uint32_t q = (uint32_t)(w / maxlen), j = (uint32_t)(w - (uint64_t)q * maxlen);
+  const uint32_t len = off[q + 1] - off[q];
+  float sc = __builtin_inff();
+  uint32_t id = IDX_NONE;
+  if (j < len) {
+    id = pos[off[q] + j];
+    if (id != IDX_NONE) {
+      float acc = 0.f;
+      const float *qr = queries + (size_t)q * dpad;
+      for (uint32_t c = lane; c < dpad; c += 64) {
+        const float b = base[blocked_offset(id, c, dpad)];
+        const float x = qr[c];
+        if (metric == METRIC_L2) { const float d = x - b; acc = fmaf(d, d, acc); }
+        else acc = fmaf(x, b, acc);
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+      sc = (metric == METRIC_L2) ? acc : (metric == METRIC_IP ? -acc : 1.f - acc);
+    }
+  }
+  if (lane == 0) {
+    out_s[w] = sc;
+    out_i[w] = id;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // IVF plan kernels: turn the per-query probe lists into list-major work.
 // ---------------------------------------------------------------------------------------------
 struct PlanArgs {

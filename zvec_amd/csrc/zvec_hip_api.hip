@@ -724,6 +724,56 @@ int zvec_hip_flat_search(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *quer
   return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, c->cur);
 }
 
+int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count,
+                                const uint32_t *ids, const uint32_t *offsets, uint32_t topk, float threshold,
+                                const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
+                                uint32_t *out_counts) {
+  if (!h || !queries || !ids || !offsets || !out_keys || !out_scores || !out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if ((size_t)topk * 12 + 16 > 60 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = c->cur;
+  const Store &st = h->st;
+  // host-side sanitising: positions out of range or excluded by the filter bitset become holes
+  const uint32_t total = offsets[count];
+  uint32_t maxlen = 1;
+  for (uint32_t q = 0; q < count; ++q) {
+    if (offsets[q + 1] < offsets[q]) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+    maxlen = std::max(maxlen, offsets[q + 1] - offsets[q]);
+  }
+  std::vector<uint32_t> clean(std::max<uint32_t>(total, 1));
+  for (uint32_t i = 0; i < total; ++i) {
+    uint32_t id = ids[i];
+    bool ok = id < st.n;
+    if (ok && exclude_bitset) ok = ((exclude_bitset[id >> 6] >> (id & 63)) & 1ull) == 0;
+    clean[i] = ok ? id : IDX_NONE;
+  }
+  ZRET(host_search_wrap_begin(c, queries, (size_t)count * st.dim_in * 4, nullptr, 0, count, topk, s));
+  ZRET(prep_queries(c, st, c->io_q.as<float>(), count, threshold, s));
+  ZRET(c->plan.ensure(((size_t)total + count + 8) * sizeof(uint32_t)));
+  uint32_t *d_pos = c->plan.as<uint32_t>();
+  uint32_t *d_off = d_pos + std::max<uint32_t>(total, 1);
+  ZCHK(hipMemcpyAsync(d_pos, clean.data(), (size_t)std::max<uint32_t>(total, 1) * 4, hipMemcpyHostToDevice, s));
+  ZCHK(hipMemcpyAsync(d_off, offsets, ((size_t)count + 1) * 4, hipMemcpyHostToDevice, s));
+  const uint64_t pairs = (uint64_t)count * maxlen;
+  ZRET(c->part_s.ensure(pairs * 4));
+  ZRET(c->part_i.ensure(pairs * 4));
+  hipLaunchKernelGGL(pkeys_score_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
+                     st.dpad, st.metric, d_pos, d_off, count, maxlen, c->part_s.as<float>(), c->part_i.as<uint32_t>());
+  ZCHK(hipGetLastError());
+  MergeArgs m{};
+  m.part_s = c->part_s.as<float>(); m.part_i = c->part_i.as<uint32_t>(); m.part_keys = nullptr; m.slot_begin = nullptr;
+  m.slots_per_q = 1; m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = maxlen; m.threshold = threshold;
+  m.keymap = st.keys; m.out_keys = c->io_keys.as<uint64_t>(); m.out_scores = c->io_scores.as<float>(); m.out_idx = nullptr;
+  m.out_counts = c->io_counts.as<uint32_t>();
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, s, m);
+  ZCHK(hipGetLastError());
+  return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, s);
+}
+
 // ---- IVF ------------------------------------------------------------------------------------
 int zvec_hip_ivf_create(uint32_t dim, int dtype, int metric, int device, zvec_hip_ivf_t *out) {
   if (!out || dim == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;

@@ -250,6 +250,38 @@ class _FlatBase:
     # brute force == the flat scan itself (flat_streamer.cc:304-344)
     search_bf_impl = search_impl
 
+    def search_bf_by_p_keys_impl(self, query, p_keys, count, ctx):
+        """FlatStreamer::search_bf_by_p_keys_impl (flat_streamer.cc:346-389): p_keys[q] = primary keys query q
+        is compared with; unknown keys are skipped; the context's filter applies per key."""
+        if ctx is None or ctx.topk() == 0:
+            return IndexError_.InvalidArgument
+        q = np.ascontiguousarray(query, np.float32).reshape(-1)
+        if q.size != int(count) * self.dim or len(p_keys) != count:
+            return IndexError_.InvalidArgument
+        allk = self._all_keys()
+        if getattr(self, "_key2pos_n", -1) != len(allk):
+            self._key2pos = {int(k): i for i, k in enumerate(allk)}
+            self._key2pos_n = len(allk)
+        ids, offs = [], [0]
+        for keys in p_keys:
+            for key in keys:
+                pos = self._key2pos.get(int(key))
+                if pos is not None and not (ctx._filter_fn and ctx._filter_fn(int(key))):
+                    ids.append(pos)
+            offs.append(len(ids))
+        ids = np.asarray(ids if ids else [0], np.uint32)
+        offs = np.asarray(offs, np.uint32)
+        k = ctx.topk()
+        keys_o = np.zeros((count, k), np.uint64)
+        scores = np.zeros((count, k), np.float32)
+        counts = np.zeros(count, np.uint32)
+        rc = _lib.lib().zvec_hip_flat_search_by_ids(self._h, ctx._h, _np_ptr(q), count, _np_ptr(ids), _np_ptr(offs), k,
+                                                    ctx.threshold(), _np_ptr(ctx._exclude), _np_ptr(keys_o),
+                                                    _np_ptr(scores), _np_ptr(counts))
+        if rc == 0:
+            ctx._set_results(keys_o, scores, counts)
+        return rc
+
     def search_dev(self, d_queries, count, topk, d_out_keys, d_out_scores, d_out_counts, ctx,
                    threshold=FLT_MAX, d_exclude=None, stream=None):
         """device-pointer form (async): all arguments are raw device pointers (ints)."""
