@@ -91,7 +91,7 @@ struct ScanArgs {
 
 // LDS footprint in bytes for a given NG / k (host mirrors this)
 __host__ __device__ inline size_t scan_lds_bytes(int ng, uint32_t k, bool m16 = false) {
-  size_t rows = m16 ? 16 : (size_t)ng * QGROUP;
+  size_t rows = m16 ? 32 : (size_t)ng * QGROUP;
   return (2 * rows * TILE_K + 2 * (size_t)SLAB + 6 * rows + 4 + 2 * rows * k) * 4;
 }
 
@@ -288,8 +288,10 @@ __device__ __forceinline__ void stage_store(const StageRegs<NG> &sr, float *Bb, 
 // The scan kernel.  256 threads = 4 waves; wave w owns tile columns [32w, 32w+32); all waves share the
 // ROWS query rows of the work item.  Two matrix-core shapes:
 //   M16 = false : ROWS = NG*32, v_mfma_f32_32x32x2_f32   (flat scans, coarse assign: many queries per tile)
-//   M16 = true  : ROWS = 16,    v_mfma_f32_16x16x4_f32   (IVF list scan: a list is probed by ~10 queries
-//                 of the batch, so 16-row tiles waste half as many matrix-core cycles as 32-row ones)
+//   M16 = true  : ROWS = 32 as two 16-row halves, v_mfma_f32_16x16x4_f32   (IVF list scan: a list is probed
+//                 by ~10 queries of the batch; the second half is skipped — wave-uniformly — when the item
+//                 has <= 16 query rows, so a 16-row item costs half the matrix-core cycles of a 32x32 tile,
+//                 while a list probed by 17..32 queries is still streamed from HBM only once)
 // EXCL selects the bitmap-gated variant (the filter word is fetched with the tile, unconditionally, so
 // the no-filter variant carries no extra load).
 // Persistent loop over work items: static grid-stride for flat, a device work queue for IVF (every
@@ -299,7 +301,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 template <int NG, bool M16>
 struct ScanShape {
-  static constexpr int ROWS = M16 ? 16 : NG * QGROUP;
+  static constexpr int ROWS = M16 ? 32 : NG * QGROUP;
   static constexpr int QLOADS = M16 ? 1 : NG;           // 16-byte query loads per thread per k-step
 };
 
@@ -307,7 +309,7 @@ template <int NG, bool M16, bool EXCL>
 __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
   constexpr int ROWS = ScanShape<NG, M16>::ROWS;
   constexpr int QL = ScanShape<NG, M16>::QLOADS;
-  constexpr int QROWMASK = M16 ? 15 : 31;
+  constexpr int QROWMASK = 31;
   extern __shared__ f32x4 zvk_smem4[];
   float *smem = reinterpret_cast<float *>(zvk_smem4);
   float *Qs = smem;                      // [2][ROWS*32]
@@ -331,7 +333,7 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
   const int wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;                 // 32x32x2 operand coordinates
   const int r16 = lane & 15, kq = lane >> 4;              // 16x16x4 operand coordinates
-  const int srow = (tid >> 3) & QROWMASK, schunk = tid & 7;   // staging coordinates (M16: threads >= 128 duplicate)
+  const int srow = (tid >> 3) & QROWMASK, schunk = tid & 7;   // staging coordinates
   const int sswz = schunk ^ ((srow >> 1) & 7);            // swizzled chunk for the Q image
   const uint32_t dpad = a.dpad, nks = a.nks, k = a.k;
 
@@ -427,10 +429,11 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
     constexpr int PF = (NG <= 2) ? 2 : 1;
     StageRegs<QL> sr[2];
     floatx16 acc[M16 ? 1 : NG];
-    floatx4 acc16[2];
+    floatx4 acc16[4];                 // [row half][column block]
+    const bool two = nrows > 16;      // uniform: second 16-row half in use
     if constexpr (M16) {
-      acc16[0] = floatx4{0.f, 0.f, 0.f, 0.f};
-      acc16[1] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc16[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
       for (int g = 0; g < NG; ++g)
@@ -503,15 +506,23 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
 #pragma unroll
           for (int kk2 = 0; kk2 < 2; ++kk2) {
             const int c = (kq + 4 * kk2) ^ swz;
-            const f32x4 af = *reinterpret_cast<const f32x4 *>(Qb + (r16 * 8 + c) * 4);
+            const f32x4 af0 = *reinterpret_cast<const f32x4 *>(Qb + (r16 * 8 + c) * 4);
+            f32x4 af1 = af0;
+            if (two) af1 = *reinterpret_cast<const f32x4 *>(Qb + ((16 + r16) * 8 + c) * 4);
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
               const int brow = wave * 32 + cb * 16 + r16;
               const f32x4 bf = *reinterpret_cast<const f32x4 *>(Bb + (brow * 8 + c) * 4);
-              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc16[cb], 0, 0, 0);
-              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc16[cb], 0, 0, 0);
-              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc16[cb], 0, 0, 0);
-              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc16[cb], 0, 0, 0);
+              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.x, bf.x, acc16[cb], 0, 0, 0);
+              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.y, bf.y, acc16[cb], 0, 0, 0);
+              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.z, bf.z, acc16[cb], 0, 0, 0);
+              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.w, bf.w, acc16[cb], 0, 0, 0);
+              if (two) {
+                acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.x, bf.x, acc16[2 + cb], 0, 0, 0);
+                acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.y, bf.y, acc16[2 + cb], 0, 0, 0);
+                acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.z, bf.z, acc16[2 + cb], 0, 0, 0);
+                acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.w, bf.w, acc16[2 + cb], 0, 0, 0);
+              }
             }
           }
         } else {
@@ -550,24 +561,28 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
           const bool v0 = (local0 + r16 < rows_valid_total) && (ex0 == 0);
           const bool v1 = (local0 + 16 + r16 < rows_valid_total) && (ex1 == 0);
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            const float bn = cb ? bn1 : bn0;
-            const bool cv = cb ? v1 : v0;
+          for (int g = 0; g < 2; ++g) {
+            if (g == 1 && !two) break;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int row_l = kq * 4 + e;
-              const float dot = acc16[cb][e];
-              float sc;
-              if (a.metric == METRIC_L2) sc = fmaxf(fmaf(-2.f, dot, qn_s[row_l] + bn), 0.f);
-              else if (a.metric == METRIC_IP) sc = -dot;
-              else sc = 1.f - dot;
-              Sc[row_l * TILE_N + wave * 32 + cb * 16 + r16] = cv ? sc : __builtin_inff();
-              acc16[cb][e] = 0.f;
+            for (int cb = 0; cb < 2; ++cb) {
+              const float bn = cb ? bn1 : bn0;
+              const bool cv = cb ? v1 : v0;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int row_l = g * 16 + kq * 4 + e;
+                const float dot = acc16[g * 2 + cb][e];
+                float sc;
+                if (a.metric == METRIC_L2) sc = fmaxf(fmaf(-2.f, dot, qn_s[row_l] + bn), 0.f);
+                else if (a.metric == METRIC_IP) sc = -dot;
+                else sc = 1.f - dot;
+                Sc[row_l * TILE_N + wave * 32 + cb * 16 + r16] = cv ? sc : __builtin_inff();
+                acc16[g * 2 + cb][e] = 0.f;
+              }
             }
           }
           __syncthreads();
 #pragma unroll 1
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < 8; ++i) {
             const int row = i * 4 + wave;                    // rows dealt round-robin to the 4 waves
             if ((uint32_t)row < nrows) {
               const f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + row * TILE_N + 2 * lane);

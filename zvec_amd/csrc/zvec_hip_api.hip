@@ -434,11 +434,11 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   }
 
   // 2. plan: list-major work items
-  // list scan shape: 16-row tiles (16x16x4 MFMA); a list probed by more than 16 queries of the batch is
-  // dealt as several 16-row groups (its slabs come back from L2 / Infinity Cache for the later groups)
+  // list scan shape: 16x16x4 MFMA tiles, 32 query rows per work item as two 16-row halves (the second is
+  // skipped when the item has <= 16 rows); a list probed by more than 32 queries is dealt as several items
   const int ng = 0;
   if (scan_lds_bytes(1, topk, true) > LDS_LIMIT - 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
-  const uint32_t rows_per_group = 16;
+  const uint32_t rows_per_group = 32;
   const uint64_t npairs = (uint64_t)count * (brute_force ? nlist : nprobe);
   // layout of the plan buffer (u32 words)
   size_t off = 0;
