@@ -1,0 +1,182 @@
+"""BASELINE.json full-size cases on the GPU, checked through size-independent properties (the oracle
+cannot scan 10M x 768 for hundreds of queries in seconds) plus oracle spot checks on a few queries.
+
+  configs[0]  Flat L2, SIFT-1M-shaped (1M x 128, uint8-valued fp32), batch 1      -> bit-exact vs oracle
+  configs[1]  Flat IP, 1M x 768 fp32, batch 256                                   -> self-query / order / oracle spot
+  configs[2]  IVF-Flat nlist 4096, 10M x 768 fp32, batch 1024                     -> bf==flat, shard union, self-query
+  configs[4]  filtered scan, 10M x 768 + bitmap, batch 512                        -> gate respected, equals unfiltered∖mask
+Data is generated on the GPU with torch (seeded), indexes are built through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.util import tie_tolerant_compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zv():
+    import zvec_amd
+    return zvec_amd
+
+
+def _stream():
+    s = torch.cuda.Stream()
+    torch.cuda.set_stream(s)
+    return s.cuda_stream
+
+
+def _search_dev(idx, ctx, q, k, stream, exclude=None, **kw):
+    nq = q.shape[0]
+    keys = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+    scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+    counts = torch.empty((nq,), dtype=torch.int32, device=q.device)
+    rc = idx.search_dev(q.data_ptr(), nq, k, *kw.get("args", ()), keys.data_ptr(), scores.data_ptr(), counts.data_ptr(), ctx,
+                        d_exclude=exclude.data_ptr() if exclude is not None else None, stream=stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return keys.cpu().numpy().astype(np.uint64), scores.cpu().numpy(), counts.cpu().numpy().astype(np.uint32)
+
+
+def test_config0_flat_l2_sift1m_shape_batch1_bit_exact(zv, oracle):
+    stream = _stream()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260320)
+    n, dim, k = 1_000_000, 128, 10
+    base = torch.randint(0, 256, (n, dim), generator=g, device=dev).float()
+    qs = torch.randint(0, 256, (4, dim), generator=g, device=dev).float()
+    flat = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert flat.add_batch_dev(base.data_ptr(), n, stream=stream) == 0
+    ctx = flat.create_context()
+    ctx.set_stream(stream)
+    hb = base.cpu().numpy()
+    for i in range(4):                                    # batch = 1, as the config says
+        gk, gs, gc = _search_dev(flat, ctx, qs[i:i + 1].contiguous(), k, stream)
+        ok, os_, _, oc = oracle.flat_search(hb, qs[i:i + 1].cpu().numpy(), k, threads=8)
+        tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="config0 q%d" % i)   # atol=rtol=0: bit exact
+
+
+def test_config1_flat_ip_1m_768_batch256_properties(zv, oracle):
+    stream = _stream()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260321)
+    n, dim, nq, k = 1_000_000, 768, 256, 10
+    base = torch.randn((n, dim), generator=g, device=dev)
+    base /= base.norm(dim=1, keepdim=True)                # unit rows: the best IP match of a row is itself
+    sel = torch.randint(0, n, (nq,), generator=g, device=dev)
+    q = base[sel].contiguous()
+    flat = zv.HipFlatSearcher(dim, "InnerProduct")
+    assert flat.add_batch_dev(base.data_ptr(), n, stream=stream) == 0
+    ctx = flat.create_context()
+    ctx.set_stream(stream)
+    gk, gs, gc = _search_dev(flat, ctx, q, k, stream)
+    assert (gc == k).all()
+    assert np.array_equal(gk[:, 0], sel.cpu().numpy().astype(np.uint64))         # self-query => itself first
+    assert np.all(np.abs(gs[:, 0] + 1.0) < 1e-5)                                 # score = -<x,x> = -1
+    assert np.all(np.diff(gs, axis=1) >= 0)                                      # ascending
+    # permutation invariance of the batch (no cross-query leakage): reversed batch gives reversed rows
+    rk, rs, rc = _search_dev(flat, ctx, q.flip(0).contiguous(), k, stream)
+    assert np.array_equal(rk[::-1], gk) and np.array_equal(rs[::-1], gs)
+    # oracle spot check on 3 queries of the batch
+    hb = base.cpu().numpy()
+    hq = q[:3].cpu().numpy()
+    ok, os_, _, oc = oracle.flat_search(hb, hq, k, O.METRIC_IP, threads=8)
+    tie_tolerant_compare(gk[:3], gs[:3], gc[:3], ok, os_, oc, rtol=4e-6, scale=1.0, what="config1 spot")
+
+
+@pytest.fixture(scope="module")
+def ten_million(zv):
+    stream = _stream()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260322)
+    n, dim, r = 10_000_000, 768, 12
+    proj = torch.randn((r, dim), generator=g, device=dev)
+    base = torch.empty((n, dim), device=dev)
+    for o in range(0, n, 1 << 20):
+        m = min(1 << 20, n - o)
+        torch.mm(torch.randn((m, r), generator=g, device=dev), proj, out=base[o:o + m])
+    torch.cuda.synchronize()
+    return dict(stream=stream, dev=dev, g=g, n=n, dim=dim, base=base, proj=proj)
+
+
+def test_config2_ivf_10m_768_batch1024_properties(zv, oracle, ten_million):
+    t = ten_million
+    stream, dev, n, dim, base = t["stream"], t["dev"], t["n"], t["dim"], t["base"]
+    nq, k, nlist, nprobe = 1024, 10, 4096, 32
+    sel = torch.randint(0, n, (nq,), generator=t["g"], device=dev)
+    q = base[sel].contiguous()
+    ivf = zv.HipIVFSearcher(dim, "SquaredEuclidean")
+    assert ivf.build_dev(base.data_ptr(), n, nlist, kmeans_iters=4, stream=stream) == 0
+    cnt, nl = ivf.info()
+    assert cnt == n and nl == nlist
+    ctx = ivf.create_context()
+    ctx.set_stream(stream)
+    gk, gs, gc = _search_dev(ivf, ctx, q, k, stream, args=(nprobe, n))
+    assert (gc == k).all() and np.all(np.diff(gs, axis=1) >= 0)
+    # self-query: every row's own list is its nearest centroid's => found at distance 0 (duplicates aside)
+    assert (gs[:, 0] == 0).all()
+    assert (gk[:, 0] == sel.cpu().numpy().astype(np.uint64)).mean() > 0.999
+    scanned, probes = ivf.last_stats(ctx, nq)
+    assert (probes == nprobe).all()
+    # shard union: lists l%2==0 / l%2==1 searched separately and merged == the unsharded answer
+    parts = []
+    for r in range(2):
+        sh = zv.HipIVFSearcher(dim, "SquaredEuclidean")
+        assert sh.set_shard(r, 2) == 0
+        assert sh.build_dev(base.data_ptr(), n, nlist, kmeans_iters=4, stream=stream) == 0
+        c = sh.create_context()
+        c.set_stream(stream)
+        parts.append(_search_dev(sh, c, q, k, stream, args=(nprobe, n)))
+        del sh, c
+    from zvec_amd.index import merge_topk
+    mk, ms, mc = merge_topk(ctx, np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]),
+                            np.stack([p[2] for p in parts]), k)
+    tie_tolerant_compare(mk, ms, mc, gk, gs, gc, what="10M shard union")
+    # oracle spot check: 2 queries against the exported index (same centroids, same list order)
+    cent, offs, rows = ivf.export()
+    hq = q[:2].cpu().numpy()
+    rows_t = torch.from_numpy(rows.astype(np.int64)).to(dev)
+    # only the probed lists are needed on the host: take them from the oracle's own probe set
+    _, _, _, _, _, pr = oracle.ivf_search(cent, np.zeros(nlist + 1, np.uint64), np.zeros((0, dim), np.float32), hq, k,
+                                          nprobe, n, want_probes=True)
+    need = np.unique(pr[pr != 0xffffffff])
+    sizes = np.diff(offs.astype(np.int64))
+    sub_offs = np.zeros(nlist + 1, np.int64)
+    sub_offs[1:][need] = sizes[need]
+    sub_offs = np.cumsum(sub_offs)
+    idx = np.concatenate([np.arange(offs[l], offs[l + 1]) for l in need]).astype(np.int64)
+    sub_vecs = base.index_select(0, rows_t[torch.from_numpy(idx).to(dev)]).cpu().numpy()
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, sub_offs.astype(np.uint64), sub_vecs, hq, k, nprobe, n, keys=rows[idx])
+    qn = (hq.astype(np.float64) ** 2).sum(1)
+    tie_tolerant_compare(gk[:2], gs[:2], gc[:2], ok, os_, oc, rtol=2e-6, atol=1e-6, select_band=4e-6 * (2 * qn.max() + 1),
+                         what="10M oracle spot")
+
+
+def test_config4_filtered_scan_10m_bitmap_batch512(zv, ten_million):
+    t = ten_million
+    stream, dev, n, dim, base = t["stream"], t["dev"], t["n"], t["dim"], t["base"]
+    nq, k = 512, 10
+    q = (torch.randn((nq, t["proj"].shape[0]), generator=t["g"], device=dev) @ t["proj"]).contiguous()
+    flat = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert flat.add_batch_dev(base.data_ptr(), n, stream=stream) == 0
+    ctx = flat.create_context()
+    ctx.set_stream(stream)
+    uk, us, uc = _search_dev(flat, ctx, q, 4 * k, stream)                        # unfiltered top-40
+    for p_keep in (0.5, 0.1):
+        keep = torch.rand((n,), generator=t["g"], device=dev) < p_keep
+        excl = (~keep).cpu().numpy()
+        words = torch.from_numpy(O.pack_bits(excl).view(np.int64)).to(dev)
+        fk, fs, fc = _search_dev(flat, ctx, q, k, stream, exclude=words)
+        assert (fc == k).all()
+        assert not excl[fk.astype(np.int64)].any()                              # gate respected
+        # equals the unfiltered ranking with the excluded rows struck out (wherever 40 candidates suffice)
+        for i in range(nq):
+            allowed = [(s, kk) for s, kk in zip(us[i], uk[i]) if not excl[int(kk)]]
+            if len(allowed) >= k:
+                assert [kk for _, kk in allowed[:k]] == fk[i].tolist() or np.array_equal(
+                    np.array([s for s, _ in allowed[:k]], np.float32), fs[i])

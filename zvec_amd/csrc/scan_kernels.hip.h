@@ -854,6 +854,73 @@ __global__ void fill_keys_kernel(uint64_t *keys, uint64_t pos0, uint64_t n, cons
 // 32-bit word i/32 on a little-endian host/device, so the kernel reads it as uint32 words directly.
 
 // ---------------------------------------------------------------------------------------------
+// L2 refinement of the final lists.  The scan forms squared distances as |q|^2 + |b|^2 - 2 q.b on the
+// matrix cores, whose rounding error scales with the NORMS; the reference sums (q-b)^2 directly
+// (euclidean_distance_matrix_fp32.cc:229-283), whose error scales with the DISTANCE (an identical vector
+// scores exactly 0).  The k winners of every query are therefore re-scored directly (one wave per
+// (query, result): a 3 KiB gather each, ~30 MB per 1024x10 batch) and the list is re-sorted by the
+// refined score, previous rank breaking ties.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rescore_l2_kernel(const float *base, const float *queries, uint32_t dpad,
+                                                         const uint32_t *idx, const uint32_t *counts, uint32_t nq,
+                                                         uint32_t k, float *scores) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (uint64_t)nq * k) return;
+  const uint32_t q = (uint32_t)(w / k), j = (uint32_t)(w - (uint64_t)q * k);
+  if (j >= counts[q]) return;
+  const uint32_t id = idx[w];
+  const float *qr = queries + (size_t)q * dpad;
+  float acc = 0.f;
+  for (uint32_t c = lane; c < dpad; c += 64) {
+    const float d = qr[c] - base[blocked_offset(id, c, dpad)];
+    acc = fmaf(d, d, acc);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) scores[w] = acc;
+}
+
+// one wave per query: stable re-sort of (score, key, idx) by score through LDS
+__global__ void __launch_bounds__(64) resort_kernel(uint64_t *keys, float *scores, uint32_t *idx, uint32_t *counts,
+                                                    uint32_t k, float threshold) {
+  extern __shared__ f32x4 zvk_smem4[];
+  float *S = reinterpret_cast<float *>(zvk_smem4);            // [k]
+  uint32_t *I = reinterpret_cast<uint32_t *>(S + k);          // [k]
+  uint64_t *K = reinterpret_cast<uint64_t *>(I + k + (k & 1)); // [k], 8-byte aligned
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  const uint32_t c = counts[q];
+  for (uint32_t j = lane; j < c; j += 64) {
+    S[j] = scores[(size_t)q * k + j];
+    I[j] = idx[(size_t)q * k + j];
+    K[j] = keys[(size_t)q * k + j];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t j = lane; j < c; j += 64) {
+    const float v = S[j];
+    uint32_t rank = 0;
+    for (uint32_t u = 0; u < c; ++u) {
+      const float w = S[u];
+      rank += (w < v || (w == v && u < j)) ? 1u : 0u;
+    }
+    const size_t o = (size_t)q * k + rank;
+    scores[o] = v;
+    idx[o] = I[j];
+    keys[o] = K[j];
+  }
+  // RNN radius on the refined score: results past the threshold are cut (topk_to_result,
+  // ivf_searcher_context.h:184-208 / flat_streamer_context.h)
+  uint32_t keep = 0;
+  for (uint32_t j0 = 0; j0 < c; j0 += 64) {
+    const uint32_t j = j0 + lane;
+    keep += (uint32_t)__popcll(__ballot(j < c && S[j] <= threshold));
+  }
+  if (lane == 0 && keep != c) counts[q] = keep;
+}
+
+// ---------------------------------------------------------------------------------------------
 // brute force by primary keys (FlatStreamer::search_bf_by_p_keys_impl, flat_streamer.cc:346-389): every
 // query comes with its own short list of storage positions; one wave scores one (query, position) pair
 // DIRECTLY (sum of (q-b)^2 / q.b over the row, no norm expansion) — the path is taken when a filter is so

@@ -112,7 +112,7 @@ struct zvec_hip_ctx_s {
   hipStream_t cur = nullptr;
   std::mutex mu;
   // workspace
-  DevBuf gtau;
+  DevBuf gtau, ridx;
   DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
   DevBuf plan;        // all u32 plan arrays
   DevBuf io_q, io_ex, io_keys, io_scores, io_counts;   // staging for host-pointer entry points
@@ -257,8 +257,19 @@ struct SearchOut {
 };
 
 // flat scan of `st` for `count` prepared queries (ctx->qpad / qnorm already filled)
+int refine_l2(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold, uint64_t *keys,
+              float *scores, uint32_t *idx, uint32_t *counts, hipStream_t stream);
+
+// `user_facing`: a search whose lists go back to the caller (profiled, L2-refined); false for the IVF
+// coarse pass and the k-means labelling, which only need the ranking
 int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold,
-                       const uint64_t *d_exclude, const SearchOut &out, hipStream_t stream, bool profile_it) {
+                       const uint64_t *d_exclude, const SearchOut &out_in, hipStream_t stream, bool user_facing) {
+  const bool profile_it = user_facing;
+  SearchOut out = out_in;
+  if (user_facing && st.metric == ZVEC_HIP_METRIC_L2 && out.idx == nullptr) {
+    ZRET(ctx->ridx.ensure((size_t)count * topk * sizeof(uint32_t)));
+    out.idx = ctx->ridx.as<uint32_t>();
+  }
   if (st.n == 0) {
     // no rows: empty results
     MergeArgs m{};
@@ -296,6 +307,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
       m.keymap = st.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
       hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
       ZCHK(hipGetLastError());
+      if (user_facing) ZRET(refine_l2(ctx, st, count, topk, threshold, out.keys, out.scores, out.idx, out.counts, stream));
       return 0;
     }
   }
@@ -342,12 +354,27 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   m.keymap = st.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
   hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
   ZCHK(hipGetLastError());
+  if (user_facing) ZRET(refine_l2(ctx, st, count, topk, threshold, out.keys, out.scores, out.idx, out.counts, stream));
   return 0;
 }
 
 int reset_gtau(zvec_hip_ctx_s *ctx, uint32_t count, float threshold, hipStream_t stream) {
   ZRET(ctx->gtau.ensure((size_t)count * sizeof(uint32_t)));
   hipLaunchKernelGGL(fill_gtau_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, ctx->gtau.as<uint32_t>(), count, threshold);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+// L2 only: direct re-scoring + re-sort of the final lists (see rescore_l2_kernel)
+int refine_l2(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold, uint64_t *keys,
+              float *scores, uint32_t *idx, uint32_t *counts, hipStream_t stream) {
+  if (st.metric != ZVEC_HIP_METRIC_L2) return 0;
+  if ((size_t)topk * 16 + 16 > 60 * 1024) return 0;   // huge k: keep the expansion scores
+  const uint64_t pairs = (uint64_t)count * topk;
+  hipLaunchKernelGGL(rescore_l2_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, st.base,
+                     ctx->qpad.as<float>(), st.dpad, idx, counts, count, topk, scores);
+  hipLaunchKernelGGL(resort_kernel, dim3(count), dim3(64), (size_t)topk * 16 + 16, stream, keys, scores, idx, counts, topk,
+                     threshold);
   ZCHK(hipGetLastError());
   return 0;
 }
@@ -402,7 +429,7 @@ void ctx_free(zvec_hip_ctx_s *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own) (void)hipStreamSynchronize(c->own);
-  c->gtau.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
+  c->gtau.release(); c->ridx.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
   c->coarse_keys.release(); c->coarse_scores.release(); c->coarse_idx.release(); c->coarse_cnt.release();
   c->plan.release(); c->io_q.release(); c->io_ex.release(); c->io_keys.release(); c->io_scores.release();
   c->io_counts.release(); c->stats.release();
@@ -512,9 +539,15 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   MergeArgs m{};
   m.part_s = a.part_s; m.part_i = a.part_i; m.part_keys = nullptr; m.slot_begin = p.slot_begin; m.slots_per_q = 0;
   m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = topk; m.threshold = threshold; m.keymap = h->lists.keys;
-  m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
+  uint32_t *ridx = out.idx;
+  if (h->metric == ZVEC_HIP_METRIC_L2 && ridx == nullptr) {
+    ZRET(ctx->ridx.ensure((size_t)count * topk * sizeof(uint32_t)));
+    ridx = ctx->ridx.as<uint32_t>();
+  }
+  m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = ridx; m.out_counts = out.counts;
   hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
   ZCHK(hipGetLastError());
+  ZRET(refine_l2(ctx, h->lists, count, topk, threshold, out.keys, out.scores, ridx, out.counts, stream));
   return 0;
 }
 
