@@ -180,3 +180,41 @@ def test_ivf_gpu_build_then_same_index_on_oracle(zv, oracle):
     fk, _, _, _ = oracle.flat_search(base, q, k)
     recall = np.mean([len(set(ctx.keys[i].tolist()) & set(fk[i].tolist())) / k for i in range(nq)])
     assert recall >= 0.95, recall
+
+
+@pytest.mark.parametrize("metric_name,metric", [("InnerProduct", O.METRIC_IP), ("Cosine", O.METRIC_COSINE)])
+def test_ivf_ip_and_cosine(zv, oracle, metric_name, metric):
+    """IVF with the other two metrics of the path: coarse assign and list scan both use the index metric
+    (MinusInnerProduct: inner_product_matrix_fp32.cc:870; Cosine: 1 - ip on normalised rows carrying their
+    norm as an extra float, cosine_distance_matrix.h:32-50 / cosine_converter.cc:112-127)."""
+    rng = np.random.default_rng(43)
+    n, dim, nlist, nq, k = 6000, 48, 40, 64, 10
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    if metric == O.METRIC_COSINE:
+        base, q = oracle.cosine_transform(base), oracle.cosine_transform(q)
+    ed = base.shape[1]
+    lab = rng.integers(0, nlist, n)
+    order = np.argsort(lab, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(lab, minlength=nlist))]).astype(np.uint64)
+    cent = np.stack([base[lab == l].mean(0) for l in range(nlist)]).astype(np.float32)
+    if metric == O.METRIC_COSINE:
+        cent = oracle.cosine_transform(cent[:, :dim])
+    vecs, keys = base[order], order.astype(np.uint64)
+    se = zv.HipIVFSearcher(ed, metric_name, scan_ratio=0.3, brute_force_threshold=100)
+    assert se.load(cent, offs, vecs, keys) == 0
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, metric=metric, keys=keys)
+    # the probe set is decided by coarse scores; compare the queries whose nprobe-th / (nprobe+1)-th coarse
+    # scores are separated by more than the fp32 band
+    cs = np.sort(np.array([[oracle.dist(metric, c, qq) for c in cent] for qq in q]), 1)
+    sel = np.nonzero(cs[:, nprobe] - cs[:, nprobe - 1] > 1e-4)[0]
+    assert len(sel) > nq // 2
+    scale = 1.0 if metric == O.METRIC_COSINE else float(np.abs(os_).max())
+    tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel], rtol=4e-6, scale=scale,
+                         what="ivf " + metric_name)
+    for p in (0, n - 1):
+        assert np.array_equal(se.get_vector_by_id(p), vecs[p])
