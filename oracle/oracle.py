@@ -67,6 +67,20 @@ class Oracle:
                                        _f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32,
                                        C.c_uint32, C.c_int, _u64p, _u64p, _f32p, _u32p, _u32p,
                                        _u32p, C.c_int]
+        _u16p = C.POINTER(C.c_uint16)
+        for name in ("zo_sqeuclid_f16", "zo_ip_f16", "zo_minus_ip_f16"):
+            f = getattr(L, name)
+            f.restype = C.c_float
+            f.argtypes = [_u16p, _u16p, C.c_size_t]
+        L.zo_set_distance_override_f16.restype = None
+        L.zo_set_distance_override_f16.argtypes = [C.c_int, C.c_void_p]
+        L.zo_flat_search_mt_t.restype = C.c_int
+        L.zo_flat_search_mt_t.argtypes = [C.c_int, C.c_void_p, _u64p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p,
+                                          C.c_uint32, C.c_uint32, C.c_float, _u64p, _u64p, _f32p, _u32p, _u32p, C.c_int]
+        L.zo_ivf_search_mt_t.restype = C.c_int
+        L.zo_ivf_search_mt_t.argtypes = [C.c_int, C.c_void_p, C.c_uint32, _u64p, C.c_void_p, _u64p, C.c_uint32, C.c_int,
+                                         C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, C.c_int,
+                                         _u64p, _u64p, _f32p, _u32p, _u32p, _u32p, C.c_int]
         L.zo_merge_topk.restype = C.c_int
         L.zo_merge_topk.argtypes = [_u64p, _f32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, _u64p,
                                     _f32p, _u32p]
@@ -83,6 +97,13 @@ class Oracle:
             R.zref_norm2_f32.argtypes = [_f32p, C.c_size_t]
             R.zref_normalize_l2_f32.restype = None
             R.zref_normalize_l2_f32.argtypes = [_f32p, C.c_size_t, _f32p]
+            _u16p = C.POINTER(C.c_uint16)
+            for name in ("zref_sqeuclid_f16", "zref_minus_ip_f16"):
+                f = getattr(R, name)
+                f.restype = C.c_float
+                f.argtypes = [_u16p, _u16p, C.c_size_t]
+            R.zref_to_fp16.restype = None
+            R.zref_to_fp16.argtypes = [_f32p, C.c_size_t, _u16p]
             R.zref_heap_replay.restype = C.c_size_t
             R.zref_heap_replay.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_float, _u32p, _f32p]
 
@@ -93,6 +114,22 @@ class Oracle:
         lib, pre = (self.ref, "zref_") if use_ref else (self.lib, "zo_")
         fn = {METRIC_L2: "sqeuclid_f32", METRIC_IP: "minus_ip_f32", METRIC_COSINE: "cosine_f32"}[metric]
         return float(getattr(lib, pre + fn)(_ptr(m, _f32p), _ptr(q, _f32p), m.size))
+
+    def dist16(self, metric, m, q, use_ref=False):
+        """fp16 rows (numpy float16): SquaredEuclidean / MinusInnerProduct with fp32 accumulation."""
+        m = np.ascontiguousarray(m, np.float16)
+        q = np.ascontiguousarray(q, np.float16)
+        _u16p = C.POINTER(C.c_uint16)
+        lib, pre = (self.ref, "zref_") if use_ref else (self.lib, "zo_")
+        fn = {METRIC_L2: "sqeuclid_f16", METRIC_IP: "minus_ip_f16"}[metric]
+        return float(getattr(lib, pre + fn)(m.ctypes.data_as(_u16p), q.ctypes.data_as(_u16p), m.size))
+
+    def to_fp16_ref(self, x):
+        """FloatHelper::ToFP16 of the reference (needs _ref)."""
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty(x.shape, np.float16)
+        self.ref.zref_to_fp16(_ptr(x, _f32p), x.size, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+        return out
 
     def ip(self, m, q, use_ref=False):
         m = np.ascontiguousarray(m, np.float32)
@@ -135,13 +172,18 @@ class Oracle:
         for m, nm in names.items():
             addr = C.cast(getattr(self.ref, nm), C.c_void_p) if (on and self.ref) else None
             self.lib.zo_set_distance_override(m, addr)
+        for m, nm in {METRIC_L2: "zref_sqeuclid_f16", METRIC_IP: "zref_minus_ip_f16"}.items():
+            addr = C.cast(getattr(self.ref, nm), C.c_void_p) if (on and self.ref) else None
+            self.lib.zo_set_distance_override_f16(m, addr)
         return bool(on and self.ref)
 
     # -- scans ---------------------------------------------------------------------------------
     def flat_search(self, base, queries, topk, metric=METRIC_L2, keys=None, threshold=FLT_MAX,
                     exclude_bits=None, threads=1):
-        base = np.ascontiguousarray(base, np.float32)
-        queries = np.ascontiguousarray(np.atleast_2d(queries), np.float32)
+        half = np.asarray(base).dtype == np.float16          # fp16 rows => fp16 queries (HalfFloatReformer)
+        dt = np.float16 if half else np.float32
+        base = np.ascontiguousarray(base, dt)
+        queries = np.ascontiguousarray(np.atleast_2d(queries), dt)
         n, dim = base.shape
         nq = queries.shape[0]
         keys = None if keys is None else np.ascontiguousarray(keys, np.uint64)
@@ -150,10 +192,10 @@ class Oracle:
         os_ = np.full((nq, topk), np.inf, np.float32)
         oi = np.zeros((nq, topk), np.uint32)
         oc = np.zeros(nq, np.uint32)
-        rc = self.lib.zo_flat_search_mt(_ptr(base, _f32p), _ptr(keys, _u64p), n, dim, metric,
-                                        _ptr(queries, _f32p), nq, topk, threshold, _ptr(ex, _u64p),
-                                        _ptr(ok, _u64p), _ptr(os_, _f32p), _ptr(oi, _u32p),
-                                        _ptr(oc, _u32p), threads)
+        rc = self.lib.zo_flat_search_mt_t(int(half), C.c_void_p(base.ctypes.data), _ptr(keys, _u64p), n, dim, metric,
+                                          C.c_void_p(queries.ctypes.data), nq, topk, threshold, _ptr(ex, _u64p),
+                                          _ptr(ok, _u64p), _ptr(os_, _f32p), _ptr(oi, _u32p),
+                                          _ptr(oc, _u32p), threads)
         if rc != 0:
             raise RuntimeError("zo_flat_search rc=%d" % rc)
         return ok, os_, oi, oc
@@ -161,9 +203,11 @@ class Oracle:
     def ivf_search(self, centroids, list_offsets, vecs, queries, topk, nprobe, max_scan_count,
                    metric=METRIC_L2, keys=None, threshold=FLT_MAX, brute_force=False,
                    exclude_bits=None, threads=1, want_probes=False):
-        centroids = np.ascontiguousarray(centroids, np.float32)
-        vecs = np.ascontiguousarray(vecs, np.float32)
-        queries = np.ascontiguousarray(np.atleast_2d(queries), np.float32)
+        half = np.asarray(vecs).dtype == np.float16
+        dt = np.float16 if half else np.float32
+        centroids = np.ascontiguousarray(centroids, dt)
+        vecs = np.ascontiguousarray(vecs, dt)
+        queries = np.ascontiguousarray(np.atleast_2d(queries), dt)
         lo = np.ascontiguousarray(list_offsets, np.uint64)
         nlist, dim = centroids.shape
         nq = queries.shape[0]
@@ -176,6 +220,7 @@ class Oracle:
         osc = np.zeros(nq, np.uint32)
         npb = max(1, min(nprobe, nlist))
         if want_probes:
+            assert not half, "probe listing is only wired for fp32"
             op = np.zeros((nq, npb), np.uint32)
             rc = self.lib.zo_ivf_search(_ptr(centroids, _f32p), nlist, _ptr(lo, _u64p),
                                         _ptr(vecs, _f32p), _ptr(keys, _u64p), dim, metric,
@@ -185,12 +230,12 @@ class Oracle:
                                         _ptr(oc, _u32p), _ptr(osc, _u32p), _ptr(op, _u32p))
         else:
             op = None
-            rc = self.lib.zo_ivf_search_mt(_ptr(centroids, _f32p), nlist, _ptr(lo, _u64p),
-                                           _ptr(vecs, _f32p), _ptr(keys, _u64p), dim, metric,
-                                           _ptr(queries, _f32p), nq, topk, threshold, nprobe,
-                                           max_scan_count, int(brute_force), _ptr(ex, _u64p),
-                                           _ptr(ok, _u64p), _ptr(os_, _f32p), _ptr(oi, _u32p),
-                                           _ptr(oc, _u32p), _ptr(osc, _u32p), threads)
+            rc = self.lib.zo_ivf_search_mt_t(int(half), C.c_void_p(centroids.ctypes.data), nlist, _ptr(lo, _u64p),
+                                             C.c_void_p(vecs.ctypes.data), _ptr(keys, _u64p), dim, metric,
+                                             C.c_void_p(queries.ctypes.data), nq, topk, threshold, nprobe,
+                                             max_scan_count, int(brute_force), _ptr(ex, _u64p),
+                                             _ptr(ok, _u64p), _ptr(os_, _f32p), _ptr(oi, _u32p),
+                                             _ptr(oc, _u32p), _ptr(osc, _u32p), threads)
         if rc != 0:
             raise RuntimeError("zo_ivf_search rc=%d" % rc)
         if want_probes:

@@ -9,6 +9,9 @@
 //   ailego::Norm2Matrix<float,1>::Compute                       src/ailego/math/norm2_matrix_fp32.cc:47
 //   ailego::Normalizer<float>::L2                               src/ailego/math/normalizer.h:46
 //   ailego::Heap<T>                                             src/include/zvec/ailego/container/heap.h
+//   ailego::SquaredEuclideanDistanceMatrix<Float16,1,1>         src/ailego/math/euclidean_distance_matrix_fp16.cc:137
+//   ailego::MinusInnerProductMatrix<Float16,1,1>                src/ailego/math/inner_product_matrix_fp16.cc:166
+//   ailego::FloatHelper::ToFP16                                 src/ailego/utility/float_helper.cc
 #include <cstddef>
 #include <cstdint>
 #include <limits>
@@ -18,6 +21,7 @@
 #include <ailego/math/norm2_matrix.h>
 #include <ailego/math/normalizer.h>
 #include <zvec/ailego/container/heap.h>
+#include <zvec/ailego/utility/float_helper.h>
 
 using namespace zvec::ailego;
 
@@ -64,6 +68,21 @@ float zref_norm2_f32(const float *m, size_t dim) {
 void zref_normalize_l2_f32(float *arr, size_t dim, float *norm) {
   Normalizer<float>::L2(arr, dim, norm);
 }
+
+// fp16 rows: Float16 is a 2-byte POD over uint16_t (src/include/zvec/ailego/utility/float_helper.h)
+float zref_sqeuclid_f16(const uint16_t *m, const uint16_t *q, size_t dim) {
+  float out;
+  SquaredEuclideanDistanceMatrix<Float16, 1, 1>::Compute(reinterpret_cast<const Float16 *>(m),
+                                                         reinterpret_cast<const Float16 *>(q), dim, &out);
+  return out;
+}
+float zref_minus_ip_f16(const uint16_t *m, const uint16_t *q, size_t dim) {
+  float out;
+  MinusInnerProductMatrix<Float16, 1, 1>::Compute(reinterpret_cast<const Float16 *>(m),
+                                                  reinterpret_cast<const Float16 *>(q), dim, &out);
+  return out;
+}
+void zref_to_fp16(const float *in, size_t n, uint16_t *out) { FloatHelper::ToFP16(in, n, out); }
 
 // Replays n emplace() calls through the reference Heap and returns the heap array as laid out.
 size_t zref_heap_replay(const float *scores, size_t n, size_t limit, float threshold,

@@ -106,6 +106,92 @@ float zo_cosine_f32(const float *m, const float *q, size_t dim_with_norm) {
   return 1 - lane_ip(m, q, d);
 }
 
+/* ---- fp16 rows (IndexMeta::DT_FP16, HalfFloatConverter / HalfFloatReformer) ------------------------
+ * SquaredEuclideanDistanceMatrix<Float16,1,1> / (Minus)InnerProductMatrix<Float16,1,1> on an AVX-512 CPU
+ * WITHOUT AVX512-FP16 (euclidean_distance_matrix_fp16.cc:137-158, inner_product_matrix_fp16.cc:143-186):
+ * ACCUM_FP16_1X1_AVX512 (distance_matrix_accum_fp16.i:554-594) converts halves to fp32 (exact) and keeps
+ * ONE 16-lane fp32 accumulator: per 32 elements two FMA steps (low 16 then high 16), one more 16-step if
+ * it fits, fold 16 -> 8 lanes (low + high), one 8-lane step if it fits, the last < 8 elements as one
+ * zero-padded 8-lane step, then ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)). */
+static float half_to_float(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
+  if (exp == 0) {
+    if (man == 0) bits = sign;
+    else {
+      int e = -1;
+      do { man <<= 1; ++e; } while (!(man & 0x400u));
+      bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+  else bits = sign | ((exp + 112) << 23) | (man << 13);
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+/* fp32 -> fp16, round to nearest even (what _mm_cvtps_ph(…, _MM_FROUND_TO_NEAREST_INT) / FloatHelper::ToFP16 do) */
+uint16_t zo_float_to_half(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  int32_t exp = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+  uint32_t man = x & 0x7fffffu;
+  if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u | (man >> 13) : 0));
+  if (exp >= 31) return (uint16_t)(sign | 0x7c00u);
+  if (exp <= 0) {
+    if (exp < -10) return (uint16_t)sign;
+    man |= 0x800000u;
+    uint32_t shift = (uint32_t)(14 - exp);
+    uint32_t half = man >> shift;
+    uint32_t rem = man & ((1u << shift) - 1), mid = 1u << (shift - 1);
+    if (rem > mid || (rem == mid && (half & 1))) ++half;
+    return (uint16_t)(sign | half);
+  }
+  uint32_t half = ((uint32_t)exp << 10) | (man >> 13);
+  uint32_t rem = man & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (half & 1))) ++half;   /* may carry into the exponent: correct */
+  return (uint16_t)(sign | half);
+}
+float zo_half_to_float(uint16_t h) { return half_to_float(h); }
+
+#define ZO_DEFINE_F16_KERNEL(NAME, STEP)                                                          \
+  static float NAME(const uint16_t *m, const uint16_t *q, size_t dim) {                           \
+    float s[16];                                                                                  \
+    for (int i = 0; i < 16; ++i) s[i] = 0.0f;                                                     \
+    size_t aligned = (dim >> 5) << 5, p = 0;                                                      \
+    for (; p != aligned; p += 32) {                                                               \
+      for (int i = 0; i < 16; ++i) s[i] = STEP(half_to_float(m[p + i]), half_to_float(q[p + i]), s[i]);            \
+      for (int i = 0; i < 16; ++i) s[i] = STEP(half_to_float(m[p + 16 + i]), half_to_float(q[p + 16 + i]), s[i]);  \
+    }                                                                                             \
+    if (dim >= aligned + 16) {                                                                    \
+      for (int i = 0; i < 16; ++i) s[i] = STEP(half_to_float(m[p + i]), half_to_float(q[p + i]), s[i]);            \
+      p += 16;                                                                                    \
+    }                                                                                             \
+    float y[8];                                                                                   \
+    for (int i = 0; i < 8; ++i) y[i] = s[i] + s[i + 8];                                           \
+    if (dim >= p + 8) {                                                                           \
+      for (int i = 0; i < 8; ++i) y[i] = STEP(half_to_float(m[p + i]), half_to_float(q[p + i]), y[i]);             \
+      p += 8;                                                                                     \
+    }                                                                                             \
+    if (p < dim) { /* MATRIX_FP16_MASK_AVX: one zero-padded 8-lane step; a tail of exactly ONE element */  \
+      size_t left = dim - p; /* sits in lane 7 (its _mm_set_epi16 lists it first = highest lane, :96-107) */ \
+      if (left == 1) {                                                                            \
+        y[7] = STEP(half_to_float(m[p]), half_to_float(q[p]), y[7]);                              \
+      } else {                                                                                    \
+        for (size_t i = 0; i < left; ++i)                                                         \
+          y[i] = STEP(half_to_float(m[p + i]), half_to_float(q[p + i]), y[i]);                    \
+      }                                                                                           \
+    }                                                                                             \
+    return hadd_lanes(y, 8);                                                                      \
+  }
+ZO_DEFINE_F16_KERNEL(lane_ssd_f16, step_ssd)
+ZO_DEFINE_F16_KERNEL(lane_ip_f16, step_fma)
+
+float zo_sqeuclid_f16(const uint16_t *m, const uint16_t *q, size_t dim) { return lane_ssd_f16(m, q, dim); }
+float zo_ip_f16(const uint16_t *m, const uint16_t *q, size_t dim) { return lane_ip_f16(m, q, dim); }
+float zo_minus_ip_f16(const uint16_t *m, const uint16_t *q, size_t dim) { return -lane_ip_f16(m, q, dim); }
+
 /* Norm2Matrix<float,1>::Compute, AVX-512 build: NORM_FP32_1_AVX512 (norm_matrix_fp32.i:120-157)
  * two 16-lane accumulators, one extra 16-chunk and the masked tail both go to accumulator 0,
  * then add + horizontal add + sqrt.  (With AVX512F compiled in, this macro is used for every dim.) */
@@ -142,6 +228,19 @@ void zo_cosine_transform_f32(const float *in, size_t dim, float *out) {
   float norm = 0.0f;
   zo_normalize_l2_f32(out, dim, &norm);
   out[dim] = norm;
+}
+
+static zo_dist_fn g_override16[3] = {NULL, NULL, NULL};
+void zo_set_distance_override_f16(int metric, zo_dist_fn fn) {
+  if (metric >= 0 && metric < 3) g_override16[metric] = fn;
+}
+
+/* dtype: 0 = fp32 rows, 1 = fp16 rows (cosine over fp16 rows is not restated) */
+static inline float zo_distance_t(int dtype, int metric, const void *m, const void *q, size_t dim) {
+  if (dtype == 0) return zo_distance(metric, (const float *)m, (const float *)q, dim);
+  if (g_override16[metric]) return g_override16[metric]((const float *)m, (const float *)q, dim);
+  if (metric == ZO_METRIC_L2) return lane_ssd_f16((const uint16_t *)m, (const uint16_t *)q, dim);
+  return -lane_ip_f16((const uint16_t *)m, (const uint16_t *)q, dim);
 }
 
 float zo_distance(int metric, const float *m, const float *q, size_t dim) {
@@ -253,21 +352,23 @@ static inline int bit_set(const uint64_t *bits, uint64_t pos) {
  * (The single-query loops :420-560 and FlatStreamerEntity::search flat_streamer_entity.cc:212-316
  * visit vectors in the same storage order, so the same restatement covers them.)
  * ======================================================================================== */
-static int flat_search_range(const float *base, const uint64_t *keys, uint64_t n, uint32_t dim,
-                             int metric, const float *queries, uint32_t q0, uint32_t q1,
+static int flat_search_range(int dtype, const void *base_v, const uint64_t *keys, uint64_t n, uint32_t dim,
+                             int metric, const void *queries_v, uint32_t q0, uint32_t q1,
                              uint32_t topk, float threshold, const uint64_t *exclude_bits,
                              uint64_t *out_keys, float *out_scores, uint32_t *out_index,
                              uint32_t *out_counts) {
   if (topk == 0) return -31; /* IndexError_InvalidArgument */
   zo_doc *st = (zo_doc *)malloc(sizeof(zo_doc) * topk);
   if (!st) return -2;
+  const size_t rb = (size_t)dim * (dtype ? 2 : 4);   /* row bytes */
+  const char *base = (const char *)base_v, *queries = (const char *)queries_v;
   for (uint32_t q = q0; q < q1; ++q) {
     zo_heap h;
     zo_heap_init(&h, st, topk, threshold);
-    const float *qv = queries + (size_t)q * dim;
+    const char *qv = queries + (size_t)q * rb;
     for (uint64_t i = 0; i < n; ++i) {
       if (bit_set(exclude_bits, i)) continue;
-      float s = zo_distance(metric, base + (size_t)i * dim, qv, dim);
+      float s = zo_distance_t(dtype, metric, base + (size_t)i * rb, qv, dim);
       zo_heap_emplace(&h, keys ? keys[i] : i, s, (uint32_t)i);
     }
     zo_heap_sort(&h);
@@ -286,7 +387,7 @@ int zo_flat_search(const float *base, const uint64_t *keys, uint64_t n, uint32_t
                    const float *queries, uint32_t nq, uint32_t topk, float threshold,
                    const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores,
                    uint32_t *out_index, uint32_t *out_counts) {
-  return flat_search_range(base, keys, n, dim, metric, queries, 0, nq, topk, threshold,
+  return flat_search_range(0, base, keys, n, dim, metric, queries, 0, nq, topk, threshold,
                            exclude_bits, out_keys, out_scores, out_index, out_counts);
 }
 
@@ -304,9 +405,9 @@ int zo_flat_search(const float *base, const uint64_t *keys, uint64_t n, uint32_t
  *              in list-id order (ivf_entity.cc:719-745).
  *  final:    heap.sort(); topk_to_result truncates at score > threshold (ivf_searcher_context.h:184-208).
  * ======================================================================================== */
-static int ivf_search_range(const float *centroids, uint32_t nlist, const uint64_t *list_offsets,
-                            const float *vecs, const uint64_t *keys, uint32_t dim, int metric,
-                            const float *queries, uint32_t q0, uint32_t q1, uint32_t topk,
+static int ivf_search_range(int dtype, const void *centroids_v, uint32_t nlist, const uint64_t *list_offsets,
+                            const void *vecs_v, const uint64_t *keys, uint32_t dim, int metric,
+                            const void *queries_v, uint32_t q0, uint32_t q1, uint32_t topk,
                             float threshold, uint32_t nprobe, uint32_t max_scan_count,
                             int brute_force, const uint64_t *exclude_bits, uint64_t *out_keys,
                             float *out_scores, uint32_t *out_index, uint32_t *out_counts,
@@ -317,8 +418,10 @@ static int ivf_search_range(const float *centroids, uint32_t nlist, const uint64
   zo_doc *st = (zo_doc *)malloc(sizeof(zo_doc) * topk);
   zo_doc *cst = (zo_doc *)malloc(sizeof(zo_doc) * nprobe);
   if (!st || !cst) return -2;
+  const size_t rb = (size_t)dim * (dtype ? 2 : 4);
+  const char *centroids = (const char *)centroids_v, *vecs = (const char *)vecs_v, *queries = (const char *)queries_v;
   for (uint32_t q = q0; q < q1; ++q) {
-    const float *qv = queries + (size_t)q * dim;
+    const char *qv = queries + (size_t)q * rb;
     zo_heap h;
     zo_heap_init(&h, st, topk, threshold);
     uint32_t total_scan = 0;
@@ -328,7 +431,7 @@ static int ivf_search_range(const float *centroids, uint32_t nlist, const uint64
       for (uint32_t l = 0; l < nlist; ++l) {
         for (uint64_t p = list_offsets[l]; p < list_offsets[l + 1]; ++p) {
           if (bit_set(exclude_bits, p)) continue;
-          float s = zo_distance(metric, vecs + (size_t)p * dim, qv, dim);
+          float s = zo_distance_t(dtype, metric, vecs + (size_t)p * rb, qv, dim);
           zo_heap_emplace(&h, keys ? keys[p] : p, s, (uint32_t)p);
         }
         total_scan += (uint32_t)(list_offsets[l + 1] - list_offsets[l]);
@@ -337,7 +440,7 @@ static int ivf_search_range(const float *centroids, uint32_t nlist, const uint64
       zo_heap ch;
       zo_heap_init(&ch, cst, nprobe, FLT_MAX);
       for (uint32_t c = 0; c < nlist; ++c) {
-        float s = zo_distance(metric, centroids + (size_t)c * dim, qv, dim);
+        float s = zo_distance_t(dtype, metric, centroids + (size_t)c * rb, qv, dim);
         zo_heap_emplace(&ch, c, s, c);
       }
       zo_heap_sort(&ch);
@@ -346,7 +449,7 @@ static int ivf_search_range(const float *centroids, uint32_t nlist, const uint64
         if (out_probes) out_probes[(size_t)q * nprobe + i] = l;
         for (uint64_t p = list_offsets[l]; p < list_offsets[l + 1]; ++p) {
           if (bit_set(exclude_bits, p)) continue;
-          float s = zo_distance(metric, vecs + (size_t)p * dim, qv, dim);
+          float s = zo_distance_t(dtype, metric, vecs + (size_t)p * rb, qv, dim);
           zo_heap_emplace(&h, keys ? keys[p] : p, s, (uint32_t)p);
         }
         total_scan += (uint32_t)(list_offsets[l + 1] - list_offsets[l]);
@@ -376,7 +479,7 @@ int zo_ivf_search(const float *centroids, uint32_t nlist, const uint64_t *list_o
                   const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores,
                   uint32_t *out_index, uint32_t *out_counts, uint32_t *out_scanned,
                   uint32_t *out_probes) {
-  return ivf_search_range(centroids, nlist, list_offsets, vecs, keys, dim, metric, queries, 0, nq,
+  return ivf_search_range(0, centroids, nlist, list_offsets, vecs, keys, dim, metric, queries, 0, nq,
                           topk, threshold, nprobe, max_scan_count, brute_force, exclude_bits,
                           out_keys, out_scores, out_index, out_counts, out_scanned, out_probes);
 }
@@ -385,15 +488,16 @@ int zo_ivf_search(const float *centroids, uint32_t nlist, const uint64_t *list_o
  * shared index; one query is always scanned by a single thread). */
 typedef struct {
   int kind; /* 0 flat, 1 ivf */
-  const float *centroids;
+  int dtype;
+  const void *centroids;
   uint32_t nlist;
   const uint64_t *list_offsets;
-  const float *base;
+  const void *base;
   const uint64_t *keys;
   uint64_t n;
   uint32_t dim;
   int metric;
-  const float *queries;
+  const void *queries;
   uint32_t q0, q1, topk;
   float threshold;
   uint32_t nprobe, max_scan;
@@ -408,11 +512,11 @@ typedef struct {
 static void *zo_worker(void *arg) {
   zo_job *j = (zo_job *)arg;
   if (j->kind == 0)
-    j->rc = flat_search_range(j->base, j->keys, j->n, j->dim, j->metric, j->queries, j->q0, j->q1,
+    j->rc = flat_search_range(j->dtype, j->base, j->keys, j->n, j->dim, j->metric, j->queries, j->q0, j->q1,
                               j->topk, j->threshold, j->exclude_bits, j->out_keys, j->out_scores,
                               j->out_index, j->out_counts);
   else
-    j->rc = ivf_search_range(j->centroids, j->nlist, j->list_offsets, j->base, j->keys, j->dim,
+    j->rc = ivf_search_range(j->dtype, j->centroids, j->nlist, j->list_offsets, j->base, j->keys, j->dim,
                              j->metric, j->queries, j->q0, j->q1, j->topk, j->threshold,
                              j->nprobe, j->max_scan, j->brute_force, j->exclude_bits, j->out_keys,
                              j->out_scores, j->out_index, j->out_counts, j->out_scanned, NULL);
@@ -493,6 +597,33 @@ int zo_ivf_search_mt(const float *centroids, uint32_t nlist, const uint64_t *lis
   p.out_index = out_index;
   p.out_counts = out_counts;
   p.out_scanned = out_scanned;
+  return run_jobs(p, nq, threads);
+}
+
+int zo_flat_search_mt_t(int dtype, const void *base, const uint64_t *keys, uint64_t n, uint32_t dim, int metric,
+                        const void *queries, uint32_t nq, uint32_t topk, float threshold,
+                        const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores, uint32_t *out_index,
+                        uint32_t *out_counts, int threads) {
+  zo_job p;
+  memset(&p, 0, sizeof(p));
+  p.kind = 0; p.dtype = dtype; p.base = base; p.keys = keys; p.n = n; p.dim = dim; p.metric = metric;
+  p.queries = queries; p.topk = topk; p.threshold = threshold; p.exclude_bits = exclude_bits;
+  p.out_keys = out_keys; p.out_scores = out_scores; p.out_index = out_index; p.out_counts = out_counts;
+  return run_jobs(p, nq, threads);
+}
+
+int zo_ivf_search_mt_t(int dtype, const void *centroids, uint32_t nlist, const uint64_t *list_offsets,
+                       const void *vecs, const uint64_t *keys, uint32_t dim, int metric, const void *queries,
+                       uint32_t nq, uint32_t topk, float threshold, uint32_t nprobe, uint32_t max_scan_count,
+                       int brute_force, const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores,
+                       uint32_t *out_index, uint32_t *out_counts, uint32_t *out_scanned, int threads) {
+  zo_job p;
+  memset(&p, 0, sizeof(p));
+  p.kind = 1; p.dtype = dtype; p.centroids = centroids; p.nlist = nlist; p.list_offsets = list_offsets;
+  p.base = vecs; p.keys = keys; p.dim = dim; p.metric = metric; p.queries = queries; p.topk = topk;
+  p.threshold = threshold; p.nprobe = nprobe; p.max_scan = max_scan_count; p.brute_force = brute_force;
+  p.exclude_bits = exclude_bits; p.out_keys = out_keys; p.out_scores = out_scores; p.out_index = out_index;
+  p.out_counts = out_counts; p.out_scanned = out_scanned;
   return run_jobs(p, nq, threads);
 }
 

@@ -52,6 +52,14 @@ void zo_cosine_transform_f32(const float *in, size_t dim, float *out);
 /* generic dispatch by metric, `dim` is the element dimension (d+1 for cosine) */
 float zo_distance(int metric, const float *m, const float *q, size_t dim);
 
+/* fp16 rows (DT_FP16): halves as uint16_t; restated AVX-512 (no FP16 ISA) order, fp32 accumulation */
+float zo_sqeuclid_f16(const uint16_t *m, const uint16_t *q, size_t dim);
+float zo_ip_f16(const uint16_t *m, const uint16_t *q, size_t dim);
+float zo_minus_ip_f16(const uint16_t *m, const uint16_t *q, size_t dim);
+uint16_t zo_float_to_half(float f);   /* round to nearest even (HalfFloatConverter / Reformer) */
+float zo_half_to_float(uint16_t h);
+void zo_set_distance_override_f16(int metric, zo_dist_fn fn);
+
 /* ---- bounded heap (ailego::Heap<IndexDocument> + IndexDocumentHeap) ------------------- */
 typedef struct {
   uint64_t key;
@@ -107,6 +115,17 @@ int zo_ivf_search_mt(const float *centroids, uint32_t nlist, const uint64_t *lis
                      const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores,
                      uint32_t *out_index, uint32_t *out_counts, uint32_t *out_scanned,
                      int threads);
+
+/* dtype-generic forms: dtype 0 = fp32 rows, 1 = fp16 rows (centroids, vectors and queries all of that type) */
+int zo_flat_search_mt_t(int dtype, const void *base, const uint64_t *keys, uint64_t n, uint32_t dim, int metric,
+                        const void *queries, uint32_t nq, uint32_t topk, float threshold,
+                        const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores, uint32_t *out_index,
+                        uint32_t *out_counts, int threads);
+int zo_ivf_search_mt_t(int dtype, const void *centroids, uint32_t nlist, const uint64_t *list_offsets,
+                       const void *vecs, const uint64_t *keys, uint32_t dim, int metric, const void *queries,
+                       uint32_t nq, uint32_t topk, float threshold, uint32_t nprobe, uint32_t max_scan_count,
+                       int brute_force, const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores,
+                       uint32_t *out_index, uint32_t *out_counts, uint32_t *out_scanned, int threads);
 
 /* ---- shard merge (CombinedVectorColumnIndexer::Search, combined_vector_column_indexer.cc:172-232)
  * concat partial lists, sort by score, truncate to topk. */

@@ -1,0 +1,110 @@
+"""fp16 rows (IndexMeta::DT_FP16 — BASELINE configs[3] stores the corpus in fp16): HalfFloatConverter output on the
+base side, HalfFloatReformer output on the query side, fp32 accumulation.  The GPU multiplies halves on the f16
+matrix cores (products exact in fp32) and accumulates in fp32; the oracle restates the reference's AVX-512
+(no FP16 ISA) kernels bit for bit (distance_matrix_accum_fp16.i:554-594)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import tie_tolerant_compare, kmeans_lists, exact_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zv():
+    import zvec_amd
+    return zvec_amd
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(1000, 16, 5, 3), (3000, 100, 40, 10), (5000, 768, 33, 10), (2000, 65, 130, 20)])
+def test_flat_fp16_integer_bit_exact(zv, oracle, n, dim, nq, k):
+    rng = np.random.default_rng(n + dim)
+    hi = 64 if dim <= 128 else 16
+    base = rng.integers(0, hi, (n, dim)).astype(np.float16)       # integers are exact in fp16
+    q = rng.integers(0, hi, (nq, dim)).astype(np.float16)
+    for metric, name in ((O.METRIC_L2, "SquaredEuclidean"), (O.METRIC_IP, "InnerProduct")):
+        se = zv.HipFlatSearcher(dim, name, dtype="fp16")
+        assert se.load(base) == 0
+        ctx = se.create_context()
+        ctx.set_topk(k)
+        assert se.search_impl(q, nq, ctx) == 0
+        ok, os_, _, oc = oracle.flat_search(base, q, k, metric)
+        tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="fp16 %s" % name)
+    got = se.get_vector_by_id(n - 1)
+    assert got.dtype == np.float16 and np.array_equal(got, base[n - 1])
+
+
+def test_flat_fp16_gaussian_tolerance(zv, oracle):
+    rng = np.random.default_rng(5)
+    n, dim, nq, k = 4000, 768, 24, 10
+    base = rng.standard_normal((n, dim)).astype(np.float16)        # HalfFloatConverter: RNE, == numpy astype
+    q = rng.standard_normal((nq, dim)).astype(np.float16)
+    qn = (q.astype(np.float64) ** 2).sum(1)
+    bn = (base.astype(np.float64) ** 2).sum(1).max()
+    se = zv.HipFlatSearcher(dim, "SquaredEuclidean", dtype="fp16")
+    assert se.load(base) == 0
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc = oracle.flat_search(base, q, k, O.METRIC_L2)
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, rtol=2e-6, atol=1e-6, select_band=4e-6 * (qn + bn),
+                         what="fp16 L2 gaussian")
+    se = zv.HipFlatSearcher(dim, "InnerProduct", dtype="fp16")
+    assert se.load(base) == 0
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc = oracle.flat_search(base, q, k, O.METRIC_IP)
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, rtol=4e-6, scale=np.sqrt(qn * bn), what="fp16 IP gaussian")
+
+
+def test_ivf_fp16_same_index_on_both_sides(zv, oracle):
+    rng = np.random.default_rng(8)
+    n, dim, nlist, nq, k = 8000, 64, 50, 90, 10
+    base32 = rng.integers(0, 40, (n, dim)).astype(np.float32)
+    q = rng.integers(0, 40, (nq, dim)).astype(np.float16)
+    cent, offs, order = kmeans_lists(rng, base32, nlist)
+    cent = np.round(cent).astype(np.float16)
+    vecs, keys = base32[order].astype(np.float16), order.astype(np.uint64)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=0.2, brute_force_threshold=100, dtype="fp16")
+    assert se.load(cent, offs, vecs, keys) == 0
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, osc = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys)
+    cd = np.sort(exact_l2(cent.astype(np.float32), q.astype(np.float32)), 1)
+    sel = np.nonzero(cd[:, nprobe - 1] != cd[:, nprobe])[0]
+    tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel], what="ivf fp16")
+    scanned, _ = se.last_stats(ctx, nq)
+    assert np.array_equal(scanned[sel], osc[sel])
+    c2, o2, rows = se.export()
+    assert c2.dtype == np.float16 and np.array_equal(c2, cent) and np.array_equal(o2, offs)
+
+
+def test_ivf_fp16_gpu_build(zv, oracle):
+    rng = np.random.default_rng(9)
+    n, dim, nlist, nq, k = 20000, 96, 48, 60, 10
+    base = (rng.standard_normal((n, 8)) @ rng.standard_normal((8, dim))).astype(np.float16)
+    q = (rng.standard_normal((nq, 8)) @ rng.standard_normal((8, dim))).astype(np.float16)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=8 / 48., brute_force_threshold=n - 1, dtype="fp16")
+    assert se.build(base, nlist, kmeans_iters=6, sample_per_list=128) == 0
+    cent, offs, rows = se.export()
+    assert cent.dtype == np.float16 and offs[-1] == n
+    vecs = base[rows.astype(np.int64)]
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=rows)
+    qn = (q.astype(np.float64) ** 2).sum(1)
+    bn = (base.astype(np.float64) ** 2).sum(1).max()
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, rtol=2e-6, atol=1e-5,
+                         select_band=4e-6 * (qn + bn), what="ivf fp16 built")
+    fk, _, _, _ = oracle.flat_search(base, q, k, threads=4)
+    recall = np.mean([len(set(ctx.keys[i].tolist()) & set(fk[i].tolist())) / k for i in range(nq)])
+    assert recall > 0.9, recall
+
+
+def test_fp16_cosine_is_refused(zv):
+    with pytest.raises(RuntimeError):
+        zv.HipFlatSearcher(17, "Cosine", dtype="fp16")

@@ -34,6 +34,7 @@ constexpr uint32_t IDX_NONE = 0xffffffffu;
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 enum { METRIC_L2 = 0, METRIC_IP = 1, METRIC_COSINE = 2 };
 
@@ -305,7 +306,11 @@ struct ScanShape {
   static constexpr int QLOADS = M16 ? 1 : NG;           // 16-byte query loads per thread per k-step
 };
 
-template <int NG, bool M16, bool EXCL>
+// F16: rows and queries are IEEE half (DT_FP16); products are exact in fp32 and accumulated in fp32 by
+// v_mfma_f32_16x16x32_f16 / v_mfma_f32_32x32x16_f16 — the reference converts to fp32 and accumulates in fp32
+// too (distance_matrix_accum_fp16.i:554-594).  The staging is byte-identical: a row segment per k-step is
+// 128 B either way (32 floats or 64 halves); `dpad` counts 4-byte words per row.
+template <int NG, bool M16, bool EXCL, bool F16>
 __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
   constexpr int ROWS = ScanShape<NG, M16>::ROWS;
   constexpr int QL = ScanShape<NG, M16>::QLOADS;
@@ -513,15 +518,20 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
             for (int cb = 0; cb < 2; ++cb) {
               const int brow = wave * 32 + cb * 16 + r16;
               const f32x4 bf = *reinterpret_cast<const f32x4 *>(Bb + (brow * 8 + c) * 4);
-              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.x, bf.x, acc16[cb], 0, 0, 0);
-              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.y, bf.y, acc16[cb], 0, 0, 0);
-              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.z, bf.z, acc16[cb], 0, 0, 0);
-              acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.w, bf.w, acc16[cb], 0, 0, 0);
-              if (two) {
-                acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.x, bf.x, acc16[2 + cb], 0, 0, 0);
-                acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.y, bf.y, acc16[2 + cb], 0, 0, 0);
-                acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.z, bf.z, acc16[2 + cb], 0, 0, 0);
-                acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.w, bf.w, acc16[2 + cb], 0, 0, 0);
+              if constexpr (F16) {
+                acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af0), __builtin_bit_cast(f16x8, bf), acc16[cb], 0, 0, 0);
+                if (two) acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af1), __builtin_bit_cast(f16x8, bf), acc16[2 + cb], 0, 0, 0);
+              } else {
+                acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.x, bf.x, acc16[cb], 0, 0, 0);
+                acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.y, bf.y, acc16[cb], 0, 0, 0);
+                acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.z, bf.z, acc16[cb], 0, 0, 0);
+                acc16[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0.w, bf.w, acc16[cb], 0, 0, 0);
+                if (two) {
+                  acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.x, bf.x, acc16[2 + cb], 0, 0, 0);
+                  acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.y, bf.y, acc16[2 + cb], 0, 0, 0);
+                  acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.z, bf.z, acc16[2 + cb], 0, 0, 0);
+                  acc16[2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1.w, bf.w, acc16[2 + cb], 0, 0, 0);
+                }
               }
             }
           }
@@ -536,10 +546,14 @@ __global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
               const f32x4 af = *reinterpret_cast<const f32x4 *>(Qb + ((g * 32 + r) * 8 + c) * 4);
-              acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[g], 0, 0, 0);
-              acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[g], 0, 0, 0);
-              acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[g], 0, 0, 0);
-              acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[g], 0, 0, 0);
+              if constexpr (F16) {
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, bf), acc[g], 0, 0, 0);
+              } else {
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[g], 0, 0, 0);
+              }
             }
           }
         }
@@ -772,10 +786,36 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
 // ---------------------------------------------------------------------------------------------
 // data-movement kernels
 // ---------------------------------------------------------------------------------------------
-// one wave per row: rows [n][dim_in] (row-major, fp32) -> blocked store at positions pos0 + i
-// (or dst_pos[i]); writes the squared norm of the scanned dims; zero-fills the k padding.
-__global__ void __launch_bounds__(256) pack_rows_kernel(const float *src, uint64_t n, uint32_t dim_in,
-                                                        uint32_t dscan, uint32_t dpad,
+// element (pos, e) of a blocked store whose rows hold fp32 (F16=false) or halves (F16=true); dpadw = words/row
+template <bool F16>
+__device__ __forceinline__ float load_elem(const float *base, uint64_t pos, uint32_t e, uint32_t dpadw) {
+  if constexpr (F16) {
+    const _Float16 *h = reinterpret_cast<const _Float16 *>(base);
+    return (float)h[blocked_offset(pos, e >> 1, dpadw) * 2 + (e & 1)];
+  } else {
+    return base[blocked_offset(pos, e, dpadw)];
+  }
+}
+template <bool F16>
+__device__ __forceinline__ void store_elem(float *base, uint64_t pos, uint32_t e, uint32_t dpadw, float v) {
+  if constexpr (F16) {
+    _Float16 *h = reinterpret_cast<_Float16 *>(base);
+    h[blocked_offset(pos, e >> 1, dpadw) * 2 + (e & 1)] = (_Float16)v;    // exact: v came from a half
+  } else {
+    base[blocked_offset(pos, e, dpadw)] = v;
+  }
+}
+template <bool F16>
+__device__ __forceinline__ float load_row_elem(const void *rows, size_t row, uint32_t dim_in, uint32_t c) {
+  if constexpr (F16) return (float)reinterpret_cast<const _Float16 *>(rows)[row * dim_in + c];
+  else return reinterpret_cast<const float *>(rows)[row * dim_in + c];
+}
+
+// one wave per row: rows [n][dim_in] (row-major, fp32 or fp16) -> blocked store at positions pos0 + i
+// (or dst_pos[i]); writes the squared norm of the scanned dims (fp32); zero-fills the k padding.
+template <bool F16>
+__global__ void __launch_bounds__(256) pack_rows_kernel(const void *src, uint64_t n, uint32_t dim_in,
+                                                        uint32_t dscan, uint32_t dpadw,
                                                         const uint64_t *src_row,   // nullable gather
                                                         uint64_t pos0, const uint64_t *dst_pos,
                                                         float *base, float *bnorm, float *extra /*cosine norm*/) {
@@ -784,44 +824,35 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const float *src, uint64
   if (i >= n) return;
   uint64_t sr = src_row ? src_row[i] : i;
   uint64_t pos = dst_pos ? dst_pos[i] : pos0 + i;
-  const float *row = src + (size_t)sr * dim_in;
+  const uint32_t nelem = dpadw * (F16 ? 2u : 1u);
   float acc = 0.f;
-  for (uint32_t c = lane; c < dpad; c += 64) {
-    float v = (c < dscan) ? row[c] : 0.f;
-    base[blocked_offset(pos, c, dpad)] = v;
+  for (uint32_t c = lane; c < nelem; c += 64) {
+    float v = (c < dscan) ? load_row_elem<F16>(src, sr, dim_in, c) : 0.f;
+    store_elem<F16>(base, pos, c, dpadw, v);
     acc = fmaf(v, v, acc);
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
   if (lane == 0) {
     if (bnorm) bnorm[pos] = acc;
-    if (extra) extra[pos] = (dim_in > dscan) ? row[dscan] : 0.f;
+    if (extra) extra[pos] = (dim_in > dscan) ? load_row_elem<F16>(src, sr, dim_in, dscan) : 0.f;
   }
 }
 
-// zero-fill padded rows [pos_begin, pos_end) of the blocked store (list tails)
-__global__ void __launch_bounds__(256) zero_rows_kernel(float *base, float *bnorm, uint32_t dpad,
-                                                        const uint64_t *pos_list, uint64_t count) {
-  const int lane = threadIdx.x & 63;
-  uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= count) return;
-  uint64_t pos = pos_list[i];
-  for (uint32_t c = lane; c < dpad; c += 64) base[blocked_offset(pos, c, dpad)] = 0.f;
-  if (lane == 0 && bnorm) bnorm[pos] = 0.f;
-}
-
-// queries [nq][dim_in] -> padded row-major [nq][dpad] + squared norms
-__global__ void __launch_bounds__(256) prep_queries_kernel(const float *src, uint32_t nq, uint32_t dim_in,
-                                                           uint32_t dscan, uint32_t dpad, float *dst,
+// queries [nq][dim_in] (fp32 or fp16) -> padded row-major [nq][dpadw words] of the same element type + squared norms
+template <bool F16>
+__global__ void __launch_bounds__(256) prep_queries_kernel(const void *src, uint32_t nq, uint32_t dim_in,
+                                                           uint32_t dscan, uint32_t dpadw, float *dst,
                                                            float *qnorm, uint32_t *gtau, float threshold) {
   const int lane = threadIdx.x & 63;
   uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= nq) return;
-  const float *row = src + (size_t)i * dim_in;
+  const uint32_t nelem = dpadw * (F16 ? 2u : 1u);
   float acc = 0.f;
-  for (uint32_t c = lane; c < dpad; c += 64) {
-    float v = (c < dscan) ? row[c] : 0.f;
-    dst[(size_t)i * dpad + c] = v;
+  for (uint32_t c = lane; c < nelem; c += 64) {
+    float v = (c < dscan) ? load_row_elem<F16>(src, i, dim_in, c) : 0.f;
+    if constexpr (F16) reinterpret_cast<_Float16 *>(dst)[(size_t)i * nelem + c] = (_Float16)v;
+    else dst[(size_t)i * dpadw + c] = v;
     acc = fmaf(v, v, acc);
   }
 #pragma unroll
@@ -832,11 +863,14 @@ __global__ void __launch_bounds__(256) prep_queries_kernel(const float *src, uin
   }
 }
 
-// blocked row -> plain row (get_vector_by_id)
+// blocked row -> plain row (get_vector_by_id), in the store's element type
+template <bool F16>
 __global__ void unpack_row_kernel(const float *base, const float *extra, uint64_t pos, uint32_t dscan,
-                                  uint32_t dim_out, uint32_t dpad, float *out) {
+                                  uint32_t dim_out, uint32_t dpadw, void *out) {
   for (uint32_t c = threadIdx.x; c < dim_out; c += blockDim.x) {
-    out[c] = (c < dscan) ? base[blocked_offset(pos, c, dpad)] : (extra ? extra[pos] : 0.f);
+    float v = (c < dscan) ? load_elem<F16>(base, pos, c, dpadw) : (extra ? extra[pos] : 0.f);
+    if constexpr (F16) reinterpret_cast<_Float16 *>(out)[c] = (_Float16)v;
+    else reinterpret_cast<float *>(out)[c] = v;
   }
 }
 
@@ -861,7 +895,8 @@ __global__ void fill_keys_kernel(uint64_t *keys, uint64_t pos0, uint64_t n, cons
 // (query, result): a 3 KiB gather each, ~30 MB per 1024x10 batch) and the list is re-sorted by the
 // refined score, previous rank breaking ties.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) rescore_l2_kernel(const float *base, const float *queries, uint32_t dpad,
+template <bool F16>
+__global__ void __launch_bounds__(256) rescore_l2_kernel(const float *base, const float *queries, uint32_t dpadw,
                                                          const uint32_t *idx, const uint32_t *counts, uint32_t nq,
                                                          uint32_t k, float *scores) {
   const int lane = threadIdx.x & 63;
@@ -870,10 +905,13 @@ __global__ void __launch_bounds__(256) rescore_l2_kernel(const float *base, cons
   const uint32_t q = (uint32_t)(w / k), j = (uint32_t)(w - (uint64_t)q * k);
   if (j >= counts[q]) return;
   const uint32_t id = idx[w];
-  const float *qr = queries + (size_t)q * dpad;
+  const uint32_t nelem = dpadw * (F16 ? 2u : 1u);
   float acc = 0.f;
-  for (uint32_t c = lane; c < dpad; c += 64) {
-    const float d = qr[c] - base[blocked_offset(id, c, dpad)];
+  for (uint32_t c = lane; c < nelem; c += 64) {
+    float x;
+    if constexpr (F16) x = (float)reinterpret_cast<const _Float16 *>(queries)[(size_t)q * nelem + c];
+    else x = queries[(size_t)q * dpadw + c];
+    const float d = x - load_elem<F16>(base, id, c, dpadw);
     acc = fmaf(d, d, acc);
   }
 #pragma unroll
@@ -926,7 +964,8 @@ __global__ void __launch_bounds__(64) resort_kernel(uint64_t *keys, float *score
 // DIRECTLY (sum of (q-b)^2 / q.b over the row, no norm expansion) — the path is taken when a filter is so
 // selective that gathering beats scanning.  Scores land in a padded [nq][maxlen] matrix for merge_kernel.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) pkeys_score_kernel(const float *base, const float *queries, uint32_t dpad,
+template <bool F16>
+__global__ void __launch_bounds__(256) pkeys_score_kernel(const float *base, const float *queries, uint32_t dpadw,
                                                           int metric, const uint32_t *pos, const uint32_t *off,
                                                           uint32_t nq, uint32_t maxlen, float *out_s, uint32_t *out_i) {
   const int lane = threadIdx.x & 63;
@@ -934,16 +973,18 @@ __global__ void __launch_bounds__(256) pkeys_score_kernel(const float *base, con
   if (w >= (uint64_t)nq * maxlen) return;
   const uint32_t q = (uint32_t)(w / maxlen), j = (uint32_t)(w - (uint64_t)q * maxlen);
   const uint32_t len = off[q + 1] - off[q];
+  const uint32_t nelem = dpadw * (F16 ? 2u : 1u);
   float sc = __builtin_inff();
   uint32_t id = IDX_NONE;
   if (j < len) {
     id = pos[off[q] + j];
     if (id != IDX_NONE) {
       float acc = 0.f;
-      const float *qr = queries + (size_t)q * dpad;
-      for (uint32_t c = lane; c < dpad; c += 64) {
-        const float b = base[blocked_offset(id, c, dpad)];
-        const float x = qr[c];
+      for (uint32_t c = lane; c < nelem; c += 64) {
+        const float b = load_elem<F16>(base, id, c, dpadw);
+        float x;
+        if constexpr (F16) x = (float)reinterpret_cast<const _Float16 *>(queries)[(size_t)q * nelem + c];
+        else x = queries[(size_t)q * dpadw + c];
         if (metric == METRIC_L2) { const float d = x - b; acc = fmaf(d, d, acc); }
         else acc = fmaf(x, b, acc);
       }
@@ -1100,24 +1141,29 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
 // ---------------------------------------------------------------------------------------------
 // k-means helpers (IVF build): mean of member rows per cluster, members given as CSR of row ids.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) centroid_mean_kernel(const float *rows, uint32_t dim,
+template <bool F16>
+__global__ void __launch_bounds__(256) centroid_mean_kernel(const void *rows, uint32_t dim,
                                                             const uint64_t *member_off,
-                                                            const uint64_t *members, float *centroids) {
+                                                            const uint64_t *members, void *centroids) {
   const uint32_t c = blockIdx.x;
   const uint64_t b = member_off[c], e = member_off[c + 1];
   if (e == b) return;  // empty cluster keeps its previous centroid
   const float inv = 1.0f / (float)(e - b);
   for (uint32_t col = threadIdx.x; col < dim; col += blockDim.x) {
     float acc = 0.f;
-    for (uint64_t m = b; m < e; ++m) acc += rows[(size_t)members[m] * dim + col];
-    centroids[(size_t)c * dim + col] = acc * inv;
+    for (uint64_t m = b; m < e; ++m) acc += load_row_elem<F16>(rows, members[m], dim, col);
+    if constexpr (F16) reinterpret_cast<_Float16 *>(centroids)[(size_t)c * dim + col] = (_Float16)(acc * inv);   // RNE
+    else reinterpret_cast<float *>(centroids)[(size_t)c * dim + col] = acc * inv;
   }
 }
 
-__global__ void gather_rows_kernel(const float *rows, uint32_t dim, const uint64_t *ids, uint64_t n, float *out) {
+// row gather in bytes (element-type agnostic)
+__global__ void gather_rows_kernel(const void *rows, uint32_t row_bytes, const uint64_t *ids, uint64_t n, void *out) {
   uint64_t i = blockIdx.x;
   if (i >= n) return;
-  for (uint32_t c = threadIdx.x; c < dim; c += blockDim.x) out[(size_t)i * dim + c] = rows[(size_t)ids[i] * dim + c];
+  const uint16_t *src = reinterpret_cast<const uint16_t *>(rows) + (size_t)ids[i] * (row_bytes / 2);
+  uint16_t *dst = reinterpret_cast<uint16_t *>(out) + (size_t)i * (row_bytes / 2);
+  for (uint32_t c = threadIdx.x; c < row_bytes / 2; c += blockDim.x) dst[c] = src[c];
 }
 
 }  // namespace zvk

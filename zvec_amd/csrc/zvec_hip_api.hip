@@ -58,7 +58,9 @@ struct DevBuf {
 struct Store {
   uint32_t dim_in = 0;   // element dimension at the ABI (cosine: d+1)
   uint32_t dscan = 0;    // scanned dims
-  uint32_t dpad = 0;     // multiple of 32
+  uint32_t dpad = 0;     // 4-byte WORDS per stored row, multiple of 32 (fp32: dscan up to 32; fp16: dscan up to 64, halved)
+  uint32_t elem = 4;     // bytes per element: 4 (fp32) or 2 (fp16)
+  bool f16 = false;
   int metric = 0;
   uint64_t n = 0;        // padded positions in use
   uint64_t cap_tiles = 0;
@@ -67,12 +69,15 @@ struct Store {
   float *extra = nullptr;   // cosine: stored norm column
   uint64_t *keys = nullptr;
 
-  void configure(uint32_t dim, int met) {
+  void configure(uint32_t dim, int met, int dtype = ZVEC_HIP_DT_FP32) {
     dim_in = dim;
     metric = met;
+    f16 = (dtype == ZVEC_HIP_DT_FP16);
+    elem = f16 ? 2 : 4;
     dscan = (met == ZVEC_HIP_METRIC_COSINE) ? dim - 1 : dim;
-    dpad = (dscan + TILE_K - 1) / TILE_K * TILE_K;
+    dpad = f16 ? ((dscan + 63) / 64 * 64) / 2 : (dscan + TILE_K - 1) / TILE_K * TILE_K;
   }
+  size_t row_bytes() const { return (size_t)dim_in * elem; }
   int reserve(uint64_t rows, hipStream_t stream) {
     uint64_t tiles = (rows + TILE_N - 1) / TILE_N;
     if (tiles <= cap_tiles) return 0;
@@ -152,7 +157,7 @@ struct zvec_hip_ivf_s {
   std::vector<uint32_t> h_size, h_size_global, h_tile0;
   std::vector<uint64_t> h_dense0;      // local dense offsets (nlist+1)
   std::vector<uint64_t> h_row_ids;     // local dense position -> original row
-  std::vector<float> h_centroids;      // [nlist][dim]
+  std::vector<char> h_centroids;       // [nlist][dim] in the index element type
   uint32_t *d_size = nullptr, *d_size_global = nullptr, *d_tile0 = nullptr, *d_order = nullptr;
   uint32_t tiles_per_chunk = 8;
   uint64_t *d_dense0 = nullptr;
@@ -169,40 +174,43 @@ struct KernelInfo {
 KernelInfo g_info[16];
 std::mutex g_info_mu;
 
-template <int NG, bool M16, bool EXCL>
+template <int NG, bool M16, bool EXCL, bool F16>
 int launch_scan_t(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
   static bool attr_set[16] = {false};
   size_t lds = scan_lds_bytes(NG, a.k, M16);
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_set[dev & 15]) {
-    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<NG, M16, EXCL>),
+    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<NG, M16, EXCL, F16>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     attr_set[dev & 15] = true;
   }
   int occ = 0;
-  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<NG, M16, EXCL>, 256, lds));
+  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<NG, M16, EXCL, F16>, 256, lds));
   if (occ < 1) occ = 1;
   uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)max_items, (uint64_t)cus * (uint64_t)occ);
   if (grid == 0) return 0;
-  hipLaunchKernelGGL((scan_kernel<NG, M16, EXCL>), dim3(grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((scan_kernel<NG, M16, EXCL, F16>), dim3(grid), dim3(256), lds, stream, a);
   ZCHK(hipGetLastError());
   return 0;
 }
 
 template <int NG, bool M16>
-int launch_scan(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
-  return a.exclude ? launch_scan_t<NG, M16, true>(a, max_items, cus, stream)
-                   : launch_scan_t<NG, M16, false>(a, max_items, cus, stream);
+int launch_scan(const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStream_t stream) {
+  if (f16)
+    return a.exclude ? launch_scan_t<NG, M16, true, true>(a, max_items, cus, stream)
+                     : launch_scan_t<NG, M16, false, true>(a, max_items, cus, stream);
+  return a.exclude ? launch_scan_t<NG, M16, true, false>(a, max_items, cus, stream)
+                   : launch_scan_t<NG, M16, false, false>(a, max_items, cus, stream);
 }
 
-// ng == 0 selects the 16-row (16x16x4 MFMA) shape
-int launch_scan_ng(int ng, const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
+// ng == 0 selects the 16-row-halves (16x16 MFMA) shape
+int launch_scan_ng(int ng, const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStream_t stream) {
   switch (ng) {
-    case 0: return launch_scan<1, true>(a, max_items, cus, stream);
-    case 1: return launch_scan<1, false>(a, max_items, cus, stream);
-    case 2: return launch_scan<2, false>(a, max_items, cus, stream);
-    case 4: return launch_scan<4, false>(a, max_items, cus, stream);
+    case 0: return launch_scan<1, true>(a, f16, max_items, cus, stream);
+    case 1: return launch_scan<1, false>(a, f16, max_items, cus, stream);
+    case 2: return launch_scan<2, false>(a, f16, max_items, cus, stream);
+    case 4: return launch_scan<4, false>(a, f16, max_items, cus, stream);
   }
   return ZVEC_HIP_ERR_INVALID_ARGUMENT;
 }
@@ -300,7 +308,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
       a.gtau = ctx->gtau.as<uint32_t>();
       a.dump = ctx->part_s.as<float>(); a.dump_stride = (uint32_t)(ntiles_d * TILE_N);
       a.part_s = nullptr; a.part_i = nullptr;
-      ZRET(launch_scan_ng(ngd, a, (uint32_t)ntiles_d * nqt, cus_d, stream));
+      ZRET(launch_scan_ng(ngd, a, st.f16, (uint32_t)ntiles_d * nqt, cus_d, stream));
       MergeArgs m{};
       m.part_s = a.dump; m.part_i = nullptr; m.part_keys = nullptr; m.slot_begin = nullptr; m.slots_per_q = 1;
       m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = a.dump_stride; m.threshold = threshold;
@@ -341,11 +349,11 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
   int pi = -1;
   if (profile_it) {
-    double bytes = (double)st.n * st.dscan * 4.0 + (double)count * st.dscan * 4.0 + (double)count * topk * 12.0;
+    double bytes = (double)st.n * st.dscan * st.elem + (double)count * st.dscan * st.elem + (double)count * topk * 12.0;
     double flops = 2.0 * (double)count * (double)st.n * st.dscan;
     pi = prof_begin(ctx, stream, bytes, flops, 0);
   }
-  ZRET(launch_scan_ng(ng, a, nchunks * nqtiles, cus, stream));
+  ZRET(launch_scan_ng(ng, a, st.f16, nchunks * nqtiles, cus, stream));
   prof_end(ctx, stream, pi);
 
   MergeArgs m{};
@@ -371,32 +379,60 @@ int refine_l2(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t top
   if (st.metric != ZVEC_HIP_METRIC_L2) return 0;
   if ((size_t)topk * 16 + 16 > 60 * 1024) return 0;   // huge k: keep the expansion scores
   const uint64_t pairs = (uint64_t)count * topk;
-  hipLaunchKernelGGL(rescore_l2_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, st.base,
-                     ctx->qpad.as<float>(), st.dpad, idx, counts, count, topk, scores);
+  if (st.f16)
+    hipLaunchKernelGGL(rescore_l2_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, st.base,
+                       ctx->qpad.as<float>(), st.dpad, idx, counts, count, topk, scores);
+  else
+    hipLaunchKernelGGL(rescore_l2_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, st.base,
+                       ctx->qpad.as<float>(), st.dpad, idx, counts, count, topk, scores);
   hipLaunchKernelGGL(resort_kernel, dim3(count), dim3(64), (size_t)topk * 16 + 16, stream, keys, scores, idx, counts, topk,
                      threshold);
   ZCHK(hipGetLastError());
   return 0;
 }
 
-int prep_queries(zvec_hip_ctx_s *ctx, const Store &st, const float *d_queries, uint32_t count, float threshold,
+int prep_queries(zvec_hip_ctx_s *ctx, const Store &st, const void *d_queries, uint32_t count, float threshold,
                  hipStream_t stream) {
   ZRET(ctx->qpad.ensure((size_t)count * st.dpad * sizeof(float)));
   ZRET(ctx->qnorm.ensure((size_t)count * sizeof(float)));
   ZRET(ctx->gtau.ensure((size_t)count * sizeof(uint32_t)));
-  hipLaunchKernelGGL(prep_queries_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, d_queries, count,
-                     st.dim_in, st.dscan, st.dpad, ctx->qpad.as<float>(), ctx->qnorm.as<float>(),
-                     ctx->gtau.as<uint32_t>(), threshold);
+  if (st.f16)
+    hipLaunchKernelGGL(prep_queries_kernel<true>, dim3((count + 3) / 4), dim3(256), 0, stream, d_queries, count,
+                       st.dim_in, st.dscan, st.dpad, ctx->qpad.as<float>(), ctx->qnorm.as<float>(),
+                       ctx->gtau.as<uint32_t>(), threshold);
+  else
+    hipLaunchKernelGGL(prep_queries_kernel<false>, dim3((count + 3) / 4), dim3(256), 0, stream, d_queries, count,
+                       st.dim_in, st.dscan, st.dpad, ctx->qpad.as<float>(), ctx->qnorm.as<float>(),
+                       ctx->gtau.as<uint32_t>(), threshold);
   ZCHK(hipGetLastError());
   return 0;
 }
 
-int store_append_dev(Store &st, const float *d_vecs, uint64_t n, const uint64_t *d_keys, hipStream_t stream) {
+int launch_pack(const Store &st, const void *d_rows, uint64_t n, const uint64_t *d_src, uint64_t pos0,
+                const uint64_t *d_dst, hipStream_t stream) {
+  if (st.f16)
+    hipLaunchKernelGGL(pack_rows_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_rows, n, st.dim_in,
+                       st.dscan, st.dpad, d_src, pos0, d_dst, st.base, st.bnorm, st.extra);
+  else
+    hipLaunchKernelGGL(pack_rows_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_rows, n, st.dim_in,
+                       st.dscan, st.dpad, d_src, pos0, d_dst, st.base, st.bnorm, st.extra);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int launch_unpack(const Store &st, uint64_t pos, void *d_out, hipStream_t stream) {
+  if (st.f16)
+    hipLaunchKernelGGL(unpack_row_kernel<true>, dim3(1), dim3(256), 0, stream, st.base, st.extra, pos, st.dscan, st.dim_in, st.dpad, d_out);
+  else
+    hipLaunchKernelGGL(unpack_row_kernel<false>, dim3(1), dim3(256), 0, stream, st.base, st.extra, pos, st.dscan, st.dim_in, st.dpad, d_out);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int store_append_dev(Store &st, const void *d_vecs, uint64_t n, const uint64_t *d_keys, hipStream_t stream) {
   if (n == 0) return 0;
   ZRET(st.reserve(st.n + n, stream));
-  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_vecs, n, st.dim_in,
-                     st.dscan, st.dpad, (const uint64_t *)nullptr, st.n, (const uint64_t *)nullptr, st.base,
-                     st.bnorm, st.extra);
+  ZRET(launch_pack(st, d_vecs, n, nullptr, st.n, nullptr, stream));
   ZCHK(hipGetLastError());
   hipLaunchKernelGGL(fill_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st.keys, st.n, n, d_keys);
   ZCHK(hipGetLastError());
@@ -440,7 +476,7 @@ void ctx_free(zvec_hip_ctx_s *c) {
 }
 
 // ---- IVF search core (device pointers) ------------------------------------------------------
-int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queries, uint32_t count, uint32_t topk,
+int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_queries, uint32_t count, uint32_t topk,
                     float threshold, uint32_t nprobe, uint32_t max_scan_count, int brute_force,
                     const uint64_t *d_exclude, const SearchOut &out, hipStream_t stream) {
   const int cus = device_cus(ctx);
@@ -530,9 +566,9 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const float *d_queri
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
   // algorithmic bytes of the list scan = rows of the DISTINCT probed lists (counted on device from
   // the plan, see ivf_work_stats_kernel) + the query rows + the result lists
-  int pi = prof_begin(ctx, stream, (double)count * h->lists.dscan * 4.0 + (double)count * topk * 12.0, 0, 1);
-  if (pi >= 0) ctx->prof_dscan[pi] = h->lists.dscan;
-  ZRET(launch_scan_ng(ng, a, 0x7fffffffu, cus, stream));
+  int pi = prof_begin(ctx, stream, (double)count * h->lists.dscan * h->lists.elem + (double)count * topk * 12.0, 0, 1);
+  if (pi >= 0) ctx->prof_dscan[pi] = h->lists.dscan | (h->lists.f16 ? 0x80000000u : 0u);
+  ZRET(launch_scan_ng(ng, a, h->lists.f16, 0x7fffffffu, cus, stream));
   prof_end(ctx, stream, pi);
 
   // 4. merge the per-(query, probe, chunk) partial lists in probe order
@@ -641,15 +677,16 @@ int zvec_hip_ctx_set_stream(zvec_hip_ctx_t ctx, void *stream) {
 // ---- flat -----------------------------------------------------------------------------------
 int zvec_hip_flat_create(uint32_t dim, int dtype, int metric, int device, zvec_hip_flat_t *out) {
   if (!out || dim == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
-  if (dtype != ZVEC_HIP_DT_FP32) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (dtype != ZVEC_HIP_DT_FP32 && dtype != ZVEC_HIP_DT_FP16) return ZVEC_HIP_ERR_UNSUPPORTED;
   if (metric < 0 || metric > 2) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (metric == ZVEC_HIP_METRIC_COSINE && dtype == ZVEC_HIP_DT_FP16) return ZVEC_HIP_ERR_UNSUPPORTED;   // fp16 cosine rows carry the norm in 2 halves: not served yet
   if (metric == ZVEC_HIP_METRIC_COSINE && dim < 2) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   zvec_hip_ctx_s *c = nullptr;
   ZRET(ctx_new(device, &c));
   zvec_hip_flat_s *h = new (std::nothrow) zvec_hip_flat_s();
   if (!h) { ctx_free(c); return ZVEC_HIP_ERR_NO_MEMORY; }
   h->device = device; h->dtype = dtype; h->defctx = c;
-  h->st.configure(dim, metric);
+  h->st.configure(dim, metric, dtype);
   *out = h;
   return 0;
 }
@@ -676,7 +713,7 @@ int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n, 
   std::lock_guard<std::mutex> g(h->mu);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(h->defctx, stream);
-  return store_append_dev(h->st, reinterpret_cast<const float *>(d_vecs), n, d_keys, s);
+  return store_append_dev(h->st, d_vecs, n, d_keys, s);
 }
 
 int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const uint64_t *keys) {
@@ -686,17 +723,17 @@ int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const 
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
   // stage through the device in slices of <= 1 GiB
-  const uint64_t rows_per = std::max<uint64_t>(1, ((uint64_t)1 << 30) / ((uint64_t)h->st.dim_in * 4));
+  const size_t rb = h->st.row_bytes();
+  const uint64_t rows_per = std::max<uint64_t>(1, ((uint64_t)1 << 30) / (uint64_t)rb);
   DevBuf tmp, tk;
   for (uint64_t o = 0; o < n; o += rows_per) {
     uint64_t m = std::min(rows_per, n - o);
-    int rc = tmp.ensure((size_t)m * h->st.dim_in * 4);
+    int rc = tmp.ensure((size_t)m * rb);
     if (rc == 0 && keys) rc = tk.ensure((size_t)m * 8);
     if (rc != 0) { tmp.release(); tk.release(); return rc; }
-    ZCHK(hipMemcpyAsync(tmp.p, reinterpret_cast<const float *>(vecs) + (size_t)o * h->st.dim_in,
-                        (size_t)m * h->st.dim_in * 4, hipMemcpyHostToDevice, s));
+    ZCHK(hipMemcpyAsync(tmp.p, reinterpret_cast<const char *>(vecs) + (size_t)o * rb, (size_t)m * rb, hipMemcpyHostToDevice, s));
     if (keys) ZCHK(hipMemcpyAsync(tk.p, keys + o, (size_t)m * 8, hipMemcpyHostToDevice, s));
-    rc = store_append_dev(h->st, tmp.as<float>(), m, keys ? tk.as<uint64_t>() : nullptr, s);
+    rc = store_append_dev(h->st, tmp.p, m, keys ? tk.as<uint64_t>() : nullptr, s);
     if (rc != 0) { tmp.release(); tk.release(); return rc; }
     ZCHK(hipStreamSynchronize(s));
   }
@@ -716,10 +753,9 @@ int zvec_hip_flat_get_vector(zvec_hip_flat_t h, uint64_t pos, void *out) {
   if (pos >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
   ZCHK(hipSetDevice(h->device));
   zvec_hip_ctx_s *c = h->defctx;
-  ZRET(c->io_q.ensure((size_t)h->st.dim_in * 4));
-  hipLaunchKernelGGL(unpack_row_kernel, dim3(1), dim3(256), 0, c->own, h->st.base, h->st.extra, pos, h->st.dscan,
-                     h->st.dim_in, h->st.dpad, c->io_q.as<float>());
-  ZCHK(hipMemcpyAsync(out, c->io_q.p, (size_t)h->st.dim_in * 4, hipMemcpyDeviceToHost, c->own));
+  ZRET(c->io_q.ensure(h->st.row_bytes()));
+  ZRET(launch_unpack(h->st, pos, c->io_q.p, c->own));
+  ZCHK(hipMemcpyAsync(out, c->io_q.p, h->st.row_bytes(), hipMemcpyDeviceToHost, c->own));
   ZCHK(hipStreamSynchronize(c->own));
   return 0;
 }
@@ -734,7 +770,7 @@ int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *
   std::lock_guard<std::mutex> g(c->mu);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(c, stream);
-  ZRET(prep_queries(c, h->st, reinterpret_cast<const float *>(d_queries), count, threshold, s));
+  ZRET(prep_queries(c, h->st, d_queries, count, threshold, s));
   SearchOut out{d_out_keys, d_out_scores, nullptr, d_out_counts};
   return flat_scan_prepared(c, h->st, count, topk, threshold, d_exclude_bitset, out, s, true);
 }
@@ -749,7 +785,7 @@ int zvec_hip_flat_search(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *quer
   {
     std::lock_guard<std::mutex> g(c->mu);
     ZCHK(hipSetDevice(h->device));
-    ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->st.dim_in * 4, exclude_bitset, h->st.n, count, topk, c->cur));
+    ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->st.row_bytes(), exclude_bitset, h->st.n, count, topk, c->cur));
   }
   ZRET(zvec_hip_flat_search_dev(h, c, c->io_q.p, count, topk, threshold, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr,
                                 c->io_keys.as<uint64_t>(), c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
@@ -784,8 +820,8 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
     if (ok && exclude_bitset) ok = ((exclude_bitset[id >> 6] >> (id & 63)) & 1ull) == 0;
     clean[i] = ok ? id : IDX_NONE;
   }
-  ZRET(host_search_wrap_begin(c, queries, (size_t)count * st.dim_in * 4, nullptr, 0, count, topk, s));
-  ZRET(prep_queries(c, st, c->io_q.as<float>(), count, threshold, s));
+  ZRET(host_search_wrap_begin(c, queries, (size_t)count * st.row_bytes(), nullptr, 0, count, topk, s));
+  ZRET(prep_queries(c, st, c->io_q.p, count, threshold, s));
   ZRET(c->plan.ensure(((size_t)total + count + 8) * sizeof(uint32_t)));
   uint32_t *d_pos = c->plan.as<uint32_t>();
   uint32_t *d_off = d_pos + std::max<uint32_t>(total, 1);
@@ -794,8 +830,12 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
   const uint64_t pairs = (uint64_t)count * maxlen;
   ZRET(c->part_s.ensure(pairs * 4));
   ZRET(c->part_i.ensure(pairs * 4));
-  hipLaunchKernelGGL(pkeys_score_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
-                     st.dpad, st.metric, d_pos, d_off, count, maxlen, c->part_s.as<float>(), c->part_i.as<uint32_t>());
+  if (st.f16)
+    hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
+                       st.dpad, st.metric, d_pos, d_off, count, maxlen, c->part_s.as<float>(), c->part_i.as<uint32_t>());
+  else
+    hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
+                       st.dpad, st.metric, d_pos, d_off, count, maxlen, c->part_s.as<float>(), c->part_i.as<uint32_t>());
   ZCHK(hipGetLastError());
   MergeArgs m{};
   m.part_s = c->part_s.as<float>(); m.part_i = c->part_i.as<uint32_t>(); m.part_keys = nullptr; m.slot_begin = nullptr;
@@ -810,16 +850,17 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
 // ---- IVF ------------------------------------------------------------------------------------
 int zvec_hip_ivf_create(uint32_t dim, int dtype, int metric, int device, zvec_hip_ivf_t *out) {
   if (!out || dim == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
-  if (dtype != ZVEC_HIP_DT_FP32) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (dtype != ZVEC_HIP_DT_FP32 && dtype != ZVEC_HIP_DT_FP16) return ZVEC_HIP_ERR_UNSUPPORTED;
   if (metric < 0 || metric > 2) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (metric == ZVEC_HIP_METRIC_COSINE && dtype == ZVEC_HIP_DT_FP16) return ZVEC_HIP_ERR_UNSUPPORTED;
   if (metric == ZVEC_HIP_METRIC_COSINE && dim < 2) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   zvec_hip_ctx_s *c = nullptr;
   ZRET(ctx_new(device, &c));
   zvec_hip_ivf_s *h = new (std::nothrow) zvec_hip_ivf_s();
   if (!h) { ctx_free(c); return ZVEC_HIP_ERR_NO_MEMORY; }
   h->device = device; h->dtype = dtype; h->dim = dim; h->metric = metric; h->defctx = c;
-  h->cent.configure(dim, metric);
-  h->lists.configure(dim, metric);
+  h->cent.configure(dim, metric, dtype);
+  h->lists.configure(dim, metric, dtype);
   *out = h;
   return 0;
 }
@@ -854,10 +895,11 @@ int zvec_hip_ivf_keep_shard(zvec_hip_ivf_t h, uint32_t shard, uint32_t nshards) 
 }
 
 // pack rows (device, row-major [n][dim]) given per-row labels (host) into the inverted-list store
-static int ivf_pack(zvec_hip_ivf_s *h, const float *d_rows, uint64_t n, const uint64_t *keys,
-                    const std::vector<uint32_t> &labels, const float *h_centroids, uint32_t nlist, hipStream_t s) {
+static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uint64_t *keys,
+                    const std::vector<uint32_t> &labels, const void *h_centroids, uint32_t nlist, hipStream_t s) {
+  const size_t rb = h->lists.row_bytes();
   h->nlist = nlist;
-  h->h_centroids.assign(h_centroids, h_centroids + (size_t)nlist * h->dim);
+  h->h_centroids.assign(reinterpret_cast<const char *>(h_centroids), reinterpret_cast<const char *>(h_centroids) + (size_t)nlist * rb);
   h->h_size_global.assign(nlist, 0);
   for (uint64_t i = 0; i < n; ++i) h->h_size_global[labels[i]] += 1;
   h->h_size.assign(nlist, 0);
@@ -903,10 +945,7 @@ static int ivf_pack(zvec_hip_ivf_s *h, const float *d_rows, uint64_t n, const ui
     ZCHK(hipMalloc(&d_dst, dense * 8));
     ZCHK(hipMemcpyAsync(d_src, h->h_row_ids.data(), dense * 8, hipMemcpyHostToDevice, s));
     ZCHK(hipMemcpyAsync(d_dst, dst.data(), dense * 8, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((dense + 3) / 4)), dim3(256), 0, s, d_rows, dense, h->dim,
-                       h->lists.dscan, h->lists.dpad, d_src, (uint64_t)0, d_dst, h->lists.base, h->lists.bnorm,
-                       h->lists.extra);
-    ZCHK(hipGetLastError());
+    ZRET(launch_pack(h->lists, d_rows, dense, d_src, 0, d_dst, s));
     ZCHK(hipMemcpyAsync(h->lists.keys, hkeys.data(), hkeys.size() * 8, hipMemcpyHostToDevice, s));
     ZCHK(hipStreamSynchronize(s));
     (void)hipFree(d_src);
@@ -915,9 +954,9 @@ static int ivf_pack(zvec_hip_ivf_s *h, const float *d_rows, uint64_t n, const ui
   // centroids as a flat store
   h->cent.n = 0;
   {
-    float *d_c = nullptr;
-    ZCHK(hipMalloc(&d_c, (size_t)nlist * h->dim * 4));
-    ZCHK(hipMemcpyAsync(d_c, h_centroids, (size_t)nlist * h->dim * 4, hipMemcpyHostToDevice, s));
+    void *d_c = nullptr;
+    ZCHK(hipMalloc(&d_c, (size_t)nlist * rb));
+    ZCHK(hipMemcpyAsync(d_c, h_centroids, (size_t)nlist * rb, hipMemcpyHostToDevice, s));
     int rc = store_append_dev(h->cent, d_c, nlist, nullptr, s);
     ZCHK(hipStreamSynchronize(s));
     (void)hipFree(d_c);
@@ -961,14 +1000,14 @@ int zvec_hip_ivf_load(zvec_hip_ivf_t h, const void *centroids, uint32_t nlist, c
     if (list_offsets[l + 1] < list_offsets[l]) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
     for (uint64_t i = list_offsets[l]; i < list_offsets[l + 1]; ++i) labels[i] = l;
   }
-  float *d_rows = nullptr;
+  void *d_rows = nullptr;
   if (n) {
-    ZCHK(hipMalloc(&d_rows, (size_t)n * h->dim * 4));
-    ZCHK(hipMemcpyAsync(d_rows, vecs, (size_t)n * h->dim * 4, hipMemcpyHostToDevice, s));
+    ZCHK(hipMalloc(&d_rows, (size_t)n * h->lists.row_bytes()));
+    ZCHK(hipMemcpyAsync(d_rows, vecs, (size_t)n * h->lists.row_bytes(), hipMemcpyHostToDevice, s));
   }
   bool was_loaded = h->loaded;
   if (was_loaded) ivf_release(h);
-  int rc = ivf_pack(h, d_rows, n, keys, labels, reinterpret_cast<const float *>(centroids), nlist, s);
+  int rc = ivf_pack(h, d_rows, n, keys, labels, centroids, nlist, s);
   if (d_rows) (void)hipFree(d_rows);
   return rc;
 }
@@ -981,8 +1020,10 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
   ZCHK(hipSetDevice(h->device));
   zvec_hip_ctx_s *c = h->defctx;
   hipStream_t s = pick_stream(c, stream);
-  const float *rows = reinterpret_cast<const float *>(d_vecs);
+  const char *rows = reinterpret_cast<const char *>(d_vecs);
   const uint32_t dim = h->dim;
+  const bool f16 = h->lists.f16;
+  const size_t rb = h->lists.row_bytes();
   if (sample_per_list == 0) sample_per_list = 256;
   if (h->loaded) ivf_release(h);
 
@@ -991,12 +1032,12 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
   std::vector<uint64_t> sample_ids(S);
   for (uint64_t i = 0; i < S; ++i) sample_ids[i] = (uint64_t)(((unsigned __int128)i * n) / S);
   uint64_t *d_ids = nullptr;
-  float *d_sample = nullptr, *d_cent = nullptr;
+  char *d_sample = nullptr, *d_cent = nullptr;
   ZCHK(hipMalloc(&d_ids, S * 8));
-  ZCHK(hipMalloc(&d_sample, (size_t)S * dim * 4));
-  ZCHK(hipMalloc(&d_cent, (size_t)nlist * dim * 4));
+  ZCHK(hipMalloc(&d_sample, (size_t)S * rb));
+  ZCHK(hipMalloc(&d_cent, (size_t)nlist * rb));
   ZCHK(hipMemcpyAsync(d_ids, sample_ids.data(), S * 8, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)S), dim3(256), 0, s, rows, dim, d_ids, S, d_sample);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)S), dim3(256), 0, s, (const void *)rows, (uint32_t)rb, d_ids, S, (void *)d_sample);
   ZCHK(hipGetLastError());
   // ---- initial centroids: nlist distinct sample rows picked by a seeded partial shuffle ----
   {
@@ -1009,13 +1050,13 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
       std::swap(perm[i], perm[j]);
     }
     ZCHK(hipMemcpyAsync(d_ids, perm.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(nlist), dim3(256), 0, s, d_sample, dim, d_ids, (uint64_t)nlist, d_cent);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nlist), dim3(256), 0, s, (const void *)d_sample, (uint32_t)rb, d_ids, (uint64_t)nlist, (void *)d_cent);
     ZCHK(hipGetLastError());
     ZCHK(hipStreamSynchronize(s));
   }
   // ---- Lloyd iterations on the sample ----
   Store cs;
-  cs.configure(dim, h->metric);
+  cs.configure(dim, h->metric, h->dtype);
   uint64_t *d_lab_keys = nullptr; float *d_lab_scores = nullptr; uint32_t *d_lab_idx = nullptr, *d_lab_cnt = nullptr;
   const uint64_t BATCH = 1u << 18;
   uint64_t maxq = std::max<uint64_t>(std::min<uint64_t>(S, BATCH), std::min<uint64_t>(n, BATCH));
@@ -1027,10 +1068,10 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
   ZCHK(hipMalloc(&d_moff, ((size_t)nlist + 1) * 8));
   ZCHK(hipMalloc(&d_members, S * 8));
   std::vector<uint32_t> lab(std::max<uint64_t>(S, n));
-  auto assign = [&](const float *q, uint64_t nq, uint32_t *host_labels) -> int {
+  auto assign = [&](const char *q, uint64_t nq, uint32_t *host_labels) -> int {
     for (uint64_t o = 0; o < nq; o += BATCH) {
       uint32_t m = (uint32_t)std::min<uint64_t>(BATCH, nq - o);
-      ZRET(prep_queries(c, cs, q + (size_t)o * dim, m, FLT_MAX, s));
+      ZRET(prep_queries(c, cs, q + (size_t)o * rb, m, FLT_MAX, s));
       SearchOut out{d_lab_keys, d_lab_scores, d_lab_idx, d_lab_cnt};
       ZRET(flat_scan_prepared(c, cs, m, 1, FLT_MAX, nullptr, out, s, false));
       ZCHK(hipMemcpyAsync(host_labels + o, d_lab_idx, (size_t)m * 4, hipMemcpyDeviceToHost, s));
@@ -1049,7 +1090,8 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
     for (uint64_t i = 0; i < S; ++i) members[cur[lab[i] < nlist ? lab[i] : 0]++] = i;
     ZCHK(hipMemcpyAsync(d_moff, moff.data(), moff.size() * 8, hipMemcpyHostToDevice, s));
     ZCHK(hipMemcpyAsync(d_members, members.data(), S * 8, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(centroid_mean_kernel, dim3(nlist), dim3(256), 0, s, d_sample, dim, d_moff, d_members, d_cent);
+    if (f16) hipLaunchKernelGGL(centroid_mean_kernel<true>, dim3(nlist), dim3(256), 0, s, (const void *)d_sample, dim, d_moff, d_members, (void *)d_cent);
+    else hipLaunchKernelGGL(centroid_mean_kernel<false>, dim3(nlist), dim3(256), 0, s, (const void *)d_sample, dim, d_moff, d_members, (void *)d_cent);
     ZCHK(hipGetLastError());
     ZCHK(hipStreamSynchronize(s));
     // empty clusters: split the currently largest one (tiny symmetric perturbation), as k-means trainers do
@@ -1057,28 +1099,36 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
     std::vector<uint64_t> sizes(nlist);
     for (uint32_t l = 0; l < nlist; ++l) { sizes[l] = moff[l + 1] - moff[l]; if (sizes[l] == 0) empties.push_back(l); }
     if (!empties.empty() && it + 1 < kmeans_iters) {
-      std::vector<float> hc((size_t)nlist * dim);
-      ZCHK(hipMemcpy(hc.data(), d_cent, hc.size() * 4, hipMemcpyDeviceToHost));
+      std::vector<char> hcb((size_t)nlist * rb);
+      ZCHK(hipMemcpy(hcb.data(), d_cent, hcb.size(), hipMemcpyDeviceToHost));
       for (uint32_t e : empties) {
         uint32_t b = (uint32_t)(std::max_element(sizes.begin(), sizes.end()) - sizes.begin());
         if (sizes[b] < 2) break;
         for (uint32_t c = 0; c < dim; ++c) {
-          float v = hc[(size_t)b * dim + c];
-          hc[(size_t)e * dim + c] = v * (1.0f + 1.0f / 1024.0f);
-          hc[(size_t)b * dim + c] = v * (1.0f - 1.0f / 1024.0f);
+          if (f16) {
+            _Float16 *hp = reinterpret_cast<_Float16 *>(hcb.data());
+            float v = (float)hp[(size_t)b * dim + c];
+            hp[(size_t)e * dim + c] = (_Float16)(v * (1.0f + 1.0f / 256.0f));
+            hp[(size_t)b * dim + c] = (_Float16)(v * (1.0f - 1.0f / 256.0f));
+          } else {
+            float *hp = reinterpret_cast<float *>(hcb.data());
+            float v = hp[(size_t)b * dim + c];
+            hp[(size_t)e * dim + c] = v * (1.0f + 1.0f / 1024.0f);
+            hp[(size_t)b * dim + c] = v * (1.0f - 1.0f / 1024.0f);
+          }
         }
         sizes[e] = sizes[b] / 2;
         sizes[b] -= sizes[e];
       }
-      ZCHK(hipMemcpy(d_cent, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+      ZCHK(hipMemcpy(d_cent, hcb.data(), hcb.size(), hipMemcpyHostToDevice));
     }
   }
   // ---- label every row with its nearest centroid (ivf_builder.h:253-274) ----
   cs.n = 0;
   ZRET(store_append_dev(cs, d_cent, nlist, nullptr, s));
   ZRET(assign(rows, n, lab.data()));
-  std::vector<float> hc((size_t)nlist * dim);
-  ZCHK(hipMemcpy(hc.data(), d_cent, hc.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<char> hc((size_t)nlist * rb);
+  ZCHK(hipMemcpy(hc.data(), d_cent, hc.size(), hipMemcpyDeviceToHost));
   cs.release();
   (void)hipFree(d_ids); (void)hipFree(d_sample); (void)hipFree(d_cent); (void)hipFree(d_lab_keys);
   (void)hipFree(d_lab_scores); (void)hipFree(d_lab_idx); (void)hipFree(d_lab_cnt); (void)hipFree(d_moff); (void)hipFree(d_members);
@@ -1091,9 +1141,9 @@ int zvec_hip_ivf_build(zvec_hip_ivf_t h, const void *vecs, uint64_t n, const uin
                        uint32_t kmeans_iters, uint32_t sample_per_list, uint64_t seed) {
   if (!h || !vecs || n == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   ZCHK(hipSetDevice(h->device));
-  float *d_rows = nullptr;
-  ZCHK(hipMalloc(&d_rows, (size_t)n * h->dim * 4));
-  ZCHK(hipMemcpy(d_rows, vecs, (size_t)n * h->dim * 4, hipMemcpyHostToDevice));
+  void *d_rows = nullptr;
+  ZCHK(hipMalloc(&d_rows, (size_t)n * h->lists.row_bytes()));
+  ZCHK(hipMemcpy(d_rows, vecs, (size_t)n * h->lists.row_bytes(), hipMemcpyHostToDevice));
   int rc = zvec_hip_ivf_build_dev(h, d_rows, n, keys, nlist, kmeans_iters, sample_per_list, seed, nullptr);
   (void)hipFree(d_rows);
   return rc;
@@ -1109,7 +1159,7 @@ int zvec_hip_ivf_info(zvec_hip_ivf_t h, uint64_t *count, uint32_t *nlist) {
 int zvec_hip_ivf_export(zvec_hip_ivf_t h, void *centroids, uint64_t *list_offsets, uint64_t *row_ids) {
   if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
-  if (centroids) memcpy(centroids, h->h_centroids.data(), h->h_centroids.size() * 4);
+  if (centroids) memcpy(centroids, h->h_centroids.data(), h->h_centroids.size());
   if (list_offsets) memcpy(list_offsets, h->h_dense0.data(), h->h_dense0.size() * 8);
   if (row_ids) memcpy(row_ids, h->h_row_ids.data(), h->h_row_ids.size() * 8);
   return 0;
@@ -1124,10 +1174,9 @@ int zvec_hip_ivf_get_vector(zvec_hip_ivf_t h, uint64_t list_pos, void *out) {
   uint32_t l = (uint32_t)(std::upper_bound(h->h_dense0.begin(), h->h_dense0.end(), list_pos) - h->h_dense0.begin()) - 1;
   uint64_t pos = (uint64_t)h->h_tile0[l] * TILE_N + (list_pos - h->h_dense0[l]);
   zvec_hip_ctx_s *c = h->defctx;
-  ZRET(c->io_q.ensure((size_t)h->dim * 4));
-  hipLaunchKernelGGL(unpack_row_kernel, dim3(1), dim3(256), 0, c->own, h->lists.base, h->lists.extra, pos,
-                     h->lists.dscan, h->dim, h->lists.dpad, c->io_q.as<float>());
-  ZCHK(hipMemcpyAsync(out, c->io_q.p, (size_t)h->dim * 4, hipMemcpyDeviceToHost, c->own));
+  ZRET(c->io_q.ensure(h->lists.row_bytes()));
+  ZRET(launch_unpack(h->lists, pos, c->io_q.p, c->own));
+  ZCHK(hipMemcpyAsync(out, c->io_q.p, h->lists.row_bytes(), hipMemcpyDeviceToHost, c->own));
   ZCHK(hipStreamSynchronize(c->own));
   return 0;
 }
@@ -1145,7 +1194,7 @@ static int ivf_search_dev_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void 
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(c, stream);
   SearchOut out{d_out_keys, d_out_scores, nullptr, d_out_counts};
-  int rc = ivf_search_core(h, c, reinterpret_cast<const float *>(d_queries), count, topk, threshold, nprobe,
+  int rc = ivf_search_core(h, c, d_queries, count, topk, threshold, nprobe,
                            max_scan_count, brute_force, d_exclude, out, s);
   if (rc == 0 && c->profile && c->nprof > 0 && c->nprof <= PROFILE_MAX && c->stats.p) {
     int i = c->nprof - 1;
@@ -1178,7 +1227,7 @@ static int ivf_search_host_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void
   {
     std::lock_guard<std::mutex> g(c->mu);
     ZCHK(hipSetDevice(h->device));
-    ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->dim * 4, exclude_bitset, h->count_local, count, topk, c->cur));
+    ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->lists.row_bytes(), exclude_bitset, h->count_local, count, topk, c->cur));
   }
   ZRET(ivf_search_dev_impl(h, c, c->io_q.p, count, topk, threshold, nprobe, max_scan_count, brute_force,
                            exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr, c->io_keys.as<uint64_t>(),
@@ -1290,8 +1339,9 @@ int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *sc
   }
   for (int i = 0; i < ctx->nprof && !st.empty(); ++i) {
     if (!ctx->launch_is_ivf[i]) continue;
-    bytes += (double)st[2 * (size_t)i] * ctx->prof_dscan[i] * 4.0;          // distinct probed rows
-    flops += (double)st[2 * (size_t)i + 1] * ctx->prof_dscan[i] * 2.0;      // (query, row) pairs
+    const double ds = (double)(ctx->prof_dscan[i] & 0x7fffffffu), eb = (ctx->prof_dscan[i] & 0x80000000u) ? 2.0 : 4.0;
+    bytes += (double)st[2 * (size_t)i] * ds * eb;            // distinct probed rows
+    flops += (double)st[2 * (size_t)i + 1] * ds * 2.0;       // (query, row) pairs
   }
   if (launches) *launches = (uint64_t)ctx->nprof;
   if (scan_ms) *scan_ms = ms;

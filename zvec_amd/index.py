@@ -15,7 +15,15 @@ import numpy as np
 from . import _lib
 
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
-DT_FP32 = 0
+DT_FP32, DT_FP16 = 0, 1
+
+
+def _dtype_of(dtype):
+    """IndexMeta::DataType of the rows: "fp32" (DT_FP32) or "fp16" (DT_FP16: what HalfFloatConverter writes and
+    HalfFloatReformer turns queries into, src/core/quantizer/half_float_converter.cc / half_float_reformer.cc)."""
+    if dtype in ("fp16", "float16", np.float16, DT_FP16) and dtype is not False and dtype != 0:
+        return DT_FP16, np.float16
+    return DT_FP32, np.float32
 FLT_MAX = float(np.finfo(np.float32).max)
 
 _METRIC_NAMES = {
@@ -164,14 +172,15 @@ def _np_ptr(a):
 class _FlatBase:
     """Common body of HipFlatStreamer / HipFlatSearcher: one HBM-resident blocked store."""
 
-    def __init__(self, dim, metric=METRIC_L2, device=0):
+    def __init__(self, dim, metric=METRIC_L2, device=0, dtype="fp32"):
         if isinstance(metric, str):
             metric = metric_from_name(metric)
         self.dim = int(dim)
         self.metric = metric
         self.device = device
+        self.dtype, self.np_dtype = _dtype_of(dtype)
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().zvec_hip_flat_create(self.dim, DT_FP32, metric, device, C.byref(self._h)),
+        _lib.check(_lib.lib().zvec_hip_flat_create(self.dim, self.dtype, metric, device, C.byref(self._h)),
                    "zvec_hip_flat_create")
         self._keys_host = []      # for IndexFilter sweeps
 
@@ -195,7 +204,7 @@ class _FlatBase:
         return _lib.lib().zvec_hip_flat_reserve(self._h, int(n))
 
     def add_batch(self, vecs, keys=None):
-        vecs = np.ascontiguousarray(vecs, np.float32)
+        vecs = np.ascontiguousarray(vecs, self.np_dtype)
         if vecs.ndim != 2 or vecs.shape[1] != self.dim:
             return IndexError_.InvalidArgument
         n0 = self.count()
@@ -225,7 +234,7 @@ class _FlatBase:
         return np.concatenate(parts) if parts else np.zeros(0, np.uint64)
 
     def get_vector_by_id(self, pos):
-        out = np.zeros(self.dim, np.float32)
+        out = np.zeros(self.dim, self.np_dtype)
         rc = _lib.lib().zvec_hip_flat_get_vector(self._h, int(pos), _np_ptr(out))
         return out if rc == 0 else None
 
@@ -233,7 +242,7 @@ class _FlatBase:
         """IndexRunner::search_impl(query, qmeta, count, context); query: [count][dim] fp32."""
         if ctx is None or ctx.topk() == 0:
             return IndexError_.InvalidArgument      # flat_searcher.cc:194-198
-        q = np.ascontiguousarray(query, np.float32).reshape(-1)
+        q = np.ascontiguousarray(query, self.np_dtype).reshape(-1)
         if q.size != int(count) * self.dim:
             return IndexError_.InvalidArgument
         k = ctx.topk()
@@ -255,7 +264,7 @@ class _FlatBase:
         is compared with; unknown keys are skipped; the context's filter applies per key."""
         if ctx is None or ctx.topk() == 0:
             return IndexError_.InvalidArgument
-        q = np.ascontiguousarray(query, np.float32).reshape(-1)
+        q = np.ascontiguousarray(query, self.np_dtype).reshape(-1)
         if q.size != int(count) * self.dim or len(p_keys) != count:
             return IndexError_.InvalidArgument
         allk = self._all_keys()
@@ -295,7 +304,7 @@ class HipFlatStreamer(_FlatBase):
     """stands where "FlatStreamer" is registered (flat_streamer.cc:486-489): mutable, add + search."""
 
     def add_impl(self, key, vec, ctx=None):
-        return self.add_batch(np.asarray(vec, np.float32).reshape(1, -1), np.array([key], np.uint64))
+        return self.add_batch(np.asarray(vec, self.np_dtype).reshape(1, -1), np.array([key], np.uint64))
 
 
 class HipFlatSearcher(_FlatBase):
@@ -308,17 +317,18 @@ class HipFlatSearcher(_FlatBase):
 class HipIVFSearcher:
     """stands where "IVFSearcher"/"IVFStreamer" are registered (ivf_searcher.cc:183-250)."""
 
-    def __init__(self, dim, metric=METRIC_L2, device=0, scan_ratio=0.1, brute_force_threshold=1000):
+    def __init__(self, dim, metric=METRIC_L2, device=0, scan_ratio=0.1, brute_force_threshold=1000, dtype="fp32"):
         if isinstance(metric, str):
             metric = metric_from_name(metric)
         self.dim = int(dim)
         self.metric = metric
         self.device = device
+        self.dtype, self.np_dtype = _dtype_of(dtype)
         # IVFSearcherContext defaults (ivf_searcher_context.h:211-213)
         self.scan_ratio = float(scan_ratio)
         self.brute_force_threshold = int(brute_force_threshold)
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().zvec_hip_ivf_create(self.dim, DT_FP32, metric, device, C.byref(self._h)),
+        _lib.check(_lib.lib().zvec_hip_ivf_create(self.dim, self.dtype, metric, device, C.byref(self._h)),
                    "zvec_hip_ivf_create")
         self._list_keys = None    # keys in list order (filter sweeps)
         self._orig_keys = None    # keys per original row (build)
@@ -339,9 +349,9 @@ class HipIVFSearcher:
         return _lib.lib().zvec_hip_ivf_keep_shard(self._h, shard, nshards)
 
     def load(self, centroids, list_offsets, vecs, keys=None):
-        centroids = np.ascontiguousarray(centroids, np.float32)
+        centroids = np.ascontiguousarray(centroids, self.np_dtype)
         lo = np.ascontiguousarray(list_offsets, np.uint64)
-        vecs = np.ascontiguousarray(vecs, np.float32)
+        vecs = np.ascontiguousarray(vecs, self.np_dtype)
         k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
         rc = _lib.lib().zvec_hip_ivf_load(self._h, _np_ptr(centroids), centroids.shape[0], _np_ptr(lo),
                                           _np_ptr(vecs), _np_ptr(k))
@@ -352,7 +362,7 @@ class HipIVFSearcher:
         return rc
 
     def build(self, vecs, nlist, keys=None, kmeans_iters=10, sample_per_list=256, seed=20260320):
-        vecs = np.ascontiguousarray(vecs, np.float32)
+        vecs = np.ascontiguousarray(vecs, self.np_dtype)
         k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
         rc = _lib.lib().zvec_hip_ivf_build(self._h, _np_ptr(vecs), vecs.shape[0], _np_ptr(k), nlist,
                                            kmeans_iters, sample_per_list, seed)
@@ -382,7 +392,7 @@ class HipIVFSearcher:
 
     def export(self):
         n, nlist = self.info()
-        cent = np.zeros((nlist, self.dim), np.float32)
+        cent = np.zeros((nlist, self.dim), self.np_dtype)
         lo = np.zeros(nlist + 1, np.uint64)
         rows = np.zeros(n, np.uint64)
         _lib.check(_lib.lib().zvec_hip_ivf_export(self._h, _np_ptr(cent), _np_ptr(lo), _np_ptr(rows)),
@@ -390,7 +400,7 @@ class HipIVFSearcher:
         return cent, lo, rows
 
     def get_vector_by_id(self, list_pos):
-        out = np.zeros(self.dim, np.float32)
+        out = np.zeros(self.dim, self.np_dtype)
         rc = _lib.lib().zvec_hip_ivf_get_vector(self._h, int(list_pos), _np_ptr(out))
         return out if rc == 0 else None
 
@@ -422,7 +432,7 @@ class HipIVFSearcher:
             return IndexError_.InvalidArgument      # ivf_searcher.cc:197-200
         if self.total_count <= self.brute_force_threshold:
             return self.search_bf_impl(query, count, ctx)   # ivf_searcher.cc:188-190
-        q = np.ascontiguousarray(query, np.float32).reshape(-1)
+        q = np.ascontiguousarray(query, self.np_dtype).reshape(-1)
         if q.size != int(count) * self.dim:
             return IndexError_.InvalidArgument
         k = ctx.topk()
@@ -441,7 +451,7 @@ class HipIVFSearcher:
     def search_bf_impl(self, query, count, ctx):
         if ctx is None or ctx.topk() == 0:
             return IndexError_.InvalidArgument
-        q = np.ascontiguousarray(query, np.float32).reshape(-1)
+        q = np.ascontiguousarray(query, self.np_dtype).reshape(-1)
         if q.size != int(count) * self.dim:
             return IndexError_.InvalidArgument
         k = ctx.topk()
