@@ -32,10 +32,13 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA peak (no xf32 on gfx950)
 
 WORKLOADS = {
-    # name: (kind, n, dim, nlist, nprobe, batch)
-    "ivf10m": ("ivf", 10_000_000, 768, 4096, 32, 1024),    # BASELINE configs[2]  (headline)
-    "ivf1m": ("ivf", 1_000_000, 768, 1024, 16, 1024),      # small rehearsal
-    "flat1m": ("flat", 1_000_000, 768, 0, 0, 256),         # BASELINE configs[1]
+    # name: (kind, n, dim, nlist, nprobe, batch, dtype)
+    "ivf10m": ("ivf", 10_000_000, 768, 4096, 32, 1024, "fp32"),       # BASELINE configs[2]  (headline)
+    "ivf1m": ("ivf", 1_000_000, 768, 1024, 16, 1024, "fp32"),         # small rehearsal
+    "flat1m": ("flat", 1_000_000, 768, 0, 0, 256, "fp32"),            # BASELINE configs[1]
+    "ivf10m_fp16": ("ivf", 10_000_000, 768, 4096, 32, 1024, "fp16"),  # BASELINE configs[3]'s storage type at 1-GPU size
+    "ivf100m_fp16": ("ivf", 100_000_000, 768, 16384, 64, 1024, "fp16"),  # BASELINE configs[3] (needs 8 GPUs' HBM for the build)
+    "filter10m": ("flat", 10_000_000, 768, 0, 0, 512, "fp32"),        # BASELINE configs[4]: bitmap-gated scan, keep 10 %
 }
 
 
@@ -44,7 +47,7 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def gen_corpus(torch, n, dim, device, seed, intrinsic_dim=12, noise=0.02, chunk=1 << 20, proj=None):
+def gen_corpus(torch, n, dim, device, seed, intrinsic_dim=12, noise=0.02, chunk=1 << 20, proj=None, out_dtype=None):
     """Seeded synthetic corpus with realistic neighbourhood structure: a Gaussian of low intrinsic
     dimension embedded in R^dim by a fixed random projection, plus small isotropic noise
     (x = z A + noise, z ~ N(0, I_r)).  i.i.d. Gaussians in 768-d have no cluster structure at all
@@ -58,12 +61,13 @@ def gen_corpus(torch, n, dim, device, seed, intrinsic_dim=12, noise=0.02, chunk=
         pg = torch.Generator(device=device)
         pg.manual_seed(SEED + 7)
         proj = torch.randn((intrinsic_dim, dim), generator=pg, device=device, dtype=torch.float32)
-    out = torch.empty((n, dim), device=device, dtype=torch.float32)
+    out = torch.empty((n, dim), device=device, dtype=out_dtype or torch.float32)
     for o in range(0, n, chunk):
         m = min(chunk, n - o)
         z = torch.randn((m, proj.shape[0]), generator=g, device=device, dtype=torch.float32)
-        torch.mm(z, proj, out=out[o:o + m])
-        out[o:o + m] += torch.randn((m, dim), generator=g, device=device, dtype=torch.float32) * noise
+        x = torch.mm(z, proj)
+        x += torch.randn((m, dim), generator=g, device=device, dtype=torch.float32) * noise
+        out[o:o + m] = x          # (fp16 workloads: round to nearest even here)
     return out, proj
 
 
@@ -81,6 +85,7 @@ def main():
     ap.add_argument("--gt-queries", type=int, default=256)
     ap.add_argument("--intrinsic-dim", type=int, default=12)
     ap.add_argument("--target-recall", type=float, default=0.99)
+    ap.add_argument("--keep", type=float, default=0.1, help="filter workloads: fraction of rows the bitmap keeps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="0 = one whole batch")
     args = ap.parse_args()
@@ -106,7 +111,8 @@ def main():
     import zvec_amd
     from zvec_amd.dist import ShardedIVF
 
-    kind, n, dim, nlist, nprobe, batch = WORKLOADS[args.workload]
+    kind, n, dim, nlist, nprobe, batch, dtype = WORKLOADS[args.workload]
+    tdtype = torch.float16 if dtype == "fp16" else torch.float32
     n = args.n or n
     batch = args.batch or batch
     nprobe = args.nprobe or nprobe
@@ -117,16 +123,17 @@ def main():
     log("workload %s: n=%d dim=%d nlist=%d nprobe=%d batch=%d k=%d world=%d" % (args.workload, n, dim, nlist, nprobe, batch, topk, world))
 
     # ---------------- synthetic corpus + queries (identical on every rank) ----------------
-    base, proj = gen_corpus(torch, n, dim, dev, SEED, intrinsic_dim=args.intrinsic_dim)
+    base, proj = gen_corpus(torch, n, dim, dev, SEED, intrinsic_dim=args.intrinsic_dim, out_dtype=tdtype)
     nqueries = max(batch, args.gt_queries)
-    queries, _ = gen_corpus(torch, nqueries, dim, dev, SEED + 1, intrinsic_dim=args.intrinsic_dim, proj=proj)   # held-out draws
+    queries, _ = gen_corpus(torch, nqueries, dim, dev, SEED + 1, intrinsic_dim=args.intrinsic_dim, proj=proj,
+                            out_dtype=tdtype)   # held-out draws; fp16 workloads: HalfFloatConverter/Reformer = RNE cast
     torch.cuda.synchronize()
     log("data generated in %.1fs" % (time.time() - t0))
     stream_ptr = torch.cuda.current_stream().cuda_stream
 
     # ---------------- exact ground truth for recall (flat scan on the GPU, rank-local) ----------------
     ngt = min(args.gt_queries, nqueries)
-    flat = zvec_amd.HipFlatSearcher(dim, "SquaredEuclidean", device=local_rank)
+    flat = zvec_amd.HipFlatSearcher(dim, "SquaredEuclidean", device=local_rank, dtype=dtype)
     t1 = time.time()
     zvec_amd._lib.check(flat.add_batch_dev(base.data_ptr(), n, stream=stream_ptr), "flat append")
     torch.cuda.synchronize()
@@ -151,7 +158,7 @@ def main():
         torch.cuda.synchronize()
         # ---------------- IVF build on the GPU (same seed on every rank => same centroids) ----------------
         t1 = time.time()
-        ivf = zvec_amd.HipIVFSearcher(dim, "SquaredEuclidean", device=local_rank)
+        ivf = zvec_amd.HipIVFSearcher(dim, "SquaredEuclidean", device=local_rank, dtype=dtype)
         zvec_amd._lib.check(ivf.set_shard(rank, world), "set_shard")
         zvec_amd._lib.check(ivf.build_dev(base.data_ptr(), n, nlist, kmeans_iters=args.kmeans_iters, seed=SEED,
                                           stream=stream_ptr), "ivf build")
@@ -229,7 +236,7 @@ def main():
             "metric": "QPS @ recall@10>=0.99, 10Mx768 fp32, batch=1024" if args.workload == "ivf10m" else "QPS (%s)" % args.workload,
             "value": result["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": result["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if dtype == "fp32" else "f16 rows, f32 accumulate", "data": "synthetic",
             "config": {"workload": "%s: %s n=%d dim=%d%s batch=%d k=%d" % (
                 args.workload, "IVF-Flat L2" if kind == "ivf" else "Flat L2", n, dim,
                 (" nlist=%d nprobe=%d" % (nlist, nprobe)) if kind == "ivf" else "", batch, topk),
@@ -248,8 +255,22 @@ def run_flat(torch, dist, zvec_amd, flat, fctx, q, n, dim, topk, args, dev, stre
     os_ = torch.empty((batch, topk), dtype=torch.float32, device=dev)
     oc = torch.empty((batch,), dtype=torch.int32, device=dev)
 
+    excl = None
+    if args.workload.startswith("filter"):
+        # BASELINE configs[4]: bitmap predicate, Bernoulli keep-mask p = --keep, packed 1 bit / doc,
+        # bit set = excluded (IndexFilter true = exclude)
+        g = torch.Generator(device=dev)
+        g.manual_seed(SEED + 2)
+        drop = (torch.rand((n,), generator=g, device=dev) >= args.keep).cpu().numpy()
+        words = np.zeros((n + 63) // 64, np.uint64)
+        idx = np.nonzero(drop)[0]
+        np.bitwise_or.at(words, idx // 64, np.uint64(1) << (idx % 64).astype(np.uint64))
+        excl = torch.from_numpy(words.view(np.int64)).to(dev)
+        log("filter: keep %.3f of %d rows" % (1.0 - drop.mean(), n))
+
     def step():
         zvec_amd._lib.check(flat.search_dev(q.data_ptr(), batch, topk, ok.data_ptr(), os_.data_ptr(), oc.data_ptr(), fctx,
+                                            d_exclude=excl.data_ptr() if excl is not None else None,
                                             stream=stream_ptr), "flat search")
     for _ in range(args.warmup):
         step()
@@ -296,7 +317,7 @@ def cpu_baseline_ivf(torch, ivf, base, q, topk, nprobe, max_scan, args):
     t0 = time.time()
     cent, offs, rows = ivf.export()
     n, dim = base.shape
-    vecs = np.empty((n, dim), np.float32)
+    vecs = np.empty((n, dim), np.float16 if base.dtype == torch.float16 else np.float32)
     rows_t = torch.from_numpy(rows.astype(np.int64)).to(base.device)
     step = 1 << 20
     for s in range(0, n, step):

@@ -54,6 +54,22 @@ for t in range(64):
     hl.append((n, k, len(idx)))
     hi.append(idx)
     hv.append(sc)
+# fp16 rows: SquaredEuclideanDistanceMatrix<Float16,1,1> / MinusInnerProductMatrix<Float16,1,1>, FloatHelper::ToFP16
+H_A, H_B, H_L2, H_MIP = [], [], [], []
+for d in dims:
+    a = (rng.standard_normal(d) * 3).astype(np.float16)
+    b = (rng.standard_normal(d) * 3).astype(np.float16)
+    H_A.append(a)
+    H_B.append(b)
+    H_L2.append(o.dist16(O.METRIC_L2, a, b, use_ref=True))
+    H_MIP.append(o.dist16(O.METRIC_IP, a, b, use_ref=True))
+out["h_a"] = np.concatenate(H_A).view(np.uint16)
+out["h_b"] = np.concatenate(H_B).view(np.uint16)
+out["h_l2"] = np.array(H_L2, np.float32)
+out["h_minus_ip"] = np.array(H_MIP, np.float32)
+cv = np.concatenate([(rng.standard_normal(4096) * s_).astype(np.float32) for s_ in (1e-6, 1e-3, 1.0, 300.0, 7e4)])
+out["tofp16_in"] = cv
+out["tofp16_out"] = o.to_fp16_ref(cv).view(np.uint16)
 out["heap_scores"] = np.concatenate(hs)
 out["heap_meta"] = np.array(hl, np.int32)
 out["heap_index"] = np.concatenate(hi)

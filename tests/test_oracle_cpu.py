@@ -63,6 +63,14 @@ def test_bit_exact_vs_reference_vectors(oracle, golden_dir):
             b1 = oracle.cosine_transform(b)[0]
             assert np.float32(oracle.dist(O.METRIC_COSINE, a1, b1)) == z["cosine"][i], d
         off += d
+    off = 0
+    for i, d in enumerate(z["dims"]):                       # fp16 rows
+        a, b = z["h_a"][off:off + d].view(np.float16), z["h_b"][off:off + d].view(np.float16)
+        assert np.float32(oracle.dist16(O.METRIC_L2, a, b)) == z["h_l2"][i], d
+        assert np.float32(oracle.dist16(O.METRIC_IP, a, b)) == z["h_minus_ip"][i], d
+        off += d
+    with np.errstate(over="ignore"):                        # HalfFloatConverter == numpy round-to-nearest-even
+        assert np.array_equal(z["tofp16_in"].astype(np.float16).view(np.uint16), z["tofp16_out"])
     so = io = 0
     for n, k, kept in z["heap_meta"]:
         s = z["heap_scores"][so:so + n]
@@ -84,6 +92,12 @@ def test_live_vs_compiled_reference(oracle):
             for m in (O.METRIC_L2, O.METRIC_IP):
                 assert oracle.dist(m, a, b) == oracle.dist(m, a, b, use_ref=True), (d, m)
             assert oracle.norm2(a) == oracle.norm2(a, use_ref=True)
+    for d in list(range(1, 70)) + [127, 128, 768, 769]:
+        for _ in range(3):
+            a = (rng.standard_normal(d) * 2).astype(np.float16)
+            b = (rng.standard_normal(d) * 2).astype(np.float16)
+            for m in (O.METRIC_L2, O.METRIC_IP):
+                assert oracle.dist16(m, a, b) == oracle.dist16(m, a, b, use_ref=True), (d, m)
     for _ in range(100):
         n, k = int(rng.integers(1, 400)), int(rng.integers(1, 64))
         s = rng.integers(0, 9, n).astype(np.float32)
