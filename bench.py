@@ -220,11 +220,21 @@ def main():
         bytes_per_launch = prof["bytes"] / max(prof["launches"], 1)
         flops_per_launch = prof["flops"] / max(prof["launches"], 1)
         achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        # HBM traffic of one launch from the PMC counters: rocprofv3 cannot run inside this process, so the value
+        # is the one measured by separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command
+        # (profiles/README.md) and corrected as MI355X_MICROARCH.md §HBM prescribes; null for other workloads
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if world == 1 and not args.n and not args.batch and not args.nprobe:
+                traffic = pmc.get(args.workload)
+        except (OSError, ValueError):
+            pass
         result = {
             "value": batch * args.steps / elapsed,
             "ms_per_step": elapsed / args.steps * 1e3,
             "roofline": {"bound": "hbm", "kernel": "zvk::scan_kernel<1> (IVF list scan)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": per_launch_ms, "algorithmic_bytes": bytes_per_launch,
                          "algorithmic_flops": flops_per_launch,
                          "mfma_tflops": flops_per_launch / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0},
