@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--intrinsic-dim", type=int, default=12)
     ap.add_argument("--target-recall", type=float, default=0.99)
     ap.add_argument("--keep", type=float, default=0.1, help="filter workloads: fraction of rows the bitmap keeps")
+    ap.add_argument("--flat-threshold", type=float, default=None,
+                    help="diagnostic: RNN radius for the flat workloads (a huge negative value admits nothing => distance-only time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="0 = one whole batch")
     args = ap.parse_args()
@@ -278,10 +280,12 @@ def run_flat(torch, dist, zvec_amd, flat, fctx, q, n, dim, topk, args, dev, stre
         excl = torch.from_numpy(words.view(np.int64)).to(dev)
         log("filter: keep %.3f of %d rows" % (1.0 - drop.mean(), n))
 
+    thr = {} if args.flat_threshold is None else {"threshold": args.flat_threshold}
+
     def step():
         zvec_amd._lib.check(flat.search_dev(q.data_ptr(), batch, topk, ok.data_ptr(), os_.data_ptr(), oc.data_ptr(), fctx,
                                             d_exclude=excl.data_ptr() if excl is not None else None,
-                                            stream=stream_ptr), "flat search")
+                                            stream=stream_ptr, **thr), "flat search")
     for _ in range(args.warmup):
         step()
     fctx.profile(True)

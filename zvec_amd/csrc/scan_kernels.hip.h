@@ -311,7 +311,7 @@ struct ScanShape {
 // too (distance_matrix_accum_fp16.i:554-594).  The staging is byte-identical: a row segment per k-step is
 // 128 B either way (32 floats or 64 halves); `dpad` counts 4-byte words per row.
 template <int NG, bool M16, bool EXCL, bool F16>
-__global__ void __launch_bounds__(256) scan_kernel(const ScanArgs a) {
+__global__ void __launch_bounds__(256, (NG >= 4 ? 2 : 1)) scan_kernel(const ScanArgs a) {
   constexpr int ROWS = ScanShape<NG, M16>::ROWS;
   constexpr int QL = ScanShape<NG, M16>::QLOADS;
   constexpr int QROWMASK = 31;

@@ -330,9 +330,10 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   const uint32_t rows = ng * QGROUP;
   const uint32_t nqtiles = (count + rows - 1) / rows;
   const uint64_t ntiles = (st.n + TILE_N - 1) / TILE_N;
-  // aim at ~2 items per resident work-group, each chunk >= 1 tile
-  uint64_t resident = (uint64_t)cus * (ng >= 4 ? 1 : (ng == 2 ? 2 : 3));
-  uint64_t want_chunks = std::max<uint64_t>(1, (2 * resident + nqtiles - 1) / nqtiles);
+  uint64_t resident = (uint64_t)cus * (ng >= 4 ? 2 : (ng == 2 ? 2 : 3));   // work-groups per CU each shape reaches
+  // items are equal-sized in a flat scan, so ONE wave of work-groups (items == resident slots) is the balanced
+  // choice and gives the longest tile runs per top-k warm-up
+  uint64_t want_chunks = std::max<uint64_t>(1, (resident + nqtiles - 1) / nqtiles);
   uint64_t tpc = std::max<uint64_t>(1, (ntiles + want_chunks - 1) / want_chunks);
   tpc = std::max<uint64_t>(tpc, std::min<uint64_t>(ntiles, 4));   // >= 4 tiles per top-k warm-up
   uint32_t nchunks = (uint32_t)((ntiles + tpc - 1) / tpc);
