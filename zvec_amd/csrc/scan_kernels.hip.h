@@ -93,7 +93,7 @@ struct ScanArgs {
 // LDS footprint in bytes for a given NG / k (host mirrors this)
 __host__ __device__ inline size_t scan_lds_bytes(int ng, uint32_t k, bool m16 = false) {
   size_t rows = m16 ? 32 : (size_t)ng * QGROUP;
-  return (2 * rows * TILE_K + 2 * (size_t)SLAB + 6 * rows + 4 + 2 * rows * k) * 4;
+  return (2 * rows * TILE_K + 2 * (size_t)SLAB + 7 * rows + 4 + 2 * rows * k) * 4;
 }
 
 // broadcast of lane `l` (wave-uniform index) without touching the LDS crossbar: v_readlane_b32
@@ -121,6 +121,7 @@ struct RowState {
   uint32_t *Li;      // [rows][k] positions
   uint32_t k;
   float *gt;         // [rows] query-wide bound fetched from gtau at the start of the tile epilogue
+  float *tq;         // [rows] min(tau, gt): the one value the fast path reads
   uint32_t *gtau;    // global [nq] keys: min over all work-groups of a FULL local list's k-th score
   const uint32_t *qrow;  // [rows] global query row of each local row
 };
@@ -207,16 +208,17 @@ __device__ __forceinline__ bool sorted_insert(float *L, uint32_t *O, uint32_t *I
 
 // Owner-wave admission of one row of the score tile: lane holds the scores of columns 2*lane and
 // 2*lane+1 (s0, s1); pos0 = padded position of column 0 of the tile.
-__device__ __forceinline__ void owner_row(const RowState &st, int row, float s0, float s1, uint32_t pos0, int lane) {
-  // admission bound = min(this list's k-th score, the query-wide bound shared by every work-group that
-  // scans for the same query).  A score above the shared bound cannot be in the final top-k: some
-  // work-group already holds k candidates at or below it.  Ties (==) are kept; the merge orders them.
+__device__ __forceinline__ void owner_row(const RowState &st, int row, float s0, float s1, float t0, uint32_t pos0, int lane) {
+  // admission bound t0 = min(this list's k-th score, the query-wide bound shared by every work-group that
+  // scans for the same query), pre-read by the caller together with the scores.  A score above the shared
+  // bound cannot be in the final top-k: some work-group already holds k candidates at or below it.  Ties (==)
+  // are kept; the merge orders them.
+  uint64_t m0 = __ballot(s0 <= t0);
+  uint64_t m1 = __ballot(s1 <= t0);
+  if ((m0 | m1) == 0) return;
   float tl = st.tau[row];
   const float tg = st.gt[row];
   float t = fminf(tl, tg);
-  uint64_t m0 = __ballot(s0 <= t);
-  uint64_t m1 = __ballot(s1 <= t);
-  if ((m0 | m1) == 0) return;
   const uint32_t k = st.k;
   uint32_t c = st.cnt[row];
   float *L = st.Ls + (size_t)row * k;
@@ -247,6 +249,7 @@ __device__ __forceinline__ void owner_row(const RowState &st, int row, float s0,
   if (lane == 0) {
     st.cnt[row] = c;
     st.tau[row] = tl;
+    st.tq[row] = fminf(tl, tg);
     if (improved && c == k && tl < tg) atomicMin(&st.gtau[st.qrow[row]], fkey(tl));
   }
 }
@@ -328,9 +331,10 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : 1)) scan_kernel(const Scan
   uint32_t *item_s = slot_s + ROWS;          // [4] work-queue hand-off word
   st.k = a.k;
   st.gt = reinterpret_cast<float *>(item_s + 4);
+  st.tq = st.gt + ROWS;
   st.gtau = a.gtau;
   st.qrow = qrow_s;
-  st.Ls = st.gt + ROWS;
+  st.Ls = st.tq + ROWS;
   st.Li = reinterpret_cast<uint32_t *>(st.Ls + (size_t)ROWS * a.k);
 
   const int tid = threadIdx.x;
@@ -416,6 +420,7 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : 1)) scan_kernel(const Scan
       qn_s[j] = (a.metric == METRIC_L2) ? a.qnorm[qrow] : 0.f;
       st.tau[j] = a.threshold;
       st.gt[j] = a.threshold;
+      st.tq[j] = a.threshold;
       st.cnt[j] = 0;
     }
     __syncthreads();
@@ -566,8 +571,11 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : 1)) scan_kernel(const Scan
       // (row i of the group belongs to wave i % 4): no locks, no atomics.
       if (ks == nks - 1) {
         if (a.dump == nullptr)
-          for (int j = tid; j < ROWS; j += 256)    // refresh the query-wide bounds (visible after the barrier below)
-            st.gt[j] = fkey_inv(__hip_atomic_load(&a.gtau[qrow_s[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          for (int j = tid; j < ROWS; j += 256) {  // refresh the query-wide bounds (visible after the barrier below)
+            const float g_ = fkey_inv(__hip_atomic_load(&a.gtau[qrow_s[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            st.gt[j] = g_;
+            st.tq[j] = fminf(st.tau[j], g_);       // (tau[j] is only written by the owner wave, in earlier epilogues)
+          }
         float *Sc = Bs + (buf ^ 1) * SLAB;                                  // [<=32 rows][128 cols]
         const uint32_t local0 = (tile - tile0) * TILE_N + wave * 32;        // row index inside list/store, lane 0
         const uint32_t pos0 = tile * TILE_N;                                // padded position of column 0
@@ -595,13 +603,23 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : 1)) scan_kernel(const Scan
             }
           }
           __syncthreads();
+          {
+            // rows dealt round-robin to the 4 waves; the next row's scores and bound are fetched from LDS while
+            // the current one is examined (the fast path is otherwise one exposed LDS latency per row)
+            f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + wave * TILE_N + 2 * lane);
+            float t0 = st.tq[wave];
 #pragma unroll 1
-          for (int i = 0; i < 8; ++i) {
-            const int row = i * 4 + wave;                    // rows dealt round-robin to the 4 waves
-            if ((uint32_t)row < nrows) {
-              const f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + row * TILE_N + 2 * lane);
-              if (a.dump) *reinterpret_cast<f32x2 *>(a.dump + (size_t)qrow_s[row] * a.dump_stride + pos0 + 2 * lane) = v;
-              else owner_row(st, row, v.x, v.y, pos0, lane);
+            for (int i = 0; i < 8; ++i) {
+              const int row = i * 4 + wave;
+              const int nrow = min(row + 4, ROWS - 1);
+              const f32x2 vn = *reinterpret_cast<const f32x2 *>(Sc + nrow * TILE_N + 2 * lane);
+              const float tn = st.tq[nrow];
+              if ((uint32_t)row < nrows) {
+                if (a.dump) *reinterpret_cast<f32x2 *>(a.dump + (size_t)qrow_s[row] * a.dump_stride + pos0 + 2 * lane) = v;
+                else owner_row(st, row, v.x, v.y, t0, pos0, lane);
+              }
+              v = vn;
+              t0 = tn;
             }
           }
           __syncthreads();
@@ -621,14 +639,22 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : 1)) scan_kernel(const Scan
               acc[g][e] = 0.f;
             }
             __syncthreads();
+            {
+              f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + wave * TILE_N + 2 * lane);
+              float t0 = st.tq[g * 32 + wave];
 #pragma unroll 1
-            for (int i = 0; i < 8; ++i) {
-              const int row_l = i * 4 + wave;                  // rows dealt round-robin to the 4 waves
-              const int row = g * 32 + row_l;
-              if ((uint32_t)row < nrows) {
-                const f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + row_l * TILE_N + 2 * lane);
-                if (a.dump) *reinterpret_cast<f32x2 *>(a.dump + (size_t)qrow_s[row] * a.dump_stride + pos0 + 2 * lane) = v;
-                else owner_row(st, row, v.x, v.y, pos0, lane);
+              for (int i = 0; i < 8; ++i) {
+                const int row_l = i * 4 + wave;                  // rows dealt round-robin to the 4 waves
+                const int row = g * 32 + row_l;
+                const int nrow_l = min(row_l + 4, 31);
+                const f32x2 vn = *reinterpret_cast<const f32x2 *>(Sc + nrow_l * TILE_N + 2 * lane);
+                const float tn = st.tq[g * 32 + nrow_l];
+                if ((uint32_t)row < nrows) {
+                  if (a.dump) *reinterpret_cast<f32x2 *>(a.dump + (size_t)qrow_s[row] * a.dump_stride + pos0 + 2 * lane) = v;
+                  else owner_row(st, row, v.x, v.y, t0, pos0, lane);
+                }
+                v = vn;
+                t0 = tn;
               }
             }
             __syncthreads();
