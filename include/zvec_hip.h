@@ -176,6 +176,16 @@ int zvec_hip_merge_topk_dev(zvec_hip_ctx_t ctx, const uint64_t *d_keys, const fl
                             uint32_t topk, uint64_t *d_out_keys, float *d_out_scores,
                             uint32_t *d_out_counts, void *stream);
 
+/* Packed form for the shard exchange: one buffer per part laid out
+ *   [count*topk keys u64][count*topk scores f32][count counts u32]  padded to a multiple of 16 bytes
+ * (zvec_hip_packed_bytes), parts `part_stride` bytes apart — exactly what one all-gather of the per-rank
+ * buffers produces, so the candidate lists go search -> RCCL -> merge without any repacking kernel.
+ * zvec_hip_packed_layout returns the three offsets inside one part. */
+uint64_t zvec_hip_packed_bytes(uint32_t count, uint32_t topk);
+int zvec_hip_merge_topk_packed_dev(zvec_hip_ctx_t ctx, const void *d_packed, uint64_t part_stride,
+                                   uint32_t nparts, uint32_t count, uint32_t topk, uint64_t *d_out_keys,
+                                   float *d_out_scores, uint32_t *d_out_counts, void *stream);
+
 /* ---- measurement hook ---------------------------------------------------------------------
  * Records HIP events around the dominant scan kernel of each search on ctx (on the stream the
  * kernel is launched on) and returns the accumulated launch count / milliseconds since the last

@@ -58,6 +58,9 @@ SYMBOLS = {
                                       _u64p, _f32p, _u32p]),
     "zvec_hip_merge_topk_dev": (C.c_int, [_h, _u64p, _f32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                           _u64p, _f32p, _u32p, C.c_void_p]),
+    "zvec_hip_packed_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32]),
+    "zvec_hip_merge_topk_packed_dev": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 _u64p, _f32p, _u32p, C.c_void_p]),
     "zvec_hip_ctx_profile": (C.c_int, [_h, C.c_int]),
     "zvec_hip_ctx_profile_read": (C.c_int, [_h, C.POINTER(C.c_uint64), C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),

@@ -695,6 +695,9 @@ struct MergeArgs {
   const uint32_t *part_counts;   // optional [slots] valid entries per slot (shard merge)
   uint32_t k;
   uint32_t slot_len;             // candidates per slot (k for partial lists; the row length for dense scores)
+  // packed shard exchange: part j's arrays start packed_stride BYTES after part j-1's (one all-gather buffer:
+  // per rank [count*k keys u64][count*k scores f32][count counts u32], padded to 16 B); 0 = separate arrays
+  uint64_t packed_stride;
   float threshold;
   const uint64_t *keymap;        // position -> key (nullable => key = position)
   uint64_t *out_keys;            // [nq][k]
@@ -757,12 +760,15 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
       const uint64_t e = base + (uint64_t)u * 64 + lane;
       bool valid = e < total;
       const uint32_t j = valid ? (uint32_t)(e / sl) : 0, t = valid ? (uint32_t)(e - (uint64_t)j * sl) : 0;
-      const size_t o = ((size_t)sb + (size_t)j * a.slot_stride) * sl + t;
+      const size_t o = a.packed_stride ? ((size_t)q * sl + t) : (((size_t)sb + (size_t)j * a.slot_stride) * sl + t);
+      const size_t pbytes = (size_t)j * a.packed_stride;
       float s = __builtin_inff();
       uint32_t idx = IDX_NONE;
-      if (valid && a.part_counts) valid = t < a.part_counts[sb + (size_t)j * a.slot_stride];
+      if (valid && a.part_counts)
+        valid = t < (a.packed_stride ? *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(a.part_counts + q) + pbytes)
+                                     : a.part_counts[sb + (size_t)j * a.slot_stride]);
       if (valid) {
-        s = a.part_s[o];
+        s = a.packed_stride ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.part_s + o) + pbytes) : a.part_s[o];
         idx = a.part_i ? a.part_i[o] : t;
         if (a.part_i && idx == IDX_NONE) valid = false;
       }
@@ -795,7 +801,9 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
       const float v = Ls[j];
       const uint32_t vo = Lo[j], vi = Li[j];
       uint64_t key;
-      if (a.part_keys) key = a.part_keys[((size_t)sb + (size_t)vo * a.slot_stride) * sl + vi];
+      if (a.part_keys)
+        key = a.packed_stride ? *reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(a.part_keys + (size_t)q * sl + vi) + (size_t)vo * a.packed_stride)
+                              : a.part_keys[((size_t)sb + (size_t)vo * a.slot_stride) * sl + vi];
       else key = a.keymap ? a.keymap[vi] : (uint64_t)vi;
       a.out_keys[o] = key;
       a.out_scores[o] = v;

@@ -1284,6 +1284,34 @@ int zvec_hip_merge_topk_dev(zvec_hip_ctx_t ctx, const uint64_t *d_keys, const fl
   return 0;
 }
 
+uint64_t zvec_hip_packed_bytes(uint32_t count, uint32_t topk) {
+  uint64_t b = (uint64_t)count * topk * 12 + (uint64_t)count * 4;
+  return (b + 15) & ~(uint64_t)15;
+}
+
+int zvec_hip_merge_topk_packed_dev(zvec_hip_ctx_t ctx, const void *d_packed, uint64_t part_stride, uint32_t nparts,
+                                   uint32_t count, uint32_t topk, uint64_t *d_out_keys, float *d_out_scores,
+                                   uint32_t *d_out_counts, void *stream) {
+  if (!ctx || !d_packed || !d_out_keys || !d_out_scores || !d_out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (topk == 0 || nparts == 0 || part_stride < zvec_hip_packed_bytes(count, topk) || (part_stride & 7)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if ((size_t)topk * 12 + 16 > 64 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ZCHK(hipSetDevice(ctx->device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const char *p0 = reinterpret_cast<const char *>(d_packed);
+  MergeArgs m{};
+  m.part_keys = reinterpret_cast<const uint64_t *>(p0);
+  m.part_s = reinterpret_cast<const float *>(p0 + (size_t)count * topk * 8);
+  m.part_counts = reinterpret_cast<const uint32_t *>(p0 + (size_t)count * topk * 12);
+  m.part_i = nullptr; m.slot_begin = nullptr; m.slots_per_q = nparts; m.slot_stride = count; m.packed_stride = part_stride;
+  m.k = topk; m.slot_len = topk; m.threshold = FLT_MAX; m.keymap = nullptr;
+  m.out_keys = d_out_keys; m.out_scores = d_out_scores; m.out_idx = nullptr; m.out_counts = d_out_counts;
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, s, m);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
 int zvec_hip_merge_topk(zvec_hip_ctx_t ctx, const uint64_t *keys, const float *scores, const uint32_t *counts,
                         uint32_t nparts, uint32_t count, uint32_t topk, uint64_t *out_keys, float *out_scores,
                         uint32_t *out_counts) {

@@ -52,7 +52,11 @@ def all_gather_candidates(keys, scores, counts, group=None):
 
 
 class ShardedIVF:
-    """rank-local shard of an IVF index + the exchange/merge step."""
+    """rank-local shard of an IVF index + the exchange/merge step.
+
+    The scan writes keys / scores / counts straight into one packed per-rank buffer (zvec_hip_packed_bytes
+    layout), that buffer is all-gathered as is, and the merge kernel reads the gathered buffer with a part
+    stride: search -> RCCL -> merge with no repacking kernels in between."""
 
     def __init__(self, searcher, ctx, rank, world, group=None):
         self.searcher = searcher
@@ -63,18 +67,24 @@ class ShardedIVF:
     def _buffers(self, count, topk, device):
         key = (count, topk)
         if key not in self._buf:
+            from . import _lib
+            pb = int(_lib.lib().zvec_hip_packed_bytes(count, topk))
+            mine = torch.zeros(pb, dtype=torch.uint8, device=device)
+            kb, sb = count * topk * 8, count * topk * 4
             self._buf[key] = dict(
-                keys=torch.empty((count, topk), dtype=torch.int64, device=device),
-                scores=torch.empty((count, topk), dtype=torch.float32, device=device),
-                counts=torch.empty((count,), dtype=torch.int32, device=device),
+                pb=pb, mine=mine,
+                keys=mine[:kb].view(torch.int64).view(count, topk),
+                scores=mine[kb:kb + sb].view(torch.float32).view(count, topk),
+                counts=mine[kb + sb:kb + sb + count * 4].view(torch.int32),
+                gathered=torch.empty(self.world * pb, dtype=torch.uint8, device=device),
                 okeys=torch.empty((count, topk), dtype=torch.int64, device=device),
                 oscores=torch.empty((count, topk), dtype=torch.float32, device=device),
                 ocounts=torch.empty((count,), dtype=torch.int32, device=device))
         return self._buf[key]
 
     def search(self, d_queries, topk, nprobe, max_scan, stream_ptr):
-        """d_queries: torch float32 [count][dim] on this rank's GPU.  Returns (keys, scores, counts)
-        tensors of the GLOBAL top-k (identical on every rank)."""
+        """d_queries: torch tensor [count][dim] (index element type) on this rank's GPU.  Returns
+        (keys, scores, counts) tensors of the GLOBAL top-k (identical on every rank)."""
         from . import _lib
         import ctypes as C
         count = d_queries.shape[0]
@@ -92,14 +102,20 @@ class ShardedIVF:
             self.ctx.synchronize()
         if self.world == 1:
             return b["keys"], b["scores"], b["counts"]
-        gk, gs, gc = all_gather_candidates(b["keys"], b["scores"], b["counts"], self.group)
+        if dist.get_backend(self.group) == "gloo":
+            # rehearsal of the N>1 path on a box without RCCL peers: stage through the host
+            host = torch.empty(self.world * b["pb"], dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, b["mine"].cpu(), group=self.group)
+            b["gathered"].copy_(host)
+        else:
+            dist.all_gather_into_tensor(b["gathered"], b["mine"], group=self.group)
         if legacy:
             torch.cuda.current_stream().synchronize()
-        rc = _lib.lib().zvec_hip_merge_topk_dev(self.ctx._h, C.c_void_p(gk.data_ptr()), C.c_void_p(gs.data_ptr()),
-                                                C.c_void_p(gc.data_ptr()), self.world, count, topk,
-                                                C.c_void_p(b["okeys"].data_ptr()), C.c_void_p(b["oscores"].data_ptr()),
-                                                C.c_void_p(b["ocounts"].data_ptr()), C.c_void_p(stream_ptr))
-        _lib.check(rc, "zvec_hip_merge_topk_dev")
+        rc = _lib.lib().zvec_hip_merge_topk_packed_dev(self.ctx._h, C.c_void_p(b["gathered"].data_ptr()), b["pb"], self.world,
+                                                       count, topk, C.c_void_p(b["okeys"].data_ptr()),
+                                                       C.c_void_p(b["oscores"].data_ptr()), C.c_void_p(b["ocounts"].data_ptr()),
+                                                       C.c_void_p(stream_ptr))
+        _lib.check(rc, "zvec_hip_merge_topk_packed_dev")
         if legacy:
             self.ctx.synchronize()
         return b["okeys"], b["oscores"], b["ocounts"]
