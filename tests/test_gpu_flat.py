@@ -237,3 +237,53 @@ def test_search_bf_by_p_keys(zv, oracle):
     assert st.search_bf_by_p_keys_impl(q, p_keys, nq, ctx) == 0
     for i in range(nq):
         assert all(d.key() % 2 == 1 for d in ctx.result(i))
+
+
+def test_concurrent_contexts(zv, oracle):
+    """search_* are const and called concurrently from many threads, each with its own context
+    (SURVEY §8(b) threading; flat_streamer_test.cc:509-729 multi-thread search tests)."""
+    import threading
+    rng = np.random.default_rng(53)
+    n, dim, k = 20000, 64, 10
+    base = rng.integers(0, 120, (n, dim)).astype(np.float32)
+    se = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert se.load(base) == 0
+    qs = [rng.integers(0, 120, (17 + 3 * t, dim)).astype(np.float32) for t in range(6)]
+    expect = [oracle.flat_search(base, q, k, threads=2) for q in qs]
+    errs = []
+
+    def worker(t):
+        try:
+            ctx = se.create_context()
+            ctx.set_topk(k)
+            for _ in range(5):
+                assert se.search_impl(qs[t], qs[t].shape[0], ctx) == 0
+                ok, os_, _, oc = expect[t]
+                tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="thread %d" % t)
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+
+
+def test_add_between_searches_keeps_earlier_rows(zv, oracle):
+    """streamer semantics: rows appended after a search are visible to the next one, earlier positions and
+    keys are stable across capacity growth (flat_streamer_test.cc TestAddAndSearch)."""
+    rng = np.random.default_rng(59)
+    dim, k = 32, 5
+    st = zv.HipFlatStreamer(dim, "InnerProduct")
+    ctx = st.create_context()
+    ctx.set_topk(k)
+    have = np.zeros((0, dim), np.float32)
+    q = rng.integers(-20, 20, (8, dim)).astype(np.float32)
+    for step in range(12):
+        add = rng.integers(-20, 20, (int(rng.integers(1, 400)), dim)).astype(np.float32)
+        assert st.add_batch(add) == 0
+        have = np.concatenate([have, add])
+        assert st.search_impl(q, 8, ctx) == 0
+        ok, os_, _, oc = oracle.flat_search(have, q, k, O.METRIC_IP)
+        tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="step %d" % step)
+        assert np.array_equal(st.get_vector_by_id(0), have[0])
