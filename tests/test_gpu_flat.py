@@ -287,3 +287,25 @@ def test_add_between_searches_keeps_earlier_rows(zv, oracle):
         ok, os_, _, oc = oracle.flat_search(have, q, k, O.METRIC_IP)
         tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="step %d" % step)
         assert np.array_equal(st.get_vector_by_id(0), have[0])
+
+
+@pytest.mark.parametrize("keep", [0.3, 0.02, 0.0])
+def test_sparse_keep_set_is_compacted_and_exact(zv, oracle, keep):
+    """bitmap-gated scan with a minority keep-set (>= 64k rows): the kept rows are compacted on the GPU and
+    scanned densely; the answer must equal the gated scan's (oracle with the same exclusion bits)."""
+    rng = np.random.default_rng(61)
+    n, dim, nq, k = 100_000, 48, 24, 10
+    base = rng.integers(0, 100, (n, dim)).astype(np.float32)
+    q = rng.integers(0, 100, (nq, dim)).astype(np.float32)
+    keys = (rng.permutation(3 * n)[:n]).astype(np.uint64)
+    excl = rng.random(n) >= keep
+    words = O.pack_bits(excl)
+    for name, metric in (("SquaredEuclidean", O.METRIC_L2), ("InnerProduct", O.METRIC_IP)):
+        se = zv.HipFlatSearcher(dim, name)
+        assert se.load(base, keys) == 0
+        ctx = se.create_context()
+        ctx.set_topk(k)
+        ctx.set_exclude_bitset(words)
+        assert se.search_impl(q, nq, ctx) == 0
+        ok, os_, _, oc = oracle.flat_search(base, q, k, metric, keys=keys, exclude_bits=words, threads=4)
+        tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="compacted keep=%g %s" % (keep, name))

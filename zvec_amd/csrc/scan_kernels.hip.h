@@ -993,6 +993,112 @@ __global__ void __launch_bounds__(64) resort_kernel(uint64_t *keys, float *score
 }
 
 // ---------------------------------------------------------------------------------------------
+// Sparse keep-sets (bitmap-gated scan, BASELINE configs[4]): when the predicate keeps a minority of the rows
+// the kept rows are first compacted into a temporary blocked store (stream compaction of the bitset, then a
+// row copy between two blocked layouts) and the dense scan runs over that — work proportional to the KEPT rows,
+// as on the CPU where filtered rows are skipped before the distance (flat_searcher_context.h:949-963).
+//   1. keep_count_kernel : kept rows per 2048-bit chunk      2. (host-launched) exclusive scan of the counts
+//   3. keep_fill_kernel  : kept positions, ascending         4. compact_rows_kernel: row copy + norms + keys
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) keep_count_kernel(const uint32_t *excl, uint64_t n, uint32_t *chunk_cnt) {
+  // one work-group per 2048 rows = 64 words; 64 lanes of wave 0 suffice
+  const uint64_t w0 = (uint64_t)blockIdx.x * 64;
+  const int lane = threadIdx.x;
+  if (lane >= 64) return;
+  const uint64_t w = w0 + lane;
+  const uint64_t nwords = (n + 31) / 32;
+  uint32_t keep = 0;
+  if (w < nwords) {
+    uint32_t bits = ~excl[w];
+    const uint64_t rem = n - w * 32;
+    if (rem < 32) bits &= (1u << rem) - 1u;
+    keep = (uint32_t)__popc(bits);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) keep += __shfl_xor(keep, off);
+  if (lane == 0) chunk_cnt[blockIdx.x] = keep;
+}
+
+__global__ void __launch_bounds__(1024) u32_exclusive_scan_kernel(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 1024) {
+    const uint32_t i = base + tid;
+    const uint32_t v = (i < n) ? in[i] : 0;
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint32_t t = (tid >= off) ? sh[tid - off] : 0;
+      __syncthreads();
+      sh[tid] += t;
+      __syncthreads();
+    }
+    const uint32_t incl = sh[tid], c = carry;
+    if (i < n) out[i] = c + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry = c + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(64) keep_fill_kernel(const uint32_t *excl, uint64_t n, const uint32_t *chunk_off, uint32_t *pos) {
+  const int lane = threadIdx.x;
+  const uint64_t w = (uint64_t)blockIdx.x * 64 + lane;
+  const uint64_t nwords = (n + 31) / 32;
+  uint32_t bits = 0;
+  if (w < nwords) {
+    bits = ~excl[w];
+    const uint64_t rem = n - w * 32;
+    if (rem < 32) bits &= (1u << rem) - 1u;
+  }
+  const uint32_t cnt = (uint32_t)__popc(bits);
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  uint32_t o = chunk_off[blockIdx.x] + incl - cnt;
+  while (bits) {
+    const int b = __builtin_ctz(bits);
+    bits &= bits - 1;
+    pos[o++] = (uint32_t)(w * 32 + b);
+  }
+}
+
+// one wave per kept row: copy the row between two blocked stores (same dpadw), with its norm, key and extra
+__global__ void __launch_bounds__(256) compact_rows_kernel(const float *src, const float *src_norm, const float *src_extra,
+                                                           const uint64_t *src_keys, const uint32_t *pos, uint32_t kept,
+                                                           uint32_t dpadw, float *dst, float *dst_norm, float *dst_extra,
+                                                           uint64_t *dst_keys) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= kept) return;
+  const uint32_t p = pos[i];
+  // 16-byte chunks: chunk c of row r lives at word offset tile*128*dpadw + (c/8)*4096 + (r*8 + ((c%8) ^ swz(r)))*4
+  const uint32_t nchunks = dpadw / 4;
+  const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
+  f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
+  const uint32_t sr = p & 127, dr = i & 127;
+  const size_t sbase = (size_t)(p >> 7) * TILE_N * dpadw / 4, dbase = (size_t)(i >> 7) * TILE_N * dpadw / 4;
+  for (uint32_t c = lane; c < nchunks; c += 64) {
+    const uint32_t ks = c >> 3, cc = c & 7;
+    const size_t so = sbase + (size_t)ks * (SLAB / 4) + sr * 8 + (cc ^ ((sr >> 1) & 7));
+    const size_t dofs = dbase + (size_t)ks * (SLAB / 4) + dr * 8 + (cc ^ ((dr >> 1) & 7));
+    d4[dofs] = s4[so];
+  }
+  if (lane == 0) {
+    dst_norm[i] = src_norm[p];
+    dst_keys[i] = src_keys[p];
+    if (dst_extra && src_extra) dst_extra[i] = src_extra[p];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // brute force by primary keys (FlatStreamer::search_bf_by_p_keys_impl, flat_streamer.cc:346-389): every
 // query comes with its own short list of storage positions; one wave scores one (query, position) pair
 // DIRECTLY (sum of (q-b)^2 / q.b over the row, no norm expansion) — the path is taken when a filter is so

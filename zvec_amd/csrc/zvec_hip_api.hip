@@ -118,6 +118,7 @@ struct zvec_hip_ctx_s {
   std::mutex mu;
   // workspace
   DevBuf gtau, ridx;
+  DevBuf cmp_base, cmp_norm, cmp_extra, cmp_keys, cmp_pos, cmp_cnt;   // compacted keep-set (sparse filters)
   DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
   DevBuf plan;        // all u32 plan arrays
   DevBuf io_q, io_ex, io_keys, io_scores, io_counts;   // staging for host-pointer entry points
@@ -284,6 +285,44 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     ZCHK(hipMemsetAsync(out.counts, 0, sizeof(uint32_t) * count, stream));
     ZCHK(hipMemsetAsync(out.keys, 0xff, sizeof(uint64_t) * (size_t)count * topk, stream));
     return 0;
+  }
+  // Sparse keep-set: compact the kept rows and scan those (work ~ kept rows, like the CPU's skip-before-distance)
+  if (d_exclude != nullptr && user_facing && st.n >= 65536) {
+    const uint32_t nchunks_b = (uint32_t)((st.n + 2047) / 2048);
+    ZRET(ctx->cmp_cnt.ensure(((size_t)2 * nchunks_b + 8) * sizeof(uint32_t)));
+    uint32_t *d_cnt = ctx->cmp_cnt.as<uint32_t>(), *d_off = d_cnt + nchunks_b, *d_total = d_off + nchunks_b;
+    const uint32_t *ex32 = reinterpret_cast<const uint32_t *>(d_exclude);
+    hipLaunchKernelGGL(keep_count_kernel, dim3(nchunks_b), dim3(64), 0, stream, ex32, st.n, d_cnt);
+    hipLaunchKernelGGL(u32_exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, d_cnt, d_off, nchunks_b, d_total);
+    ZCHK(hipGetLastError());
+    uint32_t kept = 0;
+    ZCHK(hipMemcpyAsync(&kept, d_total, 4, hipMemcpyDeviceToHost, stream));
+    ZCHK(hipStreamSynchronize(stream));
+    if ((double)kept <= 0.5 * (double)st.n) {
+      if (kept == 0) {
+        ZCHK(hipMemsetAsync(out.counts, 0, sizeof(uint32_t) * count, stream));
+        ZCHK(hipMemsetAsync(out.keys, 0xff, sizeof(uint64_t) * (size_t)count * topk, stream));
+        return 0;
+      }
+      const uint64_t ktiles = ((uint64_t)kept + TILE_N - 1) / TILE_N;
+      ZRET(ctx->cmp_pos.ensure((size_t)kept * 4));
+      ZRET(ctx->cmp_base.ensure((size_t)ktiles * TILE_N * st.dpad * 4));
+      ZRET(ctx->cmp_norm.ensure((size_t)ktiles * TILE_N * 4));
+      ZRET(ctx->cmp_keys.ensure((size_t)ktiles * TILE_N * 8));
+      if (st.extra) ZRET(ctx->cmp_extra.ensure((size_t)ktiles * TILE_N * 4));
+      hipLaunchKernelGGL(keep_fill_kernel, dim3(nchunks_b), dim3(64), 0, stream, ex32, st.n, d_off, ctx->cmp_pos.as<uint32_t>());
+      hipLaunchKernelGGL(compact_rows_kernel, dim3((kept + 3) / 4), dim3(256), 0, stream, st.base, st.bnorm, st.extra, st.keys,
+                         ctx->cmp_pos.as<uint32_t>(), kept, st.dpad, ctx->cmp_base.as<float>(), ctx->cmp_norm.as<float>(),
+                         st.extra ? ctx->cmp_extra.as<float>() : nullptr, ctx->cmp_keys.as<uint64_t>());
+      ZCHK(hipGetLastError());
+      Store tmp = st;                       // a view: same shape parameters, compacted arrays
+      tmp.base = ctx->cmp_base.as<float>(); tmp.bnorm = ctx->cmp_norm.as<float>();
+      tmp.extra = st.extra ? ctx->cmp_extra.as<float>() : nullptr; tmp.keys = ctx->cmp_keys.as<uint64_t>();
+      tmp.n = kept; tmp.cap_tiles = ktiles;
+      int rc = flat_scan_prepared(ctx, tmp, count, topk, threshold, nullptr, out_in, stream, user_facing);
+      tmp.base = nullptr; tmp.bnorm = nullptr; tmp.extra = nullptr; tmp.keys = nullptr;   // the view owns nothing
+      return rc;
+    }
   }
   // Dense-score path for small cache-resident bases searched by many queries with a large k (the IVF
   // coarse step: 1024 x 4096 centroids, k = nprobe): the fused admission would spend longer warming up
@@ -466,7 +505,7 @@ void ctx_free(zvec_hip_ctx_s *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own) (void)hipStreamSynchronize(c->own);
-  c->gtau.release(); c->ridx.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
+  c->gtau.release(); c->ridx.release(); c->cmp_base.release(); c->cmp_norm.release(); c->cmp_extra.release(); c->cmp_keys.release(); c->cmp_pos.release(); c->cmp_cnt.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
   c->coarse_keys.release(); c->coarse_scores.release(); c->coarse_idx.release(); c->coarse_cnt.release();
   c->plan.release(); c->io_q.release(); c->io_ex.release(); c->io_keys.release(); c->io_scores.release();
   c->io_counts.release(); c->stats.release();
