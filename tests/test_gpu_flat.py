@@ -309,3 +309,25 @@ def test_sparse_keep_set_is_compacted_and_exact(zv, oracle, keep):
         assert se.search_impl(q, nq, ctx) == 0
         ok, os_, _, oc = oracle.flat_search(base, q, k, metric, keys=keys, exclude_bits=words, threads=4)
         tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="compacted keep=%g %s" % (keep, name))
+
+
+@pytest.mark.parametrize("k", [600, 2000])
+def test_flat_large_topk(zv, oracle, k):
+    """topk beyond the LDS-resident lists: dense-score path + whole-row selection (the reference's heap has no
+    limit; its tests use topk up to the corpus size)."""
+    rng = np.random.default_rng(67)
+    n, dim, nq = 5000, 24, 6
+    base = rng.integers(0, 200, (n, dim)).astype(np.float32)
+    q = rng.integers(0, 200, (nq, dim)).astype(np.float32)
+    se = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert se.load(base) == 0
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc = oracle.flat_search(base, q, k)
+    assert np.array_equal(ctx.counts, oc)
+    assert np.array_equal(ctx.scores, os_)              # integer data: exact scores, rank by rank
+    for i in range(nq):                                 # ids equal wherever the score is unique in the list
+        s_ = os_[i]
+        uniq = np.concatenate([[True], np.diff(s_) != 0]) & np.concatenate([np.diff(s_) != 0, [True]])
+        assert np.array_equal(ctx.keys[i][uniq], ok[i][uniq])

@@ -324,36 +324,47 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
       return rc;
     }
   }
-  // Dense-score path for small cache-resident bases searched by many queries with a large k (the IVF
-  // coarse step: 1024 x 4096 centroids, k = nprobe): the fused admission would spend longer warming up
-  // 1024 top-40 lists per tile run than the matrix cores need for the distances, so the scores are
-  // written once (16 MiB, stays in L2 / Infinity Cache) and each query row is selected by one wave.
+  // Dense-score path: the scores of a sub-batch of queries are written once to a [queries][positions] matrix by
+  // the same kernel in dump mode and every row is then selected by one wave of merge_kernel.  Used
+  //  (a) for small cache-resident bases searched by many queries with a large k (the IVF coarse step: 1024 x 4096
+  //      centroids, k = nprobe): the fused admission would spend longer warming up 1024 top-40 lists per tile
+  //      run than the matrix cores need for the distances; the 16 MiB of scores stay in L2 / Infinity Cache;
+  //  (b) as the large-k path: topk too big for the LDS-resident lists of the fused kernel (k up to ~5000).
   {
     const uint64_t ntiles_d = (st.n + TILE_N - 1) / TILE_N;
-    const double dump_bytes = (double)count * (double)ntiles_d * TILE_N * 4.0;
+    const double row_bytes_d = (double)ntiles_d * TILE_N * 4.0;
     const bool small_base = (double)st.n * st.dpad * 4.0 <= 64.0 * 1024 * 1024;
-    if (small_base && d_exclude == nullptr && topk > 8 && count >= 64 && dump_bytes <= 128.0 * 1024 * 1024 &&
-        (size_t)topk * 12 + 16 <= 60 * 1024) {
+    const bool k_fits_merge = (size_t)topk * 12 + 16 <= 60 * 1024;
+    const bool want_a = small_base && d_exclude == nullptr && topk > 8 && count >= 64 && row_bytes_d * count <= 128.0 * 1024 * 1024;
+    const bool want_b = pick_ng(count, topk) < 1;
+    if (want_b && !k_fits_merge) return ZVEC_HIP_ERR_UNSUPPORTED;
+    if ((want_a || want_b) && k_fits_merge) {
       const int cus_d = device_cus(ctx);
-      const int ngd = pick_ng(count, 1);
-      const uint32_t rows_d = ngd * QGROUP;
-      const uint32_t nqt = (count + rows_d - 1) / rows_d;
-      ZRET(ctx->part_s.ensure((size_t)dump_bytes));
-      ScanArgs a{};
-      a.base = st.base; a.bnorm = st.bnorm; a.exclude = nullptr;
-      a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
-      a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = 1; a.threshold = threshold;
-      a.mode = 0; a.nq = count; a.n = st.n; a.ndense = st.n; a.tiles_per_chunk = 1; a.nchunks = (uint32_t)ntiles_d; a.nqtiles = nqt;
-      a.gtau = ctx->gtau.as<uint32_t>();
-      a.dump = ctx->part_s.as<float>(); a.dump_stride = (uint32_t)(ntiles_d * TILE_N);
-      a.part_s = nullptr; a.part_i = nullptr;
-      ZRET(launch_scan_ng(ngd, a, st.f16, (uint32_t)ntiles_d * nqt, cus_d, stream));
-      MergeArgs m{};
-      m.part_s = a.dump; m.part_i = nullptr; m.part_keys = nullptr; m.slot_begin = nullptr; m.slots_per_q = 1;
-      m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = a.dump_stride; m.threshold = threshold;
-      m.keymap = st.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
-      hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
-      ZCHK(hipGetLastError());
+      // sub-batches so that the score matrix stays <= 1 GiB
+      const uint32_t sub = (uint32_t)std::max<double>(1.0, std::min<double>((double)count, std::floor(1073741824.0 / row_bytes_d)));
+      ZRET(ctx->part_s.ensure((size_t)(row_bytes_d * sub)));
+      for (uint32_t q0 = 0; q0 < count; q0 += sub) {
+        const uint32_t cnt = std::min(sub, count - q0);
+        const int ngd = pick_ng(cnt, 1);
+        const uint32_t rows_d = ngd * QGROUP;
+        const uint32_t nqt = (cnt + rows_d - 1) / rows_d;
+        ScanArgs a{};
+        a.base = st.base; a.bnorm = st.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
+        a.queries = ctx->qpad.as<float>() + (size_t)q0 * st.dpad; a.qnorm = ctx->qnorm.as<float>() + q0;
+        a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = 1; a.threshold = threshold;
+        a.mode = 0; a.nq = cnt; a.n = st.n; a.ndense = st.n; a.tiles_per_chunk = 1; a.nchunks = (uint32_t)ntiles_d; a.nqtiles = nqt;
+        a.gtau = ctx->gtau.as<uint32_t>() + q0;
+        a.dump = ctx->part_s.as<float>(); a.dump_stride = (uint32_t)(ntiles_d * TILE_N);
+        a.part_s = nullptr; a.part_i = nullptr;
+        ZRET(launch_scan_ng(ngd, a, st.f16, (uint32_t)ntiles_d * nqt, cus_d, stream));
+        MergeArgs m{};
+        m.part_s = a.dump; m.part_i = nullptr; m.part_keys = nullptr; m.slot_begin = nullptr; m.slots_per_q = 1;
+        m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = a.dump_stride; m.threshold = threshold;
+        m.keymap = st.keys; m.out_keys = out.keys + (size_t)q0 * topk; m.out_scores = out.scores + (size_t)q0 * topk;
+        m.out_idx = out.idx ? out.idx + (size_t)q0 * topk : nullptr; m.out_counts = out.counts + q0;
+        hipLaunchKernelGGL(merge_kernel, dim3(cnt), dim3(64), (size_t)topk * 12 + 16, stream, m);
+        ZCHK(hipGetLastError());
+      }
       if (user_facing) ZRET(refine_l2(ctx, st, count, topk, threshold, out.keys, out.scores, out.idx, out.counts, stream));
       return 0;
     }
