@@ -352,8 +352,13 @@ def cpu_baseline_ivf(torch, ivf, base, q, topk, nprobe, max_scan, args):
         dt = time.perf_counter() - t1
         best = dt if best is None else min(best, dt)
         reps += 1
+    # single-thread figure as well (report T = 1 and T = all cores), on a 32-query sample
+    n1 = min(32, nq)
+    t1 = time.perf_counter()
+    o.ivf_search(cent, offs, vecs, qh[:n1], topk, nprobe, max_scan, keys=rows, threads=1)
+    one = n1 / (time.perf_counter() - t1)
     o.use_reference_kernels(False)
-    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": "port",
+    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": "port", "value_1_thread": one,
             "sample": "%d queries of the timed batch, same IVF index (exported), %d threads across queries, best of %d; "
                       "scan loops = oracle restatement, 1x1 distance kernel = %s" % (
                           nq, threads, reps, "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")}
