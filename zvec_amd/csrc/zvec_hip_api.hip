@@ -54,6 +54,21 @@ struct DevBuf {
   template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// scope-owned device temporary: freed on every exit path of the enclosing function
+template <typename T>
+struct Scoped {
+  T *p = nullptr;
+  Scoped() {}
+  Scoped(const Scoped &) = delete;
+  Scoped &operator=(const Scoped &) = delete;
+  ~Scoped() { if (p) (void)hipFree(p); }
+  int alloc(size_t count) {
+    ZCHK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+    return 0;
+  }
+  operator T *() const { return p; }
+};
+
 // a blocked, HBM-resident set of rows (flat store, IVF centroids, IVF inverted lists)
 struct Store {
   uint32_t dim_in = 0;   // element dimension at the ABI (cosine: d+1)
@@ -991,27 +1006,23 @@ static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uin
   ZRET(h->lists.reserve(std::max<uint64_t>(tiles * TILE_N, 1), s));
   h->lists.n = tiles * TILE_N;
   if (dense) {
-    uint64_t *d_src = nullptr, *d_dst = nullptr;
-    ZCHK(hipMalloc(&d_src, dense * 8));
-    ZCHK(hipMalloc(&d_dst, dense * 8));
+    Scoped<uint64_t> d_src, d_dst;
+    ZRET(d_src.alloc(dense));
+    ZRET(d_dst.alloc(dense));
     ZCHK(hipMemcpyAsync(d_src, h->h_row_ids.data(), dense * 8, hipMemcpyHostToDevice, s));
     ZCHK(hipMemcpyAsync(d_dst, dst.data(), dense * 8, hipMemcpyHostToDevice, s));
     ZRET(launch_pack(h->lists, d_rows, dense, d_src, 0, d_dst, s));
     ZCHK(hipMemcpyAsync(h->lists.keys, hkeys.data(), hkeys.size() * 8, hipMemcpyHostToDevice, s));
     ZCHK(hipStreamSynchronize(s));
-    (void)hipFree(d_src);
-    (void)hipFree(d_dst);
   }
   // centroids as a flat store
   h->cent.n = 0;
   {
-    void *d_c = nullptr;
-    ZCHK(hipMalloc(&d_c, (size_t)nlist * rb));
+    Scoped<char> d_c;
+    ZRET(d_c.alloc((size_t)nlist * rb));
     ZCHK(hipMemcpyAsync(d_c, h_centroids, (size_t)nlist * rb, hipMemcpyHostToDevice, s));
-    int rc = store_append_dev(h->cent, d_c, nlist, nullptr, s);
+    ZRET(store_append_dev(h->cent, d_c, nlist, nullptr, s));
     ZCHK(hipStreamSynchronize(s));
-    (void)hipFree(d_c);
-    if (rc != 0) return rc;
   }
   // list tables
   if (h->d_size) { (void)hipFree(h->d_size); (void)hipFree(h->d_size_global); (void)hipFree(h->d_tile0); (void)hipFree(h->d_dense0); (void)hipFree(h->d_order); }
@@ -1051,16 +1062,13 @@ int zvec_hip_ivf_load(zvec_hip_ivf_t h, const void *centroids, uint32_t nlist, c
     if (list_offsets[l + 1] < list_offsets[l]) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
     for (uint64_t i = list_offsets[l]; i < list_offsets[l + 1]; ++i) labels[i] = l;
   }
-  void *d_rows = nullptr;
+  Scoped<char> d_rows;
   if (n) {
-    ZCHK(hipMalloc(&d_rows, (size_t)n * h->lists.row_bytes()));
+    ZRET(d_rows.alloc((size_t)n * h->lists.row_bytes()));
     ZCHK(hipMemcpyAsync(d_rows, vecs, (size_t)n * h->lists.row_bytes(), hipMemcpyHostToDevice, s));
   }
-  bool was_loaded = h->loaded;
-  if (was_loaded) ivf_release(h);
-  int rc = ivf_pack(h, d_rows, n, keys, labels, centroids, nlist, s);
-  if (d_rows) (void)hipFree(d_rows);
-  return rc;
+  if (h->loaded) ivf_release(h);
+  return ivf_pack(h, d_rows, n, keys, labels, centroids, nlist, s);
 }
 
 int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, const uint64_t *keys, uint32_t nlist,
@@ -1082,11 +1090,11 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
   uint64_t S = std::min<uint64_t>(n, (uint64_t)sample_per_list * nlist);
   std::vector<uint64_t> sample_ids(S);
   for (uint64_t i = 0; i < S; ++i) sample_ids[i] = (uint64_t)(((unsigned __int128)i * n) / S);
-  uint64_t *d_ids = nullptr;
-  char *d_sample = nullptr, *d_cent = nullptr;
-  ZCHK(hipMalloc(&d_ids, S * 8));
-  ZCHK(hipMalloc(&d_sample, (size_t)S * rb));
-  ZCHK(hipMalloc(&d_cent, (size_t)nlist * rb));
+  Scoped<uint64_t> d_ids;
+  Scoped<char> d_sample, d_cent;
+  ZRET(d_ids.alloc(S));
+  ZRET(d_sample.alloc((size_t)S * rb));
+  ZRET(d_cent.alloc((size_t)nlist * rb));
   ZCHK(hipMemcpyAsync(d_ids, sample_ids.data(), S * 8, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)S), dim3(256), 0, s, (const void *)rows, (uint32_t)rb, d_ids, S, (void *)d_sample);
   ZCHK(hipGetLastError());
@@ -1107,23 +1115,24 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
   }
   // ---- Lloyd iterations on the sample ----
   Store cs;
+  struct StoreGuard { Store &s; ~StoreGuard() { s.release(); } } cs_guard{cs};   // the k-means codebook store
   cs.configure(dim, h->metric, h->dtype);
-  uint64_t *d_lab_keys = nullptr; float *d_lab_scores = nullptr; uint32_t *d_lab_idx = nullptr, *d_lab_cnt = nullptr;
+  Scoped<uint64_t> d_lab_keys; Scoped<float> d_lab_scores; Scoped<uint32_t> d_lab_idx, d_lab_cnt;
   const uint64_t BATCH = 1u << 18;
   uint64_t maxq = std::max<uint64_t>(std::min<uint64_t>(S, BATCH), std::min<uint64_t>(n, BATCH));
-  ZCHK(hipMalloc(&d_lab_keys, maxq * 8));
-  ZCHK(hipMalloc(&d_lab_scores, maxq * 4));
-  ZCHK(hipMalloc(&d_lab_idx, maxq * 4));
-  ZCHK(hipMalloc(&d_lab_cnt, maxq * 4));
-  uint64_t *d_moff = nullptr, *d_members = nullptr;
-  ZCHK(hipMalloc(&d_moff, ((size_t)nlist + 1) * 8));
-  ZCHK(hipMalloc(&d_members, S * 8));
+  ZRET(d_lab_keys.alloc(maxq));
+  ZRET(d_lab_scores.alloc(maxq));
+  ZRET(d_lab_idx.alloc(maxq));
+  ZRET(d_lab_cnt.alloc(maxq));
+  Scoped<uint64_t> d_moff, d_members;
+  ZRET(d_moff.alloc((size_t)nlist + 1));
+  ZRET(d_members.alloc(S));
   std::vector<uint32_t> lab(std::max<uint64_t>(S, n));
   auto assign = [&](const char *q, uint64_t nq, uint32_t *host_labels) -> int {
     for (uint64_t o = 0; o < nq; o += BATCH) {
       uint32_t m = (uint32_t)std::min<uint64_t>(BATCH, nq - o);
       ZRET(prep_queries(c, cs, q + (size_t)o * rb, m, FLT_MAX, s));
-      SearchOut out{d_lab_keys, d_lab_scores, d_lab_idx, d_lab_cnt};
+      SearchOut out{d_lab_keys.p, d_lab_scores.p, d_lab_idx.p, d_lab_cnt.p};
       ZRET(flat_scan_prepared(c, cs, m, 1, FLT_MAX, nullptr, out, s, false));
       ZCHK(hipMemcpyAsync(host_labels + o, d_lab_idx, (size_t)m * 4, hipMemcpyDeviceToHost, s));
       ZCHK(hipStreamSynchronize(s));
@@ -1180,9 +1189,6 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
   ZRET(assign(rows, n, lab.data()));
   std::vector<char> hc((size_t)nlist * rb);
   ZCHK(hipMemcpy(hc.data(), d_cent, hc.size(), hipMemcpyDeviceToHost));
-  cs.release();
-  (void)hipFree(d_ids); (void)hipFree(d_sample); (void)hipFree(d_cent); (void)hipFree(d_lab_keys);
-  (void)hipFree(d_lab_scores); (void)hipFree(d_lab_idx); (void)hipFree(d_lab_cnt); (void)hipFree(d_moff); (void)hipFree(d_members);
   lab.resize(n);
   for (uint64_t i = 0; i < n; ++i) if (lab[i] >= nlist) lab[i] = 0;
   return ivf_pack(h, rows, n, keys, lab, hc.data(), nlist, s);
@@ -1192,12 +1198,10 @@ int zvec_hip_ivf_build(zvec_hip_ivf_t h, const void *vecs, uint64_t n, const uin
                        uint32_t kmeans_iters, uint32_t sample_per_list, uint64_t seed) {
   if (!h || !vecs || n == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   ZCHK(hipSetDevice(h->device));
-  void *d_rows = nullptr;
-  ZCHK(hipMalloc(&d_rows, (size_t)n * h->lists.row_bytes()));
+  Scoped<char> d_rows;
+  ZRET(d_rows.alloc((size_t)n * h->lists.row_bytes()));
   ZCHK(hipMemcpy(d_rows, vecs, (size_t)n * h->lists.row_bytes(), hipMemcpyHostToDevice));
-  int rc = zvec_hip_ivf_build_dev(h, d_rows, n, keys, nlist, kmeans_iters, sample_per_list, seed, nullptr);
-  (void)hipFree(d_rows);
-  return rc;
+  return zvec_hip_ivf_build_dev(h, d_rows, n, keys, nlist, kmeans_iters, sample_per_list, seed, nullptr);
 }
 
 int zvec_hip_ivf_info(zvec_hip_ivf_t h, uint64_t *count, uint32_t *nlist) {
@@ -1369,9 +1373,9 @@ int zvec_hip_merge_topk(zvec_hip_ctx_t ctx, const uint64_t *keys, const float *s
   if (count == 0) return 0;
   ZCHK(hipSetDevice(ctx->device));
   size_t ne = (size_t)nparts * count * topk;
-  uint64_t *dk = nullptr, *dok = nullptr; float *ds = nullptr, *dos = nullptr; uint32_t *dc = nullptr, *doc = nullptr;
-  ZCHK(hipMalloc(&dk, ne * 8)); ZCHK(hipMalloc(&ds, ne * 4)); ZCHK(hipMalloc(&dc, (size_t)nparts * count * 4));
-  ZCHK(hipMalloc(&dok, (size_t)count * topk * 8)); ZCHK(hipMalloc(&dos, (size_t)count * topk * 4)); ZCHK(hipMalloc(&doc, (size_t)count * 4));
+  Scoped<uint64_t> dk, dok; Scoped<float> ds, dos; Scoped<uint32_t> dc, doc;
+  ZRET(dk.alloc(ne)); ZRET(ds.alloc(ne)); ZRET(dc.alloc((size_t)nparts * count));
+  ZRET(dok.alloc((size_t)count * topk)); ZRET(dos.alloc((size_t)count * topk)); ZRET(doc.alloc(count));
   ZCHK(hipMemcpy(dk, keys, ne * 8, hipMemcpyHostToDevice));
   ZCHK(hipMemcpy(ds, scores, ne * 4, hipMemcpyHostToDevice));
   ZCHK(hipMemcpy(dc, counts, (size_t)nparts * count * 4, hipMemcpyHostToDevice));
@@ -1382,7 +1386,6 @@ int zvec_hip_merge_topk(zvec_hip_ctx_t ctx, const uint64_t *keys, const float *s
     ZCHK(hipMemcpy(out_scores, dos, (size_t)count * topk * 4, hipMemcpyDeviceToHost));
     ZCHK(hipMemcpy(out_counts, doc, (size_t)count * 4, hipMemcpyDeviceToHost));
   }
-  (void)hipFree(dk); (void)hipFree(ds); (void)hipFree(dc); (void)hipFree(dok); (void)hipFree(dos); (void)hipFree(doc);
   return rc;
 }
 
