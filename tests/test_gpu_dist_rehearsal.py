@@ -74,9 +74,9 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu(world):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    assert dict(out) == {0: True, 1: True}
+    assert dict(out) == {r: True for r in range(world)}

@@ -497,6 +497,7 @@ int launch_unpack(const Store &st, uint64_t pos, void *d_out, hipStream_t stream
 
 int store_append_dev(Store &st, const void *d_vecs, uint64_t n, const uint64_t *d_keys, hipStream_t stream) {
   if (n == 0) return 0;
+  if (st.n + n >= 0xfffffff0ull) return ZVEC_HIP_ERR_OUT_OF_RANGE;   // positions are 32-bit (IDX_NONE reserved)
   ZRET(st.reserve(st.n + n, stream));
   ZRET(launch_pack(st, d_vecs, n, nullptr, st.n, nullptr, stream));
   ZCHK(hipGetLastError());
@@ -833,6 +834,17 @@ int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *
   if (count == 0) return 0;
   if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;   // "Invalid context or topk not set yet" flat_searcher.cc:194
   zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  // the kernels address the padded query matrix with 32-bit word offsets: very large batches go in slices
+  const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(h->st.dpad, 1u));
+  if (count > maxq) {
+    for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
+      const uint32_t m = std::min(maxq, count - q0);
+      ZRET(zvec_hip_flat_search_dev(h, ctx, reinterpret_cast<const char *>(d_queries) + (size_t)q0 * h->st.row_bytes(), m, topk,
+                                    threshold, d_exclude_bitset, d_out_keys + (size_t)q0 * topk, d_out_scores + (size_t)q0 * topk,
+                                    d_out_counts + q0, stream));
+    }
+    return 0;
+  }
   std::lock_guard<std::mutex> g(c->mu);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(c, stream);
@@ -1245,6 +1257,18 @@ static int ivf_search_dev_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void 
   if (count == 0) return 0;
   if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;   // ivf_searcher.cc:197-200
   zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  {
+    const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(h->lists.dpad, 1u));
+    if (count > maxq) {   // 32-bit word offsets into the padded query matrix: slice very large batches
+      for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
+        const uint32_t m = std::min(maxq, count - q0);
+        ZRET(ivf_search_dev_impl(h, ctx, reinterpret_cast<const char *>(d_queries) + (size_t)q0 * h->lists.row_bytes(), m, topk,
+                                 threshold, nprobe, max_scan_count, brute_force, d_exclude, d_out_keys + (size_t)q0 * topk,
+                                 d_out_scores + (size_t)q0 * topk, d_out_counts + q0, stream));
+      }
+      return 0;
+    }
+  }
   std::lock_guard<std::mutex> g(c->mu);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(c, stream);
