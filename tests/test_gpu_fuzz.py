@@ -1,0 +1,96 @@
+"""Randomised shape sweep: GPU (through the C ABI) vs the oracle on integer-valued data (bit-exact bar), over
+metric x dtype x ragged sizes x filters x thresholds x IVF probe settings.  Seeds are fixed: failures reproduce."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import tie_tolerant_compare, exact_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zv():
+    import zvec_amd
+    return zvec_amd
+
+
+def _data(rng, n, dim, dtype):
+    hi = 24 if dim > 200 else 60
+    lo = -hi if rng.random() < 0.5 else 0
+    return rng.integers(lo, hi, (n, dim)).astype(dtype)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_flat_fuzz(zv, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.choice([1, 2, 3, 7, 8, 15, 16, 31, 32, 33, 63, 64, 65, 96, 100, 128, 200, 257, 768]))
+    n = int(rng.choice([1, 2, 31, 127, 128, 129, 255, 256, 257, 1000, 2049, 5000]))
+    nq = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 64, 65, 128, 129, 300]))
+    k = int(rng.choice([1, 2, 3, 10, 17, 64, 65, 100, 200]))
+    half = bool(rng.random() < 0.35)
+    dt = np.float16 if half else np.float32
+    name, metric = [("SquaredEuclidean", O.METRIC_L2), ("InnerProduct", O.METRIC_IP)][int(rng.integers(0, 2))]
+    base, q = _data(rng, n, dim, dt), _data(rng, nq, dim, dt)
+    keys = rng.permutation(4 * n + 5)[:n].astype(np.uint64)
+    se = zv.HipFlatSearcher(dim, name, dtype="fp16" if half else "fp32")
+    assert se.load(base, keys) == 0
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    words = None
+    if rng.random() < 0.5:
+        words = O.pack_bits(rng.random(n) < rng.choice([0.1, 0.5, 0.9, 1.0]))
+        ctx.set_exclude_bitset(words)
+    thr = O.FLT_MAX
+    if rng.random() < 0.3:
+        thr = float(np.median(oracle.flat_search(base, q[:1], min(k, n), metric)[1]))
+        ctx.set_threshold(thr)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc = oracle.flat_search(base, q, k, metric, keys=keys, threshold=thr, exclude_bits=words)
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc,
+                         what="flat fuzz seed=%d n=%d d=%d nq=%d k=%d %s %s" % (seed, n, dim, nq, k, name, dt.__name__))
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_ivf_fuzz(zv, oracle, seed):
+    rng = np.random.default_rng(2000 + seed)
+    dim = int(rng.choice([4, 8, 17, 32, 64, 100, 129, 768]))
+    n = int(rng.choice([50, 300, 1000, 4000, 9000]))
+    nlist = int(rng.choice([1, 2, 7, 16, 33, 64]))
+    nlist = min(nlist, n)
+    nq = int(rng.choice([1, 5, 16, 17, 33, 64, 150]))
+    k = int(rng.choice([1, 5, 10, 40, 100]))
+    half = bool(rng.random() < 0.35)
+    dt = np.float16 if half else np.float32
+    base, q = _data(rng, n, dim, dt), _data(rng, nq, dim, dt)
+    # random (possibly very unbalanced, possibly empty) lists; centroids = integer-rounded means (or a data row)
+    lab = rng.integers(0, nlist, n) if rng.random() < 0.7 else np.minimum(rng.geometric(0.4, n) - 1, nlist - 1)
+    order = np.argsort(lab, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(lab, minlength=nlist))]).astype(np.uint64)
+    cent = np.stack([np.round(base[lab == l].astype(np.float32).mean(0)) if (lab == l).any() else base[0].astype(np.float32)
+                     for l in range(nlist)]).astype(dt)
+    vecs, keys = base[order], (order.astype(np.uint64) * 3 + 1)
+    ratio = float(rng.choice([0.05, 0.2, 0.5, 1.0]))
+    bft = int(rng.choice([0, 10, n + 1]))
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=ratio, brute_force_threshold=bft, dtype="fp16" if half else "fp32")
+    assert se.load(cent, offs, vecs, keys) == 0
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    words = None
+    if rng.random() < 0.4:
+        words = O.pack_bits(rng.random(n) < 0.5)
+        ctx.set_exclude_bitset(words)
+    assert se.search_impl(q, nq, ctx) == 0
+    bf = n <= bft
+    ok, os_, _, oc, osc = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys, brute_force=bf, exclude_bits=words)
+    if bf or nprobe >= nlist:
+        sel = np.arange(nq)
+    else:   # the probe set is only well defined where the coarse ranking has no tie across the cut
+        cd = np.sort(exact_l2(cent.astype(np.float32), q.astype(np.float32)), 1)
+        sel = np.nonzero((np.diff(cd[:, :min(nprobe + 1, nlist)], axis=1) != 0).all(1))[0]
+    tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel],
+                         what="ivf fuzz seed=%d n=%d d=%d nlist=%d nq=%d k=%d ratio=%g bft=%d %s" % (seed, n, dim, nlist, nq, k, ratio, bft, dt.__name__))
+    if not bf:
+        scanned, _ = se.last_stats(ctx, nq)
+        assert np.array_equal(scanned[sel], osc[sel])
