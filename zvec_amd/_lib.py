@@ -84,7 +84,8 @@ def lib():
     """Load (building first if the sources are newer) the HIP shared library. Raises if absent."""
     global _LIB
     if _LIB is None:
-        path = _build.build()
+        # ZVEC_HIP_LIBRARY: another build of the same library (kernel A/B experiments on one GPU box)
+        path = os.environ.get("ZVEC_HIP_LIBRARY") or _build.build()
         if not os.path.exists(path):
             raise RuntimeError("zvec_amd: %s missing — the HIP extension is required (no CPU fallback)" % path)
         L = C.CDLL(path)

@@ -314,7 +314,7 @@ struct ScanShape {
 // too (distance_matrix_accum_fp16.i:554-594).  The staging is byte-identical: a row segment per k-step is
 // 128 B either way (32 floats or 64 halves); `dpad` counts 4-byte words per row.
 template <int NG, bool M16, bool EXCL, bool F16>
-__global__ void __launch_bounds__(256, (NG >= 4 ? 2 : 1)) scan_kernel(const ScanArgs a) {
+__global__ void __launch_bounds__(256, (NG >= 4 ? 2 : (NG == 2 && !M16 ? 3 : 1))) scan_kernel(const ScanArgs a) {
   constexpr int ROWS = ScanShape<NG, M16>::ROWS;
   constexpr int QL = ScanShape<NG, M16>::QLOADS;
   constexpr int QROWMASK = 31;
@@ -681,6 +681,232 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : 1)) scan_kernel(const Scan
 }
 
 // ---------------------------------------------------------------------------------------------
+// The wide flat-scan kernel: 512 threads = 8 waves as 2 (query-row halves) x 4 (column blocks) over a
+// 128-query x 128-row tile.  Same LDS images, K-step, epilogue and list logic as scan_kernel<4,..>, but
+// the staging of one K-step (16 KiB base slab + 16 KiB query rows) is shared by 8 waves instead of 4 and
+// each wave carries only 2 accumulator groups (32 registers), so the kernel fits 128 VGPRs and runs at
+// 4 waves per SIMD (two work-groups per CU): twice the resident waves of the 4-wave NG=4 shape at the
+// same base-row reuse, which is what the matrix cores need to stay busy across barriers and epilogues.
+// Flat mode only (mode 0); the IVF list scan keeps the 16-row shape above.
+// ---------------------------------------------------------------------------------------------
+constexpr int W8_ROWS = 128;
+__host__ __device__ inline size_t scan8_lds_bytes(uint32_t k) {
+  return (2 * (size_t)W8_ROWS * TILE_K + 2 * (size_t)SLAB + 7 * (size_t)W8_ROWS + 4 + 2 * (size_t)W8_ROWS * k) * 4;
+}
+
+template <bool EXCL, bool F16>
+__global__ void __launch_bounds__(512, 4) scan8_kernel(const ScanArgs a) {
+  constexpr int ROWS = W8_ROWS;
+  extern __shared__ f32x4 zvk_smem4[];
+  float *smem = reinterpret_cast<float *>(zvk_smem4);
+  float *Qs = smem;                      // [2][ROWS*32]
+  float *Bs = Qs + 2 * ROWS * TILE_K;    // [2][SLAB]
+  float *qn_s = Bs + 2 * SLAB;           // [ROWS]
+  RowState st;
+  st.tau = qn_s + ROWS;
+  st.cnt = reinterpret_cast<uint32_t *>(st.tau + ROWS);
+  uint32_t *qrow_s = st.cnt + ROWS;
+  uint32_t *slot_s = qrow_s + ROWS;
+  st.k = a.k;
+  st.gt = reinterpret_cast<float *>(slot_s + ROWS + 4);
+  st.tq = st.gt + ROWS;
+  st.gtau = a.gtau;
+  st.qrow = qrow_s;
+  st.Ls = st.tq + ROWS;
+  st.Li = reinterpret_cast<uint32_t *>(st.Ls + (size_t)ROWS * a.k);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wn = wave & 3, wm = wave >> 2;               // column block, query-row half
+  const int r = lane & 31, h = lane >> 5;                 // 32x32x2 operand coordinates
+  const int srow = tid >> 3, schunk = tid & 7;            // staging coordinates: rows srow and srow + 64
+  const int sswz = schunk ^ ((srow >> 1) & 7);
+  const uint32_t dpad = a.dpad, nks = a.nks, k = a.k;
+  const uint32_t ntiles_total = (uint32_t)((a.n + TILE_N - 1) / TILE_N);
+  const uint32_t rows_valid_total = (uint32_t)min((uint64_t)0xffffffffu, a.n);
+
+  // XCD-aware item order: work-groups whose ids agree modulo 8 share an XCD (and its L2), so the query tiles that
+  // stream the SAME chunk of the base are given ids of one residue class: the chunk is then fetched from HBM once
+  // and the other query tiles read it from that XCD's L2.  (A speed choice only; any placement is correct.)
+  const uint32_t vtotal = ((a.nchunks + 7) / 8) * 8 * a.nqtiles;
+  for (uint32_t v = blockIdx.x; v < vtotal; v += gridDim.x) {   // uniform exit
+    const uint32_t qtile = (v >> 3) % a.nqtiles;
+    const uint32_t chunk = ((v >> 3) / a.nqtiles) * 8 + (v & 7);
+    if (chunk >= a.nchunks) continue;
+    const uint32_t tile_begin = chunk * a.tiles_per_chunk;
+    const uint32_t tile_end = min(tile_begin + a.tiles_per_chunk, ntiles_total);
+    const uint32_t r0 = qtile * ROWS;
+    const uint32_t nrows = min((uint32_t)ROWS, a.nq - r0);
+
+    for (int j = tid; j < ROWS; j += 512) {
+      const bool live = (uint32_t)j < nrows;
+      const uint32_t qrow = live ? r0 + j : r0;
+      qrow_s[j] = qrow;
+      slot_s[j] = live ? qrow * a.nchunks + chunk : IDX_NONE;
+      qn_s[j] = (a.metric == METRIC_L2) ? a.qnorm[qrow] : 0.f;
+      st.tau[j] = a.threshold;
+      st.gt[j] = a.threshold;
+      st.tq[j] = a.threshold;
+      st.cnt[j] = 0;
+    }
+    __syncthreads();
+
+    const uint32_t nsteps = (tile_end - tile_begin) * nks;
+
+    // Staging by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write pass).  One wave-instruction writes
+    // 1 KiB of LDS linearly in lane order, which is exactly a piece of the base slab (stored in HBM as its LDS
+    // image); the query image's XOR swizzle is applied on the SOURCE side instead: the lane whose LDS slot is
+    // chunk p of row `srow` fetches chunk p ^ ((srow >> 1) & 7) of that query row.
+    const uint32_t gq0 = qrow_s[srow] * dpad + (uint32_t)sswz * 4u;
+    const uint32_t gq1 = qrow_s[srow + 64] * dpad + (uint32_t)sswz * 4u;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto stage_glds = [&](uint32_t t_, uint32_t k_, float *Bb, float *Qb) {
+      const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(a.base + (size_t)t_ * TILE_N * dpad + (size_t)k_ * SLAB) + tid;
+      char *bl = reinterpret_cast<char *>(Bb) + wave * 1024;      // wave-uniform destinations
+      char *ql = reinterpret_cast<char *>(Qb) + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void *)bsrc, (lds_void *)bl, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(bsrc + 512), (lds_void *)(bl + 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(a.queries + (size_t)(gq0 + k_ * TILE_K)), (lds_void *)ql, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(a.queries + (size_t)(gq1 + k_ * TILE_K)), (lds_void *)(ql + 8192), 16, 0, 0);
+    };
+    floatx16 acc[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+
+    uint32_t tile = tile_begin, ks = 0;          // step being computed
+    uint32_t ptile = tile_begin, pks = 0;        // next step to fetch
+    uint32_t fetched = 0;
+    auto advance = [&](uint32_t &t_, uint32_t &k_) { if (++k_ == nks) { k_ = 0; ++t_; } };
+    if (nsteps > 0) {
+      stage_glds(ptile, pks, Bs, Qs);
+      if (nsteps > 1) advance(ptile, pks);
+      fetched = 1;
+    }
+    // metric fix-up as one fused multiply-add + clamp: L2 -2*dot + (|q|^2 + |b|^2) clamped at 0; IP -dot; cosine 1 - dot
+    const float m_alpha = (a.metric == METRIC_L2) ? -2.f : -1.f;
+    const float m_beta = (a.metric == METRIC_COSINE) ? 1.f : 0.f;
+    const float m_nrm = (a.metric == METRIC_L2) ? 1.f : 0.f;
+    const float m_lo = (a.metric == METRIC_L2) ? 0.f : -__builtin_inff();
+
+    float bn0 = 0.f;
+    uint32_t ex0 = 0;
+    for (uint32_t s0 = 0; s0 < nsteps; s0 += 2) {
+#pragma unroll
+     for (int u = 0; u < 2; ++u) {
+      const uint32_t s = s0 + u;
+      if (s >= nsteps) break;                      // uniform
+      const int buf = u;
+      const bool has_next = (s + 1 < nsteps);
+      // Step s: the barrier (preceded by each wave's vmcnt(0), which retires its own DMA pieces) publishes buffer
+      // `buf`, filled during step s-1, and retires every read of the other buffer, which is then refilled with step
+      // s+1 under this step's matrix work.
+      __syncthreads();
+      if (has_next) stage_glds(ptile, pks, Bs + (buf ^ 1) * SLAB, Qs + (buf ^ 1) * ROWS * TILE_K);
+      if (fetched + 1 < nsteps) advance(ptile, pks);
+      ++fetched;
+      {
+        const uint32_t pos0 = tile * TILE_N + wn * 32;
+        bn0 = a.bnorm[(size_t)pos0 + r];
+        if constexpr (EXCL) {
+          const uint64_t d0 = min((uint64_t)pos0 + r, a.ndense - 1);
+          ex0 = (a.exclude[d0 >> 5] >> (d0 & 31)) & 1u;
+        }
+      }
+      {
+        const float *Qb = Qs + buf * ROWS * TILE_K + wm * 64 * TILE_K;
+        const float *Bb = Bs + buf * SLAB;
+        const int brow = wn * 32 + r;
+        const int swz = (r >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int c = (2 * kk + h) ^ swz;
+          const f32x4 bf = *reinterpret_cast<const f32x4 *>(Bb + (brow * 8 + c) * 4);
+          const f32x4 af0 = *reinterpret_cast<const f32x4 *>(Qb + (r * 8 + c) * 4);
+          const f32x4 af1 = *reinterpret_cast<const f32x4 *>(Qb + ((32 + r) * 8 + c) * 4);
+          if constexpr (F16) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af0), __builtin_bit_cast(f16x8, bf), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af1), __builtin_bit_cast(f16x8, bf), acc[1], 0, 0, 0);
+          } else {
+            // (back-to-back accumulation into one group measured 3 % faster than alternating the two groups)
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0.x, bf.x, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0.y, bf.y, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0.z, bf.z, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0.w, bf.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1.x, bf.x, acc[1], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1.y, bf.y, acc[1], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1.z, bf.z, acc[1], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1.w, bf.w, acc[1], 0, 0, 0);
+          }
+        }
+      }
+
+      // ---- tile epilogue: two rounds; in round gi the row half wm transposes its group 2*wm+gi through 16 KiB of
+      // the operand buffer this step has just finished with (half 0: its base slab, half 1: its query rows) and the
+      // 4 waves of the half admit its 32 rows (row i of the group belongs to wave i % 4 of the half)
+      if (ks == nks - 1) {
+        if (a.dump == nullptr && tid < ROWS) {
+          const float g_ = fkey_inv(__hip_atomic_load(&a.gtau[qrow_s[tid]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          st.gt[tid] = g_;
+          st.tq[tid] = fminf(st.tau[tid], g_);
+        }
+        __syncthreads();                                                          // every wave is done reading `buf`
+        float *Sc = wm ? (Qs + buf * ROWS * TILE_K) : (Bs + buf * SLAB);          // [32 rows][128 cols]
+        const uint32_t pos0 = tile * TILE_N;
+        const bool colvalid = (pos0 + wn * 32 + r < rows_valid_total) && (ex0 == 0);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+          const int gbase = (wm * 2 + gi) * 32;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row_l = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float dot = acc[gi][e];
+            const float sc = fmaxf(fmaf(m_alpha, dot, fmaf(m_nrm, qn_s[gbase + row_l] + bn0, m_beta)), m_lo);
+            Sc[row_l * TILE_N + wn * 32 + r] = colvalid ? sc : __builtin_inff();
+            acc[gi][e] = 0.f;
+          }
+          __syncthreads();
+          {
+            f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + wn * TILE_N + 2 * lane);
+            float t0 = st.tq[gbase + wn];
+#pragma unroll 1
+            for (int i = 0; i < 8; ++i) {
+              const int row_l = i * 4 + wn;
+              const int row = gbase + row_l;
+              const int nrow_l = min(row_l + 4, 31);
+              const f32x2 vn = *reinterpret_cast<const f32x2 *>(Sc + nrow_l * TILE_N + 2 * lane);
+              const float tn = st.tq[gbase + nrow_l];
+              if ((uint32_t)row < nrows) {
+                if (a.dump) *reinterpret_cast<f32x2 *>(a.dump + (size_t)qrow_s[row] * a.dump_stride + pos0 + 2 * lane) = v;
+                else owner_row(st, row, v.x, v.y, t0, pos0, lane);
+              }
+              v = vn;
+              t0 = tn;
+            }
+          }
+          __syncthreads();
+        }
+      }
+
+      advance(tile, ks);
+     }
+    }
+
+    for (uint32_t j = tid; a.dump == nullptr && j < nrows * k; j += 512) {
+      uint32_t row = j / k, t = j - row * k;
+      uint32_t c = st.cnt[row];
+      size_t o = (size_t)slot_s[row] * k + t;
+      a.part_s[o] = (t < c) ? st.Ls[(size_t)row * k + t] : __builtin_inff();
+      a.part_i[o] = (t < c) ? st.Li[(size_t)row * k + t] : IDX_NONE;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // merge kernel: one wave per query; merges the query's slots (scan order = slot order, then
 // position) into the final sorted top-k.  Also used for the shard merge after the all-gather.
 // ---------------------------------------------------------------------------------------------
@@ -911,6 +1137,17 @@ __global__ void unpack_row_kernel(const float *base, const float *extra, uint64_
 __global__ void fill_gtau_kernel(uint32_t *gtau, uint32_t n, float threshold) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) gtau[i] = fkey(threshold);
+}
+
+// gtau[q] = min(gtau[q], k-th score of a sample scan, nudged up by ~1e-6 relative) — only for full sample lists.
+// The k-th best score of ANY subset of the rows bounds the final k-th score from above, so starting every
+// work-group of the main scan at that bound drops nothing it could keep; it only spares the list warm-up.
+__global__ void seed_gtau_kernel(uint32_t *gtau, const float *scores, const uint32_t *counts, uint32_t n, uint32_t k) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || counts[i] < k) return;
+  const float s = scores[(size_t)i * k + (k - 1)];
+  const float b = s + fabsf(s) * 1e-6f + 1e-30f;
+  if (b == b) atomicMin(&gtau[i], fkey(b));
 }
 
 __global__ void fill_keys_kernel(uint64_t *keys, uint64_t pos0, uint64_t n, const uint64_t *src) {

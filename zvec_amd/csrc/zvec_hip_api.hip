@@ -133,6 +133,7 @@ struct zvec_hip_ctx_s {
   std::mutex mu;
   // workspace
   DevBuf gtau, ridx;
+  DevBuf seed_keys, seed_scores, seed_counts;   // sample scan that seeds the shared admission bounds
   DevBuf cmp_base, cmp_norm, cmp_extra, cmp_keys, cmp_pos, cmp_cnt;   // compacted keep-set (sparse filters)
   DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
   DevBuf plan;        // all u32 plan arrays
@@ -220,6 +221,37 @@ int launch_scan(const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStr
                    : launch_scan_t<NG, M16, false, false>(a, max_items, cus, stream);
 }
 
+// the 8-wave 128x128 flat tile (scan8_kernel); *occ_out = work-groups per CU it reaches for this k
+template <bool EXCL, bool F16>
+int launch_scan8_t(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream, int *occ_out) {
+  static bool attr_set[16] = {false};
+  size_t lds = scan8_lds_bytes(a.k);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set[dev & 15]) {
+    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan8_kernel<EXCL, F16>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    attr_set[dev & 15] = true;
+  }
+  int occ = 0;
+  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan8_kernel<EXCL, F16>, 512, lds));
+  if (occ < 1) occ = 1;
+  if (occ_out) { *occ_out = occ; return 0; }
+  uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)max_items, (uint64_t)cus * (uint64_t)occ);
+  if (grid == 0) return 0;
+  hipLaunchKernelGGL((scan8_kernel<EXCL, F16>), dim3(grid), dim3(512), lds, stream, a);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int launch_scan8(const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStream_t stream, int *occ_out = nullptr) {
+  if (f16)
+    return a.exclude ? launch_scan8_t<true, true>(a, max_items, cus, stream, occ_out)
+                     : launch_scan8_t<false, true>(a, max_items, cus, stream, occ_out);
+  return a.exclude ? launch_scan8_t<true, false>(a, max_items, cus, stream, occ_out)
+                   : launch_scan8_t<false, false>(a, max_items, cus, stream, occ_out);
+}
+
 // ng == 0 selects the 16-row-halves (16x16 MFMA) shape
 int launch_scan_ng(int ng, const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStream_t stream) {
   switch (ng) {
@@ -232,7 +264,9 @@ int launch_scan_ng(int ng, const ScanArgs &a, bool f16, uint32_t max_items, int 
 }
 
 int pick_ng(uint32_t rows_wanted, uint32_t k) {
-  int ng = 4;   // 128 query rows per work-group is the largest tile whose accumulators + staging fit 512 registers
+  int ng = 4;
+  if (const char *f = getenv("ZVEC_HIP_MAX_NG")) ng = std::max(1, std::min(4, atoi(f)));   // tuning knob (experiments)
+  // 128 query rows per work-group is the largest tile whose accumulators + staging fit 512 registers
   while (ng > 1 && (uint32_t)(ng / 2) * QGROUP >= rows_wanted) ng /= 2;
   while (ng >= 1 && scan_lds_bytes(ng, k) > LDS_LIMIT - 1024) ng /= 2;
   return ng;  // 0 => k too large for the LDS-resident lists
@@ -384,6 +418,26 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
       return 0;
     }
   }
+  // Bound seeding: every work-group of the fused scan starts its lists empty, and filling a list costs ~k ln(rows/k)
+  // sorted insertions per (query, chunk) — with hundreds of chunks in flight that warm-up is most of the admission
+  // work.  A scan of a small prefix first (its k-th score bounds the final k-th from above) lets every chunk start
+  // with a bound that only ~k * chunk_rows / sample_rows of its rows pass.
+  static const bool no_seed = getenv("ZVEC_HIP_NO_SEED") != nullptr;   // tuning knob (experiments)
+  constexpr uint64_t SEED_ROWS = 4096;
+  if (!no_seed && st.n >= 64 * SEED_ROWS && topk <= 64 && count >= 16) {
+    ZRET(ctx->seed_keys.ensure((size_t)count * topk * sizeof(uint64_t)));
+    ZRET(ctx->seed_scores.ensure((size_t)count * topk * sizeof(float)));
+    ZRET(ctx->seed_counts.ensure((size_t)count * sizeof(uint32_t)));
+    Store view = st;                      // a view of the first SEED_ROWS rows (whole tiles of the same arrays)
+    view.n = SEED_ROWS; view.cap_tiles = SEED_ROWS / TILE_N;
+    SearchOut so{ctx->seed_keys.as<uint64_t>(), ctx->seed_scores.as<float>(), nullptr, ctx->seed_counts.as<uint32_t>()};
+    int rc = flat_scan_prepared(ctx, view, count, topk, threshold, d_exclude, so, stream, false);
+    view.base = nullptr; view.bnorm = nullptr; view.extra = nullptr; view.keys = nullptr;   // the view owns nothing
+    ZRET(rc);
+    hipLaunchKernelGGL(seed_gtau_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, ctx->gtau.as<uint32_t>(),
+                       so.scores, so.counts, count, topk);
+    ZCHK(hipGetLastError());
+  }
   int ng = pick_ng(count, topk);
   // a base that stays in the 256 MiB Infinity Cache (IVF centroids, k-means codebooks) can be re-read by
   // every query tile for free: prefer many small query tiles (more work-groups, each with a long run of
@@ -392,10 +446,19 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   if (cache_resident && ng > 1) ng = 1;
   if (ng < 1) return ZVEC_HIP_ERR_UNSUPPORTED;
   const int cus = device_cus(ctx);
-  const uint32_t rows = ng * QGROUP;
+  // wide batches over a streamed base: the 8-wave 128x128 tile (two work-groups per CU while its lists fit)
+  static const bool no_wide = getenv("ZVEC_HIP_NO_WIDE") != nullptr;   // tuning knob (experiments)
+  static const bool force_wide = getenv("ZVEC_HIP_FORCE_WIDE") != nullptr;   // tests: exercise the wide tile on small bases
+  const bool wide = !no_wide && (!cache_resident || force_wide) && pick_ng(count, topk) == 4 && count > 2 * QGROUP && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
+  int occ8 = 1;
+  ScanArgs probe{};
+  probe.k = topk; probe.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
+  if (wide) ZRET(launch_scan8(probe, st.f16, 0, cus, stream, &occ8));
+  const uint32_t rows = wide ? W8_ROWS : ng * QGROUP;
   const uint32_t nqtiles = (count + rows - 1) / rows;
   const uint64_t ntiles = (st.n + TILE_N - 1) / TILE_N;
-  uint64_t resident = (uint64_t)cus * (ng >= 4 ? 2 : (ng == 2 ? 2 : 3));   // work-groups per CU each shape reaches
+  uint64_t resident = wide ? (uint64_t)cus * occ8
+                           : (uint64_t)cus * (ng >= 4 ? 2 : (ng == 2 ? 2 : 3));   // work-groups per CU each shape reaches
   // items are equal-sized in a flat scan, so ONE wave of work-groups (items == resident slots) is the balanced
   // choice and gives the longest tile runs per top-k warm-up
   uint64_t want_chunks = std::max<uint64_t>(1, (resident + nqtiles - 1) / nqtiles);
@@ -419,7 +482,8 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     double flops = 2.0 * (double)count * (double)st.n * st.dscan;
     pi = prof_begin(ctx, stream, bytes, flops, 0);
   }
-  ZRET(launch_scan_ng(ng, a, st.f16, nchunks * nqtiles, cus, stream));
+  if (wide) ZRET(launch_scan8(a, st.f16, ((nchunks + 7) / 8) * 8 * nqtiles, cus, stream));   // ids padded to whole XCD groups
+  else ZRET(launch_scan_ng(ng, a, st.f16, nchunks * nqtiles, cus, stream));
   prof_end(ctx, stream, pi);
 
   MergeArgs m{};
