@@ -302,7 +302,7 @@ def run_flat(torch, dist, zvec_amd, flat, fctx, q, n, dim, topk, args, dev, stre
     by = prof["bytes"] / max(prof["launches"], 1)
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {"value": batch * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
-            "roofline": {"bound": "mfma", "kernel": "zvk::scan_kernel<4> (flat scan)", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
+            "roofline": {"bound": "mfma", "kernel": "zvk::scan8_kernel (flat scan)", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "kernel_ms": ms,
                          "algorithmic_bytes": by, "algorithmic_flops": fl,
                          "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0},

@@ -194,6 +194,41 @@ int zvec_hip_ctx_profile(zvec_hip_ctx_t ctx, int enable);
 int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *scan_ms,
                               double *algorithmic_bytes, double *algorithmic_flops, int reset);
 
+/* ---- predicate materialisation --------------------------------------------------------
+ * Replaces the per-candidate IndexFilter callback (index_filter.h:48-50) whose producers are
+ * DocFilter::is_filtered (src/db/sqlengine/planner/doc_filter.cc:74-87), DeleteStore::Filter
+ * (src/db/index/common/delete_store.h:61-72) and InvertedSearchResult::Filter
+ * (src/db/index/column/inverted_column/inverted_search_result.h:34-50):
+ *     excluded(id) = deleted.contains(id) || !invert_result.contains((uint32_t)id) || !forward_bool[id]
+ * evaluated once per storage position of the index (id = the key stored at that position) into the
+ * 1-bit-per-position exclude bitset the search entry points take.  Each term is optional.
+ *   delete_kind  ZVEC_HIP_ROARING_NONE / _32 (roaring_bitmap_portable_serialize, CRoaring 2.0.4) / _64MAP
+ *                (roaring::Roaring64Map::write) / _FILE (a delete-store file image: the 64-byte BitmapMetaHeader
+ *                of concurrent_roaring_bitmap.h:186-192 — magic, is_32bit, crc32c — followed by the payload)
+ *   invert       32-bit portable roaring (the inverted-index result set: ids that MATCH), or NULL
+ *   forward_bits Arrow boolean buffer, LSB first, forward_len bits (ids beyond it are not excluded, doc_filter.cc:104)
+ * A 32-bit delete bitmap is probed with (uint32_t)id, like ConcurrentRoaringBitmap64::contains (:196-203).
+ * Pointers in the descriptor are HOST memory; out_words is (count+63)/64 uint64 on the device (out_on_device != 0)
+ * or on the host.  Returns InvalidArgument for a malformed stream, Mismatch (-24) for a bad magic / checksum. */
+enum { ZVEC_HIP_ROARING_NONE = 0, ZVEC_HIP_ROARING_32 = 1, ZVEC_HIP_ROARING_64MAP = 2, ZVEC_HIP_ROARING_FILE = 3 };
+typedef struct {
+  const void *delete_bitmap;
+  uint64_t delete_bytes;
+  int32_t delete_kind;
+  int32_t reserved_;
+  const void *invert_bitmap;
+  uint64_t invert_bytes;
+  const uint8_t *forward_bits;
+  uint64_t forward_len;
+} zvec_hip_doc_filter_t;
+int zvec_hip_flat_build_filter(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const zvec_hip_doc_filter_t *filter,
+                               uint64_t *out_words, int out_on_device, void *stream);
+/* positions are list-order positions, as for zvec_hip_ivf_search's exclude_bitset */
+int zvec_hip_ivf_build_filter(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const zvec_hip_doc_filter_t *filter,
+                              uint64_t *out_words, int out_on_device, void *stream);
+/* ailego::Crc32c::Hash (src/ailego/hash/crc32c.cc:626-634): raw CRC-32C update, no pre/post inversion */
+uint32_t zvec_hip_crc32c(const void *data, uint64_t len, uint32_t crc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,28 @@ static int TestFilter() {
   EXPECT(99 == results2[0].key());
   EXPECT(102 == results2[1].key());
   EXPECT(98 == results2[2].key());
+  // the same predicate as data: a delete store holding {100, 101} in roaring portable form
+  // (cookie 12346, 1 container; key 0, cardinality-1 = 1; offset 16; values) — materialised on the GPU
+  const uint8_t deleted[20] = {0x3a, 0x30, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 16, 0, 0, 0, 100, 0, 101, 0};
+  zvec_hip_doc_filter_t df{};
+  df.delete_bitmap = deleted; df.delete_bytes = sizeof(deleted); df.delete_kind = ZVEC_HIP_ROARING_32;
+  ctx->reset_filter();
+  ctx->set_doc_filter(df);
+  ASSERT(0 == streamer.search_impl(vec.data(), qmeta, ctx));
+  auto &results3 = ctx->result();
+  ASSERT(10 == results3.size());
+  EXPECT(99 == results3[0].key());
+  EXPECT(102 == results3[1].key());
+  EXPECT(98 == results3[2].key());
+  // an inverted-index result set {98, 99, 100}: everything else is excluded, 100 is deleted
+  const uint8_t matched[22] = {0x3a, 0x30, 0, 0, 1, 0, 0, 0, 0, 0, 2, 0, 16, 0, 0, 0, 98, 0, 99, 0, 100, 0};
+  df.invert_bitmap = matched; df.invert_bytes = sizeof(matched);
+  ctx->set_doc_filter(df);
+  ASSERT(0 == streamer.search_impl(vec.data(), qmeta, ctx));
+  auto &results4 = ctx->result();
+  ASSERT(2 == results4.size());
+  EXPECT(99 == results4[0].key());
+  EXPECT(98 == results4[1].key());
   return 0;
 }
 

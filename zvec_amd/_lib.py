@@ -13,6 +13,15 @@ _u64p = C.c_void_p
 _u32p = C.c_void_p
 _h = C.c_void_p
 
+class DocFilterDesc(C.Structure):
+    """zvec_hip_doc_filter_t (include/zvec_hip.h): the composite document filter's three optional terms."""
+    _fields_ = [("delete_bitmap", C.c_void_p), ("delete_bytes", C.c_uint64), ("delete_kind", C.c_int32),
+                ("reserved_", C.c_int32), ("invert_bitmap", C.c_void_p), ("invert_bytes", C.c_uint64),
+                ("forward_bits", C.c_void_p), ("forward_len", C.c_uint64)]
+
+
+ROARING_NONE, ROARING_32, ROARING_64MAP, ROARING_FILE = 0, 1, 2, 3
+
 # every symbol include/zvec_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "zvec_hip_abi_version": (C.c_int, []),
@@ -61,6 +70,9 @@ SYMBOLS = {
     "zvec_hip_packed_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32]),
     "zvec_hip_merge_topk_packed_dev": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  _u64p, _f32p, _u32p, C.c_void_p]),
+    "zvec_hip_flat_build_filter": (C.c_int, [_h, _h, C.POINTER(DocFilterDesc), _u64p, C.c_int, C.c_void_p]),
+    "zvec_hip_ivf_build_filter": (C.c_int, [_h, _h, C.POINTER(DocFilterDesc), _u64p, C.c_int, C.c_void_p]),
+    "zvec_hip_crc32c": (C.c_uint32, [C.c_void_p, C.c_uint64, C.c_uint32]),
     "zvec_hip_ctx_profile": (C.c_int, [_h, C.c_int]),
     "zvec_hip_ctx_profile_read": (C.c_int, [_h, C.POINTER(C.c_uint64), C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),

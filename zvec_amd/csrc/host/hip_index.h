@@ -121,10 +121,16 @@ class Context {
   void set_threshold(float v) { threshold_ = v; }
   float threshold() const { return threshold_; }
   template <typename T> void set_filter(T &&fn) { filter_.set(std::forward<T>(fn)); }
-  void reset_filter() { filter_.reset(); }
+  void reset_filter() { filter_.reset(); has_doc_ = false; has_bits_ = false; }
   const IndexFilter &filter() const { return filter_; }
   // side channel of SURVEY H4: an already materialised predicate (1 bit per storage position)
-  void set_exclude_bitset(std::vector<uint64_t> words) { bits_ = std::move(words); has_bits_ = true; }
+  void set_exclude_bitset(std::vector<uint64_t> words) { bits_ = std::move(words); has_bits_ = true; has_doc_ = false; }
+  // the composite document filter as data (doc_filter.cc:74-87): serialised roaring bitmaps + the forward bool
+  // buffer; the index materialises it on the GPU (zvec_hip_*_build_filter) instead of sweeping a callback
+  void set_doc_filter(const zvec_hip_doc_filter_t &f) { doc_ = f; has_doc_ = true; has_bits_ = false; }
+  bool has_doc_filter() const { return has_doc_; }
+  const zvec_hip_doc_filter_t &doc_filter() const { return doc_; }
+  std::vector<uint64_t> &bits() { return bits_; }
   const IndexDocumentList &result() const { return results_.at(0); }
   const IndexDocumentList &result(size_t i) const { return results_.at(i); }
   IndexDocumentList *mutable_result(size_t i) { return &results_.at(i); }
@@ -158,6 +164,8 @@ class Context {
   IndexFilter filter_;
   std::vector<uint64_t> bits_;
   bool has_bits_{false};
+  zvec_hip_doc_filter_t doc_{};
+  bool has_doc_{false};
   std::vector<IndexDocumentList> results_{1};
 };
 
@@ -212,7 +220,16 @@ class HipFlatStreamer {
     std::vector<uint64_t> keys((size_t)count * k);
     std::vector<float> scores((size_t)count * k);
     std::vector<uint32_t> counts(count);
-    int rc = zvec_hip_flat_search(h_, ctx->handle(), query, count, k, ctx->threshold(), ctx->materialise(keys_),
+    const uint64_t *bits = nullptr;
+    if (ctx->has_doc_filter()) {            // composite filter as data: materialised on the GPU
+      ctx->bits().assign((keys_.size() + 63) / 64, 0);
+      int frc = zvec_hip_flat_build_filter(h_, ctx->handle(), &ctx->doc_filter(), ctx->bits().data(), 0, nullptr);
+      if (frc != 0) return frc;
+      bits = ctx->bits().data();
+    } else {
+      bits = ctx->materialise(keys_);
+    }
+    int rc = zvec_hip_flat_search(h_, ctx->handle(), query, count, k, ctx->threshold(), bits,
                                   keys.data(), scores.data(), counts.data());
     if (rc != 0) return rc;
     ctx->take(count, k, keys, scores, counts);
@@ -308,7 +325,15 @@ class HipIVFSearcher {
     std::vector<uint64_t> keys((size_t)count * k);
     std::vector<float> scores((size_t)count * k);
     std::vector<uint32_t> counts(count);
-    const uint64_t *bits = ctx->materialise(keys_);
+    const uint64_t *bits = nullptr;
+    if (ctx->has_doc_filter()) {
+      ctx->bits().assign((keys_.size() + 63) / 64, 0);
+      int frc = zvec_hip_ivf_build_filter(h_, ctx->handle(), &ctx->doc_filter(), ctx->bits().data(), 0, nullptr);
+      if (frc != 0) return frc;
+      bits = ctx->bits().data();
+    } else {
+      bits = ctx->materialise(keys_);
+    }
     int rc = bf ? zvec_hip_ivf_search_bf(h_, ctx->handle(), query, count, k, ctx->threshold(), bits, keys.data(),
                                          scores.data(), counts.data())
                 : zvec_hip_ivf_search(h_, ctx->handle(), query, count, k, ctx->threshold(), nprobe(), max_scan_count(),

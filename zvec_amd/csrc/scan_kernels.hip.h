@@ -616,7 +616,9 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : (NG == 2 && !M16 ? 3 : 1))
               const float tn = st.tq[nrow];
               if ((uint32_t)row < nrows) {
                 if (a.dump) *reinterpret_cast<f32x2 *>(a.dump + (size_t)qrow_s[row] * a.dump_stride + pos0 + 2 * lane) = v;
+#ifndef ZVK_M16_NOEPI
                 else owner_row(st, row, v.x, v.y, t0, pos0, lane);
+#endif
               }
               v = vn;
               t0 = tn;
@@ -1227,6 +1229,97 @@ __global__ void __launch_bounds__(64) resort_kernel(uint64_t *keys, float *score
     keep += (uint32_t)__popcll(__ballot(j < c && S[j] <= threshold));
   }
   if (lane == 0 && keep != c) counts[q] = keep;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Predicate materialisation: the reference evaluates its composite document
+// filter — deleted(id) || !invert_result.contains(id) || !forward_bool[id] (doc_filter.cc:74-87, delete_store.h:
+// 61-72, inverted_search_result.h:34-50) — once per CANDIDATE through a std::function.  Here the same predicate
+// is evaluated once per STORAGE POSITION into the 1-bit-per-position exclude set the scan kernels gate on: one
+// thread per position, one 64-bit output word per wave (a ballot).  The roaring bitmaps stay in their portable
+// serialised form (CRoaring 2.0.4 `roaring_bitmap_portable_serialize`, RoaringFormatSpec) in HBM; the host only
+// parses the container directory.  HBM-bound integer work: 8 B of key in, 1 bit out per position, plus the
+// (cache-resident) container probes.
+// ---------------------------------------------------------------------------------------------
+struct RoaringView {
+  const uint64_t *ckey;     // [nc] ascending: (high 32 bits of the id << 16) | container key
+  const uint32_t *cinfo;    // [nc] type (bits 0-1: 0 array, 1 bitmap, 2 run) | element / run count << 2
+  const uint64_t *coff;     // [nc] byte offset of the container payload inside `bytes`
+  const uint8_t *bytes;     // the serialised stream
+  uint32_t nc;
+  uint32_t present;         // 0 = this term of the predicate is absent
+  uint32_t trunc32;         // ids are cast to uint32 before the probe (32-bit bitmap behind a 64-bit id API)
+};
+
+struct DocFilterArgs {
+  const uint64_t *keys;     // [n] document id of each storage position (nullptr => id = position)
+  uint64_t n;
+  // IVF: positions are list-order (dense) positions while `keys` is laid out by padded position
+  const uint64_t *list_dense0;   // [nlist + 1] or nullptr
+  const uint32_t *list_tile0;    // [nlist]
+  uint32_t nlist;
+  RoaringView del;          // set => excluded
+  RoaringView inv;          // clear => excluded
+  const uint8_t *forward;   // Arrow boolean bitmap (LSB first), clear => excluded; nullptr = absent
+  uint64_t forward_len;     // ids >= forward_len are not excluded by this term (doc_filter.cc:104-107)
+  uint64_t *out;            // [(n + 63) / 64]
+};
+
+__device__ __forceinline__ uint32_t ld_u16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+__device__ inline bool roaring_contains(const RoaringView &v, uint64_t id) {
+  if (v.trunc32) id &= 0xffffffffull;
+  const uint64_t ck = id >> 16;
+  const uint32_t low = (uint32_t)(id & 0xffffu);
+  uint32_t lo = 0, hi = v.nc;            // first container with key >= ck
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (v.ckey[mid] < ck) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= v.nc || v.ckey[lo] != ck) return false;
+  const uint32_t info = v.cinfo[lo];
+  const uint32_t type = info & 3u, cnt = info >> 2;
+  const uint8_t *pl = v.bytes + v.coff[lo];
+  if (type == 1u) return (pl[low >> 3] >> (low & 7u)) & 1u;
+  if (type == 0u) {                      // sorted u16 values
+    uint32_t a = 0, b = cnt;
+    while (a < b) {
+      const uint32_t m = (a + b) >> 1;
+      if (ld_u16(pl + 2 * m) < low) a = m + 1; else b = m;
+    }
+    return a < cnt && ld_u16(pl + 2 * a) == low;
+  }
+  // runs (start, length - 1), ascending: last run with start <= low
+  uint32_t a = 0, b = cnt;
+  while (a < b) {
+    const uint32_t m = (a + b) >> 1;
+    if (ld_u16(pl + 4 * m) <= low) a = m + 1; else b = m;
+  }
+  if (a == 0) return false;
+  const uint32_t start = ld_u16(pl + 4 * (a - 1)), len1 = ld_u16(pl + 4 * (a - 1) + 2);
+  return low - start <= len1;
+}
+
+__global__ void __launch_bounds__(256) doc_filter_kernel(const DocFilterArgs a) {
+  const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool excl = false;
+  if (p < a.n) {
+    uint64_t kpos = p;
+    if (a.list_dense0 != nullptr) {
+      uint32_t lo = 0, hi = a.nlist;       // last list with dense0 <= p
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.list_dense0[mid] <= p) lo = mid; else hi = mid;
+      }
+      kpos = (uint64_t)a.list_tile0[lo] * TILE_N + (p - a.list_dense0[lo]);
+    }
+    const uint64_t id = a.keys ? a.keys[kpos] : kpos;
+    if (a.del.present) excl = roaring_contains(a.del, id);
+    if (!excl && a.inv.present) excl = !roaring_contains(a.inv, id);
+    if (!excl && a.forward != nullptr && id < a.forward_len) excl = !((a.forward[id >> 3] >> (id & 7u)) & 1u);
+  }
+  const uint64_t word = __ballot(excl);
+  if ((threadIdx.x & 63) == 0 && p < a.n) a.out[p >> 6] = word;
 }
 
 // ---------------------------------------------------------------------------------------------

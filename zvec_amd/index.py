@@ -70,6 +70,44 @@ class IndexDocument:
         return "IndexDocument(key=%d, score=%r)" % (self._key, self._score)
 
 
+class DocFilter:
+    """The reference's composite document filter (DocFilter::is_filtered, doc_filter.cc:74-87) as data:
+        excluded(id) = deleted.contains(id) || !invert.contains(uint32(id)) || !forward[id]
+    delete: bytes of a roaring bitmap — `kind` "roaring32" (roaring_bitmap_portable_serialize), "roaring64map"
+    (Roaring64Map::write) or "file" (a delete-store file image incl. its 64-byte header); invert: bytes of a 32-bit
+    portable roaring bitmap (ids that MATCH the inverted-index condition); forward: numpy bool array indexed by id
+    (or packed LSB-first uint8 bits with `forward_len`).  Every term is optional."""
+
+    KINDS = {"roaring32": _lib.ROARING_32, "roaring64map": _lib.ROARING_64MAP, "file": _lib.ROARING_FILE}
+
+    def __init__(self, delete=None, kind="roaring32", invert=None, forward=None, forward_len=None):
+        self.delete = None if delete is None else bytes(delete)
+        self.kind = self.KINDS[kind]
+        self.invert = None if invert is None else bytes(invert)
+        if forward is None:
+            self.forward, self.forward_len = None, 0
+        elif forward_len is None:
+            f = np.ascontiguousarray(forward, bool)
+            self.forward, self.forward_len = np.packbits(f, bitorder="little"), int(f.size)
+        else:
+            self.forward, self.forward_len = np.ascontiguousarray(forward, np.uint8), int(forward_len)
+
+    def _desc(self):
+        d = _lib.DocFilterDesc()
+        self._keep = []                      # buffers the descriptor points into
+        if self.delete is not None:
+            buf = C.create_string_buffer(self.delete, len(self.delete))
+            self._keep.append(buf)
+            d.delete_bitmap, d.delete_bytes, d.delete_kind = C.addressof(buf), len(self.delete), self.kind
+        if self.invert is not None:
+            buf = C.create_string_buffer(self.invert, len(self.invert))
+            self._keep.append(buf)
+            d.invert_bitmap, d.invert_bytes = C.addressof(buf), len(self.invert)
+        if self.forward is not None:
+            d.forward_bits, d.forward_len = self.forward.ctypes.data, self.forward_len
+        return d
+
+
 class IndexContext:
     """IndexContext subset used by the scan path (index_context.h:123-195): topk, filter, threshold,
     per-query result lists.  Owns one HIP stream + workspace (zvec_hip_ctx_t)."""
@@ -81,6 +119,7 @@ class IndexContext:
         self._threshold = FLT_MAX
         self._exclude = None      # numpy uint64 words (host) — materialised IndexFilter
         self._filter_fn = None
+        self._doc_filter = None   # DocFilter: materialised by zvec_hip_*_build_filter
         self._results = []
         self.keys = None
         self.scores = None
@@ -113,6 +152,12 @@ class IndexContext:
         self._filter_fn = fn
         self._exclude = None
 
+    def set_doc_filter(self, doc_filter):
+        """the composite filter as data (DocFilter): materialised on the GPU at the next search, no host sweep."""
+        self._doc_filter = doc_filter
+        self._filter_fn = None
+        self._exclude = None
+
     def set_exclude_bitset(self, words):
         """side channel: an already materialised predicate, 1 bit per storage position."""
         self._exclude = None if words is None else np.ascontiguousarray(words, np.uint64)
@@ -121,6 +166,7 @@ class IndexContext:
     def reset_filter(self):
         self._filter_fn = None
         self._exclude = None
+        self._doc_filter = None
 
     def result(self, index=0):
         return self._results[index]
@@ -238,6 +284,18 @@ class _FlatBase:
         rc = _lib.lib().zvec_hip_flat_get_vector(self._h, int(pos), _np_ptr(out))
         return out if rc == 0 else None
 
+    def build_filter(self, doc_filter, ctx=None, d_out=None, stream=None):
+        """DocFilter -> exclude bitset over this index's storage positions, built on the GPU.  Returns numpy
+        uint64 words, or fills the device buffer `d_out` ((count+63)//64 uint64) and returns None."""
+        n = self.count()
+        words = None if d_out is not None else np.zeros((n + 63) // 64, np.uint64)
+        desc = doc_filter._desc()
+        rc = _lib.lib().zvec_hip_flat_build_filter(self._h, ctx._h if ctx else None, C.byref(desc),
+                                                   C.c_void_p(d_out) if d_out is not None else _np_ptr(words),
+                                                   int(d_out is not None), C.c_void_p(stream or 0))
+        _lib.check(rc, "zvec_hip_flat_build_filter")
+        return words
+
     def search_impl(self, query, count, ctx):
         """IndexRunner::search_impl(query, qmeta, count, context); query: [count][dim] fp32."""
         if ctx is None or ctx.topk() == 0:
@@ -249,7 +307,10 @@ class _FlatBase:
         keys = np.zeros((count, k), np.uint64)
         scores = np.zeros((count, k), np.float32)
         counts = np.zeros(count, np.uint32)
-        ex = ctx._exclude_for(self._all_keys()) if (ctx._filter_fn or ctx._exclude is not None) else None
+        if ctx._doc_filter is not None:
+            ex = self.build_filter(ctx._doc_filter, ctx)
+        else:
+            ex = ctx._exclude_for(self._all_keys()) if (ctx._filter_fn or ctx._exclude is not None) else None
         rc = _lib.lib().zvec_hip_flat_search(self._h, ctx._h, _np_ptr(q), count, k, ctx.threshold(),
                                              _np_ptr(ex), _np_ptr(keys), _np_ptr(scores), _np_ptr(counts))
         if rc == 0:
@@ -420,7 +481,20 @@ class HipIVFSearcher:
             self._list_keys = rows if self._orig_keys is None else self._orig_keys[rows.astype(np.int64)]
         return self._list_keys
 
+    def build_filter(self, doc_filter, ctx=None, d_out=None, stream=None):
+        """DocFilter -> exclude bitset over list-order positions (see _FlatBase.build_filter)."""
+        n = self.info()[0]
+        words = None if d_out is not None else np.zeros((n + 63) // 64, np.uint64)
+        desc = doc_filter._desc()
+        rc = _lib.lib().zvec_hip_ivf_build_filter(self._h, ctx._h if ctx else None, C.byref(desc),
+                                                  C.c_void_p(d_out) if d_out is not None else _np_ptr(words),
+                                                  int(d_out is not None), C.c_void_p(stream or 0))
+        _lib.check(rc, "zvec_hip_ivf_build_filter")
+        return words
+
     def _exclude(self, ctx):
+        if ctx._doc_filter is not None:
+            return self.build_filter(ctx._doc_filter, ctx)
         if ctx._exclude is not None:
             return ctx._exclude
         if ctx._filter_fn is None:
