@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--keep", type=float, default=0.1, help="filter workloads: fraction of rows the bitmap keeps")
     ap.add_argument("--flat-threshold", type=float, default=None,
                     help="diagnostic: RNN radius for the flat workloads (a huge negative value admits nothing => distance-only time)")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="diagnostic: on ONE GPU, hold and time only shard 0 of an N-way list sharding (no exchange; "
+                         "recall is not computed) — the per-rank compute time of an N-GPU run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="0 = one whole batch")
     args = ap.parse_args()
@@ -161,7 +164,13 @@ def main():
         # ---------------- IVF build on the GPU (same seed on every rank => same centroids) ----------------
         t1 = time.time()
         ivf = zvec_amd.HipIVFSearcher(dim, "SquaredEuclidean", device=local_rank, dtype=dtype)
-        zvec_amd._lib.check(ivf.set_shard(rank, world), "set_shard")
+        if args.shard_of > 1 and world == 1:
+            zvec_amd._lib.check(ivf.set_shard(0, args.shard_of), "set_shard")
+            args.target_recall = 0.0
+            args.no_cpu_baseline = True
+            nprobe = args.nprobe or 40
+        else:
+            zvec_amd._lib.check(ivf.set_shard(rank, world), "set_shard")
         zvec_amd._lib.check(ivf.build_dev(base.data_ptr(), n, nlist, kmeans_iters=args.kmeans_iters, seed=SEED,
                                           stream=stream_ptr), "ivf build")
         torch.cuda.synchronize()

@@ -64,6 +64,7 @@ struct ScanArgs {
   uint32_t nq;
   uint64_t n;               // rows in the flat store
   uint32_t tiles_per_chunk;
+  const uint32_t *list_tpc;       // IVF: tiles per chunk of each list (shorter chunks for the lists dealt last)
   uint32_t nchunks;
   uint32_t nqtiles;
   // ivf decomposition (built on device by the plan kernels)
@@ -391,8 +392,9 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : (NG == 2 && !M16 ? 3 : 1))
       uint32_t lsize = a.list_size[li];
       uint32_t ltiles = (lsize + TILE_N - 1) / TILE_N;
       tile0 = a.list_tile0[li];
-      tile_begin = tile0 + chunk * a.tiles_per_chunk;
-      tile_end = tile0 + min((chunk + 1) * a.tiles_per_chunk, ltiles);
+      const uint32_t tpc = a.list_tpc[li];
+      tile_begin = tile0 + chunk * tpc;
+      tile_end = tile0 + min((chunk + 1) * tpc, ltiles);
       r0 = group * ROWS;
       nrows = min((uint32_t)ROWS, qcnt - r0);
       rows_valid_total = lsize;
@@ -951,7 +953,7 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
   float tau = a.threshold;     // uniform admission bound: threshold until the list is full, then its k-th score
   const uint32_t sl = a.slot_len;
   const uint64_t total = (uint64_t)nslots * sl;
-  constexpr int U = 4;           // candidate batches fetched together (hides the L2 latency of the stream)
+  constexpr int U = 16;          // candidate batches fetched together: one wave per query is latency-bound on this stream
 
   // Dense rows (coarse step): a cheap, exact upper bound of the k-th score before any insertion — every
   // lane takes the minimum of its own strided elements; those are 64 distinct candidates, so the k-th
@@ -977,6 +979,70 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
     const uint64_t hit = __ballot(rank == k - 1);
     const float bound = bcast_f(mn, __builtin_ctzll(hit));
     tau = fminf(tau, bound);
+
+    // Usually only a few dozen elements are at or below that bound: gather them (ballot compaction, no
+    // ordering yet), sort the <= 128 survivors once with a bitonic network in LDS and emit the first k — instead
+    // of one dependent sorted insertion per survivor.  More survivors than that (heavy ties, rows with fewer than
+    // k admissible elements): fall through to the general insertion path below.
+    constexpr uint32_t SURV = 128;
+    __shared__ unsigned long long surv[SURV];
+    if (nslots == 1 && total <= 0xffffffffull) {
+      surv[lane] = ~0ull;
+      surv[lane + 64] = ~0ull;
+      uint32_t ns = 0;       // uniform
+      for (uint64_t base = 0; base < total; base += 64 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint64_t e = base + (uint64_t)u * 64 + lane;
+          v[u] = (e < total) ? a.part_s[(size_t)sb * sl + e] : __builtin_inff();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool in = v[u] <= tau;          // (+inf padding and elements past the end never pass: tau <= FLT_MAX)
+          const uint64_t m = __ballot(in);
+          if (m) {
+            const uint32_t pos = ns + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (in && pos < SURV)
+              surv[pos] = ((unsigned long long)fkey(v[u] + 0.f) << 32) | (uint32_t)(base + (uint64_t)u * 64 + lane);
+            ns += (uint32_t)__popcll(m);
+          }
+        }
+      }
+      if (ns <= SURV) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t size = 2; size <= SURV; size <<= 1) {
+          for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            // 64 compare-exchanges per step: lane -> the lower index of its pair
+            const uint32_t i = ((uint32_t)lane / stride) * (stride * 2) + ((uint32_t)lane % stride);
+            const uint32_t j = i + stride;
+            const bool up = ((i & size) == 0);
+            const unsigned long long x = surv[i], y = surv[j];
+            if ((x > y) == up) { surv[i] = y; surv[j] = x; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+        const uint32_t c = min(ns, k);
+        for (uint32_t j = lane; j < k; j += 64) {
+          const size_t o = (size_t)q * k + j;
+          if (j < c) {
+            const unsigned long long w = surv[j];
+            const uint32_t vi = (uint32_t)w;
+            a.out_keys[o] = a.keymap ? a.keymap[vi] : (uint64_t)vi;
+            a.out_scores[o] = fkey_inv((uint32_t)(w >> 32));
+            if (a.out_idx) a.out_idx[o] = vi;
+          } else {
+            a.out_keys[o] = ~0ull;
+            a.out_scores[o] = __builtin_inff();
+            if (a.out_idx) a.out_idx[o] = IDX_NONE;
+          }
+        }
+        if (lane == 0) a.out_counts[q] = c;
+        return;
+      }
+    }
   }
 
   for (uint64_t base = 0; base < total; base += 64 * U) {
@@ -1136,9 +1202,13 @@ __global__ void unpack_row_kernel(const float *base, const float *extra, uint64_
   }
 }
 
-__global__ void fill_gtau_kernel(uint32_t *gtau, uint32_t n, float threshold) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) gtau[i] = fkey(threshold);
+// one launch instead of two memsets + fill_gtau before the IVF plan: zero `nzero` plan words (list_count, list_fill),
+// zero the 4 work-queue words, reset the shared bounds of `nq` queries to the threshold
+__global__ void ivf_reset_kernel(uint32_t *zero0, uint32_t nzero, uint32_t *queue, uint32_t *gtau, uint32_t nq, float threshold) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nzero) zero0[i] = 0;
+  if (i < 4) queue[i] = 0;
+  if (i < nq) gtau[i] = fkey(threshold);
 }
 
 // gtau[q] = min(gtau[q], k-th score of a sample scan, nudged up by ~1e-6 relative) — only for full sample lists.
@@ -1481,7 +1551,7 @@ struct PlanArgs {
   const uint32_t *list_size;      // stored rows (this shard)
   const uint32_t *list_size_global;  // rows of the whole index (scan-count rule)
   const uint32_t *list_order;        // [nlist] lists by stored size, largest first
-  uint32_t tiles_per_chunk;
+  const uint32_t *list_tpc;       // [nlist] tiles per chunk of each list
   uint32_t rows_per_group;        // NG*32 of the scan kernel
   // outputs
   uint32_t *q_nprobe;             // [nq] lists actually probed (IndexContext::Stats)
@@ -1539,7 +1609,7 @@ __global__ void __launch_bounds__(256) plan_wave_kernel(const PlanArgs p) {
     const uint32_t before = scanned_before + incl - szg;
     const bool probed = in && (p.brute_force || before < p.max_scan_count);
     const uint32_t szl = probed ? p.list_size[l] : 0;
-    const uint32_t ch = szl ? list_chunks(szl, p.tiles_per_chunk) : 0;
+    const uint32_t ch = szl ? list_chunks(szl, p.list_tpc[l]) : 0;
     const uint32_t chincl = wave_incl_scan(ch, lane);
     if (FILL) {
       if (szl) {
@@ -1566,30 +1636,27 @@ __global__ void __launch_bounds__(256) plan_wave_kernel(const PlanArgs p) {
 
 // single work-group exclusive scans: slot_begin over queries, list_qoff / item_off over lists
 __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
-  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t wtot[16];
   __shared__ uint32_t carry;
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  // 1024 elements per round: wave-level shuffle scan, 16 wave totals through LDS (two barriers per round)
   auto block_scan = [&](auto getv, auto putv, uint32_t n, uint32_t *total_out) {
     if (tid == 0) carry = 0;
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 1024) {
-      uint32_t i = base + tid;
-      uint32_t v = (i < n) ? getv(i) : 0;
-      sh[tid] = v;
+      const uint32_t i = base + tid;
+      const uint32_t v = (i < n) ? getv(i) : 0;
+      const uint32_t incl = wave_incl_scan(v, lane);
+      if (lane == 63) wtot[wave] = incl;
       __syncthreads();
-      for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t t = (tid >= off) ? sh[tid - off] : 0;
-        __syncthreads();
-        sh[tid] += t;
-        __syncthreads();
-      }
-      uint32_t incl = sh[tid];
-      uint32_t c = carry;
-      if (i < n) putv(i, c + incl - v);
+      uint32_t before = carry;
+      for (int w = 0; w < wave; ++w) before += wtot[w];
+      if (i < n) putv(i, before + incl - v);
       __syncthreads();
-      if (tid == 1023) carry = c + incl;
-      __syncthreads();
+      if (tid == 1023) carry = before + incl;
     }
+    __syncthreads();
     if (tid == 0) *total_out = carry;
     __syncthreads();
   };
@@ -1602,7 +1669,7 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
         const uint32_t l = p.list_order[i];
         uint32_t c = p.list_count[l];
         uint32_t groups = (c + p.rows_per_group - 1) / p.rows_per_group;
-        return groups * list_chunks(p.list_size[l], p.tiles_per_chunk);
+        return groups * list_chunks(p.list_size[l], p.list_tpc[l]);
       },
       [&](uint32_t i, uint32_t v) { p.item_off[i] = v; }, p.nlist, &p.item_off[p.nlist]);
   if (tid == 0) *p.total_items = p.item_off[p.nlist];

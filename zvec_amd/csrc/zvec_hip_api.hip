@@ -175,8 +175,9 @@ struct zvec_hip_ivf_s {
   std::vector<uint64_t> h_dense0;      // local dense offsets (nlist+1)
   std::vector<uint64_t> h_row_ids;     // local dense position -> original row
   std::vector<char> h_centroids;       // [nlist][dim] in the index element type
-  uint32_t *d_size = nullptr, *d_size_global = nullptr, *d_tile0 = nullptr, *d_order = nullptr;
+  uint32_t *d_size = nullptr, *d_size_global = nullptr, *d_tile0 = nullptr, *d_order = nullptr, *d_tpc = nullptr;
   uint32_t tiles_per_chunk = 8;
+  std::vector<uint32_t> h_tpc;         // tiles per chunk of each list
   uint64_t *d_dense0 = nullptr;
   zvec_hip_ctx_s *defctx = nullptr;
   std::mutex mu;
@@ -496,13 +497,6 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   return 0;
 }
 
-int reset_gtau(zvec_hip_ctx_s *ctx, uint32_t count, float threshold, hipStream_t stream) {
-  ZRET(ctx->gtau.ensure((size_t)count * sizeof(uint32_t)));
-  hipLaunchKernelGGL(fill_gtau_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, ctx->gtau.as<uint32_t>(), count, threshold);
-  ZCHK(hipGetLastError());
-  return 0;
-}
-
 // L2 only: direct re-scoring + re-sort of the final lists (see rescore_l2_kernel)
 int refine_l2(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold, uint64_t *keys,
               float *scores, uint32_t *idx, uint32_t *counts, hipStream_t stream) {
@@ -643,13 +637,21 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   size_t o_total = take(4), o_csrq = take(npairs), o_csrslot = take(npairs);
   ZRET(ctx->plan.ensure(off * sizeof(uint32_t)));
   uint32_t *pb = ctx->plan.as<uint32_t>();
-  ZCHK(hipMemsetAsync(pb + o_lcount, 0, (o_lqoff - o_lcount) * sizeof(uint32_t), stream));  // list_count + list_fill
-  ZCHK(hipMemsetAsync(pb + o_queue, 0, 4 * sizeof(uint32_t), stream));                       // work-queue head
+  // list_count + list_fill and the work-queue head zeroed, shared bounds reset (the coarse pass may have left
+  // centroid-score bounds behind): one launch
+  {
+    ZRET(ctx->gtau.ensure((size_t)count * sizeof(uint32_t)));
+    const uint32_t nzero = (uint32_t)(o_lqoff - o_lcount);
+    const uint32_t nthr = std::max<uint32_t>(std::max<uint32_t>(nzero, count), 4);
+    hipLaunchKernelGGL(ivf_reset_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, pb + o_lcount, nzero, pb + o_queue,
+                       ctx->gtau.as<uint32_t>(), count, threshold);
+    ZCHK(hipGetLastError());
+  }
   PlanArgs p{};
   p.coarse_idx = ctx->coarse_idx.as<uint32_t>(); p.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
   p.nq = count; p.nprobe = nprobe; p.nlist = nlist; p.max_scan_count = max_scan_count; p.brute_force = brute_force;
   p.list_size = h->d_size; p.list_size_global = h->d_size_global; p.list_order = h->d_order;
-  p.tiles_per_chunk = h->tiles_per_chunk;
+  p.list_tpc = h->d_tpc;
   p.rows_per_group = rows_per_group;
   p.q_nprobe = pb + o_qnprobe; p.q_scanned = pb + o_qscanned; p.q_nslots = pb + o_qnslots; p.slot_begin = pb + o_slotbegin;
   p.list_count = pb + o_lcount; p.list_fill = pb + o_lfill; p.list_qoff = pb + o_lqoff; p.item_off = pb + o_itemoff;
@@ -661,26 +663,20 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   hipLaunchKernelGGL(plan_wave_kernel<true>, dim3((count + 3) / 4), dim3(256), 0, stream, p);
   ZCHK(hipGetLastError());
 
-  const uint32_t TPC = h->tiles_per_chunk;
-  // 3. scan.  Upper bound of slots: every probed list contributes ceil(size/chunk_rows) chunks;
-  //    bound it by pairs * max chunks per list.
-  uint32_t max_list = 0;
-  for (uint32_t l = 0; l < nlist; ++l) max_list = std::max(max_list, h->h_size[l]);
-  uint32_t max_chunks = std::max<uint32_t>(1, ((max_list + TILE_N - 1) / TILE_N + TPC - 1) / TPC);
-  // exact worst case: each query probes its lists; bounded by the nprobe largest lists
+  // 3. scan.  Upper bound of slots: every probed list contributes its chunks; the worst case is a query that
+  //    probes the nprobe lists with the most chunks.
   std::vector<uint32_t> &sz = h->h_size;
   uint64_t slots_bound;
   {
     std::vector<uint32_t> chunks(nlist);
     for (uint32_t l = 0; l < nlist; ++l)
-      chunks[l] = sz[l] ? (((sz[l] + TILE_N - 1) / TILE_N + TPC - 1) / TPC) : 0;
+      chunks[l] = sz[l] ? (((sz[l] + TILE_N - 1) / TILE_N + h->h_tpc[l] - 1) / h->h_tpc[l]) : 0;
     uint32_t np = brute_force ? nlist : nprobe;
     std::partial_sort(chunks.begin(), chunks.begin() + np, chunks.end(), std::greater<uint32_t>());
     uint64_t s = 0;
     for (uint32_t i = 0; i < np; ++i) s += chunks[i];
     slots_bound = s * count;
   }
-  (void)max_chunks;
   if (slots_bound == 0) slots_bound = 1;
   ZRET(ctx->part_s.ensure(slots_bound * topk * sizeof(float)));
   ZRET(ctx->part_i.ensure(slots_bound * topk * sizeof(uint32_t)));
@@ -689,9 +685,8 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   a.base = h->lists.base; a.bnorm = h->lists.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
   a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
   a.dpad = h->lists.dpad; a.nks = h->lists.dpad / TILE_K; a.metric = h->metric; a.k = topk; a.threshold = threshold;
-  ZRET(reset_gtau(ctx, count, threshold, stream));   // the coarse pass may have left centroid-score bounds behind
   a.gtau = ctx->gtau.as<uint32_t>();
-  a.mode = 1; a.nq = count; a.n = h->lists.n; a.ndense = h->count_local; a.tiles_per_chunk = TPC;
+  a.mode = 1; a.nq = count; a.n = h->lists.n; a.ndense = h->count_local; a.tiles_per_chunk = h->tiles_per_chunk; a.list_tpc = h->d_tpc;
   a.total_items = p.total_items; a.queue = pb + o_queue; a.list_order = h->d_order; a.item_off = p.item_off; a.list_tile0 = h->d_tile0; a.list_size = h->d_size;
   a.list_dense0 = h->d_dense0; a.list_qoff = p.list_qoff; a.csr_q = p.csr_q; a.csr_slot = p.csr_slot; a.nlist = nlist;
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
@@ -1014,8 +1009,9 @@ static void ivf_release(zvec_hip_ivf_s *h) {
   if (h->d_size_global) (void)hipFree(h->d_size_global);
   if (h->d_tile0) (void)hipFree(h->d_tile0);
   if (h->d_order) (void)hipFree(h->d_order);
+  if (h->d_tpc) (void)hipFree(h->d_tpc);
   if (h->d_dense0) (void)hipFree(h->d_dense0);
-  h->d_size = h->d_size_global = h->d_tile0 = h->d_order = nullptr; h->d_dense0 = nullptr;
+  h->d_size = h->d_size_global = h->d_tile0 = h->d_order = h->d_tpc = nullptr; h->d_dense0 = nullptr;
   h->loaded = false;
 }
 
@@ -1101,7 +1097,7 @@ static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uin
     ZCHK(hipStreamSynchronize(s));
   }
   // list tables
-  if (h->d_size) { (void)hipFree(h->d_size); (void)hipFree(h->d_size_global); (void)hipFree(h->d_tile0); (void)hipFree(h->d_dense0); (void)hipFree(h->d_order); }
+  if (h->d_size) { (void)hipFree(h->d_size); (void)hipFree(h->d_size_global); (void)hipFree(h->d_tile0); (void)hipFree(h->d_dense0); (void)hipFree(h->d_order); (void)hipFree(h->d_tpc); }
   // largest lists are dealt first by the scan's work queue; chunk length adapts to the index size so
   // that a search has a few items per resident work-group yet long runs per top-k warm-up
   std::vector<uint32_t> order(nlist);
@@ -1110,7 +1106,24 @@ static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uin
   {
     uint64_t tpc = tiles / (4ull * 256ull * 3ull);
     h->tiles_per_chunk = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(4, tpc));
+    if (const char *e = getenv("ZVEC_HIP_IVF_TPC")) h->tiles_per_chunk = (uint32_t)std::max(1, atoi(e));   // tuning knob (experiments)
+    // The queue deals lists largest first, so the lists at the END of the order are the tail of every search: one
+    // work-group streams only ~7 GB/s (5.7 TB/s over ~768 resident groups), i.e. a 4-tile item lasts ~200 us, and a
+    // tail of such items leaves most of the chip idle.  The last quarter of the tiles is therefore cut into chunks
+    // a quarter as long (guided self-scheduling: coarse items first, fine items last).
+    uint32_t tail_tpc = std::max<uint32_t>(1, h->tiles_per_chunk / 4);
+    if (const char *e = getenv("ZVEC_HIP_IVF_TAIL_TPC")) tail_tpc = (uint32_t)std::max(1, atoi(e));          // tuning knob (experiments)
+    h->h_tpc.assign(nlist, h->tiles_per_chunk);
+    uint64_t acc = 0;
+    for (uint32_t i = nlist; i-- > 0;) {
+      const uint32_t l = order[i];
+      if (acc * 4 >= tiles) break;
+      h->h_tpc[l] = tail_tpc;
+      acc += (h->h_size[l] + TILE_N - 1) / TILE_N;
+    }
   }
+  ZCHK(hipMalloc(&h->d_tpc, std::max<uint32_t>(nlist, 1) * 4));
+  ZCHK(hipMemcpy(h->d_tpc, h->h_tpc.data(), nlist * 4, hipMemcpyHostToDevice));
   ZCHK(hipMalloc(&h->d_order, nlist * 4));
   ZCHK(hipMemcpy(h->d_order, order.data(), nlist * 4, hipMemcpyHostToDevice));
   ZCHK(hipMalloc(&h->d_size, nlist * 4));
