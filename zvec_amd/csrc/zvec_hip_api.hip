@@ -395,7 +395,10 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
       ZRET(ctx->part_s.ensure((size_t)(row_bytes_d * sub)));
       for (uint32_t q0 = 0; q0 < count; q0 += sub) {
         const uint32_t cnt = std::min(sub, count - q0);
-        const int ngd = pick_ng(cnt, 1);
+        int ngd = pick_ng(cnt, 1);
+        // one item per (tile, query tile): halve the query tile while the items would not fill two work-groups per CU
+        // (1024 x 4096 coarse scores: 256 items at 128 rows -> 512 at 64 rows, 92 -> 79 us)
+        while (ngd > 2 && ntiles_d * ((cnt + ngd * QGROUP - 1) / (ngd * QGROUP)) < 2ull * cus_d) ngd /= 2;
         const uint32_t rows_d = ngd * QGROUP;
         const uint32_t nqt = (cnt + rows_d - 1) / rows_d;
         ScanArgs a{};
@@ -490,6 +493,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   MergeArgs m{};
   m.part_s = a.part_s; m.part_i = a.part_i; m.part_keys = nullptr; m.slot_begin = nullptr;
   m.slots_per_q = nchunks; m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = topk; m.threshold = threshold;
+  m.bound_keys = a.gtau;   // the scan's shared bounds: valid upper bounds of every query's final k-th score
   m.keymap = st.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
   hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
   ZCHK(hipGetLastError());
@@ -701,6 +705,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   MergeArgs m{};
   m.part_s = a.part_s; m.part_i = a.part_i; m.part_keys = nullptr; m.slot_begin = p.slot_begin; m.slots_per_q = 0;
   m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = topk; m.threshold = threshold; m.keymap = h->lists.keys;
+  m.bound_keys = a.gtau;
   uint32_t *ridx = out.idx;
   if (h->metric == ZVEC_HIP_METRIC_L2 && ridx == nullptr) {
     ZRET(ctx->ridx.ensure((size_t)count * topk * sizeof(uint32_t)));
