@@ -11,6 +11,6 @@ for v in "$@"; do
     env:*) extra="${v#env:}";;
     *) export ZVEC_HIP_LIBRARY=$PWD/zvec_amd/_variants/libzvec_hip_$v.so;;
   esac
-  env $extra timeout -k 10 300 python bench.py --workload $W --steps 8 --warmup 2 --no-cpu-baseline $BENCH_EXTRA > gpurun_out/ab.json 2> gpurun_out/ab.log || { echo "$v FAILED"; tail -3 gpurun_out/ab.log; continue; }
+  env $extra timeout -k 10 300 python bench.py --workload $W --steps ${STEPS:-8} --warmup 2 --no-cpu-baseline $BENCH_EXTRA > gpurun_out/ab.json 2> gpurun_out/ab.log || { echo "$v FAILED"; tail -3 gpurun_out/ab.log; continue; }
   python -c "import json;d=json.load(open('gpurun_out/ab.json'));print('%-28s'%'$v', round(d['value']), round(d['roofline']['achieved'],2), round(d['roofline']['kernel_ms'],4), d.get('recall'))"
 done; done

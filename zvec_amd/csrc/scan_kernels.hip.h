@@ -271,13 +271,16 @@ struct StageRegs {
 template <int NG, bool NT>
 __device__ __forceinline__ void stage_load(StageRegs<NG> &sr, const float *base, const float *queries,
                                            const uint32_t (&qoff)[NG], uint32_t tile, uint32_t ks, uint32_t dpad,
-                                           int tid) {
+                                           int tid, uint32_t vrows = TILE_N) {
   const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(base + (size_t)tile * TILE_N * dpad + (size_t)ks * SLAB) + tid;
   if constexpr (NT) {
+    // a list's last tile is padded to 128 rows; each of the four loads covers 32 rows of the slab, and a load whose
+    // rows are all padding re-reads the first quarter instead (same lines: no new traffic, same number of loads in
+    // flight) — the padded columns are masked at admission anyway.  Saves ~2 % of the list bytes at ~2400 rows/list.
     sr.b0 = __builtin_nontemporal_load(bsrc);
-    sr.b1 = __builtin_nontemporal_load(bsrc + 256);
-    sr.b2 = __builtin_nontemporal_load(bsrc + 512);
-    sr.b3 = __builtin_nontemporal_load(bsrc + 768);
+    sr.b1 = __builtin_nontemporal_load(bsrc + (vrows > 32 ? 256 : 0));
+    sr.b2 = __builtin_nontemporal_load(bsrc + (vrows > 64 ? 512 : 0));
+    sr.b3 = __builtin_nontemporal_load(bsrc + (vrows > 96 ? 768 : 0));
   } else {
     sr.b0 = bsrc[0];
     sr.b1 = bsrc[256];
@@ -471,12 +474,12 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : (NG == 2 && !M16 ? 3 : 1))
     uint32_t fetched = 0;
     auto advance = [&](uint32_t &t_, uint32_t &k_) { if (++k_ == nks) { k_ = 0; ++t_; } };
     if (nsteps > 0) {
-      stage_load<QL, M16>(sr[0], a.base, a.queries, qoff, ptile, pks, dpad, tid);
+      stage_load<QL, M16>(sr[0], a.base, a.queries, qoff, ptile, pks, dpad, tid, rows_valid_total - (ptile - tile0) * TILE_N);
       if (nsteps > 1) advance(ptile, pks);
       fetched = 1;
       stage_store<QL>(sr[0], Bs, Qs, srow, sswz, tid);
       if (PF == 2) {
-        stage_load<QL, M16>(sr[1], a.base, a.queries, qoff, ptile, pks, dpad, tid);
+        stage_load<QL, M16>(sr[1], a.base, a.queries, qoff, ptile, pks, dpad, tid, rows_valid_total - (ptile - tile0) * TILE_N);
         if (nsteps > 2) advance(ptile, pks);
         fetched = 2;
       }
@@ -498,7 +501,7 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : (NG == 2 && !M16 ? 3 : 1))
       // give the compiler two paths with different numbers of loads in flight and it would then wait
       // for the YOUNGEST set before the LDS store below (vmcnt merges conservatively); past the end
       // the last step is simply fetched again and never used.
-      stage_load<QL, M16>(sr[(u + PF) & 1], a.base, a.queries, qoff, ptile, pks, dpad, tid);
+      stage_load<QL, M16>(sr[(u + PF) & 1], a.base, a.queries, qoff, ptile, pks, dpad, tid, rows_valid_total - (ptile - tile0) * TILE_N);
       if (fetched + 1 < nsteps) advance(ptile, pks);
       ++fetched;
       {
