@@ -72,8 +72,8 @@ int zvec_hip_ctx_set_stream(zvec_hip_ctx_t ctx, void *stream);
 /* ---- flat (brute force) -------------------------------------------------------------------
  * stands behind FlatStreamer<32> / FlatSearcher<32>
  *   (src/core/algorithm/flat/flat_streamer.cc:304-389, flat_searcher.cc:162-211).
- * `dim` is the element dimension of IndexMeta (for COSINE: d+1, the trailing float is the stored
- * norm written by CosineConverter, cosine_converter.cc:112-127; it is not scanned). */
+ * `dim` is the element dimension of IndexMeta (for COSINE: d+1 floats, or d+2 halves for DT_FP16 — the
+ * trailing fp32 norm written by CosineConverter, cosine_converter.cc:112-134,205-212; it is not scanned). */
 int zvec_hip_flat_create(uint32_t dim, int dtype, int metric, int device, zvec_hip_flat_t *out);
 int zvec_hip_flat_destroy(zvec_hip_flat_t h);
 int zvec_hip_flat_reserve(zvec_hip_flat_t h, uint64_t capacity);

@@ -157,6 +157,17 @@ class Oracle:
             self.lib.zo_cosine_transform_f32(_ptr(x[i], _f32p), x.shape[1], _ptr(out[i], _f32p))
         return out
 
+    def cosine_transform16(self, x):
+        """fp32 rows of d floats -> fp16 rows of d+2 halves: CosineConverter with original fp32 / stored fp16
+        (cosine_converter.cc:112-134): normalise in fp32, FloatHelper::ToFP16, then the fp32 norm's 4 bytes in the
+        two trailing half slots."""
+        c = self.cosine_transform(x)
+        d = c.shape[1] - 1
+        out = np.empty((c.shape[0], d + 2), np.float16)
+        out[:, :d] = self.to_fp16_ref(c[:, :d]) if self.ref is not None else c[:, :d].astype(np.float16)
+        out.view(np.uint16)[:, d:] = np.ascontiguousarray(c[:, d:]).view(np.uint16)
+        return out
+
     def heap_replay(self, scores, limit, threshold=FLT_MAX, use_ref=False):
         s = np.ascontiguousarray(scores, np.float32)
         oi = np.zeros(max(limit, 1), np.uint32)

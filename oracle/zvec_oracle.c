@@ -235,9 +235,15 @@ void zo_set_distance_override_f16(int metric, zo_dist_fn fn) {
   if (metric >= 0 && metric < 3) g_override16[metric] = fn;
 }
 
-/* dtype: 0 = fp32 rows, 1 = fp16 rows (cosine over fp16 rows is not restated) */
+/* dtype: 0 = fp32 rows, 1 = fp16 rows.  Cosine over fp16 rows: CosineDistanceMatrix<Float16,1,1>
+ * (cosine_distance_matrix.h:32-50): extra_dim = sizeof(float)/sizeof(Float16) = 2 trailing half slots hold the
+ * norm, out = 1 - InnerProductMatrix<Float16,1,1>(m, q, dim - 2). */
 static inline float zo_distance_t(int dtype, int metric, const void *m, const void *q, size_t dim) {
   if (dtype == 0) return zo_distance(metric, (const float *)m, (const float *)q, dim);
+  if (metric == ZO_METRIC_COSINE) {
+    if (g_override16[ZO_METRIC_IP]) return 1.0f - (-g_override16[ZO_METRIC_IP]((const float *)m, (const float *)q, dim - 2));
+    return 1.0f - lane_ip_f16((const uint16_t *)m, (const uint16_t *)q, dim - 2);
+  }
   if (g_override16[metric]) return g_override16[metric]((const float *)m, (const float *)q, dim);
   if (metric == ZO_METRIC_L2) return lane_ssd_f16((const uint16_t *)m, (const uint16_t *)q, dim);
   return -lane_ip_f16((const uint16_t *)m, (const uint16_t *)q, dim);

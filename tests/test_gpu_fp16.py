@@ -105,6 +105,22 @@ def test_ivf_fp16_gpu_build(zv, oracle):
     assert recall > 0.9, recall
 
 
-def test_fp16_cosine_is_refused(zv):
+@pytest.mark.parametrize("n,dim,nq,k", [(3000, 63, 40, 10), (9000, 200, 130, 7)])
+def test_fp16_cosine_rows(zv, oracle, n, dim, nq, k):
+    """fp16 cosine rows = d normalised halves + the fp32 norm in two half slots (cosine_converter.cc:112-134,205-212);
+    distance = 1 - ip over the first d halves (CosineDistanceMatrix<Float16,1,1>, cosine_distance_matrix.h:32-50)."""
+    rng = np.random.default_rng(n)
+    base = oracle.cosine_transform16(rng.standard_normal((n, dim)).astype(np.float32))
+    q = oracle.cosine_transform16(rng.standard_normal((nq, dim)).astype(np.float32))
+    assert base.shape == (n, dim + 2) and base.dtype == np.float16
+    se = zv.HipFlatSearcher(dim + 2, "Cosine", dtype="fp16")
+    assert se.load(base) == 0
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc = oracle.flat_search(base, q, k, O.METRIC_COSINE)
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, atol=2e-6, what="cosine fp16")
+    for pos in (0, 17, n - 1):            # the norm's two half slots come back bit for bit
+        assert np.array_equal(se.get_vector_by_id(pos).view(np.uint16), base[pos].view(np.uint16))
     with pytest.raises(RuntimeError):
-        zv.HipFlatSearcher(17, "Cosine", dtype="fp16")
+        zv.HipFlatSearcher(2, "Cosine", dtype="fp16")     # no room for a dimension besides the norm slots

@@ -1266,7 +1266,15 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const void *src, uint64_
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
   if (lane == 0) {
     if (bnorm) bnorm[pos] = acc;
-    if (extra) extra[pos] = (dim_in > dscan) ? load_row_elem<F16>(src, sr, dim_in, dscan) : 0.f;
+    if (extra) {
+      // the stored norm column: one float, or (fp16 rows) the two half slots that hold its bits
+      if constexpr (F16) {
+        const uint16_t *h = reinterpret_cast<const uint16_t *>(src) + sr * dim_in + dscan;
+        extra[pos] = (dim_in >= dscan + 2) ? __builtin_bit_cast(float, (uint32_t)h[0] | ((uint32_t)h[1] << 16)) : 0.f;
+      } else {
+        extra[pos] = (dim_in > dscan) ? load_row_elem<F16>(src, sr, dim_in, dscan) : 0.f;
+      }
+    }
   }
 }
 
@@ -1299,9 +1307,16 @@ template <bool F16>
 __global__ void unpack_row_kernel(const float *base, const float *extra, uint64_t pos, uint32_t dscan,
                                   uint32_t dim_out, uint32_t dpadw, void *out) {
   for (uint32_t c = threadIdx.x; c < dim_out; c += blockDim.x) {
-    float v = (c < dscan) ? load_elem<F16>(base, pos, c, dpadw) : (extra ? extra[pos] : 0.f);
-    if constexpr (F16) reinterpret_cast<_Float16 *>(out)[c] = (_Float16)v;
-    else reinterpret_cast<float *>(out)[c] = v;
+    if constexpr (F16) {
+      if (c < dscan) {
+        reinterpret_cast<_Float16 *>(out)[c] = (_Float16)load_elem<F16>(base, pos, c, dpadw);
+      } else {                                        // the norm's bits, low half first
+        const uint32_t bits = extra ? __builtin_bit_cast(uint32_t, extra[pos]) : 0u;
+        reinterpret_cast<uint16_t *>(out)[c] = (uint16_t)(c == dscan ? bits : bits >> 16);
+      }
+    } else {
+      reinterpret_cast<float *>(out)[c] = (c < dscan) ? load_elem<F16>(base, pos, c, dpadw) : (extra ? extra[pos] : 0.f);
+    }
   }
 }
 

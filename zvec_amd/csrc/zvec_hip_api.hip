@@ -89,7 +89,8 @@ struct Store {
     metric = met;
     f16 = (dtype == ZVEC_HIP_DT_FP16);
     elem = f16 ? 2 : 4;
-    dscan = (met == ZVEC_HIP_METRIC_COSINE) ? dim - 1 : dim;
+    // cosine rows end with the fp32 norm of the original vector: 1 float, or 2 half slots (cosine_converter.cc:205-212)
+    dscan = (met == ZVEC_HIP_METRIC_COSINE) ? dim - (f16 ? 2 : 1) : dim;
     dpad = f16 ? ((dscan + 63) / 64 * 64) / 2 : (dscan + TILE_K - 1) / TILE_K * TILE_K;
   }
   size_t row_bytes() const { return (size_t)dim_in * elem; }
@@ -810,8 +811,7 @@ int zvec_hip_flat_create(uint32_t dim, int dtype, int metric, int device, zvec_h
   if (!out || dim == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (dtype != ZVEC_HIP_DT_FP32 && dtype != ZVEC_HIP_DT_FP16) return ZVEC_HIP_ERR_UNSUPPORTED;
   if (metric < 0 || metric > 2) return ZVEC_HIP_ERR_UNSUPPORTED;
-  if (metric == ZVEC_HIP_METRIC_COSINE && dtype == ZVEC_HIP_DT_FP16) return ZVEC_HIP_ERR_UNSUPPORTED;   // fp16 cosine rows carry the norm in 2 halves: not served yet
-  if (metric == ZVEC_HIP_METRIC_COSINE && dim < 2) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (metric == ZVEC_HIP_METRIC_COSINE && dim < (dtype == ZVEC_HIP_DT_FP16 ? 3u : 2u)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   zvec_hip_ctx_s *c = nullptr;
   ZRET(ctx_new(device, &c));
   zvec_hip_flat_s *h = new (std::nothrow) zvec_hip_flat_s();
@@ -994,8 +994,7 @@ int zvec_hip_ivf_create(uint32_t dim, int dtype, int metric, int device, zvec_hi
   if (!out || dim == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (dtype != ZVEC_HIP_DT_FP32 && dtype != ZVEC_HIP_DT_FP16) return ZVEC_HIP_ERR_UNSUPPORTED;
   if (metric < 0 || metric > 2) return ZVEC_HIP_ERR_UNSUPPORTED;
-  if (metric == ZVEC_HIP_METRIC_COSINE && dtype == ZVEC_HIP_DT_FP16) return ZVEC_HIP_ERR_UNSUPPORTED;
-  if (metric == ZVEC_HIP_METRIC_COSINE && dim < 2) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (metric == ZVEC_HIP_METRIC_COSINE && dim < (dtype == ZVEC_HIP_DT_FP16 ? 3u : 2u)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   zvec_hip_ctx_s *c = nullptr;
   ZRET(ctx_new(device, &c));
   zvec_hip_ivf_s *h = new (std::nothrow) zvec_hip_ivf_s();
