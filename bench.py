@@ -138,7 +138,9 @@ def main():
 
     # ---------------- exact ground truth for recall (flat scan on the GPU, rank-local) ----------------
     ngt = min(args.gt_queries, nqueries)
-    flat = zvec_amd.HipFlatSearcher(dim, "SquaredEuclidean", device=local_rank, dtype=dtype)
+    # BASELINE configs[1] is a flat INNER-PRODUCT scan; every other workload is L2
+    flat_metric = "InnerProduct" if args.workload == "flat1m" else "SquaredEuclidean"
+    flat = zvec_amd.HipFlatSearcher(dim, flat_metric, device=local_rank, dtype=dtype)
     t1 = time.time()
     zvec_amd._lib.check(flat.add_batch_dev(base.data_ptr(), n, stream=stream_ptr), "flat append")
     torch.cuda.synchronize()
@@ -155,7 +157,8 @@ def main():
 
     result = {}
     if kind == "flat":
-        result = run_flat(torch, dist, zvec_amd, flat, fctx, queries[:batch].contiguous(), n, dim, topk, args, dev, stream_ptr, world)
+        result = run_flat(torch, dist, zvec_amd, flat, fctx, queries[:batch].contiguous(), n, dim, topk, args, dev, stream_ptr, world,
+                          base, flat_metric)
         recall = 1.0
     else:
         del fctx
@@ -259,7 +262,7 @@ def main():
             "ms_per_step": result["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if dtype == "fp32" else "f16 rows, f32 accumulate", "data": "synthetic",
             "config": {"workload": "%s: %s n=%d dim=%d%s batch=%d k=%d" % (
-                args.workload, "IVF-Flat L2" if kind == "ivf" else "Flat L2", n, dim,
+                args.workload, "IVF-Flat L2" if kind == "ivf" else ("Flat IP" if args.workload == "flat1m" else "Flat L2"), n, dim,
                 (" nlist=%d nprobe=%d" % (nlist, nprobe)) if kind == "ivf" else "", batch, topk),
                 "recall_at_10": recall, "nprobe_timed": nprobe if kind == "ivf" else None, "sharding": "inverted lists l %% %d, all-gather of candidates" % world if world > 1 else "single GPU"},
             "roofline": result["roofline"], "cpu_baseline": result.get("cpu_baseline"),
@@ -270,31 +273,94 @@ def main():
         dist.destroy_process_group()
 
 
-def run_flat(torch, dist, zvec_amd, flat, fctx, q, n, dim, topk, args, dev, stream_ptr, world):
+def roaring_portable(ids):
+    """Synthetic-data helper: the bytes roaring_bitmap_portable_serialize would produce for a set of uint32 ids
+    (RoaringFormatSpec, no run containers: cookie 12346, container count, (key, cardinality-1) pairs, offsets, then
+    per 64K chunk either the sorted low 16 bits (<= 4096 ids) or a 8 KiB bitset)."""
+    import struct
+    ids = np.unique(np.asarray(ids, np.uint32))
+    hi = (ids >> 16).astype(np.uint32)
+    keys, starts = np.unique(hi, return_index=True)
+    ends = np.append(starts[1:], ids.size)
+    payloads = []
+    for a_, b_ in zip(starts, ends):
+        low = (ids[a_:b_] & 0xFFFF).astype(np.uint16)
+        if low.size > 4096:
+            bits = np.zeros(65536, np.uint8)
+            bits[low] = 1
+            payloads.append(np.packbits(bits, bitorder="little").tobytes())
+        else:
+            payloads.append(low.astype("<u2").tobytes())
+    n = len(keys)
+    out = bytearray(struct.pack("<II", 12346, n))
+    for k_, a_, b_ in zip(keys, starts, ends):
+        out += struct.pack("<HH", int(k_), int(b_ - a_ - 1))
+    off = len(out) + 4 * n
+    for p_ in payloads:
+        out += struct.pack("<I", off)
+        off += len(p_)
+    for p_ in payloads:
+        out += p_
+    return bytes(out)
+
+
+def cpu_baseline_flat(torch, base, q, topk, metric_name, args):
+    """Reference CPU flat scan restated (oracle: FlatSearcherContext row-major loops + the reference's AVX-512 1x1
+    kernels when oracle/_ref travelled) on a bounded sample of the timed batch, same base rows."""
+    from oracle import oracle as O
+    o = O.get()
+    host = base.cpu().numpy()
+    threads = host_threads()
+    nq = min(q.shape[0], args.cpu_queries or 2 * threads)
+    qh = q[:nq].cpu().numpy()
+    used_ref = o.use_reference_kernels(True)
+    metric = O.METRIC_IP if metric_name == "InnerProduct" else O.METRIC_L2
+    best = None
+    for _ in range(2):
+        t1 = time.perf_counter()
+        o.flat_search(host, qh, topk, metric, threads=threads)
+        dt = time.perf_counter() - t1
+        best = dt if best is None else min(best, dt)
+    o.use_reference_kernels(False)
+    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": "%d queries of the timed batch over the same %d rows, %d threads across queries, best of 2; scan loop = "
+                      "oracle restatement, 1x1 distance kernel = %s" % (
+                          nq, host.shape[0], threads, "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")}
+
+
+def run_flat(torch, dist, zvec_amd, flat, fctx, q, n, dim, topk, args, dev, stream_ptr, world, base, metric_name):
     batch = q.shape[0]
     ok = torch.empty((batch, topk), dtype=torch.int64, device=dev)
     os_ = torch.empty((batch, topk), dtype=torch.float32, device=dev)
     oc = torch.empty((batch,), dtype=torch.int32, device=dev)
 
     excl = None
+    doc_filter = None
     if args.workload.startswith("filter"):
-        # BASELINE configs[4]: bitmap predicate, Bernoulli keep-mask p = --keep, packed 1 bit / doc,
-        # bit set = excluded (IndexFilter true = exclude)
+        # BASELINE configs[4]: CRoaring bitmap predicate.  Bernoulli keep-mask p = --keep (SURVEY §8(d)) as the result
+        # bitmap of an inverted-index condition (ids that MATCH, InvertedSearchResult) in roaring portable form; every
+        # step materialises it on the GPU into the 1-bit-per-position exclude set (zvec_hip_flat_build_filter) and
+        # runs the gated scan — both inside the timed region
         g = torch.Generator(device=dev)
         g.manual_seed(SEED + 2)
-        drop = (torch.rand((n,), generator=g, device=dev) >= args.keep).cpu().numpy()
-        words = np.zeros((n + 63) // 64, np.uint64)
-        idx = np.nonzero(drop)[0]
-        np.bitwise_or.at(words, idx // 64, np.uint64(1) << (idx % 64).astype(np.uint64))
-        excl = torch.from_numpy(words.view(np.int64)).to(dev)
-        log("filter: keep %.3f of %d rows" % (1.0 - drop.mean(), n))
+        keep = (torch.rand((n,), generator=g, device=dev) < args.keep).cpu().numpy()
+        blob = roaring_portable(np.nonzero(keep)[0])
+        doc_filter = zvec_amd.DocFilter(invert=blob)
+        excl = torch.zeros(((n + 63) // 64,), dtype=torch.int64, device=dev)
+        log("filter: keep %.3f of %d rows; predicate = %d bytes of roaring" % (keep.mean(), n, len(blob)))
 
     thr = {} if args.flat_threshold is None else {"threshold": args.flat_threshold}
 
     def step():
+        if doc_filter is not None:
+            flat.build_filter(doc_filter, fctx, d_out=excl.data_ptr(), stream=stream_ptr)
         zvec_amd._lib.check(flat.search_dev(q.data_ptr(), batch, topk, ok.data_ptr(), os_.data_ptr(), oc.data_ptr(), fctx,
                                             d_exclude=excl.data_ptr() if excl is not None else None,
                                             stream=stream_ptr, **thr), "flat search")
+
+    cpu = None
+    if not args.no_cpu_baseline and world == 1 and doc_filter is None and n <= 2_000_000:
+        cpu = cpu_baseline_flat(torch, base, q, topk, metric_name, args)
     for _ in range(args.warmup):
         step()
     fctx.profile(True)
@@ -315,7 +381,7 @@ def run_flat(torch, dist, zvec_amd, flat, fctx, q, n, dim, topk, args, dev, stre
                          "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "kernel_ms": ms,
                          "algorithmic_bytes": by, "algorithmic_flops": fl,
                          "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0},
-            "cpu_baseline": None}
+            "cpu_baseline": cpu}
 
 
 def host_threads():
