@@ -170,3 +170,27 @@ def test_filter_build_throughput_10m(zv, capsys):
     with capsys.disabled():
         print("\n[filter build] 10M positions, delete %d B + invert %d B of roaring: %.3f ms per build (parse + upload + kernel)"
               % (len(f.delete), len(f.invert), ms))
+
+
+@pytest.mark.parametrize("metric_name,metric", [("SquaredEuclidean", O.METRIC_L2), ("InnerProduct", O.METRIC_IP)])
+@pytest.mark.parametrize("keep", [0.4, 0.02])
+def test_wide_batch_sparse_filter_gathers_kept_rows(zv, oracle, metric_name, metric, keep):
+    """> 64 queries over >= 65536 rows with a minority kept: the wide kernel fetches the kept rows from their stored
+    positions (no compaction copy).  Integer data: scores and ids bit-exact against the oracle's filtered scan."""
+    rng = np.random.default_rng(int(keep * 1000) + metric)
+    n, dim, nq, k = 66_000, 40, 150, 10
+    base = rng.integers(-5, 6, (n, dim)).astype(np.float32)
+    q = rng.integers(-5, 6, (nq, dim)).astype(np.float32)
+    keys = rng.permutation(3 * n)[:n].astype(np.uint64)
+    se = zv.HipFlatSearcher(dim, metric_name)
+    assert se.load(base, keys) == 0
+    drop = rng.random(n) >= keep
+    ex = O.pack_bits(drop)
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    ctx.set_exclude_bitset(ex)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc = oracle.flat_search(base, q, k, metric, keys=keys, exclude_bits=ex)
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="gather keep=%g %s" % (keep, metric_name))
+    kept = set(keys[~drop].tolist())
+    assert all(int(x) in kept for qi in range(nq) for x in ctx.keys[qi, : ctx.counts[qi]])

@@ -65,6 +65,9 @@ struct ScanArgs {
   uint64_t n;               // rows in the flat store
   uint32_t tiles_per_chunk;
   const uint32_t *list_tpc;       // IVF: tiles per chunk of each list (shorter chunks for the lists dealt last)
+  // wide flat kernel, GATHER variant: logical row i of the scan is stored position gather_pos[i] (ascending kept
+  // positions of a sparse filter, padded to whole tiles with any valid position); n counts logical rows
+  const uint32_t *gather_pos;
   uint32_t nchunks;
   uint32_t nqtiles;
   // ivf decomposition (built on device by the plan kernels)
@@ -714,7 +717,7 @@ __host__ __device__ inline size_t scan8_lds_bytes(uint32_t k) {
   return (2 * (size_t)W8_ROWS * TILE_K + 2 * (size_t)SLAB + 7 * (size_t)W8_ROWS + 4 + 2 * (size_t)W8_ROWS * k) * 4;
 }
 
-template <bool EXCL, bool F16>
+template <bool EXCL, bool F16, bool GATHER>
 __global__ void __launch_bounds__(512, 4) scan8_kernel(const ScanArgs a) {
   constexpr int ROWS = W8_ROWS;
   extern __shared__ f32x4 zvk_smem4[];
@@ -782,12 +785,39 @@ __global__ void __launch_bounds__(512, 4) scan8_kernel(const ScanArgs a) {
     const uint32_t gq1 = qrow_s[srow + 64] * dpad + (uint32_t)sswz * 4u;
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
+    // GATHER: this lane's two slab pieces are chunk p of tile rows srow and srow+64; the rows come from stored
+    // positions gp0 / gp1, whose own in-tile row decides the swizzle they were stored with.  The positions of the
+    // tile being fetched are held in registers and the next tile's are loaded one tile ahead.
+    uint32_t gp0 = 0, gp1 = 0, gpn0 = 0, gpn1 = 0, gp_tile = ~0u;
+    auto gather_src = [&](uint32_t gp, uint32_t k_) {
+      const uint32_t rs = gp & (TILE_N - 1);
+      const uint32_t chunk = (uint32_t)schunk ^ (uint32_t)((srow >> 1) & 7) ^ ((rs >> 1) & 7u);
+      return reinterpret_cast<const f32x4 *>(a.base + (size_t)(gp >> 7) * TILE_N * dpad + (size_t)k_ * SLAB) + (rs * 8 + chunk);
+    };
     auto stage_glds = [&](uint32_t t_, uint32_t k_, float *Bb, float *Qb) {
-      const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(a.base + (size_t)t_ * TILE_N * dpad + (size_t)k_ * SLAB) + tid;
       char *bl = reinterpret_cast<char *>(Bb) + wave * 1024;      // wave-uniform destinations
       char *ql = reinterpret_cast<char *>(Qb) + wave * 1024;
-      __builtin_amdgcn_global_load_lds((glb_void *)bsrc, (lds_void *)bl, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void *)(bsrc + 512), (lds_void *)(bl + 8192), 16, 0, 0);
+      if constexpr (GATHER) {
+        if (t_ != gp_tile) {                       // uniform: first step of a new tile
+          if (gp_tile == ~0u) {
+            gp0 = a.gather_pos[(size_t)t_ * TILE_N + srow];
+            gp1 = a.gather_pos[(size_t)t_ * TILE_N + srow + 64];
+          } else {
+            gp0 = gpn0;
+            gp1 = gpn1;
+          }
+          gp_tile = t_;
+          const uint32_t tn = min(t_ + 1, tile_end - 1);
+          gpn0 = a.gather_pos[(size_t)tn * TILE_N + srow];
+          gpn1 = a.gather_pos[(size_t)tn * TILE_N + srow + 64];
+        }
+        __builtin_amdgcn_global_load_lds((glb_void *)gather_src(gp0, k_), (lds_void *)bl, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)gather_src(gp1, k_), (lds_void *)(bl + 8192), 16, 0, 0);
+      } else {
+        const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(a.base + (size_t)t_ * TILE_N * dpad + (size_t)k_ * SLAB) + tid;
+        __builtin_amdgcn_global_load_lds((glb_void *)bsrc, (lds_void *)bl, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(bsrc + 512), (lds_void *)(bl + 8192), 16, 0, 0);
+      }
       __builtin_amdgcn_global_load_lds((glb_void *)(a.queries + (size_t)(gq0 + k_ * TILE_K)), (lds_void *)ql, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((glb_void *)(a.queries + (size_t)(gq1 + k_ * TILE_K)), (lds_void *)(ql + 8192), 16, 0, 0);
     };
@@ -828,7 +858,11 @@ __global__ void __launch_bounds__(512, 4) scan8_kernel(const ScanArgs a) {
       if (has_next) stage_glds(ptile, pks, Bs + (buf ^ 1) * SLAB, Qs + (buf ^ 1) * ROWS * TILE_K);
       if (fetched + 1 < nsteps) advance(ptile, pks);
       ++fetched;
-      {
+      if constexpr (GATHER) {
+        // column norm through the position list: two dependent loads, issued at the start of the tile's last step
+        // so that they land under its matrix work
+        if (ks == nks - 1) bn0 = a.bnorm[a.gather_pos[(size_t)tile * TILE_N + wn * 32 + r]];
+      } else {
         const uint32_t pos0 = tile * TILE_N + wn * 32;
         bn0 = a.bnorm[(size_t)pos0 + r];
         if constexpr (EXCL) {
@@ -920,7 +954,9 @@ __global__ void __launch_bounds__(512, 4) scan8_kernel(const ScanArgs a) {
       uint32_t c = st.cnt[row];
       size_t o = (size_t)slot_s[row] * k + t;
       a.part_s[o] = (t < c) ? st.Ls[(size_t)row * k + t] : __builtin_inff();
-      a.part_i[o] = (t < c) ? st.Li[(size_t)row * k + t] : IDX_NONE;
+      uint32_t pi = (t < c) ? st.Li[(size_t)row * k + t] : IDX_NONE;
+      if constexpr (GATHER) { if (pi != IDX_NONE) pi = a.gather_pos[pi]; }      // logical row -> stored position
+      a.part_i[o] = pi;
     }
     __syncthreads();
   }

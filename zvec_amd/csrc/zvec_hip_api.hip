@@ -224,34 +224,38 @@ int launch_scan(const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStr
 }
 
 // the 8-wave 128x128 flat tile (scan8_kernel); *occ_out = work-groups per CU it reaches for this k
-template <bool EXCL, bool F16>
+template <bool EXCL, bool F16, bool GATHER>
 int launch_scan8_t(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream, int *occ_out) {
   static bool attr_set[16] = {false};
   size_t lds = scan8_lds_bytes(a.k);
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_set[dev & 15]) {
-    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan8_kernel<EXCL, F16>),
+    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan8_kernel<EXCL, F16, GATHER>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     attr_set[dev & 15] = true;
   }
   int occ = 0;
-  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan8_kernel<EXCL, F16>, 512, lds));
+  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan8_kernel<EXCL, F16, GATHER>, 512, lds));
   if (occ < 1) occ = 1;
   if (occ_out) { *occ_out = occ; return 0; }
   uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)max_items, (uint64_t)cus * (uint64_t)occ);
   if (grid == 0) return 0;
-  hipLaunchKernelGGL((scan8_kernel<EXCL, F16>), dim3(grid), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((scan8_kernel<EXCL, F16, GATHER>), dim3(grid), dim3(512), lds, stream, a);
   ZCHK(hipGetLastError());
   return 0;
 }
 
+// (the GATHER variant scans an already filtered position list: no exclude set)
 int launch_scan8(const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStream_t stream, int *occ_out = nullptr) {
+  if (a.gather_pos)
+    return f16 ? launch_scan8_t<false, true, true>(a, max_items, cus, stream, occ_out)
+               : launch_scan8_t<false, false, true>(a, max_items, cus, stream, occ_out);
   if (f16)
-    return a.exclude ? launch_scan8_t<true, true>(a, max_items, cus, stream, occ_out)
-                     : launch_scan8_t<false, true>(a, max_items, cus, stream, occ_out);
-  return a.exclude ? launch_scan8_t<true, false>(a, max_items, cus, stream, occ_out)
-                   : launch_scan8_t<false, false>(a, max_items, cus, stream, occ_out);
+    return a.exclude ? launch_scan8_t<true, true, false>(a, max_items, cus, stream, occ_out)
+                     : launch_scan8_t<false, true, false>(a, max_items, cus, stream, occ_out);
+  return a.exclude ? launch_scan8_t<true, false, false>(a, max_items, cus, stream, occ_out)
+                   : launch_scan8_t<false, false, false>(a, max_items, cus, stream, occ_out);
 }
 
 // ng == 0 selects the 16-row-halves (16x16 MFMA) shape
@@ -320,6 +324,68 @@ struct SearchOut {
 int refine_l2(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold, uint64_t *keys,
               float *scores, uint32_t *idx, uint32_t *counts, hipStream_t stream);
 
+// Sparse keep-set scan WITHOUT copying the kept rows: the wide kernel fetches the rows of a logical tile straight from
+// their stored positions (LDS-DMA with per-lane source addresses: every 128-byte row segment is still one full line).
+// `d_pos`: ascending kept positions, padded to whole tiles (+1 tile) with position 0; `kept` logical rows.
+int flat_scan_gather(zvec_hip_ctx_s *ctx, const Store &st, const uint32_t *d_pos, uint32_t kept, uint32_t count,
+                     uint32_t topk, float threshold, const SearchOut &out, hipStream_t stream, bool profile_it) {
+  const int cus = device_cus(ctx);
+  ScanArgs a{};
+  a.base = st.base; a.bnorm = st.bnorm; a.exclude = nullptr; a.gather_pos = d_pos;
+  a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
+  a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.threshold = threshold;
+  a.gtau = ctx->gtau.as<uint32_t>();
+  a.mode = 0; a.nq = count;
+  const uint32_t nqtiles = (count + W8_ROWS - 1) / W8_ROWS;
+  // seeded bounds from the first SEED rows of the kept set (see flat_scan_prepared)
+  constexpr uint32_t SEED_ROWS = 4096;
+  if (kept >= 64 * SEED_ROWS && topk <= 64 && (size_t)topk * 12 + 16 <= 60 * 1024) {
+    ZRET(ctx->seed_keys.ensure((size_t)count * topk * sizeof(uint64_t)));
+    ZRET(ctx->seed_scores.ensure((size_t)count * topk * sizeof(float)));
+    ZRET(ctx->seed_counts.ensure((size_t)count * sizeof(uint32_t)));
+    ZRET(ctx->part_s.ensure((size_t)count * SEED_ROWS * sizeof(float)));
+    ScanArgs d = a;
+    d.k = 1; d.n = SEED_ROWS; d.ndense = SEED_ROWS; d.tiles_per_chunk = 1; d.nchunks = SEED_ROWS / TILE_N; d.nqtiles = nqtiles;
+    d.dump = ctx->part_s.as<float>(); d.dump_stride = SEED_ROWS;
+    ZRET(launch_scan8(d, st.f16, ((d.nchunks + 7) / 8) * 8 * nqtiles, cus, stream));
+    MergeArgs m{};
+    m.part_s = d.dump; m.slots_per_q = 1; m.slot_stride = 1; m.k = topk; m.slot_len = SEED_ROWS; m.threshold = threshold;
+    m.out_keys = ctx->seed_keys.as<uint64_t>(); m.out_scores = ctx->seed_scores.as<float>(); m.out_counts = ctx->seed_counts.as<uint32_t>();
+    hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+    hipLaunchKernelGGL(seed_gtau_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, ctx->gtau.as<uint32_t>(),
+                       m.out_scores, m.out_counts, count, topk);
+    ZCHK(hipGetLastError());
+  }
+  int occ8 = 1;
+  a.k = topk;
+  ZRET(launch_scan8(a, st.f16, 0, cus, stream, &occ8));
+  const uint64_t ntiles = ((uint64_t)kept + TILE_N - 1) / TILE_N;
+  const uint64_t resident = (uint64_t)cus * occ8;
+  const uint64_t want_chunks = std::max<uint64_t>(1, (resident + nqtiles - 1) / nqtiles);
+  uint64_t tpc = std::max<uint64_t>(1, (ntiles + want_chunks - 1) / want_chunks);
+  tpc = std::max<uint64_t>(tpc, std::min<uint64_t>(ntiles, 4));
+  const uint32_t nchunks = (uint32_t)((ntiles + tpc - 1) / tpc);
+  const uint64_t slots = (uint64_t)count * nchunks;
+  ZRET(ctx->part_s.ensure(slots * topk * sizeof(float)));
+  ZRET(ctx->part_i.ensure(slots * topk * sizeof(uint32_t)));
+  a.n = kept; a.ndense = kept; a.tiles_per_chunk = (uint32_t)tpc; a.nchunks = nchunks; a.nqtiles = nqtiles;
+  a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
+  int pi = -1;
+  if (profile_it) {
+    double bytes = (double)kept * st.dscan * st.elem + (double)count * st.dscan * st.elem + (double)count * topk * 12.0;
+    pi = prof_begin(ctx, stream, bytes, 2.0 * (double)count * (double)kept * st.dscan, 0);
+  }
+  ZRET(launch_scan8(a, st.f16, ((nchunks + 7) / 8) * 8 * nqtiles, cus, stream));
+  prof_end(ctx, stream, pi);
+  MergeArgs m{};
+  m.part_s = a.part_s; m.part_i = a.part_i; m.slots_per_q = nchunks; m.slot_stride = 1; m.k = topk; m.slot_len = topk;
+  m.threshold = threshold; m.bound_keys = a.gtau; m.keymap = st.keys;
+  m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
 // `user_facing`: a search whose lists go back to the caller (profiled, L2-refined); false for the IVF
 // coarse pass and the k-means labelling, which only need the ranking
 int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold,
@@ -356,6 +422,18 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
         return 0;
       }
       const uint64_t ktiles = ((uint64_t)kept + TILE_N - 1) / TILE_N;
+      static const bool no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;   // tuning knob (experiments)
+      if (!no_gather && count > 2 * QGROUP && pick_ng(count, topk) == 4 && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024) {
+        // wide batch: gather the kept rows inside the scan instead of copying them first
+        const size_t padded = (size_t)(ktiles + 1) * TILE_N;
+        ZRET(ctx->cmp_pos.ensure(padded * 4));
+        ZCHK(hipMemsetAsync(ctx->cmp_pos.as<uint32_t>() + kept, 0, (padded - kept) * 4, stream));
+        hipLaunchKernelGGL(keep_fill_kernel, dim3(nchunks_b), dim3(64), 0, stream, ex32, st.n, d_off, ctx->cmp_pos.as<uint32_t>());
+        ZCHK(hipGetLastError());
+        ZRET(flat_scan_gather(ctx, st, ctx->cmp_pos.as<uint32_t>(), kept, count, topk, threshold, out, stream, profile_it));
+        if (user_facing) ZRET(refine_l2(ctx, st, count, topk, threshold, out.keys, out.scores, out.idx, out.counts, stream));
+        return 0;
+      }
       ZRET(ctx->cmp_pos.ensure((size_t)kept * 4));
       ZRET(ctx->cmp_base.ensure((size_t)ktiles * TILE_N * st.dpad * 4));
       ZRET(ctx->cmp_norm.ensure((size_t)ktiles * TILE_N * 4));
