@@ -173,7 +173,7 @@ def test_filter_build_throughput_10m(zv, capsys):
 
 
 @pytest.mark.parametrize("metric_name,metric", [("SquaredEuclidean", O.METRIC_L2), ("InnerProduct", O.METRIC_IP)])
-@pytest.mark.parametrize("keep", [0.4, 0.02])
+@pytest.mark.parametrize("keep", [0.8, 0.4, 0.02])
 def test_wide_batch_sparse_filter_gathers_kept_rows(zv, oracle, metric_name, metric, keep):
     """> 64 queries over >= 65536 rows with a minority kept: the wide kernel fetches the kept rows from their stored
     positions (no compaction copy).  Integer data: scores and ids bit-exact against the oracle's filtered scan."""

@@ -1358,11 +1358,14 @@ __global__ void unpack_row_kernel(const float *base, const float *extra, uint64_
 
 // one launch instead of two memsets + fill_gtau before the IVF plan: zero `nzero` plan words (list_count, list_fill),
 // zero the 4 work-queue words, reset the shared bounds of `nq` queries to the threshold
-__global__ void ivf_reset_kernel(uint32_t *zero0, uint32_t nzero, uint32_t *queue, uint32_t *gtau, uint32_t nq, float threshold) {
+// ... and set this search's chunk length of every list: `tpc` tiles, a quarter of that for the lists flagged as the tail
+__global__ void ivf_reset_kernel(uint32_t *zero0, uint32_t nzero, uint32_t *queue, uint32_t *gtau, uint32_t nq, float threshold,
+                                 uint32_t *list_tpc, const uint32_t *list_tail, uint32_t nlist, uint32_t tpc) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nzero) zero0[i] = 0;
   if (i < 4) queue[i] = 0;
   if (i < nq) gtau[i] = fkey(threshold);
+  if (i < nlist) list_tpc[i] = list_tail[i] ? max(1u, tpc >> 2) : tpc;
 }
 
 // gtau[q] = min(gtau[q], k-th score of a sample scan, nudged up by ~1e-6 relative) — only for full sample lists.

@@ -176,9 +176,10 @@ struct zvec_hip_ivf_s {
   std::vector<uint64_t> h_dense0;      // local dense offsets (nlist+1)
   std::vector<uint64_t> h_row_ids;     // local dense position -> original row
   std::vector<char> h_centroids;       // [nlist][dim] in the index element type
-  uint32_t *d_size = nullptr, *d_size_global = nullptr, *d_tile0 = nullptr, *d_order = nullptr, *d_tpc = nullptr;
+  uint32_t *d_size = nullptr, *d_size_global = nullptr, *d_tile0 = nullptr, *d_order = nullptr, *d_tail = nullptr;
   uint32_t tiles_per_chunk = 8;
-  std::vector<uint32_t> h_tpc;         // tiles per chunk of each list
+  std::vector<uint32_t> h_tail;        // 1 = list belongs to the tail of the deal order (shorter chunks)
+  uint64_t local_tiles = 0;            // tiles of the lists held by this shard
   uint64_t *d_dense0 = nullptr;
   zvec_hip_ctx_s *defctx = nullptr;
   std::mutex mu;
@@ -415,15 +416,18 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     uint32_t kept = 0;
     ZCHK(hipMemcpyAsync(&kept, d_total, 4, hipMemcpyDeviceToHost, stream));
     ZCHK(hipStreamSynchronize(stream));
-    if ((double)kept <= 0.5 * (double)st.n) {
+    // copying the kept rows pays below one half kept; gathering them inside the wide kernel costs ~1.5 % and pays
+    // whenever a tenth of the rows can be skipped
+    static const bool no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;   // tuning knob (experiments)
+    const bool can_gather = !no_gather && count > 2 * QGROUP && pick_ng(count, topk) == 4 && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
+    if ((double)kept <= (can_gather ? 0.9 : 0.5) * (double)st.n) {
       if (kept == 0) {
         ZCHK(hipMemsetAsync(out.counts, 0, sizeof(uint32_t) * count, stream));
         ZCHK(hipMemsetAsync(out.keys, 0xff, sizeof(uint64_t) * (size_t)count * topk, stream));
         return 0;
       }
       const uint64_t ktiles = ((uint64_t)kept + TILE_N - 1) / TILE_N;
-      static const bool no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;   // tuning knob (experiments)
-      if (!no_gather && count > 2 * QGROUP && pick_ng(count, topk) == 4 && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024) {
+      if (can_gather) {
         // wide batch: gather the kept rows inside the scan instead of copying them first
         const size_t padded = (size_t)(ktiles + 1) * TILE_N;
         ZRET(ctx->cmp_pos.ensure(padded * 4));
@@ -716,25 +720,37 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
   size_t o_qnprobe = take(count), o_qscanned = take(count), o_qnslots = take(count), o_slotbegin = take(count + 1);
   size_t o_lcount = take(nlist), o_lfill = take(nlist), o_lqoff = take(nlist + 1), o_itemoff = take(nlist + 1);
-  size_t o_queue = take(4);   // right after item_off; zeroed with list_count/list_fill? no: separate memset below
+  size_t o_queue = take(4);
+  size_t o_ltpc = take(nlist);
   size_t o_total = take(4), o_csrq = take(npairs), o_csrslot = take(npairs);
   ZRET(ctx->plan.ensure(off * sizeof(uint32_t)));
   uint32_t *pb = ctx->plan.as<uint32_t>();
   // list_count + list_fill and the work-queue head zeroed, shared bounds reset (the coarse pass may have left
   // centroid-score bounds behind): one launch
+  // chunk length of this search: the lists it can touch (at most count x nprobe of them) should give a few items per
+  // resident work-group — a single query probing 40 lists needs one-tile items to use the chip at all, a batch of
+  // 1024 the index-wide default
+  uint32_t tpc = h->tiles_per_chunk;
+  {
+    const uint64_t lists_touched = std::min<uint64_t>(nlist, (uint64_t)count * (brute_force ? nlist : nprobe));
+    const uint64_t est_tiles = std::max<uint64_t>(1, h->local_tiles * lists_touched / std::max<uint32_t>(nlist, 1));
+    const uint64_t t = est_tiles / (4ull * (uint64_t)device_cus(ctx) * 3ull);
+    tpc = (uint32_t)std::min<uint64_t>(h->tiles_per_chunk, std::max<uint64_t>(1, t));
+    if (getenv("ZVEC_HIP_IVF_TPC")) tpc = h->tiles_per_chunk;
+  }
   {
     ZRET(ctx->gtau.ensure((size_t)count * sizeof(uint32_t)));
     const uint32_t nzero = (uint32_t)(o_lqoff - o_lcount);
-    const uint32_t nthr = std::max<uint32_t>(std::max<uint32_t>(nzero, count), 4);
+    const uint32_t nthr = std::max<uint32_t>(std::max<uint32_t>(nzero, count), std::max<uint32_t>(nlist, 4));
     hipLaunchKernelGGL(ivf_reset_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, pb + o_lcount, nzero, pb + o_queue,
-                       ctx->gtau.as<uint32_t>(), count, threshold);
+                       ctx->gtau.as<uint32_t>(), count, threshold, pb + o_ltpc, h->d_tail, nlist, tpc);
     ZCHK(hipGetLastError());
   }
   PlanArgs p{};
   p.coarse_idx = ctx->coarse_idx.as<uint32_t>(); p.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
   p.nq = count; p.nprobe = nprobe; p.nlist = nlist; p.max_scan_count = max_scan_count; p.brute_force = brute_force;
   p.list_size = h->d_size; p.list_size_global = h->d_size_global; p.list_order = h->d_order;
-  p.list_tpc = h->d_tpc;
+  p.list_tpc = pb + o_ltpc;
   p.rows_per_group = rows_per_group;
   p.q_nprobe = pb + o_qnprobe; p.q_scanned = pb + o_qscanned; p.q_nslots = pb + o_qnslots; p.slot_begin = pb + o_slotbegin;
   p.list_count = pb + o_lcount; p.list_fill = pb + o_lfill; p.list_qoff = pb + o_lqoff; p.item_off = pb + o_itemoff;
@@ -753,7 +769,10 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   {
     std::vector<uint32_t> chunks(nlist);
     for (uint32_t l = 0; l < nlist; ++l)
-      chunks[l] = sz[l] ? (((sz[l] + TILE_N - 1) / TILE_N + h->h_tpc[l] - 1) / h->h_tpc[l]) : 0;
+    {
+      const uint32_t t = h->h_tail[l] ? std::max<uint32_t>(1, tpc >> 2) : tpc;
+      chunks[l] = sz[l] ? (((sz[l] + TILE_N - 1) / TILE_N + t - 1) / t) : 0;
+    }
     uint32_t np = brute_force ? nlist : nprobe;
     std::partial_sort(chunks.begin(), chunks.begin() + np, chunks.end(), std::greater<uint32_t>());
     uint64_t s = 0;
@@ -769,7 +788,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
   a.dpad = h->lists.dpad; a.nks = h->lists.dpad / TILE_K; a.metric = h->metric; a.k = topk; a.threshold = threshold;
   a.gtau = ctx->gtau.as<uint32_t>();
-  a.mode = 1; a.nq = count; a.n = h->lists.n; a.ndense = h->count_local; a.tiles_per_chunk = h->tiles_per_chunk; a.list_tpc = h->d_tpc;
+  a.mode = 1; a.nq = count; a.n = h->lists.n; a.ndense = h->count_local; a.tiles_per_chunk = tpc; a.list_tpc = pb + o_ltpc;
   a.total_items = p.total_items; a.queue = pb + o_queue; a.list_order = h->d_order; a.item_off = p.item_off; a.list_tile0 = h->d_tile0; a.list_size = h->d_size;
   a.list_dense0 = h->d_dense0; a.list_qoff = p.list_qoff; a.csr_q = p.csr_q; a.csr_slot = p.csr_slot; a.nlist = nlist;
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
@@ -1091,9 +1110,9 @@ static void ivf_release(zvec_hip_ivf_s *h) {
   if (h->d_size_global) (void)hipFree(h->d_size_global);
   if (h->d_tile0) (void)hipFree(h->d_tile0);
   if (h->d_order) (void)hipFree(h->d_order);
-  if (h->d_tpc) (void)hipFree(h->d_tpc);
+  if (h->d_tail) (void)hipFree(h->d_tail);
   if (h->d_dense0) (void)hipFree(h->d_dense0);
-  h->d_size = h->d_size_global = h->d_tile0 = h->d_order = h->d_tpc = nullptr; h->d_dense0 = nullptr;
+  h->d_size = h->d_size_global = h->d_tile0 = h->d_order = h->d_tail = nullptr; h->d_dense0 = nullptr;
   h->loaded = false;
 }
 
@@ -1179,7 +1198,7 @@ static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uin
     ZCHK(hipStreamSynchronize(s));
   }
   // list tables
-  if (h->d_size) { (void)hipFree(h->d_size); (void)hipFree(h->d_size_global); (void)hipFree(h->d_tile0); (void)hipFree(h->d_dense0); (void)hipFree(h->d_order); (void)hipFree(h->d_tpc); }
+  if (h->d_size) { (void)hipFree(h->d_size); (void)hipFree(h->d_size_global); (void)hipFree(h->d_tile0); (void)hipFree(h->d_dense0); (void)hipFree(h->d_order); (void)hipFree(h->d_tail); }
   // largest lists are dealt first by the scan's work queue; chunk length adapts to the index size so
   // that a search has a few items per resident work-group yet long runs per top-k warm-up
   std::vector<uint32_t> order(nlist);
@@ -1193,19 +1212,18 @@ static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uin
     // work-group streams only ~7 GB/s (5.7 TB/s over ~768 resident groups), i.e. a 4-tile item lasts ~200 us, and a
     // tail of such items leaves most of the chip idle.  The last quarter of the tiles is therefore cut into chunks
     // a quarter as long (guided self-scheduling: coarse items first, fine items last).
-    uint32_t tail_tpc = std::max<uint32_t>(1, h->tiles_per_chunk / 4);
-    if (const char *e = getenv("ZVEC_HIP_IVF_TAIL_TPC")) tail_tpc = (uint32_t)std::max(1, atoi(e));          // tuning knob (experiments)
-    h->h_tpc.assign(nlist, h->tiles_per_chunk);
+    h->h_tail.assign(nlist, 0);
+    h->local_tiles = tiles;
     uint64_t acc = 0;
     for (uint32_t i = nlist; i-- > 0;) {
       const uint32_t l = order[i];
       if (acc * 4 >= tiles) break;
-      h->h_tpc[l] = tail_tpc;
+      h->h_tail[l] = 1;
       acc += (h->h_size[l] + TILE_N - 1) / TILE_N;
     }
   }
-  ZCHK(hipMalloc(&h->d_tpc, std::max<uint32_t>(nlist, 1) * 4));
-  ZCHK(hipMemcpy(h->d_tpc, h->h_tpc.data(), nlist * 4, hipMemcpyHostToDevice));
+  ZCHK(hipMalloc(&h->d_tail, std::max<uint32_t>(nlist, 1) * 4));
+  ZCHK(hipMemcpy(h->d_tail, h->h_tail.data(), nlist * 4, hipMemcpyHostToDevice));
   ZCHK(hipMalloc(&h->d_order, nlist * 4));
   ZCHK(hipMemcpy(h->d_order, order.data(), nlist * 4, hipMemcpyHostToDevice));
   ZCHK(hipMalloc(&h->d_size, nlist * 4));
