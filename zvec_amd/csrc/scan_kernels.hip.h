@@ -989,13 +989,16 @@ struct MergeArgs {
   uint32_t *out_counts;          // [nq]
 };
 
-__global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
+// Launched with 64 threads (one wave per query) or, for small batches of partial-list merges, 256: the extra waves
+// only help gathering the survivors (the one phase that streams every candidate); wave 0 finishes alone.
+__global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
   extern __shared__ f32x4 zvk_smem4[];
   const uint32_t k = a.k;
   float *Ls = reinterpret_cast<float *>(zvk_smem4);          // [k]
   uint32_t *Lo = reinterpret_cast<uint32_t *>(Ls + k);       // [k] order (slot)
   uint32_t *Li = Lo + k;                                      // [k] idx / candidate ordinal
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const uint32_t q = blockIdx.x;
   uint32_t sb, nslots;
   if (a.slot_begin) { sb = a.slot_begin[q]; nslots = a.slot_begin[q + 1] - sb; }
@@ -1012,7 +1015,7 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
   // lane takes the minimum of its own strided elements; those are 64 distinct candidates, so the k-th
   // smallest of them is >= the k-th smallest of the whole row.  Cuts the insertions to the few elements
   // at or below that bound.
-  if (a.part_i == nullptr && a.part_keys == nullptr && a.part_counts == nullptr && k <= 64 && total >= 64) {
+  if (a.part_i == nullptr && a.part_keys == nullptr && a.part_counts == nullptr && k <= 64 && total >= 64 && nwaves == 1) {
     float mn = __builtin_inff();
     for (uint64_t base = 0; base < total; base += 64 * U) {
       float v[U];
@@ -1047,15 +1050,20 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
   constexpr uint32_t GATHER = 512;               // gathered at most; between the two, one k-select trims them first
   __shared__ unsigned long long surv_hi[GATHER]; // order-preserving score key << 32 | slot
   __shared__ uint32_t surv_lo[GATHER];           // index / candidate ordinal
+  __shared__ uint32_t sh_ns;
   if (total <= 0xffffffffull && k <= SURV) {
     const uint32_t tot = (uint32_t)total;
-    surv_hi[lane] = ~0ull; surv_hi[lane + 64] = ~0ull;
-    surv_lo[lane] = IDX_NONE; surv_lo[lane + 64] = IDX_NONE;
-    uint32_t ns = 0;       // uniform
+    if (wave == 0) {
+      surv_hi[lane] = ~0ull; surv_hi[lane + 64] = ~0ull;
+      surv_lo[lane] = IDX_NONE; surv_lo[lane + 64] = IDX_NONE;
+      if (lane == 0) sh_ns = 0;
+    }
+    __syncthreads();
+    uint32_t ns = 0;       // uniform per wave: survivors seen so far (single wave) / at the last append (several waves)
     const bool dense_row = a.part_i == nullptr && a.part_keys == nullptr && a.part_counts == nullptr && nslots == 1;
     auto gather = [&](auto dense_tag) {
       constexpr bool DENSE = decltype(dense_tag)::value;
-      for (uint32_t base = 0; base < tot && ns <= GATHER; base += 64 * U) {
+      for (uint32_t base = wave * 64 * U; base < tot && ns <= GATHER; base += nwaves * 64 * U) {
         float sv[U];
         uint32_t iv[U], jv[U];
 #pragma unroll
@@ -1090,17 +1098,29 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
           const bool in = sv[u] <= tau;
           const uint64_t m = __ballot(in);
           if (m) {
-            const uint32_t pos = ns + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t add = (uint32_t)__popcll(m);
+            uint32_t first = ns;
+            if (nwaves > 1) {                      // the waves append through one LDS counter
+              uint32_t o = 0;
+              if (lane == 0) o = atomicAdd(&sh_ns, add);
+              first = bcast_u(o, 0);
+            }
+            const uint32_t pos = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (in && pos < GATHER) {
               surv_hi[pos] = ((unsigned long long)fkey(sv[u] + 0.f) << 32) | jv[u];
               surv_lo[pos] = iv[u];
             }
-            ns += (uint32_t)__popcll(m);
+            ns = first + add;
           }
         }
       }
     };
     if (dense_row) gather(std::true_type{}); else gather(std::false_type{});
+    if (nwaves > 1) {
+      __syncthreads();
+      if (wave != 0) return;                       // (no work-group barrier below this point)
+      ns = sh_ns;
+    }
     if (ns > SURV && ns <= GATHER) {
       // too many for one sort: find the k-th smallest score key among the survivors (bisection on the 32-bit key,
       // counts by ballot) and keep only the candidates at or below it (k plus ties)
@@ -1184,6 +1204,7 @@ __global__ void __launch_bounds__(64) merge_kernel(const MergeArgs a) {
     }
   }
 
+  if (wave != 0) return;       // the general path is one wave's work
   for (uint64_t base = 0; base < total; base += 64 * U) {
     float sv[U];
     uint32_t iv[U], jv[U];

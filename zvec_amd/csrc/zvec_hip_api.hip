@@ -325,6 +325,9 @@ struct SearchOut {
 int refine_l2(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold, uint64_t *keys,
               float *scores, uint32_t *idx, uint32_t *counts, hipStream_t stream);
 
+// partial-list merges of small batches: four waves per query gather the survivors (see merge_kernel)
+inline uint32_t merge_threads(uint32_t count) { return count <= 256 ? 256u : 64u; }
+
 // Sparse keep-set scan WITHOUT copying the kept rows: the wide kernel fetches the rows of a logical tile straight from
 // their stored positions (LDS-DMA with per-lane source addresses: every 128-byte row segment is still one full line).
 // `d_pos`: ascending kept positions, padded to whole tiles (+1 tile) with position 0; `kept` logical rows.
@@ -382,7 +385,7 @@ int flat_scan_gather(zvec_hip_ctx_s *ctx, const Store &st, const uint32_t *d_pos
   m.part_s = a.part_s; m.part_i = a.part_i; m.slots_per_q = nchunks; m.slot_stride = 1; m.k = topk; m.slot_len = topk;
   m.threshold = threshold; m.bound_keys = a.gtau; m.keymap = st.keys;
   m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
-  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(merge_threads(count)), (size_t)topk * 12 + 16, stream, m);
   ZCHK(hipGetLastError());
   return 0;
 }
@@ -468,7 +471,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     const double row_bytes_d = (double)ntiles_d * TILE_N * 4.0;
     const bool small_base = (double)st.n * st.dpad * 4.0 <= 64.0 * 1024 * 1024;
     const bool k_fits_merge = (size_t)topk * 12 + 16 <= 60 * 1024;
-    const bool want_a = small_base && d_exclude == nullptr && topk > 8 && count >= 64 && row_bytes_d * count <= 128.0 * 1024 * 1024;
+    const bool want_a = small_base && d_exclude == nullptr && topk > 8 && row_bytes_d * count <= 128.0 * 1024 * 1024;
     const bool want_b = pick_ng(count, topk) < 1;
     if (want_b && !k_fits_merge) return ZVEC_HIP_ERR_UNSUPPORTED;
     if ((want_a || want_b) && k_fits_merge) {
@@ -550,7 +553,9 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   // choice and gives the longest tile runs per top-k warm-up
   uint64_t want_chunks = std::max<uint64_t>(1, (resident + nqtiles - 1) / nqtiles);
   uint64_t tpc = std::max<uint64_t>(1, (ntiles + want_chunks - 1) / want_chunks);
-  tpc = std::max<uint64_t>(tpc, std::min<uint64_t>(ntiles, 4));   // >= 4 tiles per top-k warm-up
+  // >= 4 tiles per top-k warm-up — unless the base is too small to fill the chip that way (a single query over the
+  // 4096 IVF centroids: 32 one-tile items instead of 8 four-tile ones, 141 -> 40 us)
+  tpc = std::max<uint64_t>(tpc, std::min<uint64_t>(ntiles, ntiles >= 4 * resident ? 4 : 1));
   uint32_t nchunks = (uint32_t)((ntiles + tpc - 1) / tpc);
   uint64_t slots = (uint64_t)count * nchunks;
   ZRET(ctx->part_s.ensure(slots * topk * sizeof(float)));
@@ -578,7 +583,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   m.slots_per_q = nchunks; m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = topk; m.threshold = threshold;
   m.bound_keys = a.gtau;   // the scan's shared bounds: valid upper bounds of every query's final k-th score
   m.keymap = st.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
-  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(merge_threads(count)), (size_t)topk * 12 + 16, stream, m);
   ZCHK(hipGetLastError());
   if (user_facing) ZRET(refine_l2(ctx, st, count, topk, threshold, out.keys, out.scores, out.idx, out.counts, stream));
   return 0;
@@ -810,7 +815,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     ridx = ctx->ridx.as<uint32_t>();
   }
   m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = ridx; m.out_counts = out.counts;
-  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(merge_threads(count)), (size_t)topk * 12 + 16, stream, m);
   ZCHK(hipGetLastError());
   ZRET(refine_l2(ctx, h->lists, count, topk, threshold, out.keys, out.scores, ridx, out.counts, stream));
   return 0;
