@@ -157,6 +157,27 @@ class Oracle:
             self.lib.zo_cosine_transform_f32(_ptr(x[i], _f32p), x.shape[1], _ptr(out[i], _f32p))
         return out
 
+    def block_dist(self, metric, m_block, q_block, use_ref=False):
+        """M x N block kernel: m_block [dim][M] (column-major block of M vectors), q_block [dim][N] (N interleaved
+        queries) -> out [N][M].  metric L2 or IP (minus inner product).  M in {8, 16, 32}."""
+        m = np.ascontiguousarray(m_block, np.float32)
+        q = np.ascontiguousarray(q_block, np.float32)
+        dim, M = m.shape
+        N = q.shape[1]
+        assert q.shape[0] == dim and M in (8, 16, 32)
+        out = np.zeros((N, M), np.float32)
+        name = "sqeuclid" if metric == METRIC_L2 else "minus_ip"
+        if use_ref:
+            fn = getattr(self.ref, "zref_%s_block_f32" % name)
+            fn.restype = C.c_int
+            rc = fn(M, N, _ptr(m, _f32p), _ptr(q, _f32p), C.c_size_t(dim), _ptr(out, _f32p))
+            assert rc == 0
+        else:
+            fn = getattr(self.lib, "zo_%s_block_f32" % name)
+            fn.restype = None
+            fn(M, N, _ptr(m, _f32p), _ptr(q, _f32p), C.c_size_t(dim), _ptr(out, _f32p))
+        return out
+
     def cosine_transform16(self, x):
         """fp32 rows of d floats -> fp16 rows of d+2 halves: CosineConverter with original fp32 / stored fp16
         (cosine_converter.cc:112-134): normalise in fp32, FloatHelper::ToFP16, then the fp32 norm's 4 bytes in the

@@ -12,6 +12,7 @@
 //   ailego::SquaredEuclideanDistanceMatrix<Float16,1,1>         src/ailego/math/euclidean_distance_matrix_fp16.cc:137
 //   ailego::MinusInnerProductMatrix<Float16,1,1>                src/ailego/math/inner_product_matrix_fp16.cc:166
 //   ailego::FloatHelper::ToFP16                                 src/ailego/utility/float_helper.cc
+//   ailego::{SquaredEuclideanDistance,MinusInnerProduct}Matrix<float,M,N>  (block kernels, M in 2..32, N in 1..32)
 #include <cstddef>
 #include <cstdint>
 #include <limits>
@@ -83,6 +84,27 @@ float zref_minus_ip_f16(const uint16_t *m, const uint16_t *q, size_t dim) {
   return out;
 }
 void zref_to_fp16(const float *in, size_t n, uint16_t *out) { FloatHelper::ToFP16(in, n, out); }
+
+// M x N block kernels (column-major block of M vectors x N interleaved queries, out[n*M + m]):
+//   SquaredEuclideanDistanceMatrix<float,M,N>::Compute   euclidean_distance_matrix_fp32.cc:323-929
+//   MinusInnerProductMatrix<float,M,N>::Compute          inner_product_matrix_fp32.cc:588-1179
+// Returns 0 when the (M, N) pair is one of the shapes the reference specialises (euclidean_metric.cc:25-80).
+#define ZREF_BLOCK(KERNEL, M_, N_) \
+  if (M == M_ && N == N_) { KERNEL<float, M_, N_>::Compute(m, q, dim, out); return 0; }
+#define ZREF_BLOCK_ALL(KERNEL)                                                                        \
+  ZREF_BLOCK(KERNEL, 2, 1) ZREF_BLOCK(KERNEL, 2, 2) ZREF_BLOCK(KERNEL, 4, 1) ZREF_BLOCK(KERNEL, 4, 2)  \
+  ZREF_BLOCK(KERNEL, 4, 4) ZREF_BLOCK(KERNEL, 8, 1) ZREF_BLOCK(KERNEL, 8, 2) ZREF_BLOCK(KERNEL, 8, 4)  \
+  ZREF_BLOCK(KERNEL, 8, 8) ZREF_BLOCK(KERNEL, 16, 1) ZREF_BLOCK(KERNEL, 16, 2) ZREF_BLOCK(KERNEL, 16, 4) \
+  ZREF_BLOCK(KERNEL, 16, 8) ZREF_BLOCK(KERNEL, 16, 16) ZREF_BLOCK(KERNEL, 32, 1) ZREF_BLOCK(KERNEL, 32, 2) \
+  ZREF_BLOCK(KERNEL, 32, 4) ZREF_BLOCK(KERNEL, 32, 8) ZREF_BLOCK(KERNEL, 32, 16) ZREF_BLOCK(KERNEL, 32, 32)
+int zref_sqeuclid_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out) {
+  ZREF_BLOCK_ALL(SquaredEuclideanDistanceMatrix)
+  return -1;
+}
+int zref_minus_ip_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out) {
+  ZREF_BLOCK_ALL(MinusInnerProductMatrix)
+  return -1;
+}
 
 // Replays n emplace() calls through the reference Heap and returns the heap array as laid out.
 size_t zref_heap_replay(const float *scores, size_t n, size_t limit, float threshold,

@@ -100,6 +100,29 @@ float zo_ip_f32(const float *m, const float *q, size_t dim) {
 float zo_minus_ip_f32(const float *m, const float *q, size_t dim) {
   return -lane_ip(m, q, dim);
 }
+/* SquaredEuclideanDistanceMatrix<float,M,N> / MinusInnerProductMatrix<float,M,N> (M >= 2): the AVX-512 / AVX / SSE
+ * bodies (distance_matrix_accum_fp32.i) keep one accumulator lane per (vector i, query j) and step k sequentially:
+ * sum = fma(m - q, m - q, sum)  resp.  sum = fma(m, q, sum); minus-ip negates at the end. */
+void zo_sqeuclid_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out) {
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i < M; ++i) {
+      float acc = 0.0f;
+      for (size_t k = 0; k < dim; ++k) {
+        const float d = m[k * (size_t)M + i] - q[k * (size_t)N + j];
+        acc = fmaf(d, d, acc);
+      }
+      out[(size_t)j * M + i] = acc;
+    }
+}
+void zo_minus_ip_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out) {
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i < M; ++i) {
+      float acc = 0.0f;
+      for (size_t k = 0; k < dim; ++k) acc = fmaf(m[k * (size_t)M + i], q[k * (size_t)N + j], acc);
+      out[(size_t)j * M + i] = -acc;
+    }
+}
+
 /* CosineDistanceMatrix<float,1,1>::Compute  cosine_distance_matrix.h:32-50 */
 float zo_cosine_f32(const float *m, const float *q, size_t dim_with_norm) {
   size_t d = dim_with_norm - 1; /* extra_dim = sizeof(float)/sizeof(float) */

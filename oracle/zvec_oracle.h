@@ -52,6 +52,15 @@ void zo_cosine_transform_f32(const float *in, size_t dim, float *out);
 /* generic dispatch by metric, `dim` is the element dimension (d+1 for cosine) */
 float zo_distance(int metric, const float *m, const float *q, size_t dim);
 
+/* M x N block kernels (euclidean_distance_matrix_fp32.cc:323-929, inner_product_matrix_fp32.cc:588-1179; layouts
+ * euclidean_distance_matrix.h:56-95): m = column-major block m[k*M + i] of M vectors, q = N interleaved queries
+ * q[k*N + j], out[j*M + i].  For M in {8, 16, 32} — the block heights the scan paths use (FlatSearcher<32>,
+ * flat_searcher_context.h) — every (i, j) is one sequential fused-multiply-add chain over k in the reference's SIMD
+ * bodies (the vector lanes run across i, never across k): restated and pinned bit for bit.  The M = 2 / 4 bodies pack
+ * several k into one vector and are NOT restated. */
+void zo_sqeuclid_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out);
+void zo_minus_ip_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out);
+
 /* fp16 rows (DT_FP16): halves as uint16_t; restated AVX-512 (no FP16 ISA) order, fp32 accumulation */
 float zo_sqeuclid_f16(const uint16_t *m, const uint16_t *q, size_t dim);
 float zo_ip_f16(const uint16_t *m, const uint16_t *q, size_t dim);

@@ -74,6 +74,22 @@ out["heap_scores"] = np.concatenate(hs)
 out["heap_meta"] = np.array(hl, np.int32)
 out["heap_index"] = np.concatenate(hi)
 out["heap_kept_scores"] = np.concatenate(hv)
+# M x N block kernels (drawn after everything above so that the older arrays keep their values)
+BM, BQ, BL2, BIP, BSHAPE = [], [], [], [], []
+for M, N in ((8, 1), (8, 8), (16, 2), (16, 16), (32, 1), (32, 4), (32, 32)):
+    for d in (1, 3, 17, 128, 769):
+        mb = rng.standard_normal((d, M)).astype(np.float32)
+        qb = (rng.standard_normal((d, N)) * 2 + 0.25).astype(np.float32)
+        BM.append(mb.ravel())
+        BQ.append(qb.ravel())
+        BL2.append(o.block_dist(O.METRIC_L2, mb, qb, use_ref=True).ravel())
+        BIP.append(o.block_dist(O.METRIC_IP, mb, qb, use_ref=True).ravel())
+        BSHAPE.append((M, N, d))
+out["block_shapes"] = np.array(BSHAPE, np.int32)
+out["block_m"] = np.concatenate(BM)
+out["block_q"] = np.concatenate(BQ)
+out["block_l2"] = np.concatenate(BL2)
+out["block_minus_ip"] = np.concatenate(BIP)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_kernel_vectors.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes")

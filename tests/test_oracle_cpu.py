@@ -81,6 +81,28 @@ def test_bit_exact_vs_reference_vectors(oracle, golden_dir):
         io += kept
 
 
+def test_block_kernels_bit_exact_vs_reference_vectors(oracle, golden_dir):
+    """M x N block kernels: the column-major 32-row blocks x interleaved queries the CPU's dense
+    path computes (euclidean_distance_matrix_fp32.cc:323-929, inner_product_matrix_fp32.cc:588-1179), outputs of the
+    compiled reference for seeded blocks; also: a block equals the 1x1 kernel's VALUE only up to summation order,
+    which is why both are restated."""
+    z = np.load(os.path.join(golden_dir, "ref_kernel_vectors.npz"))
+    om = oq = oo = 0
+    for M, N, d in z["block_shapes"]:
+        m = z["block_m"][om:om + d * M].reshape(d, M)
+        q = z["block_q"][oq:oq + d * N].reshape(d, N)
+        l2 = oracle.block_dist(O.METRIC_L2, m, q)
+        ip = oracle.block_dist(O.METRIC_IP, m, q)
+        assert np.array_equal(l2.ravel().view(np.uint32), z["block_l2"][oo:oo + M * N].view(np.uint32)), (M, N, d)
+        assert np.array_equal(ip.ravel().view(np.uint32), z["block_minus_ip"][oo:oo + M * N].view(np.uint32)), (M, N, d)
+        # layout check against plain arithmetic: out[j][i] = sum_k (m[k][i] - q[k][j])^2
+        want = ((m.astype(np.float64)[:, None, :] - q.astype(np.float64)[:, :, None]) ** 2).sum(0)
+        assert np.allclose(l2, want, rtol=1e-5, atol=1e-5)
+        om += d * M
+        oq += d * N
+        oo += M * N
+
+
 def test_live_vs_compiled_reference(oracle):
     if oracle.ref is None:
         pytest.skip("oracle/_ref/libzvec_ref.so not present (or CPU lacks AVX-512)")
@@ -98,6 +120,16 @@ def test_live_vs_compiled_reference(oracle):
             b = (rng.standard_normal(d) * 2).astype(np.float16)
             for m in (O.METRIC_L2, O.METRIC_IP):
                 assert oracle.dist16(m, a, b) == oracle.dist16(m, a, b, use_ref=True), (d, m)
+    for M in (8, 16, 32):                                   # block kernels, every specialised width
+        for N in (1, 2, 4, 8, 16, 32):
+            if N > M:
+                continue
+            for d in (1, 7, 64, 333):
+                mb = rng.standard_normal((d, M)).astype(np.float32)
+                qb = rng.standard_normal((d, N)).astype(np.float32)
+                for m in (O.METRIC_L2, O.METRIC_IP):
+                    assert np.array_equal(oracle.block_dist(m, mb, qb).view(np.uint32),
+                                          oracle.block_dist(m, mb, qb, use_ref=True).view(np.uint32)), (M, N, d, m)
     for _ in range(100):
         n, k = int(rng.integers(1, 400)), int(rng.integers(1, 64))
         s = rng.integers(0, 9, n).astype(np.float32)
