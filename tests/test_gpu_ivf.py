@@ -218,3 +218,34 @@ def test_ivf_ip_and_cosine(zv, oracle, metric_name, metric):
                          what="ivf " + metric_name)
     for p in (0, n - 1):
         assert np.array_equal(se.get_vector_by_id(p), vecs[p])
+
+
+def test_ivf_large_topk_fallback(zv, oracle):
+    """topk beyond the LDS-resident lists of the scan kernel (k > ~470): position expansion + direct scoring.
+    Same index on both sides, integer data => bit-exact scores; includes a filter and a sharded rank."""
+    rng = np.random.default_rng(77)
+    n, dim, nlist, nq, k = 6000, 24, 12, 9, 700
+    base = rng.integers(-9, 10, (n, dim)).astype(np.float32)
+    q = rng.integers(-9, 10, (nq, dim)).astype(np.float32)
+    cent, offs, order = kmeans_lists(rng, base, nlist)
+    vecs, keys = base[order], order.astype(np.uint64)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=0.5, brute_force_threshold=100)
+    assert se.load(cent, offs, vecs, keys) == 0
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys)
+    cd = np.sort(exact_l2(cent, q), 1)
+    sel = np.nonzero(cd[:, nprobe - 1] != cd[:, min(nprobe, nlist - 1)])[0] if nprobe < nlist else np.arange(nq)
+    assert len(sel) > 0
+    tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel], what="ivf large k")
+    # with a filter over list-order positions
+    drop = rng.random(n) < 0.5
+    ex = O.pack_bits(drop)
+    ctx.set_exclude_bitset(ex)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys, exclude_bits=ex)
+    tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel], what="ivf large k filtered")
+    dropped = set(keys[drop].tolist())
+    assert not any(int(x) in dropped for qi in sel for x in ctx.keys[qi, : ctx.counts[qi]])

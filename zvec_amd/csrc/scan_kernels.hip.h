@@ -1812,6 +1812,39 @@ __global__ void __launch_bounds__(256) plan_wave_kernel(const PlanArgs p) {
   }
 }
 
+// Large-k fallback of the IVF search (k beyond the LDS-resident lists of the scan kernel): one wave per query walks
+// its probe ranks with the same probe rule as plan_wave_kernel and either counts the rows it will scan on this shard
+// (FILL = false) or writes their padded positions — excluded rows as holes — for pkeys_score_kernel (FILL = true).
+template <bool FILL>
+__global__ void __launch_bounds__(256) ivf_expand_kernel(const PlanArgs p, const uint32_t *list_tile0, const uint64_t *list_dense0,
+                                                         const uint32_t *exclude, uint32_t *q_rows, const uint32_t *q_off,
+                                                         uint32_t *pos) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= p.nq) return;
+  const uint32_t np = p.brute_force ? p.nlist : min(p.coarse_cnt[q], p.nprobe);
+  uint32_t scanned_before = 0, rows = 0;     // uniform
+  uint32_t o = FILL ? q_off[q] : 0;
+  for (uint32_t rnk = 0; rnk < np; ++rnk) {
+    if (!p.brute_force && scanned_before >= p.max_scan_count) break;
+    const uint32_t l = probe_list(p, q, rnk);
+    scanned_before += p.list_size_global[l];
+    const uint32_t sz = p.list_size[l];
+    if (FILL) {
+      const uint32_t p0 = list_tile0[l] * TILE_N;
+      const uint64_t d0 = list_dense0[l];
+      for (uint32_t j = lane; j < sz; j += 64) {
+        bool ex = false;
+        if (exclude) { const uint64_t d = d0 + j; ex = (exclude[d >> 5] >> (d & 31)) & 1u; }
+        pos[o + j] = ex ? IDX_NONE : p0 + j;
+      }
+      o += sz;
+    }
+    rows += sz;
+  }
+  if (!FILL && lane == 0) q_rows[q] = rows;
+}
+
 // single work-group exclusive scans: slot_begin over queries, list_qoff / item_off over lists
 __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
   __shared__ uint32_t wtot[16];

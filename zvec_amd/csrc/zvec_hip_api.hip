@@ -717,7 +717,62 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   // list scan shape: 16x16x4 MFMA tiles, 32 query rows per work item as two 16-row halves (the second is
   // skipped when the item has <= 16 rows); a list probed by more than 32 queries is dealt as several items
   const int ng = 0;
-  if (scan_lds_bytes(1, topk, true) > LDS_LIMIT - 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (scan_lds_bytes(1, topk, true) > LDS_LIMIT - 1024) {
+    // Large k (beyond ~470): the result lists no longer fit beside the staging buffers.  Rare, so served by the plain
+    // route: expand every query's probed lists into positions, score each (query, row) pair directly, select.
+    if ((size_t)topk * 12 + 16 > 60 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
+    PlanArgs p{};
+    p.coarse_idx = ctx->coarse_idx.as<uint32_t>(); p.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
+    p.nq = count; p.nprobe = nprobe; p.nlist = nlist; p.max_scan_count = max_scan_count; p.brute_force = brute_force;
+    p.list_size = h->d_size; p.list_size_global = h->d_size_global;
+    ZRET(ctx->plan.ensure(((size_t)2 * count + 8) * sizeof(uint32_t)));
+    uint32_t *d_rows = ctx->plan.as<uint32_t>(), *d_off = d_rows + count;
+    // upper bound of the rows one query scans here: the np largest local lists
+    uint64_t maxlen = 0;
+    {
+      std::vector<uint32_t> sz(h->h_size);
+      const uint32_t np = brute_force ? nlist : nprobe;
+      std::partial_sort(sz.begin(), sz.begin() + np, sz.end(), std::greater<uint32_t>());
+      for (uint32_t i = 0; i < np; ++i) maxlen += sz[i];
+    }
+    if (maxlen == 0) maxlen = 1;
+    if ((uint64_t)count * maxlen >= 0xffffffffull) return ZVEC_HIP_ERR_OUT_OF_RANGE;   // (slice the batch)
+    hipLaunchKernelGGL(ivf_expand_kernel<false>, dim3((count + 3) / 4), dim3(256), 0, stream, p, h->d_tile0, h->d_dense0,
+                       nullptr, d_rows, nullptr, nullptr);
+    hipLaunchKernelGGL(u32_exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, d_rows, d_off, count, d_off + count);
+    ZCHK(hipGetLastError());
+    uint32_t total_rows = 0;
+    ZCHK(hipMemcpyAsync(&total_rows, d_off + count, 4, hipMemcpyDeviceToHost, stream));
+    ZCHK(hipStreamSynchronize(stream));
+    Scoped<uint32_t> d_pos;
+    ZRET(d_pos.alloc(std::max<uint32_t>(total_rows, 1)));
+    hipLaunchKernelGGL(ivf_expand_kernel<true>, dim3((count + 3) / 4), dim3(256), 0, stream, p, h->d_tile0, h->d_dense0,
+                       reinterpret_cast<const uint32_t *>(d_exclude), nullptr, d_off, d_pos);
+    ZCHK(hipGetLastError());
+    const uint64_t pairs = (uint64_t)count * maxlen;
+    ZRET(ctx->part_s.ensure(pairs * 4));
+    ZRET(ctx->part_i.ensure(pairs * 4));
+    // (re-prepare the queries with the caller's RNN radius: the coarse pass ran without one)
+    ZRET(prep_queries(ctx, h->lists, d_queries, count, threshold, stream));
+    if (h->lists.f16)
+      hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->lists.base,
+                         ctx->qpad.as<float>(), h->lists.dpad, h->metric, d_pos, d_off, count, (uint32_t)maxlen,
+                         ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->lists.base,
+                         ctx->qpad.as<float>(), h->lists.dpad, h->metric, d_pos, d_off, count, (uint32_t)maxlen,
+                         ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
+    ZCHK(hipGetLastError());
+    MergeArgs m{};
+    m.part_s = ctx->part_s.as<float>(); m.part_i = ctx->part_i.as<uint32_t>();
+    m.slots_per_q = 1; m.slot_stride = 1; m.k = topk; m.slot_len = (uint32_t)maxlen; m.threshold = threshold;
+    m.keymap = h->lists.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
+    hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+    ZCHK(hipGetLastError());
+    ZCHK(hipStreamSynchronize(stream));    // d_pos is freed on return
+    ctx->q_nprobe = nullptr; ctx->q_scanned = nullptr; ctx->last_count = 0;
+    return 0;
+  }
   const uint32_t rows_per_group = 32;
   const uint64_t npairs = (uint64_t)count * (brute_force ? nlist : nprobe);
   // layout of the plan buffer (u32 words)
