@@ -194,6 +194,30 @@ int zvec_hip_ctx_profile(zvec_hip_ctx_t ctx, int enable);
 int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *scan_ms,
                               double *algorithmic_bytes, double *algorithmic_flops, int reset);
 
+/* FlatSearcher::load of the features segment of a dumped flat index (FlatBuilder<32>::write_row_index /
+ * write_column_index, src/core/algorithm/flat/flat_builder.cc:186-276): `count` rows of the handle's element type —
+ * row-major, or (column_major != 0) full `batch_size`-row blocks transposed in units of the element type followed by
+ * a row-major remainder.  keys: the "flat.keys" payload (uint64[count]) or NULL (key = position).  Appends. */
+int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_t bytes, uint64_t count, int column_major,
+                                uint32_t batch_size, const uint64_t *keys);
+
+/* IVFSearcher::load from the raw payloads of the segments a dumped reference index holds (SURVEY next-2):
+ *   inverted_header  "ivf.inverted_header": InvertedIndexHeader (ivf_index_format.h:26-37) + the serialised IndexMeta
+ *                    (IndexMetaFormatHeader, src/core/framework/index_meta.cc:23-34: major order, data type, dimension)
+ *   inverted_meta    "ivf.inverted_meta":   InvertedListMeta[inverted_list_count] (ivf_index_format.h:41-47)
+ *   inverted_body    "ivf.inverted_body":   32-vector blocks per list as IVFDumper writes them (ivf_dumper.cc:19-81,
+ *                    388-406): full blocks of a column-major index transposed, everything else row-major
+ *   keys             "hc.keys":             uint64[total_vector_count] in dump (= list) order
+ *   centroids        [inverted_list_count][dim] rows of the index element type (the features of the nested centroid
+ *                    index "ivf.centroid", which the caller's storage layer opens)
+ * The plugin obtains these blobs from zvec's own IndexStorage (segment->read), exactly as IVFSearcher::load does; the
+ * body is uploaded as it is and re-laid out on the GPU.  Mismatch (-24) when data type / dimension differ from the
+ * handle's, InvalidArgument for inconsistent sizes or offsets.  Parity note: the byte layouts are restated from the
+ * reference's writer code — the reference ships no dumped index to check them against. */
+int zvec_hip_ivf_load_segments(zvec_hip_ivf_t h, const void *inverted_header, uint64_t header_bytes,
+                               const void *inverted_meta, uint64_t meta_bytes, const void *inverted_body,
+                               uint64_t body_bytes, const void *keys, uint64_t keys_bytes, const void *centroids);
+
 /* ---- predicate materialisation --------------------------------------------------------
  * Replaces the per-candidate IndexFilter callback (index_filter.h:48-50) whose producers are
  * DocFilter::is_filtered (src/db/sqlengine/planner/doc_filter.cc:74-87), DeleteStore::Filter

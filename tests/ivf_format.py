@@ -1,0 +1,46 @@
+"""Test-side WRITER of the reference's dumped IVF segments, restated from its writer code (the reference holds no dumped
+index to use as a fixture — parity of the byte layout is unpinned, see include/zvec_hip.h):
+  IVFDumper::dump_inverted_vector / dump_block / dump_inverted_vector_finished   src/core/algorithm/ivf/ivf_dumper.cc:19-32,118-200,388-406
+  IVFDumper::Block::do_emplace / transpose                                       src/core/algorithm/ivf/ivf_dumper.h:131-160
+  InvertedIndexHeader / InvertedListMeta                                         src/core/algorithm/ivf/ivf_index_format.h:26-47
+  IndexMetaFormatHeader                                                          src/core/framework/index_meta.cc:23-34
+"""
+import struct
+
+import numpy as np
+
+DT_FP16, DT_FP32 = 1, 2          # IndexMeta::DataType (index_meta.h:31-41)
+MO_ROW, MO_COLUMN = 1, 2         # IndexMeta::MajorOrder (index_meta.h:45-49)
+
+
+def dump_ivf_segments(lists, dim, dtype=np.float32, column_major=False, block_vector_count=32):
+    """lists: list of (vectors [n_l][dim], keys [n_l]) per inverted list -> dict of segment payloads"""
+    unit = np.dtype(dtype).itemsize
+    elem = dim * unit
+    block_size = (block_vector_count * elem + 31) // 32 * 32
+    body = bytearray()
+    keys = []
+    metas = []
+    total = blocks = 0
+    for vecs, ks in lists:
+        vecs = np.ascontiguousarray(vecs, dtype).reshape(-1, dim)
+        off, id_off, nblk = len(body), total, 0
+        for b0 in range(0, vecs.shape[0], block_vector_count):
+            blk = vecs[b0:b0 + block_vector_count]
+            if column_major and blk.shape[0] == block_vector_count:
+                raw = np.ascontiguousarray(blk.T).tobytes()          # unit u of vector i at (u*bvc + i)*unit
+            else:
+                raw = blk.tobytes()
+            raw += b"\0" * ((len(raw) + 31) // 32 * 32 - len(raw))    # dump_block: ailego_align(bytes, 32)
+            body += raw
+            nblk += 1
+        keys.append(np.asarray(ks, np.uint64))
+        metas.append(struct.pack("<QIII16x4x", off, nblk, vecs.shape[0], id_off))   # sizeof(InvertedListMeta) == 40 (8-byte aligned)
+        total += vecs.shape[0]
+        blocks += nblk
+    index_meta = struct.pack("<9I", 4128, 0, MO_COLUMN if column_major else MO_ROW, DT_FP16 if unit == 2 else DT_FP32,
+                             dim, unit, 0, 0, 0) + b"\0" * 4092
+    header = struct.pack("<IIQIIIII28x", 64 + len(index_meta), total, len(body), len(lists), block_vector_count,
+                         block_size, blocks, len(index_meta)) + index_meta
+    return {"ivf.inverted_header": bytes(header), "ivf.inverted_meta": b"".join(metas), "ivf.inverted_body": bytes(body),
+            "hc.keys": np.concatenate(keys).astype("<u8").tobytes() if keys else b""}

@@ -331,3 +331,29 @@ def test_flat_large_topk(zv, oracle, k):
         s_ = os_[i]
         uniq = np.concatenate([[True], np.diff(s_) != 0]) & np.concatenate([np.diff(s_) != 0, [True]])
         assert np.array_equal(ctx.keys[i][uniq], ok[i][uniq])
+
+
+@pytest.mark.parametrize("dtype,column_major,n,dim", [(np.float32, True, 100, 12), (np.float32, False, 70, 9), (np.float16, True, 64, 10),
+                                                        (np.float16, True, 31, 5)])
+def test_flat_load_features_segment(zv, dtype, column_major, n, dim):
+    """the features segment of a dumped flat index (flat_builder.cc:186-276): full 32-row blocks transposed for a
+    column-major index, a row-major remainder, padding to 32 bytes — restated writer, layout parity unpinned."""
+    rng = np.random.default_rng(n)
+    base = rng.integers(-9, 10, (n, dim)).astype(dtype)
+    keys = rng.permutation(5 * n)[:n].astype(np.uint64)
+    blob = bytearray()
+    for b0 in range(0, n, 32):
+        blk = base[b0:b0 + 32]
+        blob += (np.ascontiguousarray(blk.T) if (column_major and blk.shape[0] == 32) else blk).tobytes()
+    blob += b"\0" * ((len(blob) + 31) // 32 * 32 - len(blob))
+    dt = "fp16" if dtype == np.float16 else "fp32"
+    a = zv.HipFlatSearcher(dim, "SquaredEuclidean", dtype=dt)
+    assert a.load_features(bytes(blob), n, column_major=column_major, keys=keys) == 0
+    b = zv.HipFlatSearcher(dim, "SquaredEuclidean", dtype=dt)
+    assert b.load(base, keys) == 0
+    for pos in (0, 1, 30, n // 2, n - 1):
+        assert np.array_equal(a.get_vector_by_id(pos).view(np.uint8), base[pos].view(np.uint8))
+    q = rng.integers(-9, 10, (5, dim)).astype(dtype)
+    ra, rb = _search(a, q, 7), _search(b, q, 7)
+    assert all(np.array_equal(x, y) for x, y in zip(ra[:3], rb[:3]))
+    assert a.load_features(bytes(blob)[: n * dim * base.itemsize - 1], n, column_major=column_major) == zv.IndexError_.InvalidArgument

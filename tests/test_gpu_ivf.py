@@ -249,3 +249,48 @@ def test_ivf_large_topk_fallback(zv, oracle):
     tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel], what="ivf large k filtered")
     dropped = set(keys[drop].tolist())
     assert not any(int(x) in dropped for qi in sel for x in ctx.keys[qi, : ctx.counts[qi]])
+
+
+@pytest.mark.parametrize("dtype,column_major,dim", [(np.float32, False, 24), (np.float32, True, 20), (np.float16, True, 18),
+                                                     (np.float16, False, 7)])
+def test_ivf_load_from_reference_segments(zv, oracle, dtype, column_major, dim):
+    """zvec_hip_ivf_load_segments: the dumped-index segment payloads (tests/ivf_format.py restates the reference's writer)
+    give the same device index as loading the same lists from arrays: identical export, vectors and search results."""
+    from tests.ivf_format import dump_ivf_segments
+    rng = np.random.default_rng(dim)
+    nlist = 9
+    sizes = [0, 1, 31, 32, 33, 64, 100, 257, 5]                      # empty list, partial / exact / multi-block lists
+    n = sum(sizes)
+    base = rng.integers(-9, 10, (n, dim)).astype(dtype)
+    keys = rng.permutation(10 * n)[:n].astype(np.uint64)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    cent = np.stack([base[int(offs[l]):int(offs[l + 1])].astype(np.float32).mean(0) if sizes[l] else np.full(dim, 50.0)
+                     for l in range(nlist)]).astype(dtype)
+    lists = [(base[int(offs[l]):int(offs[l + 1])], keys[int(offs[l]):int(offs[l + 1])]) for l in range(nlist)]
+    seg = dump_ivf_segments(lists, dim, dtype, column_major)
+    dt = "fp16" if dtype == np.float16 else "fp32"
+    a = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=0.5, brute_force_threshold=10, dtype=dt)
+    assert a.load_segments(seg["ivf.inverted_header"], seg["ivf.inverted_meta"], seg["ivf.inverted_body"], seg["hc.keys"], cent) == 0
+    b = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=0.5, brute_force_threshold=10, dtype=dt)
+    assert b.load(cent, offs, base, keys) == 0
+    ca, oa, ra = a.export()
+    cb, ob, rb = b.export()
+    assert np.array_equal(ca, cb) and np.array_equal(oa, ob) and np.array_equal(ra, rb)
+    for pos in (0, 1, 31, 32, 33, 95, 200, n - 1):
+        assert np.array_equal(a.get_vector_by_id(pos).view(np.uint8), base[pos].view(np.uint8))
+    q = rng.integers(-9, 10, (17, dim)).astype(dtype)
+    res = []
+    for se in (a, b):
+        ctx = se.create_context()
+        ctx.set_topk(12)
+        assert se.search_impl(q, 17, ctx) == 0
+        res.append((ctx.keys.copy(), ctx.scores.copy(), ctx.counts.copy()))
+    assert all(np.array_equal(x, y) for x, y in zip(res[0], res[1]))
+    # rejected: truncated body, wrong dimension, inconsistent list table
+    assert a.load_segments(seg["ivf.inverted_header"], seg["ivf.inverted_meta"], seg["ivf.inverted_body"][:-64], seg["hc.keys"], cent) \
+        == zv.IndexError_.InvalidArgument
+    wrong = zv.HipIVFSearcher(dim + 1, "SquaredEuclidean", dtype=dt)
+    assert wrong.load_segments(seg["ivf.inverted_header"], seg["ivf.inverted_meta"], seg["ivf.inverted_body"], seg["hc.keys"],
+                               np.zeros((nlist, dim + 1), dtype)) == zv.IndexError_.Mismatch
+    assert a.load_segments(seg["ivf.inverted_header"], seg["ivf.inverted_meta"][40:] + seg["ivf.inverted_meta"][:40],
+                           seg["ivf.inverted_body"], seg["hc.keys"], cent) == zv.IndexError_.InvalidArgument

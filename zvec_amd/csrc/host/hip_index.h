@@ -40,14 +40,15 @@ enum : int {
 };
 
 struct IndexMeta {
-  enum DataType { DT_UNDEFINED = 0, DT_FP32 = 1 };
+  enum DataType { DT_UNDEFINED = 0, DT_FP16 = 1, DT_FP32 = 2 };   // values of index_meta.h:31-41
+  static uint32_t unit_size(DataType t) { return t == DT_FP16 ? 2u : 4u; }
   IndexMeta() {}
   IndexMeta(DataType t, uint32_t dim) : type_(t), dimension_(dim) {}
   void set_metric(const std::string &name, uint32_t /*revision*/ = 0) { metric_ = name; }
   const std::string &metric_name() const { return metric_; }
   DataType data_type() const { return type_; }
   uint32_t dimension() const { return dimension_; }
-  uint32_t element_size() const { return dimension_ * 4u; }
+  uint32_t element_size() const { return dimension_ * unit_size(type_); }
   DataType type_{DT_FP32};
   uint32_t dimension_{0};
   std::string metric_{"SquaredEuclidean"};
@@ -57,7 +58,7 @@ struct IndexQueryMeta {
   IndexQueryMeta() {}
   IndexQueryMeta(IndexMeta::DataType t, uint32_t dim) : type_(t), dimension_(dim) {}
   uint32_t dimension() const { return dimension_; }
-  uint32_t element_size() const { return dimension_ * 4u; }
+  uint32_t element_size() const { return dimension_ * IndexMeta::unit_size(type_); }
   IndexMeta::DataType data_type() const { return type_; }
   IndexMeta::DataType type_{IndexMeta::DT_FP32};
   uint32_t dimension_{0};
@@ -176,14 +177,15 @@ class HipFlatStreamer {
   int init(const IndexMeta &meta, const Params & /*params*/) {
     meta_ = meta;
     metric_ = metric_from_name(meta.metric_name());
-    if (metric_ < 0 || meta.data_type() != IndexMeta::DT_FP32) return IndexError_Unsupported;
+    if (metric_ < 0 || (meta.data_type() != IndexMeta::DT_FP32 && meta.data_type() != IndexMeta::DT_FP16)) return IndexError_Unsupported;
     return 0;
   }
   int open(int device = 0) {
     device_ = device;
     static uint32_t next_magic = 0x48495031u;
     magic_ = next_magic++;
-    return zvec_hip_flat_create(meta_.dimension(), ZVEC_HIP_DT_FP32, metric_, device, &h_);
+    return zvec_hip_flat_create(meta_.dimension(), meta_.data_type() == IndexMeta::DT_FP16 ? ZVEC_HIP_DT_FP16 : ZVEC_HIP_DT_FP32,
+                                metric_, device, &h_);
   }
   int close() { int rc = h_ ? zvec_hip_flat_destroy(h_) : 0; h_ = nullptr; return rc; }
   const IndexMeta &meta() const { return meta_; }
@@ -271,15 +273,17 @@ class HipIVFSearcher {
     return 0;
   }
   //! what IVFSearcher::load reads from the ivf.* segments (ivf_index_format.h:26-60,152-164)
-  int load(const IndexMeta &meta, const float *centroids, uint32_t nlist, const uint64_t *list_offsets,
-           const float *vecs, const uint64_t *keys, int device = 0) {
+  // centroids / vecs: rows of meta.data_type() elements (fp32 or fp16)
+  int load(const IndexMeta &meta, const void *centroids, uint32_t nlist, const uint64_t *list_offsets,
+           const void *vecs, const uint64_t *keys, int device = 0) {
     meta_ = meta;
     int metric = metric_from_name(meta.metric_name());
-    if (metric < 0) return IndexError_Unsupported;
+    if (metric < 0 || (meta.data_type() != IndexMeta::DT_FP32 && meta.data_type() != IndexMeta::DT_FP16)) return IndexError_Unsupported;
     device_ = device;
     static uint32_t next_magic = 0x49564631u;
     magic_ = next_magic++;
-    int rc = zvec_hip_ivf_create(meta.dimension(), ZVEC_HIP_DT_FP32, metric, device, &h_);
+    int rc = zvec_hip_ivf_create(meta.dimension(), meta.data_type() == IndexMeta::DT_FP16 ? ZVEC_HIP_DT_FP16 : ZVEC_HIP_DT_FP32,
+                                 metric, device, &h_);
     if (rc != 0) return rc;
     rc = zvec_hip_ivf_load(h_, centroids, nlist, list_offsets, vecs, keys);
     if (rc != 0) return rc;

@@ -1004,6 +1004,42 @@ int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n, 
   return store_append_dev(h->st, d_vecs, n, d_keys, s);
 }
 
+// FlatSearcher::load of a dumped "flat.features"-style segment (FlatBuilder<32>::write_row_index / write_column_index,
+// src/core/algorithm/flat/flat_builder.cc:186-276): [count][dim] rows, or — column-major index — full 32-row blocks
+// transposed in units of the element type followed by a row-major remainder.  Appended to the store on the GPU.
+int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_t bytes, uint64_t count, int column_major,
+                                uint32_t batch_size, const uint64_t *keys) {
+  if (!h || (!features && count) || batch_size == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  const uint64_t elem = h->st.row_bytes();
+  if (bytes < count * elem) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = h->defctx->own;
+  Scoped<uint8_t> d_body;
+  Scoped<char> d_rows;
+  Scoped<uint64_t> d_tab, d_keys;
+  ZRET(d_body.alloc(count * elem));
+  ZRET(d_rows.alloc(count * elem));
+  ZRET(d_tab.alloc(3));
+  const uint64_t tab[3] = {0, 0, count};                     // list_off[0]; row0[0], row0[1]
+  ZCHK(hipMemcpyAsync(d_body, features, count * elem, hipMemcpyHostToDevice, s));
+  ZCHK(hipMemcpyAsync(d_tab, tab, sizeof(tab), hipMemcpyHostToDevice, s));
+  if (keys) {
+    ZRET(d_keys.alloc(count));
+    ZCHK(hipMemcpyAsync(d_keys, keys, count * 8, hipMemcpyHostToDevice, s));
+  }
+  IvfBodyArgs a{};
+  a.body = d_body; a.list_off = d_tab; a.list_row0 = static_cast<uint64_t *>(d_tab) + 1; a.nlist = 1; a.bvc = batch_size;
+  a.block_size = (uint32_t)(batch_size * elem); a.elem_size = (uint32_t)elem; a.unit = h->st.elem; a.column_major = column_major ? 1u : 0u;
+  a.rows = reinterpret_cast<uint8_t *>(static_cast<char *>(d_rows)); a.total = count;
+  hipLaunchKernelGGL(ivf_body_rows_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, a);
+  ZCHK(hipGetLastError());
+  int rc = store_append_dev(h->st, d_rows, count, keys ? static_cast<const uint64_t *>(d_keys) : nullptr, s);
+  ZCHK(hipStreamSynchronize(s));
+  return rc;
+}
+
 int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const uint64_t *keys) {
   if (!h || (!vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (n == 0) return 0;
@@ -1318,6 +1354,95 @@ int zvec_hip_ivf_load(zvec_hip_ivf_t h, const void *centroids, uint32_t nlist, c
   }
   if (h->loaded) ivf_release(h);
   return ivf_pack(h, d_rows, n, keys, labels, centroids, nlist, s);
+}
+
+namespace {
+// ivf_index_format.h:26-37 / :41-47 and index_meta.cc:23-34, as plain structs of the same layout
+struct RefInvertedIndexHeader {
+  uint32_t header_size, total_vector_count;
+  uint64_t inverted_body_size;
+  uint32_t inverted_list_count, block_vector_count, block_size, block_count, index_meta_size;
+  char reserved_[28];
+};
+static_assert(sizeof(RefInvertedIndexHeader) == 64, "InvertedIndexHeader is 64 bytes");
+struct RefInvertedListMeta {
+  uint64_t offset;
+  uint32_t block_count, vector_count, id_offset;
+  char reserved_[16];
+};
+static_assert(sizeof(RefInvertedListMeta) == 40, "InvertedListMeta is 40 bytes");
+struct RefIndexMetaHeader {
+  uint32_t header_size, meta_type, major_order, data_type, dimension, unit_size, space_id, attachment_offset, attachment_size;
+};
+}  // namespace
+
+int zvec_hip_ivf_load_segments(zvec_hip_ivf_t h, const void *inverted_header, uint64_t header_bytes,
+                               const void *inverted_meta, uint64_t meta_bytes, const void *inverted_body,
+                               uint64_t body_bytes, const void *keys, uint64_t keys_bytes, const void *centroids) {
+  if (!h || !inverted_header || !inverted_meta || !centroids) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (header_bytes < sizeof(RefInvertedIndexHeader) + sizeof(RefIndexMetaHeader)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  RefInvertedIndexHeader hd;
+  memcpy(&hd, inverted_header, sizeof(hd));
+  RefIndexMetaHeader im;
+  memcpy(&im, static_cast<const char *>(inverted_header) + sizeof(hd), sizeof(im));
+  // IndexMeta::DataType: DT_FP16 = 1, DT_FP32 = 2 (index_meta.h:31-41); MajorOrder: MO_ROW = 1, MO_COLUMN = 2 (:45-49)
+  const int dtype = im.data_type == 1 ? ZVEC_HIP_DT_FP16 : (im.data_type == 2 ? ZVEC_HIP_DT_FP32 : -1);
+  if (dtype < 0) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (dtype != h->dtype || im.dimension != h->dim) return ZVEC_HIP_ERR_MISMATCH;
+  const uint32_t nlist = hd.inverted_list_count, bvc = hd.block_vector_count;
+  const uint64_t total = hd.total_vector_count;
+  const uint32_t unit = dtype == ZVEC_HIP_DT_FP16 ? 2u : 4u;
+  const uint64_t elem = (uint64_t)h->dim * unit;
+  if (nlist == 0 || bvc == 0 || meta_bytes < (uint64_t)nlist * sizeof(RefInvertedListMeta)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (total && (!inverted_body || !keys || keys_bytes < total * 8)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  const uint64_t block_size = (bvc * elem + 31) / 32 * 32;                   // IVFUtility::AlignedSize
+  if (hd.block_size != 0 && hd.block_size != block_size) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  const bool column_major = im.major_order == 2;
+  std::vector<uint64_t> list_off(nlist), row0(nlist + 1), list_offsets(nlist + 1);
+  uint64_t seen = 0;
+  for (uint32_t l = 0; l < nlist; ++l) {
+    RefInvertedListMeta m;
+    memcpy(&m, static_cast<const char *>(inverted_meta) + (size_t)l * sizeof(m), sizeof(m));
+    if (m.id_offset != seen) return ZVEC_HIP_ERR_INVALID_ARGUMENT;          // lists are dumped in id order, back to back
+    const uint64_t full = m.vector_count / bvc, rem = m.vector_count % bvc;
+    const uint64_t bytes = full * block_size + (rem ? (rem * elem + 31) / 32 * 32 : 0);
+    if (m.vector_count && (m.offset > body_bytes || bytes > body_bytes - m.offset)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+    list_off[l] = m.offset;
+    row0[l] = seen;
+    list_offsets[l] = seen;
+    seen += m.vector_count;
+  }
+  row0[nlist] = seen;
+  list_offsets[nlist] = seen;
+  if (seen != total) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = h->defctx->own;
+  Scoped<char> d_rows;
+  if (total) {
+    Scoped<uint8_t> d_body;
+    Scoped<uint64_t> d_off, d_row0;
+    ZRET(d_body.alloc(body_bytes));
+    ZRET(d_off.alloc(nlist));
+    ZRET(d_row0.alloc(nlist + 1));
+    ZRET(d_rows.alloc((size_t)total * elem));
+    ZCHK(hipMemcpyAsync(d_body, inverted_body, body_bytes, hipMemcpyHostToDevice, s));
+    ZCHK(hipMemcpyAsync(d_off, list_off.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, s));
+    ZCHK(hipMemcpyAsync(d_row0, row0.data(), ((size_t)nlist + 1) * 8, hipMemcpyHostToDevice, s));
+    IvfBodyArgs a{};
+    a.body = d_body; a.list_off = d_off; a.list_row0 = d_row0; a.nlist = nlist; a.bvc = bvc; a.block_size = (uint32_t)block_size;
+    a.elem_size = (uint32_t)elem; a.unit = unit; a.column_major = column_major ? 1u : 0u;
+    a.rows = reinterpret_cast<uint8_t *>(static_cast<char *>(d_rows)); a.total = total;
+    hipLaunchKernelGGL(ivf_body_rows_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, a);
+    ZCHK(hipGetLastError());
+    ZCHK(hipStreamSynchronize(s));      // the uploaded body and tables are freed here
+  }
+  std::vector<uint32_t> labels(total);
+  for (uint32_t l = 0; l < nlist; ++l)
+    for (uint64_t i = list_offsets[l]; i < list_offsets[l + 1]; ++i) labels[i] = l;
+  if (h->loaded) ivf_release(h);
+  return ivf_pack(h, d_rows, total, static_cast<const uint64_t *>(keys), labels, centroids, nlist, s);
 }
 
 int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, const uint64_t *keys, uint32_t nlist,

@@ -368,7 +368,20 @@ class HipFlatStreamer(_FlatBase):
         return self.add_batch(np.asarray(vec, self.np_dtype).reshape(1, -1), np.array([key], np.uint64))
 
 
-class HipFlatSearcher(_FlatBase):
+class _FlatFeatures:
+    def load_features(self, features, count, column_major=False, batch_size=32, keys=None):
+        """the features segment of a dumped flat index (FlatBuilder write_row_index / write_column_index layouts)"""
+        fb = bytes(features)
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        n0 = self.count()
+        rc = _lib.lib().zvec_hip_flat_load_features(self._h, fb, len(fb), int(count), int(bool(column_major)), int(batch_size),
+                                                    _np_ptr(k))
+        if rc == 0:
+            self._keys_host.append(np.arange(n0, n0 + int(count), dtype=np.uint64) if k is None else k.copy())
+        return rc
+
+
+class HipFlatSearcher(_FlatBase, _FlatFeatures):
     """stands where "FlatSearcher" is registered (flat_searcher.cc:247-250): load once, search."""
 
     def load(self, vecs, keys=None):
@@ -419,6 +432,18 @@ class HipIVFSearcher:
         if rc == 0:
             self.total_count = int(lo[-1])
             self._orig_keys = k
+            self._list_keys = None
+        return rc
+
+    def load_segments(self, inverted_header, inverted_meta, inverted_body, keys, centroids):
+        """IVFSearcher::load from the raw segment payloads of a dumped reference index (bytes objects: "ivf.inverted_header",
+        "ivf.inverted_meta", "ivf.inverted_body", "hc.keys") + the centroid rows; see zvec_hip_ivf_load_segments."""
+        cent = np.ascontiguousarray(centroids, self.np_dtype)
+        hb, mb, bb, kb = bytes(inverted_header), bytes(inverted_meta), bytes(inverted_body), bytes(keys)
+        rc = _lib.lib().zvec_hip_ivf_load_segments(self._h, hb, len(hb), mb, len(mb), bb, len(bb), kb, len(kb), _np_ptr(cent))
+        if rc == 0:
+            self.total_count = len(kb) // 8
+            self._orig_keys = np.frombuffer(kb, np.uint64, self.total_count).copy()
             self._list_keys = None
         return rc
 
