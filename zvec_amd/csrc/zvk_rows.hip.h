@@ -1,0 +1,216 @@
+// zvk_rows.hip.h — row movement between plain and blocked layouts, query preparation, resets, L2 refinement.
+// Part of the device code of libzvec_hip (included through scan_kernels.hip.h).
+#pragma once
+#include "zvk_common.hip.h"
+
+namespace zvk {
+
+// ---------------------------------------------------------------------------------------------
+// data-movement kernels
+// ---------------------------------------------------------------------------------------------
+// element (pos, e) of a blocked store whose rows hold fp32 (F16=false) or halves (F16=true); dpadw = words/row
+template <bool F16>
+__device__ __forceinline__ float load_elem(const float *base, uint64_t pos, uint32_t e, uint32_t dpadw) {
+  if constexpr (F16) {
+    const _Float16 *h = reinterpret_cast<const _Float16 *>(base);
+    return (float)h[blocked_offset(pos, e >> 1, dpadw) * 2 + (e & 1)];
+  } else {
+    return base[blocked_offset(pos, e, dpadw)];
+  }
+}
+template <bool F16>
+__device__ __forceinline__ void store_elem(float *base, uint64_t pos, uint32_t e, uint32_t dpadw, float v) {
+  if constexpr (F16) {
+    _Float16 *h = reinterpret_cast<_Float16 *>(base);
+    h[blocked_offset(pos, e >> 1, dpadw) * 2 + (e & 1)] = (_Float16)v;    // exact: v came from a half
+  } else {
+    base[blocked_offset(pos, e, dpadw)] = v;
+  }
+}
+template <bool F16>
+__device__ __forceinline__ float load_row_elem(const void *rows, size_t row, uint32_t dim_in, uint32_t c) {
+  if constexpr (F16) return (float)reinterpret_cast<const _Float16 *>(rows)[row * dim_in + c];
+  else return reinterpret_cast<const float *>(rows)[row * dim_in + c];
+}
+
+// one wave per row: rows [n][dim_in] (row-major, fp32 or fp16) -> blocked store at positions pos0 + i
+// (or dst_pos[i]); writes the squared norm of the scanned dims (fp32); zero-fills the k padding.
+template <bool F16>
+__global__ void __launch_bounds__(256) pack_rows_kernel(const void *src, uint64_t n, uint32_t dim_in,
+                                                        uint32_t dscan, uint32_t dpadw,
+                                                        const uint64_t *src_row,   // nullable gather
+                                                        uint64_t pos0, const uint64_t *dst_pos,
+                                                        float *base, float *bnorm, float *extra /*cosine norm*/) {
+  const int lane = threadIdx.x & 63;
+  uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  uint64_t sr = src_row ? src_row[i] : i;
+  uint64_t pos = dst_pos ? dst_pos[i] : pos0 + i;
+  const uint32_t nelem = dpadw * (F16 ? 2u : 1u);
+  float acc = 0.f;
+  for (uint32_t c = lane; c < nelem; c += 64) {
+    float v = (c < dscan) ? load_row_elem<F16>(src, sr, dim_in, c) : 0.f;
+    store_elem<F16>(base, pos, c, dpadw, v);
+    acc = fmaf(v, v, acc);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) {
+    if (bnorm) bnorm[pos] = acc;
+    if (extra) {
+      // the stored norm column: one float, or (fp16 rows) the two half slots that hold its bits
+      if constexpr (F16) {
+        const uint16_t *h = reinterpret_cast<const uint16_t *>(src) + sr * dim_in + dscan;
+        extra[pos] = (dim_in >= dscan + 2) ? __builtin_bit_cast(float, (uint32_t)h[0] | ((uint32_t)h[1] << 16)) : 0.f;
+      } else {
+        extra[pos] = (dim_in > dscan) ? load_row_elem<F16>(src, sr, dim_in, dscan) : 0.f;
+      }
+    }
+  }
+}
+
+// queries [nq][dim_in] (fp32 or fp16) -> padded row-major [nq][dpadw words] of the same element type + squared norms
+template <bool F16>
+__global__ void __launch_bounds__(256) prep_queries_kernel(const void *src, uint32_t nq, uint32_t dim_in,
+                                                           uint32_t dscan, uint32_t dpadw, float *dst,
+                                                           float *qnorm, uint32_t *gtau, float threshold) {
+  const int lane = threadIdx.x & 63;
+  uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= nq) return;
+  const uint32_t nelem = dpadw * (F16 ? 2u : 1u);
+  float acc = 0.f;
+  for (uint32_t c = lane; c < nelem; c += 64) {
+    float v = (c < dscan) ? load_row_elem<F16>(src, i, dim_in, c) : 0.f;
+    if constexpr (F16) reinterpret_cast<_Float16 *>(dst)[(size_t)i * nelem + c] = (_Float16)v;
+    else dst[(size_t)i * dpadw + c] = v;
+    acc = fmaf(v, v, acc);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) {
+    qnorm[i] = acc;
+    gtau[i] = fkey(threshold);
+  }
+}
+
+// blocked row -> plain row (get_vector_by_id), in the store's element type
+template <bool F16>
+__global__ void unpack_row_kernel(const float *base, const float *extra, uint64_t pos, uint32_t dscan,
+                                  uint32_t dim_out, uint32_t dpadw, void *out) {
+  for (uint32_t c = threadIdx.x; c < dim_out; c += blockDim.x) {
+    if constexpr (F16) {
+      if (c < dscan) {
+        reinterpret_cast<_Float16 *>(out)[c] = (_Float16)load_elem<F16>(base, pos, c, dpadw);
+      } else {                                        // the norm's bits, low half first
+        const uint32_t bits = extra ? __builtin_bit_cast(uint32_t, extra[pos]) : 0u;
+        reinterpret_cast<uint16_t *>(out)[c] = (uint16_t)(c == dscan ? bits : bits >> 16);
+      }
+    } else {
+      reinterpret_cast<float *>(out)[c] = (c < dscan) ? load_elem<F16>(base, pos, c, dpadw) : (extra ? extra[pos] : 0.f);
+    }
+  }
+}
+
+// one launch instead of two memsets + fill_gtau before the IVF plan: zero `nzero` plan words (list_count, list_fill),
+// zero the 4 work-queue words, reset the shared bounds of `nq` queries to the threshold
+// ... and set this search's chunk length of every list: `tpc` tiles, a quarter of that for the lists flagged as the tail
+__global__ void ivf_reset_kernel(uint32_t *zero0, uint32_t nzero, uint32_t *queue, uint32_t *gtau, uint32_t nq, float threshold,
+                                 uint32_t *list_tpc, const uint32_t *list_tail, uint32_t nlist, uint32_t tpc) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nzero) zero0[i] = 0;
+  if (i < 4) queue[i] = 0;
+  if (i < nq) gtau[i] = fkey(threshold);
+  if (i < nlist) list_tpc[i] = list_tail[i] ? max(1u, tpc >> 2) : tpc;
+}
+
+// gtau[q] = min(gtau[q], k-th score of a sample scan, nudged up by ~1e-6 relative) — only for full sample lists.
+// The k-th best score of ANY subset of the rows bounds the final k-th score from above, so starting every
+// work-group of the main scan at that bound drops nothing it could keep; it only spares the list warm-up.
+__global__ void seed_gtau_kernel(uint32_t *gtau, const float *scores, const uint32_t *counts, uint32_t n, uint32_t k) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || counts[i] < k) return;
+  const float s = scores[(size_t)i * k + (k - 1)];
+  const float b = s + fabsf(s) * 1e-6f + 1e-30f;
+  if (b == b) atomicMin(&gtau[i], fkey(b));
+}
+
+__global__ void fill_keys_kernel(uint64_t *keys, uint64_t pos0, uint64_t n, const uint64_t *src) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[pos0 + i] = src ? src[i] : pos0 + i;
+}
+
+// bitset widening is not needed: the API bitset is uint64 words, bit i of word i/64 == bit (i&31) of
+// 32-bit word i/32 on a little-endian host/device, so the kernel reads it as uint32 words directly.
+
+// ---------------------------------------------------------------------------------------------
+// L2 refinement of the final lists.  The scan forms squared distances as |q|^2 + |b|^2 - 2 q.b on the
+// matrix cores, whose rounding error scales with the NORMS; the reference sums (q-b)^2 directly
+// (euclidean_distance_matrix_fp32.cc:229-283), whose error scales with the DISTANCE (an identical vector
+// scores exactly 0).  The k winners of every query are therefore re-scored directly (one wave per
+// (query, result): a 3 KiB gather each, ~30 MB per 1024x10 batch) and the list is re-sorted by the
+// refined score, previous rank breaking ties.
+// ---------------------------------------------------------------------------------------------
+template <bool F16>
+__global__ void __launch_bounds__(256) rescore_l2_kernel(const float *base, const float *queries, uint32_t dpadw,
+                                                         const uint32_t *idx, const uint32_t *counts, uint32_t nq,
+                                                         uint32_t k, float *scores) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (uint64_t)nq * k) return;
+  const uint32_t q = (uint32_t)(w / k), j = (uint32_t)(w - (uint64_t)q * k);
+  if (j >= counts[q]) return;
+  const uint32_t id = idx[w];
+  const uint32_t nelem = dpadw * (F16 ? 2u : 1u);
+  float acc = 0.f;
+  for (uint32_t c = lane; c < nelem; c += 64) {
+    float x;
+    if constexpr (F16) x = (float)reinterpret_cast<const _Float16 *>(queries)[(size_t)q * nelem + c];
+    else x = queries[(size_t)q * dpadw + c];
+    const float d = x - load_elem<F16>(base, id, c, dpadw);
+    acc = fmaf(d, d, acc);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) scores[w] = acc;
+}
+
+// one wave per query: stable re-sort of (score, key, idx) by score through LDS
+__global__ void __launch_bounds__(64) resort_kernel(uint64_t *keys, float *scores, uint32_t *idx, uint32_t *counts,
+                                                    uint32_t k, float threshold) {
+  extern __shared__ f32x4 zvk_smem4[];
+  float *S = reinterpret_cast<float *>(zvk_smem4);            // [k]
+  uint32_t *I = reinterpret_cast<uint32_t *>(S + k);          // [k]
+  uint64_t *K = reinterpret_cast<uint64_t *>(I + k + (k & 1)); // [k], 8-byte aligned
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  const uint32_t c = counts[q];
+  for (uint32_t j = lane; j < c; j += 64) {
+    S[j] = scores[(size_t)q * k + j];
+    I[j] = idx[(size_t)q * k + j];
+    K[j] = keys[(size_t)q * k + j];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t j = lane; j < c; j += 64) {
+    const float v = S[j];
+    uint32_t rank = 0;
+    for (uint32_t u = 0; u < c; ++u) {
+      const float w = S[u];
+      rank += (w < v || (w == v && u < j)) ? 1u : 0u;
+    }
+    const size_t o = (size_t)q * k + rank;
+    scores[o] = v;
+    idx[o] = I[j];
+    keys[o] = K[j];
+  }
+  // RNN radius on the refined score: results past the threshold are cut (topk_to_result,
+  // ivf_searcher_context.h:184-208 / flat_streamer_context.h)
+  uint32_t keep = 0;
+  for (uint32_t j0 = 0; j0 < c; j0 += 64) {
+    const uint32_t j = j0 + lane;
+    keep += (uint32_t)__popcll(__ballot(j < c && S[j] <= threshold));
+  }
+  if (lane == 0 && keep != c) counts[q] = keep;
+}
+
+}  // namespace zvk
