@@ -218,6 +218,15 @@ int zvec_hip_ivf_load_segments(zvec_hip_ivf_t h, const void *inverted_header, ui
                                const void *inverted_meta, uint64_t meta_bytes, const void *inverted_body,
                                uint64_t body_bytes, const void *keys, uint64_t keys_bytes, const void *centroids);
 
+/* Query reformers on the device, for callers that keep raw fp32 query batches in HBM:
+ *   cosine != 0: CosineReformer::transform (src/core/quantizer/cosine_reformer.cc:66-112) — q/||q|| followed by ||q||
+ *                (out rows: dim+1 floats, or dim+2 halves with the norm's bytes in the last two slots);
+ *   out_dtype == ZVEC_HIP_DT_FP16: HalfFloatReformer (round to nearest even).
+ * d_in: [count][dim] fp32, d_out: device buffer of count rows of the output width.  Bit-identical to the reference's
+ * AVX-512 host code (norm summation order, correctly rounded sqrt / divide). */
+int zvec_hip_reform_queries_dev(zvec_hip_ctx_t ctx, const float *d_in, uint32_t count, uint32_t dim, int cosine,
+                                int out_dtype, void *d_out, void *stream);
+
 /* ---- predicate materialisation --------------------------------------------------------
  * Replaces the per-candidate IndexFilter callback (index_filter.h:48-50) whose producers are
  * DocFilter::is_filtered (src/db/sqlengine/planner/doc_filter.cc:74-87), DeleteStore::Filter

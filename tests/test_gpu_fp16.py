@@ -124,3 +124,30 @@ def test_fp16_cosine_rows(zv, oracle, n, dim, nq, k):
         assert np.array_equal(se.get_vector_by_id(pos).view(np.uint16), base[pos].view(np.uint16))
     with pytest.raises(RuntimeError):
         zv.HipFlatSearcher(2, "Cosine", dtype="fp16")     # no room for a dimension besides the norm slots
+
+
+@pytest.mark.parametrize("dim", [1, 7, 16, 17, 31, 32, 33, 48, 100, 768, 769])
+def test_device_reformers_bit_exact(zv, oracle, dim):
+    """CosineReformer::transform / HalfFloatReformer on the GPU against the oracle's restatement of the host code
+    (cosine_reformer.cc:66-112, Norm2 in the AVX-512 order, FloatHelper::ToFP16): identical bits."""
+    import torch
+    rng = np.random.default_rng(dim)
+    nq = 37
+    q = (rng.standard_normal((nq, dim)) * rng.uniform(0.1, 30, (nq, 1))).astype(np.float32)
+    q[3] = 0.0                                              # zero vector: norm 0, left unnormalised
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(q).to(dev)
+    ctx = zv.IndexContext()
+    out32 = torch.zeros((nq, dim + 1), dtype=torch.float32, device=dev)
+    ctx.reform_queries_dev(d_in.data_ptr(), nq, dim, out32.data_ptr(), cosine=True, out_dtype="fp32")
+    out16 = torch.zeros((nq, dim + 2), dtype=torch.float16, device=dev)
+    ctx.reform_queries_dev(d_in.data_ptr(), nq, dim, out16.data_ptr(), cosine=True, out_dtype="fp16")
+    half = torch.zeros((nq, dim), dtype=torch.float16, device=dev)
+    ctx.reform_queries_dev(d_in.data_ptr(), nq, dim, half.data_ptr(), cosine=False, out_dtype="fp16")
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    want32 = oracle.cosine_transform(q)
+    assert np.array_equal(out32.cpu().numpy().view(np.uint32), want32.view(np.uint32))
+    assert np.array_equal(out16.cpu().numpy().view(np.uint16), oracle.cosine_transform16(q).view(np.uint16))
+    with np.errstate(over="ignore"):
+        assert np.array_equal(half.cpu().numpy().view(np.uint16), q.astype(np.float16).view(np.uint16))

@@ -75,6 +75,7 @@ SYMBOLS = {
                                                  _u64p, _f32p, _u32p, C.c_void_p]),
     "zvec_hip_flat_build_filter": (C.c_int, [_h, _h, C.POINTER(DocFilterDesc), _u64p, C.c_int, C.c_void_p]),
     "zvec_hip_ivf_build_filter": (C.c_int, [_h, _h, C.POINTER(DocFilterDesc), _u64p, C.c_int, C.c_void_p]),
+    "zvec_hip_reform_queries_dev": (C.c_int, [_h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "zvec_hip_crc32c": (C.c_uint32, [C.c_void_p, C.c_uint64, C.c_uint32]),
     "zvec_hip_ctx_profile": (C.c_int, [_h, C.c_int]),
     "zvec_hip_ctx_profile_read": (C.c_int, [_h, C.POINTER(C.c_uint64), C.POINTER(C.c_double),
@@ -99,6 +100,14 @@ def lib():
     """Load (building first if the sources are newer) the HIP shared library. Raises if absent."""
     global _LIB
     if _LIB is None:
+        # ONE HIP runtime per process: PyTorch wheels bundle their own libamdhip64 (same SONAME as the system one this
+        # library links).  Loaded after torch, this library binds to torch's copy and both share streams and
+        # allocations; loaded BEFORE torch, the process would end up with two runtimes (torch then intermittently sees
+        # "No HIP GPUs").  So when torch is installed it is imported first.  Not needed for C/C++ callers.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         # ZVEC_HIP_LIBRARY: another build of the same library (kernel A/B experiments on one GPU box)
         path = os.environ.get("ZVEC_HIP_LIBRARY") or _build.build()
         if not os.path.exists(path):

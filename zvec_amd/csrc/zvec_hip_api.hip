@@ -2020,6 +2020,20 @@ int build_filter(zvec_hip_ctx_s *c, int device, const uint64_t *d_keys, uint64_t
 
 }  // namespace
 
+extern "C" int zvec_hip_reform_queries_dev(zvec_hip_ctx_t ctx, const float *d_in, uint32_t count, uint32_t dim, int cosine,
+                                           int out_dtype, void *d_out, void *stream) {
+  if (!ctx || !d_in || !d_out || dim == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (out_dtype != ZVEC_HIP_DT_FP32 && out_dtype != ZVEC_HIP_DT_FP16) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (count == 0) return 0;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ZCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : ctx->cur;
+  hipLaunchKernelGGL(reform_queries_kernel, dim3((count + 15) / 16), dim3(256), 0, s, d_in, count, dim, cosine ? 1 : 0,
+                     out_dtype == ZVEC_HIP_DT_FP16 ? 1 : 0, d_out);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
 extern "C" uint32_t zvec_hip_crc32c(const void *data, uint64_t len, uint32_t crc) {
   return (data || len == 0) ? crc32c_update(data, len, crc) : crc;
 }

@@ -213,4 +213,65 @@ __global__ void __launch_bounds__(64) resort_kernel(uint64_t *keys, float *score
   if (lane == 0 && keep != c) counts[q] = keep;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Query reformers on the device, bit for bit what the host side of the reference produces:
+//   CosineReformer::transform (src/core/quantizer/cosine_reformer.cc:66-112): q / ||q|| followed by ||q||, with
+//   ||q|| = Norm2Matrix<float,1> in its AVX-512 order (norm_matrix_fp32.i:120-157: two 16-lane accumulators over
+//   32-element strides, a trailing 16-chunk and the masked tail into accumulator 0, acc0+acc1, low+high halves,
+//   pairwise tree, sqrt) and Normalizer<float>::L2's element-wise division;
+//   HalfFloatReformer (half_float_reformer.cc): round-to-nearest-even fp32 -> fp16.
+// 16 lanes play the 16 SIMD lanes of one query (4 queries per wave); every lane runs the same sequence of
+// correctly rounded fma / add / sqrt / div operations as its CPU lane, so the results are identical.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reform_queries_kernel(const float *in, uint32_t nq, uint32_t dim, int cosine,
+                                                             int out_f16, void *out) {
+  const int l16 = threadIdx.x & 15;
+  const uint32_t q = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (q >= nq) return;                                   // (whole 16-lane groups leave together)
+  const float *m = in + (size_t)q * dim;
+  float n = 0.f;
+  if (cosine) {
+    float s0 = 0.f, s1 = 0.f;
+    const uint32_t aligned = (dim >> 5) << 5;
+    uint32_t p = 0;
+    for (; p != aligned; p += 32) {
+      const float a = m[p + l16], b = m[p + 16 + l16];
+      s0 = fmaf(a, a, s0);
+      s1 = fmaf(b, b, s1);
+    }
+    if (dim >= aligned + 16) {
+      const float a = m[p + l16];
+      s0 = fmaf(a, a, s0);
+      p += 16;
+    }
+    if (p + l16 < dim) {
+      const float a = m[p + l16];
+      s0 = fmaf(a, a, s0);
+    }
+    float v = s0 + s1;
+    v = v + __shfl_xor(v, 8, 16);        // low256 + high256 (lanes 0..7 hold t[i] = v[i] + v[i+8])
+    v = v + __shfl_xor(v, 1, 16);        // (t0+t1), (t2+t3), ...
+    v = v + __shfl_xor(v, 2, 16);        // (t0+t1)+(t2+t3), (t4+t5)+(t6+t7)
+    v = v + __shfl_xor(v, 4, 16);
+    n = sqrtf(__shfl(v, 0, 16));
+  }
+  const uint32_t extra = cosine ? (out_f16 ? 2u : 1u) : 0u;
+  for (uint32_t c = l16; c < dim; c += 16) {
+    float x = m[c];
+    if (cosine && n > 0.f) x = x / n;
+    if (out_f16) reinterpret_cast<_Float16 *>(out)[(size_t)q * (dim + extra) + c] = (_Float16)x;
+    else reinterpret_cast<float *>(out)[(size_t)q * (dim + extra) + c] = x;
+  }
+  if (cosine && l16 == 0) {
+    if (out_f16) {
+      const uint32_t bits = __builtin_bit_cast(uint32_t, n);
+      uint16_t *o = reinterpret_cast<uint16_t *>(out) + (size_t)q * (dim + 2) + dim;
+      o[0] = (uint16_t)bits;
+      o[1] = (uint16_t)(bits >> 16);
+    } else {
+      reinterpret_cast<float *>(out)[(size_t)q * (dim + 1) + dim] = n;
+    }
+  }
+}
+
 }  // namespace zvk

@@ -194,6 +194,12 @@ class IndexContext:
             for q in range(keys.shape[0])
         ]
 
+    def reform_queries_dev(self, d_in, count, dim, d_out, cosine=False, out_dtype="fp32", stream=None):
+        """CosineReformer / HalfFloatReformer on raw fp32 queries already in HBM (device pointers)."""
+        dt, _ = _dtype_of(out_dtype)
+        _lib.check(_lib.lib().zvec_hip_reform_queries_dev(self._h, C.c_void_p(d_in), int(count), int(dim), int(bool(cosine)), dt,
+                                                          C.c_void_p(d_out), C.c_void_p(stream or 0)), "zvec_hip_reform_queries_dev")
+
     def synchronize(self):
         _lib.check(_lib.lib().zvec_hip_ctx_synchronize(self._h), "zvec_hip_ctx_synchronize")
 
