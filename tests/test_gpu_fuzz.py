@@ -94,3 +94,79 @@ def test_ivf_fuzz(zv, oracle, seed):
     if not bf:
         scanned, _ = se.last_stats(ctx, nq)
         assert np.array_equal(scanned[sel], osc[sel])
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_flat_fuzz_wide(zv, oracle, seed):
+    """shapes that take the wide 8-wave kernel (> 64 queries over a base beyond the cache-resident size), its gather
+    variant (sparse filters over >= 65536 rows) and the one-work-group-per-CU list sizes (k > 12)"""
+    rng = np.random.default_rng(3000 + seed)
+    dim = int(rng.choice([520, 768, 1000]))
+    n = int(rng.choice([23000, 33333, 70000]))
+    if n * ((dim + 31) // 32 * 32) * 4 <= 64 * 1024 * 1024:
+        n = 70000
+    nq = int(rng.choice([65, 128, 129, 256, 300, 513]))
+    k = int(rng.choice([1, 5, 10, 11, 12, 13, 40, 64, 100]))
+    half = bool(rng.random() < 0.3)
+    if half:
+        n = 70000                                             # fp16 rows are half as large: keep the base streamed
+    dt = np.float16 if half else np.float32
+    name, metric = [("SquaredEuclidean", O.METRIC_L2), ("InnerProduct", O.METRIC_IP)][int(rng.integers(0, 2))]
+    hi = 12
+    base = rng.integers(-hi, hi + 1, (n, dim)).astype(dt)
+    q = rng.integers(-hi, hi + 1, (nq, dim)).astype(dt)
+    keys = rng.permutation(2 * n)[:n].astype(np.uint64)
+    se = zv.HipFlatSearcher(dim, name, dtype="fp16" if half else "fp32")
+    assert se.load(base, keys) == 0
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    words = None
+    keep = float(rng.choice([1.0, 1.0, 0.95, 0.6, 0.2, 0.01]))
+    if keep < 1.0:
+        words = O.pack_bits(rng.random(n) >= keep)
+        ctx.set_exclude_bitset(words)
+    thr = O.FLT_MAX
+    if rng.random() < 0.25:
+        thr = float(np.median(oracle.flat_search(base, q[:1], min(3 * k, n), metric, threads=8)[1]))
+        ctx.set_threshold(thr)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc = oracle.flat_search(base, q, k, metric, keys=keys, threshold=thr, exclude_bits=words, threads=16)
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc,
+                         what="wide fuzz seed=%d n=%d d=%d nq=%d k=%d keep=%g %s %s" % (seed, n, dim, nq, k, keep, name, dt.__name__))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_ivf_fuzz_big(zv, oracle, seed):
+    """larger IVF shapes: lists probed by more than one 32-row group, every per-search chunk length, single queries,
+    the large-k fallback"""
+    from tests.util import kmeans_lists
+    rng = np.random.default_rng(4000 + seed)
+    dim = int(rng.choice([48, 64, 128]))
+    n = int(rng.choice([40000, 120000]))
+    nlist = int(rng.choice([32, 64, 256]))
+    nq = int(rng.choice([1, 3, 40, 300, 700]))
+    k = int(rng.choice([1, 10, 100, 471, 500]))
+    half = bool(rng.random() < 0.3)
+    dt = np.float16 if half else np.float32
+    base32 = rng.integers(-20, 21, (n, dim)).astype(np.float32)
+    q = rng.integers(-20, 21, (nq, dim)).astype(dt)
+    cent, offs, order = kmeans_lists(rng, base32, nlist)
+    cent = np.round(cent).astype(dt)
+    vecs, keys = base32[order].astype(dt), order.astype(np.uint64)
+    ratio = float(rng.choice([0.05, 0.1, 0.3]))
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=ratio, brute_force_threshold=100, dtype="fp16" if half else "fp32")
+    assert se.load(cent, offs, vecs, keys) == 0
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    words = None
+    if rng.random() < 0.4:
+        words = O.pack_bits(rng.random(n) < 0.5)
+        ctx.set_exclude_bitset(words)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, osc = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys, exclude_bits=words, threads=16)
+    cd = np.sort(exact_l2(cent.astype(np.float32), q.astype(np.float32)), 1)
+    sel = np.nonzero((np.diff(cd[:, :min(nprobe + 1, nlist)], axis=1) != 0).all(1))[0]
+    assert len(sel) > 0
+    tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel],
+                         what="ivf big fuzz seed=%d n=%d d=%d nlist=%d nq=%d k=%d ratio=%g %s" % (seed, n, dim, nlist, nq, k, ratio, dt.__name__))
