@@ -376,9 +376,15 @@ def run_flat(torch, dist, zvec_amd, flat, fctx, q, n, dim, topk, args, dev, stre
     fl = prof["flops"] / max(prof["launches"], 1)
     by = prof["bytes"] / max(prof["launches"], 1)
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    traffic = None          # HBM bytes per launch from separate PMC passes over this same command (profiles/README.md)
+    try:
+        if world == 1 and not args.n and not args.batch:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+    except (OSError, ValueError):
+        pass
     return {"value": batch * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
             "roofline": {"bound": "mfma", "kernel": "zvk::scan8_kernel (flat scan)", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "kernel_ms": ms,
+                         "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": traffic, "kernel_ms": ms,
                          "algorithmic_bytes": by, "algorithmic_flops": fl,
                          "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0},
             "cpu_baseline": cpu}
