@@ -270,9 +270,31 @@ int launch_scan_ng(int ng, const ScanArgs &a, bool f16, uint32_t max_items, int 
   return ZVEC_HIP_ERR_INVALID_ARGUMENT;
 }
 
+// Tuning / test knobs, read once from the environment.  None is needed in production; they exist so that kernel
+// variants can be A/B-timed on one GPU box (tools/ab_flat.sh) and so that tests can force a path onto small inputs.
+struct Knobs {
+  int max_ng = 4;             // ZVEC_HIP_MAX_NG      cap of the 4-wave kernel's query-row groups (1, 2, 4)
+  bool no_wide = false;       // ZVEC_HIP_NO_WIDE     never take the 8-wave flat tile
+  bool force_wide = false;    // ZVEC_HIP_FORCE_WIDE  take it on cache-resident bases too (tests)
+  bool no_seed = false;       // ZVEC_HIP_NO_SEED     no prefix scan to seed the admission bounds
+  bool no_gather = false;     // ZVEC_HIP_NO_GATHER   sparse filters: compact the kept rows instead of gathering them
+  int ivf_tpc = 0;            // ZVEC_HIP_IVF_TPC     fixed tiles per IVF chunk (0 = adaptive)
+  Knobs() {
+    if (const char *e = getenv("ZVEC_HIP_MAX_NG")) max_ng = std::max(1, std::min(4, atoi(e)));
+    no_wide = getenv("ZVEC_HIP_NO_WIDE") != nullptr;
+    force_wide = getenv("ZVEC_HIP_FORCE_WIDE") != nullptr;
+    no_seed = getenv("ZVEC_HIP_NO_SEED") != nullptr;
+    no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;
+    if (const char *e = getenv("ZVEC_HIP_IVF_TPC")) ivf_tpc = std::max(1, atoi(e));
+  }
+};
+const Knobs &knobs() {
+  static const Knobs k;
+  return k;
+}
+
 int pick_ng(uint32_t rows_wanted, uint32_t k) {
-  int ng = 4;
-  if (const char *f = getenv("ZVEC_HIP_MAX_NG")) ng = std::max(1, std::min(4, atoi(f)));   // tuning knob (experiments)
+  int ng = knobs().max_ng;
   // 128 query rows per work-group is the largest tile whose accumulators + staging fit 512 registers
   while (ng > 1 && (uint32_t)(ng / 2) * QGROUP >= rows_wanted) ng /= 2;
   while (ng >= 1 && scan_lds_bytes(ng, k) > LDS_LIMIT - 1024) ng /= 2;
@@ -421,8 +443,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     ZCHK(hipStreamSynchronize(stream));
     // copying the kept rows pays below one half kept; gathering them inside the wide kernel costs ~1.5 % and pays
     // whenever a tenth of the rows can be skipped
-    static const bool no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;   // tuning knob (experiments)
-    const bool can_gather = !no_gather && count > 2 * QGROUP && pick_ng(count, topk) == 4 && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
+    const bool can_gather = !knobs().no_gather && count > 2 * QGROUP && pick_ng(count, topk) == 4 && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
     if ((double)kept <= (can_gather ? 0.9 : 0.5) * (double)st.n) {
       if (kept == 0) {
         ZCHK(hipMemsetAsync(out.counts, 0, sizeof(uint32_t) * count, stream));
@@ -512,9 +533,8 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   // sorted insertions per (query, chunk) — with hundreds of chunks in flight that warm-up is most of the admission
   // work.  A scan of a small prefix first (its k-th score bounds the final k-th from above) lets every chunk start
   // with a bound that only ~k * chunk_rows / sample_rows of its rows pass.
-  static const bool no_seed = getenv("ZVEC_HIP_NO_SEED") != nullptr;   // tuning knob (experiments)
   constexpr uint64_t SEED_ROWS = 4096;
-  if (!no_seed && st.n >= 64 * SEED_ROWS && topk <= 64 && count >= 16) {
+  if (!knobs().no_seed && st.n >= 64 * SEED_ROWS && topk <= 64 && count >= 16) {
     ZRET(ctx->seed_keys.ensure((size_t)count * topk * sizeof(uint64_t)));
     ZRET(ctx->seed_scores.ensure((size_t)count * topk * sizeof(float)));
     ZRET(ctx->seed_counts.ensure((size_t)count * sizeof(uint32_t)));
@@ -537,9 +557,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   if (ng < 1) return ZVEC_HIP_ERR_UNSUPPORTED;
   const int cus = device_cus(ctx);
   // wide batches over a streamed base: the 8-wave 128x128 tile (two work-groups per CU while its lists fit)
-  static const bool no_wide = getenv("ZVEC_HIP_NO_WIDE") != nullptr;   // tuning knob (experiments)
-  static const bool force_wide = getenv("ZVEC_HIP_FORCE_WIDE") != nullptr;   // tests: exercise the wide tile on small bases
-  const bool wide = !no_wide && (!cache_resident || force_wide) && pick_ng(count, topk) == 4 && count > 2 * QGROUP && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
+  const bool wide = !knobs().no_wide && (!cache_resident || knobs().force_wide) && pick_ng(count, topk) == 4 && count > 2 * QGROUP && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
   int occ8 = 1;
   ScanArgs probe{};
   probe.k = topk; probe.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
@@ -796,7 +814,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     const uint64_t est_tiles = std::max<uint64_t>(1, h->local_tiles * lists_touched / std::max<uint32_t>(nlist, 1));
     const uint64_t t = est_tiles / (4ull * (uint64_t)device_cus(ctx) * 3ull);
     tpc = (uint32_t)std::min<uint64_t>(h->tiles_per_chunk, std::max<uint64_t>(1, t));
-    if (getenv("ZVEC_HIP_IVF_TPC")) tpc = h->tiles_per_chunk;
+    if (knobs().ivf_tpc) tpc = (uint32_t)knobs().ivf_tpc;
   }
   {
     ZRET(ctx->gtau.ensure((size_t)count * sizeof(uint32_t)));
@@ -1303,7 +1321,7 @@ static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uin
   {
     uint64_t tpc = tiles / (4ull * 256ull * 3ull);
     h->tiles_per_chunk = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(4, tpc));
-    if (const char *e = getenv("ZVEC_HIP_IVF_TPC")) h->tiles_per_chunk = (uint32_t)std::max(1, atoi(e));   // tuning knob (experiments)
+    if (knobs().ivf_tpc) h->tiles_per_chunk = (uint32_t)knobs().ivf_tpc;
     // The queue deals lists largest first, so the lists at the END of the order are the tail of every search: one
     // work-group streams only ~7 GB/s (5.7 TB/s over ~768 resident groups), i.e. a 4-tile item lasts ~200 us, and a
     // tail of such items leaves most of the chip idle.  The last quarter of the tiles is therefore cut into chunks
