@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "zvec_hip_api.hip")
 DEPS = [SRC, os.path.join(os.path.dirname(HERE), "include", "zvec_hip.h")] + sorted(
-    os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".hip.h"))
+    os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h"))
 OUT = os.path.join(HERE, "libzvec_hip.so")
 
 

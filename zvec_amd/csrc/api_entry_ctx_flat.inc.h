@@ -1,0 +1,265 @@
+// api_entry_ctx_flat.inc.h — C ABI entry points: library, contexts, flat index (inside extern "C")
+// Part of zvec_hip_api.hip (one translation unit; included in order, not standalone).
+
+int zvec_hip_abi_version(void) { return ZVEC_HIP_ABI_VERSION; }
+
+int zvec_hip_device_count(int *count) {
+  if (!count) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return ZVEC_HIP_ERR_RUNTIME; }
+  *count = n;
+  return 0;
+}
+
+const char *zvec_hip_error_string(int code) {
+  switch (code) {
+    case ZVEC_HIP_OK: return "Success";
+    case ZVEC_HIP_ERR_RUNTIME: return "Runtime error";
+    case ZVEC_HIP_ERR_UNSUPPORTED: return "Unsupported";
+    case ZVEC_HIP_ERR_OUT_OF_RANGE: return "Out of range";
+    case ZVEC_HIP_ERR_NO_MEMORY: return "Not enough space";
+    case ZVEC_HIP_ERR_NO_READY: return "No ready";
+    case ZVEC_HIP_ERR_NO_EXIST: return "No exist";
+    case ZVEC_HIP_ERR_MISMATCH: return "Mismatch";
+    case ZVEC_HIP_ERR_INVALID_ARGUMENT: return "Invalid argument";
+    case ZVEC_HIP_ERR_NO_INDEX_LOADED: return "No index loaded";
+    case ZVEC_HIP_ERR_NO_TRAINED: return "No trained";
+  }
+  return "Unknown error";
+}
+
+int zvec_hip_ctx_create(int device, zvec_hip_ctx_t *out) {
+  if (!out) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  return ctx_new(device, out);
+}
+int zvec_hip_ctx_destroy(zvec_hip_ctx_t ctx) { ctx_free(ctx); return 0; }
+int zvec_hip_ctx_synchronize(zvec_hip_ctx_t ctx) {
+  if (!ctx) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  ZCHK(hipSetDevice(ctx->device));
+  ZCHK(hipStreamSynchronize(ctx->cur));
+  return 0;
+}
+int zvec_hip_ctx_set_stream(zvec_hip_ctx_t ctx, void *stream) {
+  if (!ctx) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  ctx->cur = stream ? reinterpret_cast<hipStream_t>(stream) : ctx->own;
+  return 0;
+}
+
+// ---- flat -----------------------------------------------------------------------------------
+int zvec_hip_flat_create(uint32_t dim, int dtype, int metric, int device, zvec_hip_flat_t *out) {
+  if (!out || dim == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (dtype != ZVEC_HIP_DT_FP32 && dtype != ZVEC_HIP_DT_FP16) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (metric < 0 || metric > 2) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (metric == ZVEC_HIP_METRIC_COSINE && dim < (dtype == ZVEC_HIP_DT_FP16 ? 3u : 2u)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  zvec_hip_ctx_s *c = nullptr;
+  ZRET(ctx_new(device, &c));
+  zvec_hip_flat_s *h = new (std::nothrow) zvec_hip_flat_s();
+  if (!h) { ctx_free(c); return ZVEC_HIP_ERR_NO_MEMORY; }
+  h->device = device; h->dtype = dtype; h->defctx = c;
+  h->st.configure(dim, metric, dtype);
+  *out = h;
+  return 0;
+}
+
+int zvec_hip_flat_destroy(zvec_hip_flat_t h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  h->st.release();
+  ctx_free(h->defctx);
+  delete h;
+  return 0;
+}
+
+int zvec_hip_flat_reserve(zvec_hip_flat_t h, uint64_t capacity) {
+  if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  return h->st.reserve(capacity, h->defctx->own);
+}
+
+int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n, const uint64_t *d_keys, void *stream) {
+  if (!h || (!d_vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = pick_stream(h->defctx, stream);
+  return store_append_dev(h->st, d_vecs, n, d_keys, s);
+}
+
+// FlatSearcher::load of a dumped "flat.features"-style segment (FlatBuilder<32>::write_row_index / write_column_index,
+// src/core/algorithm/flat/flat_builder.cc:186-276): [count][dim] rows, or — column-major index — full 32-row blocks
+// transposed in units of the element type followed by a row-major remainder.  Appended to the store on the GPU.
+int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_t bytes, uint64_t count, int column_major,
+                                uint32_t batch_size, const uint64_t *keys) {
+  if (!h || (!features && count) || batch_size == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  const uint64_t elem = h->st.row_bytes();
+  if (bytes < count * elem) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = h->defctx->own;
+  Scoped<uint8_t> d_body;
+  Scoped<char> d_rows;
+  Scoped<uint64_t> d_tab, d_keys;
+  ZRET(d_body.alloc(count * elem));
+  ZRET(d_rows.alloc(count * elem));
+  ZRET(d_tab.alloc(3));
+  const uint64_t tab[3] = {0, 0, count};                     // list_off[0]; row0[0], row0[1]
+  ZCHK(hipMemcpyAsync(d_body, features, count * elem, hipMemcpyHostToDevice, s));
+  ZCHK(hipMemcpyAsync(d_tab, tab, sizeof(tab), hipMemcpyHostToDevice, s));
+  if (keys) {
+    ZRET(d_keys.alloc(count));
+    ZCHK(hipMemcpyAsync(d_keys, keys, count * 8, hipMemcpyHostToDevice, s));
+  }
+  IvfBodyArgs a{};
+  a.body = d_body; a.list_off = d_tab; a.list_row0 = static_cast<uint64_t *>(d_tab) + 1; a.nlist = 1; a.bvc = batch_size;
+  a.block_size = (uint32_t)(batch_size * elem); a.elem_size = (uint32_t)elem; a.unit = h->st.elem; a.column_major = column_major ? 1u : 0u;
+  a.rows = reinterpret_cast<uint8_t *>(static_cast<char *>(d_rows)); a.total = count;
+  hipLaunchKernelGGL(ivf_body_rows_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, a);
+  ZCHK(hipGetLastError());
+  int rc = store_append_dev(h->st, d_rows, count, keys ? static_cast<const uint64_t *>(d_keys) : nullptr, s);
+  ZCHK(hipStreamSynchronize(s));
+  return rc;
+}
+
+int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const uint64_t *keys) {
+  if (!h || (!vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = h->defctx->own;
+  // stage through the device in slices of <= 1 GiB
+  const size_t rb = h->st.row_bytes();
+  const uint64_t rows_per = std::max<uint64_t>(1, ((uint64_t)1 << 30) / (uint64_t)rb);
+  DevBuf tmp, tk;
+  for (uint64_t o = 0; o < n; o += rows_per) {
+    uint64_t m = std::min(rows_per, n - o);
+    int rc = tmp.ensure((size_t)m * rb);
+    if (rc == 0 && keys) rc = tk.ensure((size_t)m * 8);
+    if (rc != 0) { tmp.release(); tk.release(); return rc; }
+    ZCHK(hipMemcpyAsync(tmp.p, reinterpret_cast<const char *>(vecs) + (size_t)o * rb, (size_t)m * rb, hipMemcpyHostToDevice, s));
+    if (keys) ZCHK(hipMemcpyAsync(tk.p, keys + o, (size_t)m * 8, hipMemcpyHostToDevice, s));
+    rc = store_append_dev(h->st, tmp.p, m, keys ? tk.as<uint64_t>() : nullptr, s);
+    if (rc != 0) { tmp.release(); tk.release(); return rc; }
+    ZCHK(hipStreamSynchronize(s));
+  }
+  tmp.release(); tk.release();
+  return 0;
+}
+
+int zvec_hip_flat_count(zvec_hip_flat_t h, uint64_t *count) {
+  if (!h || !count) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  *count = h->st.n;
+  return 0;
+}
+
+int zvec_hip_flat_get_vector(zvec_hip_flat_t h, uint64_t pos, void *out) {
+  if (!h || !out) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  if (pos >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
+  ZCHK(hipSetDevice(h->device));
+  zvec_hip_ctx_s *c = h->defctx;
+  ZRET(c->io_q.ensure(h->st.row_bytes()));
+  ZRET(launch_unpack(h->st, pos, c->io_q.p, c->own));
+  ZCHK(hipMemcpyAsync(out, c->io_q.p, h->st.row_bytes(), hipMemcpyDeviceToHost, c->own));
+  ZCHK(hipStreamSynchronize(c->own));
+  return 0;
+}
+
+int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count,
+                             uint32_t topk, float threshold, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys,
+                             float *d_out_scores, uint32_t *d_out_counts, void *stream) {
+  if (!h || !d_queries || !d_out_keys || !d_out_scores || !d_out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;   // "Invalid context or topk not set yet" flat_searcher.cc:194
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  // the kernels address the padded query matrix with 32-bit word offsets: very large batches go in slices
+  const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(h->st.dpad, 1u));
+  if (count > maxq) {
+    for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
+      const uint32_t m = std::min(maxq, count - q0);
+      ZRET(zvec_hip_flat_search_dev(h, ctx, reinterpret_cast<const char *>(d_queries) + (size_t)q0 * h->st.row_bytes(), m, topk,
+                                    threshold, d_exclude_bitset, d_out_keys + (size_t)q0 * topk, d_out_scores + (size_t)q0 * topk,
+                                    d_out_counts + q0, stream));
+    }
+    return 0;
+  }
+  std::lock_guard<std::mutex> g(c->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = pick_stream(c, stream);
+  ZRET(prep_queries(c, h->st, d_queries, count, threshold, s));
+  SearchOut out{d_out_keys, d_out_scores, nullptr, d_out_counts};
+  return flat_scan_prepared(c, h->st, count, topk, threshold, d_exclude_bitset, out, s, true);
+}
+
+int zvec_hip_flat_search(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count, uint32_t topk,
+                         float threshold, const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
+                         uint32_t *out_counts) {
+  if (!h || !queries || !out_keys || !out_scores || !out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    ZCHK(hipSetDevice(h->device));
+    ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->st.row_bytes(), exclude_bitset, h->st.n, count, topk, c->cur));
+  }
+  ZRET(zvec_hip_flat_search_dev(h, c, c->io_q.p, count, topk, threshold, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr,
+                                c->io_keys.as<uint64_t>(), c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
+  std::lock_guard<std::mutex> g(c->mu);
+  return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, c->cur);
+}
+
+int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count,
+                                const uint32_t *ids, const uint32_t *offsets, uint32_t topk, float threshold,
+                                const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
+                                uint32_t *out_counts) {
+  if (!h || !queries || !ids || !offsets || !out_keys || !out_scores || !out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if ((size_t)topk * 12 + 16 > 60 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = c->cur;
+  const Store &st = h->st;
+  // host-side sanitising: positions out of range or excluded by the filter bitset become holes
+  const uint32_t total = offsets[count];
+  uint32_t maxlen = 1;
+  for (uint32_t q = 0; q < count; ++q) {
+    if (offsets[q + 1] < offsets[q]) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+    maxlen = std::max(maxlen, offsets[q + 1] - offsets[q]);
+  }
+  std::vector<uint32_t> clean(std::max<uint32_t>(total, 1));
+  for (uint32_t i = 0; i < total; ++i) {
+    uint32_t id = ids[i];
+    bool ok = id < st.n;
+    if (ok && exclude_bitset) ok = ((exclude_bitset[id >> 6] >> (id & 63)) & 1ull) == 0;
+    clean[i] = ok ? id : IDX_NONE;
+  }
+  ZRET(host_search_wrap_begin(c, queries, (size_t)count * st.row_bytes(), nullptr, 0, count, topk, s));
+  ZRET(prep_queries(c, st, c->io_q.p, count, threshold, s));
+  ZRET(c->plan.ensure(((size_t)total + count + 8) * sizeof(uint32_t)));
+  uint32_t *d_pos = c->plan.as<uint32_t>();
+  uint32_t *d_off = d_pos + std::max<uint32_t>(total, 1);
+  ZCHK(hipMemcpyAsync(d_pos, clean.data(), (size_t)std::max<uint32_t>(total, 1) * 4, hipMemcpyHostToDevice, s));
+  ZCHK(hipMemcpyAsync(d_off, offsets, ((size_t)count + 1) * 4, hipMemcpyHostToDevice, s));
+  const uint64_t pairs = (uint64_t)count * maxlen;
+  ZRET(c->part_s.ensure(pairs * 4));
+  ZRET(c->part_i.ensure(pairs * 4));
+  if (st.f16)
+    hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
+                       st.dpad, st.metric, d_pos, d_off, count, maxlen, c->part_s.as<float>(), c->part_i.as<uint32_t>());
+  else
+    hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
+                       st.dpad, st.metric, d_pos, d_off, count, maxlen, c->part_s.as<float>(), c->part_i.as<uint32_t>());
+  ZCHK(hipGetLastError());
+  MergeArgs m{};
+  m.part_s = c->part_s.as<float>(); m.part_i = c->part_i.as<uint32_t>(); m.part_keys = nullptr; m.slot_begin = nullptr;
+  m.slots_per_q = 1; m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = maxlen; m.threshold = threshold;
+  m.keymap = st.keys; m.out_keys = c->io_keys.as<uint64_t>(); m.out_scores = c->io_scores.as<float>(); m.out_idx = nullptr;
+  m.out_counts = c->io_counts.as<uint32_t>();
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, s, m);
+  ZCHK(hipGetLastError());
+  return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, s);
+}

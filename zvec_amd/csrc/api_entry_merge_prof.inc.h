@@ -1,0 +1,118 @@
+// api_entry_merge_prof.inc.h — C ABI entry points: shard merge, measurement hook (inside extern "C")
+// Part of zvec_hip_api.hip (one translation unit; included in order, not standalone).
+
+// ---- merge ----------------------------------------------------------------------------------
+int zvec_hip_merge_topk_dev(zvec_hip_ctx_t ctx, const uint64_t *d_keys, const float *d_scores, const uint32_t *d_counts,
+                            uint32_t nparts, uint32_t count, uint32_t topk, uint64_t *d_out_keys, float *d_out_scores,
+                            uint32_t *d_out_counts, void *stream) {
+  if (!ctx || !d_keys || !d_scores || !d_counts || !d_out_keys || !d_out_scores || !d_out_counts)
+    return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (topk == 0 || nparts == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if ((size_t)topk * 12 + 16 > 64 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ZCHK(hipSetDevice(ctx->device));
+  hipStream_t s = pick_stream(ctx, stream);
+  MergeArgs m{};
+  m.part_s = d_scores; m.part_i = nullptr; m.part_keys = d_keys; m.slot_begin = nullptr; m.slots_per_q = nparts;
+  m.slot_stride = count; m.part_counts = d_counts; m.k = topk; m.slot_len = topk; m.threshold = FLT_MAX; m.keymap = nullptr;
+  m.out_keys = d_out_keys; m.out_scores = d_out_scores; m.out_idx = nullptr; m.out_counts = d_out_counts;
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, s, m);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+uint64_t zvec_hip_packed_bytes(uint32_t count, uint32_t topk) {
+  uint64_t b = (uint64_t)count * topk * 12 + (uint64_t)count * 4;
+  return (b + 15) & ~(uint64_t)15;
+}
+
+int zvec_hip_merge_topk_packed_dev(zvec_hip_ctx_t ctx, const void *d_packed, uint64_t part_stride, uint32_t nparts,
+                                   uint32_t count, uint32_t topk, uint64_t *d_out_keys, float *d_out_scores,
+                                   uint32_t *d_out_counts, void *stream) {
+  if (!ctx || !d_packed || !d_out_keys || !d_out_scores || !d_out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (topk == 0 || nparts == 0 || part_stride < zvec_hip_packed_bytes(count, topk) || (part_stride & 7)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if ((size_t)topk * 12 + 16 > 64 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ZCHK(hipSetDevice(ctx->device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const char *p0 = reinterpret_cast<const char *>(d_packed);
+  MergeArgs m{};
+  m.part_keys = reinterpret_cast<const uint64_t *>(p0);
+  m.part_s = reinterpret_cast<const float *>(p0 + (size_t)count * topk * 8);
+  m.part_counts = reinterpret_cast<const uint32_t *>(p0 + (size_t)count * topk * 12);
+  m.part_i = nullptr; m.slot_begin = nullptr; m.slots_per_q = nparts; m.slot_stride = count; m.packed_stride = part_stride;
+  m.k = topk; m.slot_len = topk; m.threshold = FLT_MAX; m.keymap = nullptr;
+  m.out_keys = d_out_keys; m.out_scores = d_out_scores; m.out_idx = nullptr; m.out_counts = d_out_counts;
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, s, m);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int zvec_hip_merge_topk(zvec_hip_ctx_t ctx, const uint64_t *keys, const float *scores, const uint32_t *counts,
+                        uint32_t nparts, uint32_t count, uint32_t topk, uint64_t *out_keys, float *out_scores,
+                        uint32_t *out_counts) {
+  if (!ctx || !keys || !scores || !counts || !out_keys || !out_scores || !out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  ZCHK(hipSetDevice(ctx->device));
+  size_t ne = (size_t)nparts * count * topk;
+  Scoped<uint64_t> dk, dok; Scoped<float> ds, dos; Scoped<uint32_t> dc, doc;
+  ZRET(dk.alloc(ne)); ZRET(ds.alloc(ne)); ZRET(dc.alloc((size_t)nparts * count));
+  ZRET(dok.alloc((size_t)count * topk)); ZRET(dos.alloc((size_t)count * topk)); ZRET(doc.alloc(count));
+  ZCHK(hipMemcpy(dk, keys, ne * 8, hipMemcpyHostToDevice));
+  ZCHK(hipMemcpy(ds, scores, ne * 4, hipMemcpyHostToDevice));
+  ZCHK(hipMemcpy(dc, counts, (size_t)nparts * count * 4, hipMemcpyHostToDevice));
+  int rc = zvec_hip_merge_topk_dev(ctx, dk, ds, dc, nparts, count, topk, dok, dos, doc, nullptr);
+  if (rc == 0) {
+    ZCHK(hipStreamSynchronize(ctx->cur));
+    ZCHK(hipMemcpy(out_keys, dok, (size_t)count * topk * 8, hipMemcpyDeviceToHost));
+    ZCHK(hipMemcpy(out_scores, dos, (size_t)count * topk * 4, hipMemcpyDeviceToHost));
+    ZCHK(hipMemcpy(out_counts, doc, (size_t)count * 4, hipMemcpyDeviceToHost));
+  }
+  return rc;
+}
+
+// ---- measurement hook -----------------------------------------------------------------------
+int zvec_hip_ctx_profile(zvec_hip_ctx_t ctx, int enable) {
+  if (!ctx) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->profile = enable != 0;
+  if (ctx->profile) {
+    ZCHK(hipSetDevice(ctx->device));
+    ZRET(ctx->stats.ensure(sizeof(uint64_t) * 2 * PROFILE_MAX));
+  }
+  return 0;
+}
+
+int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *scan_ms, double *algorithmic_bytes,
+                              double *algorithmic_flops, int reset) {
+  if (!ctx) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ZCHK(hipSetDevice(ctx->device));
+  ZCHK(hipStreamSynchronize(ctx->cur));
+  double ms = 0, bytes = 0, flops = 0;
+  std::vector<unsigned long long> st;
+  if (ctx->nprof > 0 && ctx->stats.p) {
+    st.resize((size_t)2 * ctx->nprof);
+    ZCHK(hipMemcpy(st.data(), ctx->stats.p, st.size() * 8, hipMemcpyDeviceToHost));
+  }
+  for (int i = 0; i < ctx->nprof; ++i) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, ctx->ev0[i], ctx->ev1[i]) == hipSuccess) ms += t;
+    bytes += ctx->host_bytes[i];
+    flops += ctx->host_flops[i];
+  }
+  for (int i = 0; i < ctx->nprof && !st.empty(); ++i) {
+    if (!ctx->launch_is_ivf[i]) continue;
+    const double ds = (double)(ctx->prof_dscan[i] & 0x7fffffffu), eb = (ctx->prof_dscan[i] & 0x80000000u) ? 2.0 : 4.0;
+    bytes += (double)st[2 * (size_t)i] * ds * eb;            // distinct probed rows
+    flops += (double)st[2 * (size_t)i + 1] * ds * 2.0;       // (query, row) pairs
+  }
+  if (launches) *launches = (uint64_t)ctx->nprof;
+  if (scan_ms) *scan_ms = ms;
+  if (algorithmic_bytes) *algorithmic_bytes = bytes;
+  if (algorithmic_flops) *algorithmic_flops = flops;
+  if (reset) ctx->nprof = 0;
+  return 0;
+}

@@ -1,0 +1,529 @@
+// api_flat_scan.inc.h — kernel launchers, query preparation, the flat scan orchestration (dense / fused / wide / gather paths)
+// Part of zvec_hip_api.hip (one translation unit; included in order, not standalone).
+
+namespace {
+
+struct KernelInfo {
+  bool init = false;
+  int cus = 0;
+};
+KernelInfo g_info[16];
+std::mutex g_info_mu;
+
+template <int NG, bool M16, bool EXCL, bool F16>
+int launch_scan_t(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
+  static bool attr_set[16] = {false};
+  size_t lds = scan_lds_bytes(NG, a.k, M16);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set[dev & 15]) {
+    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<NG, M16, EXCL, F16>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    attr_set[dev & 15] = true;
+  }
+  int occ = 0;
+  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<NG, M16, EXCL, F16>, 256, lds));
+  if (occ < 1) occ = 1;
+  uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)max_items, (uint64_t)cus * (uint64_t)occ);
+  if (grid == 0) return 0;
+  hipLaunchKernelGGL((scan_kernel<NG, M16, EXCL, F16>), dim3(grid), dim3(256), lds, stream, a);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+template <int NG, bool M16>
+int launch_scan(const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStream_t stream) {
+  if (f16)
+    return a.exclude ? launch_scan_t<NG, M16, true, true>(a, max_items, cus, stream)
+                     : launch_scan_t<NG, M16, false, true>(a, max_items, cus, stream);
+  return a.exclude ? launch_scan_t<NG, M16, true, false>(a, max_items, cus, stream)
+                   : launch_scan_t<NG, M16, false, false>(a, max_items, cus, stream);
+}
+
+// the 8-wave 128x128 flat tile (scan8_kernel); *occ_out = work-groups per CU it reaches for this k
+template <bool EXCL, bool F16, bool GATHER>
+int launch_scan8_t(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream, int *occ_out) {
+  static bool attr_set[16] = {false};
+  size_t lds = scan8_lds_bytes(a.k);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set[dev & 15]) {
+    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan8_kernel<EXCL, F16, GATHER>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    attr_set[dev & 15] = true;
+  }
+  int occ = 0;
+  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan8_kernel<EXCL, F16, GATHER>, 512, lds));
+  if (occ < 1) occ = 1;
+  if (occ_out) { *occ_out = occ; return 0; }
+  uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)max_items, (uint64_t)cus * (uint64_t)occ);
+  if (grid == 0) return 0;
+  hipLaunchKernelGGL((scan8_kernel<EXCL, F16, GATHER>), dim3(grid), dim3(512), lds, stream, a);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+// (the GATHER variant scans an already filtered position list: no exclude set)
+int launch_scan8(const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStream_t stream, int *occ_out = nullptr) {
+  if (a.gather_pos)
+    return f16 ? launch_scan8_t<false, true, true>(a, max_items, cus, stream, occ_out)
+               : launch_scan8_t<false, false, true>(a, max_items, cus, stream, occ_out);
+  if (f16)
+    return a.exclude ? launch_scan8_t<true, true, false>(a, max_items, cus, stream, occ_out)
+                     : launch_scan8_t<false, true, false>(a, max_items, cus, stream, occ_out);
+  return a.exclude ? launch_scan8_t<true, false, false>(a, max_items, cus, stream, occ_out)
+                   : launch_scan8_t<false, false, false>(a, max_items, cus, stream, occ_out);
+}
+
+// ng == 0 selects the 16-row-halves (16x16 MFMA) shape
+int launch_scan_ng(int ng, const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStream_t stream) {
+  switch (ng) {
+    case 0: return launch_scan<1, true>(a, f16, max_items, cus, stream);
+    case 1: return launch_scan<1, false>(a, f16, max_items, cus, stream);
+    case 2: return launch_scan<2, false>(a, f16, max_items, cus, stream);
+    case 4: return launch_scan<4, false>(a, f16, max_items, cus, stream);
+  }
+  return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+}
+
+// Tuning / test knobs, read once from the environment.  None is needed in production; they exist so that kernel
+// variants can be A/B-timed on one GPU box (tools/ab_flat.sh) and so that tests can force a path onto small inputs.
+struct Knobs {
+  int max_ng = 4;             // ZVEC_HIP_MAX_NG      cap of the 4-wave kernel's query-row groups (1, 2, 4)
+  bool no_wide = false;       // ZVEC_HIP_NO_WIDE     never take the 8-wave flat tile
+  bool force_wide = false;    // ZVEC_HIP_FORCE_WIDE  take it on cache-resident bases too (tests)
+  bool no_seed = false;       // ZVEC_HIP_NO_SEED     no prefix scan to seed the admission bounds
+  bool no_gather = false;     // ZVEC_HIP_NO_GATHER   sparse filters: compact the kept rows instead of gathering them
+  int ivf_tpc = 0;            // ZVEC_HIP_IVF_TPC     fixed tiles per IVF chunk (0 = adaptive)
+  Knobs() {
+    if (const char *e = getenv("ZVEC_HIP_MAX_NG")) max_ng = std::max(1, std::min(4, atoi(e)));
+    no_wide = getenv("ZVEC_HIP_NO_WIDE") != nullptr;
+    force_wide = getenv("ZVEC_HIP_FORCE_WIDE") != nullptr;
+    no_seed = getenv("ZVEC_HIP_NO_SEED") != nullptr;
+    no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;
+    if (const char *e = getenv("ZVEC_HIP_IVF_TPC")) ivf_tpc = std::max(1, atoi(e));
+  }
+};
+const Knobs &knobs() {
+  static const Knobs k;
+  return k;
+}
+
+int pick_ng(uint32_t rows_wanted, uint32_t k) {
+  int ng = knobs().max_ng;
+  // 128 query rows per work-group is the largest tile whose accumulators + staging fit 512 registers
+  while (ng > 1 && (uint32_t)(ng / 2) * QGROUP >= rows_wanted) ng /= 2;
+  while (ng >= 1 && scan_lds_bytes(ng, k) > LDS_LIMIT - 1024) ng /= 2;
+  return ng;  // 0 => k too large for the LDS-resident lists
+}
+
+int device_cus(zvec_hip_ctx_s *ctx) {
+  if (ctx->cus == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
+    if (ctx->cus <= 0) ctx->cus = 256;
+  }
+  return ctx->cus;
+}
+
+int prof_begin(zvec_hip_ctx_s *ctx, hipStream_t stream, double bytes, double flops, int is_ivf) {
+  if (!ctx->profile || ctx->nprof >= PROFILE_MAX) return -1;
+  int i = ctx->nprof;
+  if ((int)ctx->ev0.size() <= i) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+    ctx->ev0.push_back(a);
+    ctx->ev1.push_back(b);
+    ctx->host_bytes.push_back(0);
+    ctx->host_flops.push_back(0);
+    ctx->launch_is_ivf.push_back(0);
+    ctx->prof_dscan.push_back(0);
+  }
+  ctx->host_bytes[i] = bytes;
+  ctx->host_flops[i] = flops;
+  ctx->launch_is_ivf[i] = is_ivf;
+  (void)hipEventRecord(ctx->ev0[i], stream);
+  return i;
+}
+void prof_end(zvec_hip_ctx_s *ctx, hipStream_t stream, int i) {
+  if (i < 0) return;
+  (void)hipEventRecord(ctx->ev1[i], stream);
+  ctx->nprof = i + 1;
+}
+
+// Outputs of a search on the device
+struct SearchOut {
+  uint64_t *keys;
+  float *scores;
+  uint32_t *idx;     // optional positions
+  uint32_t *counts;
+};
+
+// flat scan of `st` for `count` prepared queries (ctx->qpad / qnorm already filled)
+int refine_l2(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold, uint64_t *keys,
+              float *scores, uint32_t *idx, uint32_t *counts, hipStream_t stream);
+
+// partial-list merges of small batches: four waves per query gather the survivors (see merge_kernel)
+inline uint32_t merge_threads(uint32_t count) { return count <= 256 ? 256u : 64u; }
+
+// Sparse keep-set scan WITHOUT copying the kept rows: the wide kernel fetches the rows of a logical tile straight from
+// their stored positions (LDS-DMA with per-lane source addresses: every 128-byte row segment is still one full line).
+// `d_pos`: ascending kept positions, padded to whole tiles (+1 tile) with position 0; `kept` logical rows.
+int flat_scan_gather(zvec_hip_ctx_s *ctx, const Store &st, const uint32_t *d_pos, uint32_t kept, uint32_t count,
+                     uint32_t topk, float threshold, const SearchOut &out, hipStream_t stream, bool profile_it) {
+  const int cus = device_cus(ctx);
+  ScanArgs a{};
+  a.base = st.base; a.bnorm = st.bnorm; a.exclude = nullptr; a.gather_pos = d_pos;
+  a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
+  a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.threshold = threshold;
+  a.gtau = ctx->gtau.as<uint32_t>();
+  a.mode = 0; a.nq = count;
+  const uint32_t nqtiles = (count + W8_ROWS - 1) / W8_ROWS;
+  // seeded bounds from the first SEED rows of the kept set (see flat_scan_prepared)
+  constexpr uint32_t SEED_ROWS = 4096;
+  if (kept >= 64 * SEED_ROWS && topk <= 64 && (size_t)topk * 12 + 16 <= 60 * 1024) {
+    ZRET(ctx->seed_keys.ensure((size_t)count * topk * sizeof(uint64_t)));
+    ZRET(ctx->seed_scores.ensure((size_t)count * topk * sizeof(float)));
+    ZRET(ctx->seed_counts.ensure((size_t)count * sizeof(uint32_t)));
+    ZRET(ctx->part_s.ensure((size_t)count * SEED_ROWS * sizeof(float)));
+    ScanArgs d = a;
+    d.k = 1; d.n = SEED_ROWS; d.ndense = SEED_ROWS; d.tiles_per_chunk = 1; d.nchunks = SEED_ROWS / TILE_N; d.nqtiles = nqtiles;
+    d.dump = ctx->part_s.as<float>(); d.dump_stride = SEED_ROWS;
+    ZRET(launch_scan8(d, st.f16, ((d.nchunks + 7) / 8) * 8 * nqtiles, cus, stream));
+    MergeArgs m{};
+    m.part_s = d.dump; m.slots_per_q = 1; m.slot_stride = 1; m.k = topk; m.slot_len = SEED_ROWS; m.threshold = threshold;
+    m.out_keys = ctx->seed_keys.as<uint64_t>(); m.out_scores = ctx->seed_scores.as<float>(); m.out_counts = ctx->seed_counts.as<uint32_t>();
+    hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+    hipLaunchKernelGGL(seed_gtau_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, ctx->gtau.as<uint32_t>(),
+                       m.out_scores, m.out_counts, count, topk);
+    ZCHK(hipGetLastError());
+  }
+  int occ8 = 1;
+  a.k = topk;
+  ZRET(launch_scan8(a, st.f16, 0, cus, stream, &occ8));
+  const uint64_t ntiles = ((uint64_t)kept + TILE_N - 1) / TILE_N;
+  const uint64_t resident = (uint64_t)cus * occ8;
+  const uint64_t want_chunks = std::max<uint64_t>(1, (resident + nqtiles - 1) / nqtiles);
+  uint64_t tpc = std::max<uint64_t>(1, (ntiles + want_chunks - 1) / want_chunks);
+  tpc = std::max<uint64_t>(tpc, std::min<uint64_t>(ntiles, 4));
+  const uint32_t nchunks = (uint32_t)((ntiles + tpc - 1) / tpc);
+  const uint64_t slots = (uint64_t)count * nchunks;
+  ZRET(ctx->part_s.ensure(slots * topk * sizeof(float)));
+  ZRET(ctx->part_i.ensure(slots * topk * sizeof(uint32_t)));
+  a.n = kept; a.ndense = kept; a.tiles_per_chunk = (uint32_t)tpc; a.nchunks = nchunks; a.nqtiles = nqtiles;
+  a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
+  int pi = -1;
+  if (profile_it) {
+    double bytes = (double)kept * st.dscan * st.elem + (double)count * st.dscan * st.elem + (double)count * topk * 12.0;
+    pi = prof_begin(ctx, stream, bytes, 2.0 * (double)count * (double)kept * st.dscan, 0);
+  }
+  ZRET(launch_scan8(a, st.f16, ((nchunks + 7) / 8) * 8 * nqtiles, cus, stream));
+  prof_end(ctx, stream, pi);
+  MergeArgs m{};
+  m.part_s = a.part_s; m.part_i = a.part_i; m.slots_per_q = nchunks; m.slot_stride = 1; m.k = topk; m.slot_len = topk;
+  m.threshold = threshold; m.bound_keys = a.gtau; m.keymap = st.keys;
+  m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(merge_threads(count)), (size_t)topk * 12 + 16, stream, m);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+// `user_facing`: a search whose lists go back to the caller (profiled, L2-refined); false for the IVF
+// coarse pass and the k-means labelling, which only need the ranking
+int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold,
+                       const uint64_t *d_exclude, const SearchOut &out_in, hipStream_t stream, bool user_facing) {
+  const bool profile_it = user_facing;
+  SearchOut out = out_in;
+  if (user_facing && st.metric == ZVEC_HIP_METRIC_L2 && out.idx == nullptr) {
+    ZRET(ctx->ridx.ensure((size_t)count * topk * sizeof(uint32_t)));
+    out.idx = ctx->ridx.as<uint32_t>();
+  }
+  if (st.n == 0) {
+    // no rows: empty results
+    MergeArgs m{};
+    ZCHK(hipMemsetAsync(out.counts, 0, sizeof(uint32_t) * count, stream));
+    ZCHK(hipMemsetAsync(out.keys, 0xff, sizeof(uint64_t) * (size_t)count * topk, stream));
+    return 0;
+  }
+  // Sparse keep-set: compact the kept rows and scan those (work ~ kept rows, like the CPU's skip-before-distance)
+  if (d_exclude != nullptr && user_facing && st.n >= 65536) {
+    const uint32_t nchunks_b = (uint32_t)((st.n + 2047) / 2048);
+    ZRET(ctx->cmp_cnt.ensure(((size_t)2 * nchunks_b + 8) * sizeof(uint32_t)));
+    uint32_t *d_cnt = ctx->cmp_cnt.as<uint32_t>(), *d_off = d_cnt + nchunks_b, *d_total = d_off + nchunks_b;
+    const uint32_t *ex32 = reinterpret_cast<const uint32_t *>(d_exclude);
+    hipLaunchKernelGGL(keep_count_kernel, dim3(nchunks_b), dim3(64), 0, stream, ex32, st.n, d_cnt);
+    hipLaunchKernelGGL(u32_exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, d_cnt, d_off, nchunks_b, d_total);
+    ZCHK(hipGetLastError());
+    uint32_t kept = 0;
+    ZCHK(hipMemcpyAsync(&kept, d_total, 4, hipMemcpyDeviceToHost, stream));
+    ZCHK(hipStreamSynchronize(stream));
+    // copying the kept rows pays below one half kept; gathering them inside the wide kernel costs ~1.5 % and pays
+    // whenever a tenth of the rows can be skipped
+    const bool can_gather = !knobs().no_gather && count > 2 * QGROUP && pick_ng(count, topk) == 4 && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
+    if ((double)kept <= (can_gather ? 0.9 : 0.5) * (double)st.n) {
+      if (kept == 0) {
+        ZCHK(hipMemsetAsync(out.counts, 0, sizeof(uint32_t) * count, stream));
+        ZCHK(hipMemsetAsync(out.keys, 0xff, sizeof(uint64_t) * (size_t)count * topk, stream));
+        return 0;
+      }
+      const uint64_t ktiles = ((uint64_t)kept + TILE_N - 1) / TILE_N;
+      if (can_gather) {
+        // wide batch: gather the kept rows inside the scan instead of copying them first
+        const size_t padded = (size_t)(ktiles + 1) * TILE_N;
+        ZRET(ctx->cmp_pos.ensure(padded * 4));
+        ZCHK(hipMemsetAsync(ctx->cmp_pos.as<uint32_t>() + kept, 0, (padded - kept) * 4, stream));
+        hipLaunchKernelGGL(keep_fill_kernel, dim3(nchunks_b), dim3(64), 0, stream, ex32, st.n, d_off, ctx->cmp_pos.as<uint32_t>());
+        ZCHK(hipGetLastError());
+        ZRET(flat_scan_gather(ctx, st, ctx->cmp_pos.as<uint32_t>(), kept, count, topk, threshold, out, stream, profile_it));
+        if (user_facing) ZRET(refine_l2(ctx, st, count, topk, threshold, out.keys, out.scores, out.idx, out.counts, stream));
+        return 0;
+      }
+      ZRET(ctx->cmp_pos.ensure((size_t)kept * 4));
+      ZRET(ctx->cmp_base.ensure((size_t)ktiles * TILE_N * st.dpad * 4));
+      ZRET(ctx->cmp_norm.ensure((size_t)ktiles * TILE_N * 4));
+      ZRET(ctx->cmp_keys.ensure((size_t)ktiles * TILE_N * 8));
+      if (st.extra) ZRET(ctx->cmp_extra.ensure((size_t)ktiles * TILE_N * 4));
+      hipLaunchKernelGGL(keep_fill_kernel, dim3(nchunks_b), dim3(64), 0, stream, ex32, st.n, d_off, ctx->cmp_pos.as<uint32_t>());
+      hipLaunchKernelGGL(compact_rows_kernel, dim3((kept + 3) / 4), dim3(256), 0, stream, st.base, st.bnorm, st.extra, st.keys,
+                         ctx->cmp_pos.as<uint32_t>(), kept, st.dpad, ctx->cmp_base.as<float>(), ctx->cmp_norm.as<float>(),
+                         st.extra ? ctx->cmp_extra.as<float>() : nullptr, ctx->cmp_keys.as<uint64_t>());
+      ZCHK(hipGetLastError());
+      Store tmp = st;                       // a view: same shape parameters, compacted arrays
+      tmp.base = ctx->cmp_base.as<float>(); tmp.bnorm = ctx->cmp_norm.as<float>();
+      tmp.extra = st.extra ? ctx->cmp_extra.as<float>() : nullptr; tmp.keys = ctx->cmp_keys.as<uint64_t>();
+      tmp.n = kept; tmp.cap_tiles = ktiles;
+      int rc = flat_scan_prepared(ctx, tmp, count, topk, threshold, nullptr, out_in, stream, user_facing);
+      tmp.base = nullptr; tmp.bnorm = nullptr; tmp.extra = nullptr; tmp.keys = nullptr;   // the view owns nothing
+      return rc;
+    }
+  }
+  // Dense-score path: the scores of a sub-batch of queries are written once to a [queries][positions] matrix by
+  // the same kernel in dump mode and every row is then selected by one wave of merge_kernel.  Used
+  //  (a) for small cache-resident bases searched by many queries with a large k (the IVF coarse step: 1024 x 4096
+  //      centroids, k = nprobe): the fused admission would spend longer warming up 1024 top-40 lists per tile
+  //      run than the matrix cores need for the distances; the 16 MiB of scores stay in L2 / Infinity Cache;
+  //  (b) as the large-k path: topk too big for the LDS-resident lists of the fused kernel (k up to ~5000).
+  {
+    const uint64_t ntiles_d = (st.n + TILE_N - 1) / TILE_N;
+    const double row_bytes_d = (double)ntiles_d * TILE_N * 4.0;
+    const bool small_base = (double)st.n * st.dpad * 4.0 <= 64.0 * 1024 * 1024;
+    const bool k_fits_merge = (size_t)topk * 12 + 16 <= 60 * 1024;
+    const bool want_a = small_base && d_exclude == nullptr && topk > 8 && row_bytes_d * count <= 128.0 * 1024 * 1024;
+    const bool want_b = pick_ng(count, topk) < 1;
+    if (want_b && !k_fits_merge) return ZVEC_HIP_ERR_UNSUPPORTED;
+    if ((want_a || want_b) && k_fits_merge) {
+      const int cus_d = device_cus(ctx);
+      // sub-batches so that the score matrix stays <= 1 GiB
+      const uint32_t sub = (uint32_t)std::max<double>(1.0, std::min<double>((double)count, std::floor(1073741824.0 / row_bytes_d)));
+      ZRET(ctx->part_s.ensure((size_t)(row_bytes_d * sub)));
+      for (uint32_t q0 = 0; q0 < count; q0 += sub) {
+        const uint32_t cnt = std::min(sub, count - q0);
+        int ngd = pick_ng(cnt, 1);
+        // one item per (tile, query tile): halve the query tile while the items would not fill two work-groups per CU
+        // (1024 x 4096 coarse scores: 256 items at 128 rows -> 512 at 64 rows, 92 -> 79 us)
+        while (ngd > 2 && ntiles_d * ((cnt + ngd * QGROUP - 1) / (ngd * QGROUP)) < 2ull * cus_d) ngd /= 2;
+        const uint32_t rows_d = ngd * QGROUP;
+        const uint32_t nqt = (cnt + rows_d - 1) / rows_d;
+        ScanArgs a{};
+        a.base = st.base; a.bnorm = st.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
+        a.queries = ctx->qpad.as<float>() + (size_t)q0 * st.dpad; a.qnorm = ctx->qnorm.as<float>() + q0;
+        a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = 1; a.threshold = threshold;
+        a.mode = 0; a.nq = cnt; a.n = st.n; a.ndense = st.n; a.tiles_per_chunk = 1; a.nchunks = (uint32_t)ntiles_d; a.nqtiles = nqt;
+        a.gtau = ctx->gtau.as<uint32_t>() + q0;
+        a.dump = ctx->part_s.as<float>(); a.dump_stride = (uint32_t)(ntiles_d * TILE_N);
+        a.part_s = nullptr; a.part_i = nullptr;
+        ZRET(launch_scan_ng(ngd, a, st.f16, (uint32_t)ntiles_d * nqt, cus_d, stream));
+        MergeArgs m{};
+        m.part_s = a.dump; m.part_i = nullptr; m.part_keys = nullptr; m.slot_begin = nullptr; m.slots_per_q = 1;
+        m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = a.dump_stride; m.threshold = threshold;
+        m.keymap = st.keys; m.out_keys = out.keys + (size_t)q0 * topk; m.out_scores = out.scores + (size_t)q0 * topk;
+        m.out_idx = out.idx ? out.idx + (size_t)q0 * topk : nullptr; m.out_counts = out.counts + q0;
+        hipLaunchKernelGGL(merge_kernel, dim3(cnt), dim3(64), (size_t)topk * 12 + 16, stream, m);
+        ZCHK(hipGetLastError());
+      }
+      if (user_facing) ZRET(refine_l2(ctx, st, count, topk, threshold, out.keys, out.scores, out.idx, out.counts, stream));
+      return 0;
+    }
+  }
+  // Bound seeding: every work-group of the fused scan starts its lists empty, and filling a list costs ~k ln(rows/k)
+  // sorted insertions per (query, chunk) — with hundreds of chunks in flight that warm-up is most of the admission
+  // work.  A scan of a small prefix first (its k-th score bounds the final k-th from above) lets every chunk start
+  // with a bound that only ~k * chunk_rows / sample_rows of its rows pass.
+  constexpr uint64_t SEED_ROWS = 4096;
+  if (!knobs().no_seed && st.n >= 64 * SEED_ROWS && topk <= 64 && count >= 16) {
+    ZRET(ctx->seed_keys.ensure((size_t)count * topk * sizeof(uint64_t)));
+    ZRET(ctx->seed_scores.ensure((size_t)count * topk * sizeof(float)));
+    ZRET(ctx->seed_counts.ensure((size_t)count * sizeof(uint32_t)));
+    Store view = st;                      // a view of the first SEED_ROWS rows (whole tiles of the same arrays)
+    view.n = SEED_ROWS; view.cap_tiles = SEED_ROWS / TILE_N;
+    SearchOut so{ctx->seed_keys.as<uint64_t>(), ctx->seed_scores.as<float>(), nullptr, ctx->seed_counts.as<uint32_t>()};
+    int rc = flat_scan_prepared(ctx, view, count, topk, threshold, d_exclude, so, stream, false);
+    view.base = nullptr; view.bnorm = nullptr; view.extra = nullptr; view.keys = nullptr;   // the view owns nothing
+    ZRET(rc);
+    hipLaunchKernelGGL(seed_gtau_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, ctx->gtau.as<uint32_t>(),
+                       so.scores, so.counts, count, topk);
+    ZCHK(hipGetLastError());
+  }
+  int ng = pick_ng(count, topk);
+  // a base that stays in the 256 MiB Infinity Cache (IVF centroids, k-means codebooks) can be re-read by
+  // every query tile for free: prefer many small query tiles (more work-groups, each with a long run of
+  // tiles per top-k warm-up) over few large ones
+  const bool cache_resident = (double)st.n * st.dpad * 4.0 <= 64.0 * 1024 * 1024;
+  if (cache_resident && ng > 1) ng = 1;
+  if (ng < 1) return ZVEC_HIP_ERR_UNSUPPORTED;
+  const int cus = device_cus(ctx);
+  // wide batches over a streamed base: the 8-wave 128x128 tile (two work-groups per CU while its lists fit)
+  const bool wide = !knobs().no_wide && (!cache_resident || knobs().force_wide) && pick_ng(count, topk) == 4 && count > 2 * QGROUP && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
+  int occ8 = 1;
+  ScanArgs probe{};
+  probe.k = topk; probe.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
+  if (wide) ZRET(launch_scan8(probe, st.f16, 0, cus, stream, &occ8));
+  const uint32_t rows = wide ? W8_ROWS : ng * QGROUP;
+  const uint32_t nqtiles = (count + rows - 1) / rows;
+  const uint64_t ntiles = (st.n + TILE_N - 1) / TILE_N;
+  uint64_t resident = wide ? (uint64_t)cus * occ8
+                           : (uint64_t)cus * (ng >= 4 ? 2 : (ng == 2 ? 2 : 3));   // work-groups per CU each shape reaches
+  // items are equal-sized in a flat scan, so ONE wave of work-groups (items == resident slots) is the balanced
+  // choice and gives the longest tile runs per top-k warm-up
+  uint64_t want_chunks = std::max<uint64_t>(1, (resident + nqtiles - 1) / nqtiles);
+  uint64_t tpc = std::max<uint64_t>(1, (ntiles + want_chunks - 1) / want_chunks);
+  // >= 4 tiles per top-k warm-up — unless the base is too small to fill the chip that way (a single query over the
+  // 4096 IVF centroids: 32 one-tile items instead of 8 four-tile ones, 141 -> 40 us)
+  tpc = std::max<uint64_t>(tpc, std::min<uint64_t>(ntiles, ntiles >= 4 * resident ? 4 : 1));
+  uint32_t nchunks = (uint32_t)((ntiles + tpc - 1) / tpc);
+  uint64_t slots = (uint64_t)count * nchunks;
+  ZRET(ctx->part_s.ensure(slots * topk * sizeof(float)));
+  ZRET(ctx->part_i.ensure(slots * topk * sizeof(uint32_t)));
+
+  ScanArgs a{};
+  a.base = st.base; a.bnorm = st.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
+  a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
+  a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = topk; a.threshold = threshold;
+  a.gtau = ctx->gtau.as<uint32_t>();
+  a.mode = 0; a.nq = count; a.n = st.n; a.ndense = st.n; a.tiles_per_chunk = (uint32_t)tpc; a.nchunks = nchunks; a.nqtiles = nqtiles;
+  a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
+  int pi = -1;
+  if (profile_it) {
+    double bytes = (double)st.n * st.dscan * st.elem + (double)count * st.dscan * st.elem + (double)count * topk * 12.0;
+    double flops = 2.0 * (double)count * (double)st.n * st.dscan;
+    pi = prof_begin(ctx, stream, bytes, flops, 0);
+  }
+  if (wide) ZRET(launch_scan8(a, st.f16, ((nchunks + 7) / 8) * 8 * nqtiles, cus, stream));   // ids padded to whole XCD groups
+  else ZRET(launch_scan_ng(ng, a, st.f16, nchunks * nqtiles, cus, stream));
+  prof_end(ctx, stream, pi);
+
+  MergeArgs m{};
+  m.part_s = a.part_s; m.part_i = a.part_i; m.part_keys = nullptr; m.slot_begin = nullptr;
+  m.slots_per_q = nchunks; m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = topk; m.threshold = threshold;
+  m.bound_keys = a.gtau;   // the scan's shared bounds: valid upper bounds of every query's final k-th score
+  m.keymap = st.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(merge_threads(count)), (size_t)topk * 12 + 16, stream, m);
+  ZCHK(hipGetLastError());
+  if (user_facing) ZRET(refine_l2(ctx, st, count, topk, threshold, out.keys, out.scores, out.idx, out.counts, stream));
+  return 0;
+}
+
+// L2 only: direct re-scoring + re-sort of the final lists (see rescore_l2_kernel)
+int refine_l2(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold, uint64_t *keys,
+              float *scores, uint32_t *idx, uint32_t *counts, hipStream_t stream) {
+  if (st.metric != ZVEC_HIP_METRIC_L2) return 0;
+  if ((size_t)topk * 16 + 16 > 60 * 1024) return 0;   // huge k: keep the expansion scores
+  const uint64_t pairs = (uint64_t)count * topk;
+  if (st.f16)
+    hipLaunchKernelGGL(rescore_l2_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, st.base,
+                       ctx->qpad.as<float>(), st.dpad, idx, counts, count, topk, scores);
+  else
+    hipLaunchKernelGGL(rescore_l2_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, st.base,
+                       ctx->qpad.as<float>(), st.dpad, idx, counts, count, topk, scores);
+  hipLaunchKernelGGL(resort_kernel, dim3(count), dim3(64), (size_t)topk * 16 + 16, stream, keys, scores, idx, counts, topk,
+                     threshold);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int prep_queries(zvec_hip_ctx_s *ctx, const Store &st, const void *d_queries, uint32_t count, float threshold,
+                 hipStream_t stream) {
+  ZRET(ctx->qpad.ensure((size_t)count * st.dpad * sizeof(float)));
+  ZRET(ctx->qnorm.ensure((size_t)count * sizeof(float)));
+  ZRET(ctx->gtau.ensure((size_t)count * sizeof(uint32_t)));
+  if (st.f16)
+    hipLaunchKernelGGL(prep_queries_kernel<true>, dim3((count + 3) / 4), dim3(256), 0, stream, d_queries, count,
+                       st.dim_in, st.dscan, st.dpad, ctx->qpad.as<float>(), ctx->qnorm.as<float>(),
+                       ctx->gtau.as<uint32_t>(), threshold);
+  else
+    hipLaunchKernelGGL(prep_queries_kernel<false>, dim3((count + 3) / 4), dim3(256), 0, stream, d_queries, count,
+                       st.dim_in, st.dscan, st.dpad, ctx->qpad.as<float>(), ctx->qnorm.as<float>(),
+                       ctx->gtau.as<uint32_t>(), threshold);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int launch_pack(const Store &st, const void *d_rows, uint64_t n, const uint64_t *d_src, uint64_t pos0,
+                const uint64_t *d_dst, hipStream_t stream) {
+  if (st.f16)
+    hipLaunchKernelGGL(pack_rows_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_rows, n, st.dim_in,
+                       st.dscan, st.dpad, d_src, pos0, d_dst, st.base, st.bnorm, st.extra);
+  else
+    hipLaunchKernelGGL(pack_rows_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_rows, n, st.dim_in,
+                       st.dscan, st.dpad, d_src, pos0, d_dst, st.base, st.bnorm, st.extra);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int launch_unpack(const Store &st, uint64_t pos, void *d_out, hipStream_t stream) {
+  if (st.f16)
+    hipLaunchKernelGGL(unpack_row_kernel<true>, dim3(1), dim3(256), 0, stream, st.base, st.extra, pos, st.dscan, st.dim_in, st.dpad, d_out);
+  else
+    hipLaunchKernelGGL(unpack_row_kernel<false>, dim3(1), dim3(256), 0, stream, st.base, st.extra, pos, st.dscan, st.dim_in, st.dpad, d_out);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
+int store_append_dev(Store &st, const void *d_vecs, uint64_t n, const uint64_t *d_keys, hipStream_t stream) {
+  if (n == 0) return 0;
+  if (st.n + n >= 0xfffffff0ull) return ZVEC_HIP_ERR_OUT_OF_RANGE;   // positions are 32-bit (IDX_NONE reserved)
+  ZRET(st.reserve(st.n + n, stream));
+  ZRET(launch_pack(st, d_vecs, n, nullptr, st.n, nullptr, stream));
+  ZCHK(hipGetLastError());
+  hipLaunchKernelGGL(fill_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st.keys, st.n, n, d_keys);
+  ZCHK(hipGetLastError());
+  st.n += n;
+  return 0;
+}
+
+hipStream_t pick_stream(zvec_hip_ctx_s *ctx, void *stream) {
+  return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->cur;
+}
+
+int ctx_new(int device, zvec_hip_ctx_s **out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fprintf(stderr, "[zvec_hip] no HIP device available: the zvec_hip core has no CPU fallback\n");
+    return ZVEC_HIP_ERR_RUNTIME;
+  }
+  if (device < 0 || device >= ndev) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  ZCHK(hipSetDevice(device));
+  zvec_hip_ctx_s *c = new (std::nothrow) zvec_hip_ctx_s();
+  if (!c) return ZVEC_HIP_ERR_NO_MEMORY;
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking) != hipSuccess) { delete c; return ZVEC_HIP_ERR_RUNTIME; }
+  c->cur = c->own;
+  *out = c;
+  return 0;
+}
+
+void ctx_free(zvec_hip_ctx_s *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own) (void)hipStreamSynchronize(c->own);
+  c->gtau.release(); c->ridx.release(); c->cmp_base.release(); c->cmp_norm.release(); c->cmp_extra.release(); c->cmp_keys.release(); c->cmp_pos.release(); c->cmp_cnt.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
+  c->coarse_keys.release(); c->coarse_scores.release(); c->coarse_idx.release(); c->coarse_cnt.release();
+  c->plan.release(); c->io_q.release(); c->io_ex.release(); c->io_keys.release(); c->io_scores.release();
+  c->io_counts.release(); c->stats.release();
+  for (auto e : c->ev0) (void)hipEventDestroy(e);
+  for (auto e : c->ev1) (void)hipEventDestroy(e);
+  if (c->own) (void)hipStreamDestroy(c->own);
+  delete c;
+}
+
+}  // namespace

@@ -1,0 +1,226 @@
+// api_ivf_core.inc.h — IVF search on device pointers: coarse pass, plan, list scan, merge, large-k fallback
+// Part of zvec_hip_api.hip (one translation unit; included in order, not standalone).
+
+namespace {
+
+// ---- IVF search core (device pointers) ------------------------------------------------------
+int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_queries, uint32_t count, uint32_t topk,
+                    float threshold, uint32_t nprobe, uint32_t max_scan_count, int brute_force,
+                    const uint64_t *d_exclude, const SearchOut &out, hipStream_t stream) {
+  const int cus = device_cus(ctx);
+  const uint32_t nlist = h->nlist;
+  if (nprobe < 1) nprobe = 1;
+  if (nprobe > nlist) nprobe = nlist;
+  ZRET(prep_queries(ctx, h->lists, d_queries, count, FLT_MAX, stream));   // coarse pass: no RNN radius
+
+  // 1. coarse assign: flat scan over the centroids, k = nprobe (IVFCentroidIndex::search)
+  if (!brute_force) {
+    ZRET(ctx->coarse_keys.ensure((size_t)count * nprobe * sizeof(uint64_t)));
+    ZRET(ctx->coarse_scores.ensure((size_t)count * nprobe * sizeof(float)));
+    ZRET(ctx->coarse_idx.ensure((size_t)count * nprobe * sizeof(uint32_t)));
+    ZRET(ctx->coarse_cnt.ensure((size_t)count * sizeof(uint32_t)));
+    SearchOut co{ctx->coarse_keys.as<uint64_t>(), ctx->coarse_scores.as<float>(), ctx->coarse_idx.as<uint32_t>(),
+                 ctx->coarse_cnt.as<uint32_t>()};
+    ZRET(flat_scan_prepared(ctx, h->cent, count, nprobe, FLT_MAX, nullptr, co, stream, false));
+  }
+
+  // 2. plan: list-major work items
+  // list scan shape: 16x16x4 MFMA tiles, 32 query rows per work item as two 16-row halves (the second is
+  // skipped when the item has <= 16 rows); a list probed by more than 32 queries is dealt as several items
+  const int ng = 0;
+  if (scan_lds_bytes(1, topk, true) > LDS_LIMIT - 1024) {
+    // Large k (beyond ~470): the result lists no longer fit beside the staging buffers.  Rare, so served by the plain
+    // route: expand every query's probed lists into positions, score each (query, row) pair directly, select.
+    if ((size_t)topk * 12 + 16 > 60 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
+    PlanArgs p{};
+    p.coarse_idx = ctx->coarse_idx.as<uint32_t>(); p.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
+    p.nq = count; p.nprobe = nprobe; p.nlist = nlist; p.max_scan_count = max_scan_count; p.brute_force = brute_force;
+    p.list_size = h->d_size; p.list_size_global = h->d_size_global;
+    ZRET(ctx->plan.ensure(((size_t)2 * count + 8) * sizeof(uint32_t)));
+    uint32_t *d_rows = ctx->plan.as<uint32_t>(), *d_off = d_rows + count;
+    // upper bound of the rows one query scans here: the np largest local lists
+    uint64_t maxlen = 0;
+    {
+      std::vector<uint32_t> sz(h->h_size);
+      const uint32_t np = brute_force ? nlist : nprobe;
+      std::partial_sort(sz.begin(), sz.begin() + np, sz.end(), std::greater<uint32_t>());
+      for (uint32_t i = 0; i < np; ++i) maxlen += sz[i];
+    }
+    if (maxlen == 0) maxlen = 1;
+    if ((uint64_t)count * maxlen >= 0xffffffffull) return ZVEC_HIP_ERR_OUT_OF_RANGE;   // (slice the batch)
+    hipLaunchKernelGGL(ivf_expand_kernel<false>, dim3((count + 3) / 4), dim3(256), 0, stream, p, h->d_tile0, h->d_dense0,
+                       nullptr, d_rows, nullptr, nullptr);
+    hipLaunchKernelGGL(u32_exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, d_rows, d_off, count, d_off + count);
+    ZCHK(hipGetLastError());
+    uint32_t total_rows = 0;
+    ZCHK(hipMemcpyAsync(&total_rows, d_off + count, 4, hipMemcpyDeviceToHost, stream));
+    ZCHK(hipStreamSynchronize(stream));
+    Scoped<uint32_t> d_pos;
+    ZRET(d_pos.alloc(std::max<uint32_t>(total_rows, 1)));
+    hipLaunchKernelGGL(ivf_expand_kernel<true>, dim3((count + 3) / 4), dim3(256), 0, stream, p, h->d_tile0, h->d_dense0,
+                       reinterpret_cast<const uint32_t *>(d_exclude), nullptr, d_off, d_pos);
+    ZCHK(hipGetLastError());
+    const uint64_t pairs = (uint64_t)count * maxlen;
+    ZRET(ctx->part_s.ensure(pairs * 4));
+    ZRET(ctx->part_i.ensure(pairs * 4));
+    // (re-prepare the queries with the caller's RNN radius: the coarse pass ran without one)
+    ZRET(prep_queries(ctx, h->lists, d_queries, count, threshold, stream));
+    if (h->lists.f16)
+      hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->lists.base,
+                         ctx->qpad.as<float>(), h->lists.dpad, h->metric, d_pos, d_off, count, (uint32_t)maxlen,
+                         ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->lists.base,
+                         ctx->qpad.as<float>(), h->lists.dpad, h->metric, d_pos, d_off, count, (uint32_t)maxlen,
+                         ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
+    ZCHK(hipGetLastError());
+    MergeArgs m{};
+    m.part_s = ctx->part_s.as<float>(); m.part_i = ctx->part_i.as<uint32_t>();
+    m.slots_per_q = 1; m.slot_stride = 1; m.k = topk; m.slot_len = (uint32_t)maxlen; m.threshold = threshold;
+    m.keymap = h->lists.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
+    hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+    ZCHK(hipGetLastError());
+    ZCHK(hipStreamSynchronize(stream));    // d_pos is freed on return
+    ctx->q_nprobe = nullptr; ctx->q_scanned = nullptr; ctx->last_count = 0;
+    return 0;
+  }
+  const uint32_t rows_per_group = 32;
+  const uint64_t npairs = (uint64_t)count * (brute_force ? nlist : nprobe);
+  // layout of the plan buffer (u32 words)
+  size_t off = 0;
+  auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
+  size_t o_qnprobe = take(count), o_qscanned = take(count), o_qnslots = take(count), o_slotbegin = take(count + 1);
+  size_t o_lcount = take(nlist), o_lfill = take(nlist), o_lqoff = take(nlist + 1), o_itemoff = take(nlist + 1);
+  size_t o_queue = take(4);
+  size_t o_ltpc = take(nlist);
+  size_t o_total = take(4), o_csrq = take(npairs), o_csrslot = take(npairs);
+  ZRET(ctx->plan.ensure(off * sizeof(uint32_t)));
+  uint32_t *pb = ctx->plan.as<uint32_t>();
+  // list_count + list_fill and the work-queue head zeroed, shared bounds reset (the coarse pass may have left
+  // centroid-score bounds behind): one launch
+  // chunk length of this search: the lists it can touch (at most count x nprobe of them) should give a few items per
+  // resident work-group — a single query probing 40 lists needs one-tile items to use the chip at all, a batch of
+  // 1024 the index-wide default
+  uint32_t tpc = h->tiles_per_chunk;
+  {
+    const uint64_t lists_touched = std::min<uint64_t>(nlist, (uint64_t)count * (brute_force ? nlist : nprobe));
+    const uint64_t est_tiles = std::max<uint64_t>(1, h->local_tiles * lists_touched / std::max<uint32_t>(nlist, 1));
+    const uint64_t t = est_tiles / (4ull * (uint64_t)device_cus(ctx) * 3ull);
+    tpc = (uint32_t)std::min<uint64_t>(h->tiles_per_chunk, std::max<uint64_t>(1, t));
+    if (knobs().ivf_tpc) tpc = (uint32_t)knobs().ivf_tpc;
+  }
+  {
+    ZRET(ctx->gtau.ensure((size_t)count * sizeof(uint32_t)));
+    const uint32_t nzero = (uint32_t)(o_lqoff - o_lcount);
+    const uint32_t nthr = std::max<uint32_t>(std::max<uint32_t>(nzero, count), std::max<uint32_t>(nlist, 4));
+    hipLaunchKernelGGL(ivf_reset_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, pb + o_lcount, nzero, pb + o_queue,
+                       ctx->gtau.as<uint32_t>(), count, threshold, pb + o_ltpc, h->d_tail, nlist, tpc);
+    ZCHK(hipGetLastError());
+  }
+  PlanArgs p{};
+  p.coarse_idx = ctx->coarse_idx.as<uint32_t>(); p.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
+  p.nq = count; p.nprobe = nprobe; p.nlist = nlist; p.max_scan_count = max_scan_count; p.brute_force = brute_force;
+  p.list_size = h->d_size; p.list_size_global = h->d_size_global; p.list_order = h->d_order;
+  p.list_tpc = pb + o_ltpc;
+  p.rows_per_group = rows_per_group;
+  p.q_nprobe = pb + o_qnprobe; p.q_scanned = pb + o_qscanned; p.q_nslots = pb + o_qnslots; p.slot_begin = pb + o_slotbegin;
+  p.list_count = pb + o_lcount; p.list_fill = pb + o_lfill; p.list_qoff = pb + o_lqoff; p.item_off = pb + o_itemoff;
+  p.total_items = pb + o_total; p.csr_q = pb + o_csrq; p.csr_slot = pb + o_csrslot;
+  ctx->q_nprobe = p.q_nprobe; ctx->q_scanned = p.q_scanned; ctx->last_count = count;
+  ctx->last_list_count = p.list_count;
+  hipLaunchKernelGGL(plan_wave_kernel<false>, dim3((count + 3) / 4), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+  hipLaunchKernelGGL(plan_wave_kernel<true>, dim3((count + 3) / 4), dim3(256), 0, stream, p);
+  ZCHK(hipGetLastError());
+
+  // 3. scan.  Upper bound of slots: every probed list contributes its chunks; the worst case is a query that
+  //    probes the nprobe lists with the most chunks.
+  std::vector<uint32_t> &sz = h->h_size;
+  uint64_t slots_bound;
+  {
+    std::vector<uint32_t> chunks(nlist);
+    for (uint32_t l = 0; l < nlist; ++l)
+    {
+      const uint32_t t = h->h_tail[l] ? std::max<uint32_t>(1, tpc >> 2) : tpc;
+      chunks[l] = sz[l] ? (((sz[l] + TILE_N - 1) / TILE_N + t - 1) / t) : 0;
+    }
+    uint32_t np = brute_force ? nlist : nprobe;
+    std::partial_sort(chunks.begin(), chunks.begin() + np, chunks.end(), std::greater<uint32_t>());
+    uint64_t s = 0;
+    for (uint32_t i = 0; i < np; ++i) s += chunks[i];
+    slots_bound = s * count;
+  }
+  if (slots_bound == 0) slots_bound = 1;
+  ZRET(ctx->part_s.ensure(slots_bound * topk * sizeof(float)));
+  ZRET(ctx->part_i.ensure(slots_bound * topk * sizeof(uint32_t)));
+
+  ScanArgs a{};
+  a.base = h->lists.base; a.bnorm = h->lists.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
+  a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
+  a.dpad = h->lists.dpad; a.nks = h->lists.dpad / TILE_K; a.metric = h->metric; a.k = topk; a.threshold = threshold;
+  a.gtau = ctx->gtau.as<uint32_t>();
+  a.mode = 1; a.nq = count; a.n = h->lists.n; a.ndense = h->count_local; a.tiles_per_chunk = tpc; a.list_tpc = pb + o_ltpc;
+  a.total_items = p.total_items; a.queue = pb + o_queue; a.list_order = h->d_order; a.item_off = p.item_off; a.list_tile0 = h->d_tile0; a.list_size = h->d_size;
+  a.list_dense0 = h->d_dense0; a.list_qoff = p.list_qoff; a.csr_q = p.csr_q; a.csr_slot = p.csr_slot; a.nlist = nlist;
+  a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
+  // algorithmic bytes of the list scan = rows of the DISTINCT probed lists (counted on device from
+  // the plan, see ivf_work_stats_kernel) + the query rows + the result lists
+  int pi = prof_begin(ctx, stream, (double)count * h->lists.dscan * h->lists.elem + (double)count * topk * 12.0, 0, 1);
+  if (pi >= 0) ctx->prof_dscan[pi] = h->lists.dscan | (h->lists.f16 ? 0x80000000u : 0u);
+  ZRET(launch_scan_ng(ng, a, h->lists.f16, 0x7fffffffu, cus, stream));
+  prof_end(ctx, stream, pi);
+
+  // 4. merge the per-(query, probe, chunk) partial lists in probe order
+  MergeArgs m{};
+  m.part_s = a.part_s; m.part_i = a.part_i; m.part_keys = nullptr; m.slot_begin = p.slot_begin; m.slots_per_q = 0;
+  m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = topk; m.threshold = threshold; m.keymap = h->lists.keys;
+  m.bound_keys = a.gtau;
+  uint32_t *ridx = out.idx;
+  if (h->metric == ZVEC_HIP_METRIC_L2 && ridx == nullptr) {
+    ZRET(ctx->ridx.ensure((size_t)count * topk * sizeof(uint32_t)));
+    ridx = ctx->ridx.as<uint32_t>();
+  }
+  m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = ridx; m.out_counts = out.counts;
+  hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(merge_threads(count)), (size_t)topk * 12 + 16, stream, m);
+  ZCHK(hipGetLastError());
+  ZRET(refine_l2(ctx, h->lists, count, topk, threshold, out.keys, out.scores, ridx, out.counts, stream));
+  return 0;
+}
+
+// work statistics of an IVF launch (for the roofline line): distinct probed rows & pair rows
+__global__ void ivf_work_stats_kernel(const uint32_t *list_count, const uint32_t *list_size, uint32_t nlist,
+                                      unsigned long long *out2) {
+  unsigned long long rows = 0, pairs = 0;
+  for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
+    uint32_t c = list_count[l];
+    if (c) { rows += list_size[l]; pairs += (unsigned long long)c * list_size[l]; }
+  }
+  atomicAdd(&out2[0], rows);
+  atomicAdd(&out2[1], pairs);
+}
+
+int host_search_wrap_begin(zvec_hip_ctx_s *ctx, const void *queries, size_t qbytes, const uint64_t *exclude,
+                           uint64_t nbits, uint32_t count, uint32_t topk, hipStream_t stream) {
+  ZRET(ctx->io_q.ensure(qbytes));
+  ZCHK(hipMemcpyAsync(ctx->io_q.p, queries, qbytes, hipMemcpyHostToDevice, stream));
+  if (exclude) {
+    size_t words = (size_t)((nbits + 63) / 64);
+    ZRET(ctx->io_ex.ensure(words * 8 + 8));
+    ZCHK(hipMemcpyAsync(ctx->io_ex.p, exclude, words * 8, hipMemcpyHostToDevice, stream));
+  }
+  ZRET(ctx->io_keys.ensure((size_t)count * topk * sizeof(uint64_t)));
+  ZRET(ctx->io_scores.ensure((size_t)count * topk * sizeof(float)));
+  ZRET(ctx->io_counts.ensure((size_t)count * sizeof(uint32_t)));
+  return 0;
+}
+
+int host_search_wrap_end(zvec_hip_ctx_s *ctx, uint32_t count, uint32_t topk, uint64_t *out_keys, float *out_scores,
+                         uint32_t *out_counts, hipStream_t stream) {
+  ZCHK(hipMemcpyAsync(out_keys, ctx->io_keys.p, (size_t)count * topk * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  ZCHK(hipMemcpyAsync(out_scores, ctx->io_scores.p, (size_t)count * topk * sizeof(float), hipMemcpyDeviceToHost, stream));
+  ZCHK(hipMemcpyAsync(out_counts, ctx->io_counts.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  ZCHK(hipStreamSynchronize(stream));
+  return 0;
+}
+
+}  // namespace

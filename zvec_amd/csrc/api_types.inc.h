@@ -1,0 +1,169 @@
+// api_types.inc.h — error macros, device buffers, the blocked Store, context and index handle structs
+// Part of zvec_hip_api.hip (one translation unit; included in order, not standalone).
+
+#define ZCHK(expr)                                                                               \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      fprintf(stderr, "[zvec_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e),        \
+              __FILE__, __LINE__);                                                               \
+      return (_e == hipErrorOutOfMemory) ? ZVEC_HIP_ERR_NO_MEMORY : ZVEC_HIP_ERR_RUNTIME;        \
+    }                                                                                            \
+  } while (0)
+
+#define ZRET(expr)            \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != 0) return _r;   \
+  } while (0)
+
+namespace {
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+constexpr int PROFILE_MAX = 8192;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    ZCHK(hipMalloc(&p, want));
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// scope-owned device temporary: freed on every exit path of the enclosing function
+template <typename T>
+struct Scoped {
+  T *p = nullptr;
+  Scoped() {}
+  Scoped(const Scoped &) = delete;
+  Scoped &operator=(const Scoped &) = delete;
+  ~Scoped() { if (p) (void)hipFree(p); }
+  int alloc(size_t count) {
+    ZCHK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+    return 0;
+  }
+  operator T *() const { return p; }
+};
+
+// a blocked, HBM-resident set of rows (flat store, IVF centroids, IVF inverted lists)
+struct Store {
+  uint32_t dim_in = 0;   // element dimension at the ABI (cosine: d+1)
+  uint32_t dscan = 0;    // scanned dims
+  uint32_t dpad = 0;     // 4-byte WORDS per stored row, multiple of 32 (fp32: dscan up to 32; fp16: dscan up to 64, halved)
+  uint32_t elem = 4;     // bytes per element: 4 (fp32) or 2 (fp16)
+  bool f16 = false;
+  int metric = 0;
+  uint64_t n = 0;        // padded positions in use
+  uint64_t cap_tiles = 0;
+  float *base = nullptr;
+  float *bnorm = nullptr;
+  float *extra = nullptr;   // cosine: stored norm column
+  uint64_t *keys = nullptr;
+
+  void configure(uint32_t dim, int met, int dtype = ZVEC_HIP_DT_FP32) {
+    dim_in = dim;
+    metric = met;
+    f16 = (dtype == ZVEC_HIP_DT_FP16);
+    elem = f16 ? 2 : 4;
+    // cosine rows end with the fp32 norm of the original vector: 1 float, or 2 half slots (cosine_converter.cc:205-212)
+    dscan = (met == ZVEC_HIP_METRIC_COSINE) ? dim - (f16 ? 2 : 1) : dim;
+    dpad = f16 ? ((dscan + 63) / 64 * 64) / 2 : (dscan + TILE_K - 1) / TILE_K * TILE_K;
+  }
+  size_t row_bytes() const { return (size_t)dim_in * elem; }
+  int reserve(uint64_t rows, hipStream_t stream) {
+    uint64_t tiles = (rows + TILE_N - 1) / TILE_N;
+    if (tiles <= cap_tiles) return 0;
+    uint64_t nt = std::max<uint64_t>(tiles, cap_tiles + cap_tiles / 2 + 1);
+    float *nb = nullptr, *nn = nullptr, *ne = nullptr;
+    uint64_t *nk = nullptr;
+    ZCHK(hipMalloc(&nb, (size_t)nt * TILE_N * dpad * sizeof(float)));
+    ZCHK(hipMalloc(&nn, (size_t)nt * TILE_N * sizeof(float)));
+    ZCHK(hipMalloc(&nk, (size_t)nt * TILE_N * sizeof(uint64_t)));
+    if (metric == ZVEC_HIP_METRIC_COSINE) ZCHK(hipMalloc(&ne, (size_t)nt * TILE_N * sizeof(float)));
+    uint64_t used_tiles = (n + TILE_N - 1) / TILE_N;
+    if (used_tiles) {
+      ZCHK(hipMemcpyAsync(nb, base, (size_t)used_tiles * TILE_N * dpad * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      ZCHK(hipMemcpyAsync(nn, bnorm, (size_t)used_tiles * TILE_N * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      ZCHK(hipMemcpyAsync(nk, keys, (size_t)used_tiles * TILE_N * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
+      if (ne) ZCHK(hipMemcpyAsync(ne, extra, (size_t)used_tiles * TILE_N * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      ZCHK(hipStreamSynchronize(stream));
+    }
+    release();
+    base = nb; bnorm = nn; keys = nk; extra = ne; cap_tiles = nt;
+    return 0;
+  }
+  void release() {
+    if (base) (void)hipFree(base);
+    if (bnorm) (void)hipFree(bnorm);
+    if (extra) (void)hipFree(extra);
+    if (keys) (void)hipFree(keys);
+    base = bnorm = extra = nullptr; keys = nullptr; cap_tiles = 0;
+  }
+};
+
+}  // namespace
+
+struct zvec_hip_ctx_s {
+  int device = 0;
+  hipStream_t own = nullptr;
+  hipStream_t cur = nullptr;
+  std::mutex mu;
+  // workspace
+  DevBuf gtau, ridx;
+  DevBuf seed_keys, seed_scores, seed_counts;   // sample scan that seeds the shared admission bounds
+  DevBuf cmp_base, cmp_norm, cmp_extra, cmp_keys, cmp_pos, cmp_cnt;   // compacted keep-set (sparse filters)
+  DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
+  DevBuf plan;        // all u32 plan arrays
+  DevBuf io_q, io_ex, io_keys, io_scores, io_counts;   // staging for host-pointer entry points
+  DevBuf stats;       // per-launch {distinct_rows, pair_rows} u64 x PROFILE_MAX
+  uint32_t *q_scanned = nullptr, *q_nprobe = nullptr;  // inside plan
+  uint32_t *last_list_count = nullptr;                 // inside plan
+  uint32_t last_count = 0;
+  // profiling
+  bool profile = false;
+  std::vector<hipEvent_t> ev0, ev1;
+  std::vector<double> host_bytes, host_flops;   // flat launches: known on the host
+  std::vector<int> launch_is_ivf;
+  std::vector<uint32_t> prof_dscan;
+  int nprof = 0;
+  int cus = 0;
+};
+
+struct zvec_hip_flat_s {
+  int device = 0;
+  int dtype = 0;
+  Store st;
+  zvec_hip_ctx_s *defctx = nullptr;
+  std::mutex mu;
+};
+
+struct zvec_hip_ivf_s {
+  int device = 0;
+  int dtype = 0;
+  uint32_t dim = 0;
+  int metric = 0;
+  uint32_t nlist = 0;
+  uint32_t shard = 0, nshards = 1;
+  bool loaded = false;
+  Store cent;     // centroids as a flat store
+  Store lists;    // inverted lists, each padded to whole tiles
+  uint64_t count_local = 0, count_global = 0;
+  std::vector<uint32_t> h_size, h_size_global, h_tile0;
+  std::vector<uint64_t> h_dense0;      // local dense offsets (nlist+1)
+  std::vector<uint64_t> h_row_ids;     // local dense position -> original row
+  std::vector<char> h_centroids;       // [nlist][dim] in the index element type
+  uint32_t *d_size = nullptr, *d_size_global = nullptr, *d_tile0 = nullptr, *d_order = nullptr, *d_tail = nullptr;
+  uint32_t tiles_per_chunk = 8;
+  std::vector<uint32_t> h_tail;        // 1 = list belongs to the tail of the deal order (shorter chunks)
+  uint64_t local_tiles = 0;            // tiles of the lists held by this shard
+  uint64_t *d_dense0 = nullptr;
+  zvec_hip_ctx_s *defctx = nullptr;
+  std::mutex mu;
+};
