@@ -74,3 +74,42 @@ def test_sharded_build_is_deterministic_across_shards():
     assert np.array_equal(cents[0], cents[1]) and np.array_equal(cents[1], cents[2])
     allrows = np.sort(np.concatenate(rows_all))
     assert np.array_equal(allrows, np.arange(n, dtype=np.uint64))
+
+
+def test_concurrent_contexts_on_one_index(oracle):
+    """The reference hands one context to each searching thread (index.cc:24-45).  Here: one zvec_hip_ctx_t per thread
+    (own stream + workspace) on shared flat and IVF handles; ctypes drops the GIL during the calls, so the searches
+    really overlap.  Every thread must get exactly what a serial search returns."""
+    import threading
+    import zvec_amd as zv
+    rng = np.random.default_rng(21)
+    n, dim, nq, k, nlist = 30000, 32, 64, 10, 40
+    base = rng.integers(-9, 10, (n, dim)).astype(np.float32)
+    flat = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert flat.load(base) == 0
+    ivf = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=0.2, brute_force_threshold=10)
+    assert ivf.build(base, nlist, kmeans_iters=3) == 0
+    queries = [rng.integers(-9, 10, (nq, dim)).astype(np.float32) for _ in range(4)]
+    want = []
+    for q in queries:
+        c1, c2 = flat.create_context(), ivf.create_context()
+        c1.set_topk(k), c2.set_topk(k)
+        assert flat.search_impl(q, nq, c1) == 0 and ivf.search_impl(q, nq, c2) == 0
+        want.append((c1.keys.copy(), c1.scores.copy(), c2.keys.copy(), c2.scores.copy()))
+    errors = []
+
+    def worker(t):
+        try:
+            c1, c2 = flat.create_context(), ivf.create_context()
+            c1.set_topk(k), c2.set_topk(k)
+            for _ in range(25):
+                assert flat.search_impl(queries[t], nq, c1) == 0 and ivf.search_impl(queries[t], nq, c2) == 0
+                assert np.array_equal(c1.keys, want[t][0]) and np.array_equal(c1.scores, want[t][1])
+                assert np.array_equal(c2.keys, want[t][2]) and np.array_equal(c2.scores, want[t][3])
+        except Exception as e:   # noqa: BLE001 - reported below
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
