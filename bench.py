@@ -204,7 +204,10 @@ def main():
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline_ivf(torch, ivf, base, q, topk, nprobe, max_scan, args)
+            gk, gs, gc = sh.search(q, topk, nprobe, max_scan, stream_ptr)
+            torch.cuda.synchronize()
+            cpu = cpu_baseline_ivf(torch, ivf, base, q, topk, nprobe, max_scan, args,
+                                   gpu=(gk.cpu().numpy(), gs.cpu().numpy(), gc.cpu().numpy()))
         del base
         torch.cuda.empty_cache()
 
@@ -402,7 +405,7 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("ZVEC_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline_ivf(torch, ivf, base, q, topk, nprobe, max_scan, args):
+def cpu_baseline_ivf(torch, ivf, base, q, topk, nprobe, max_scan, args, gpu=None):
     """The reference's CPU path restated (oracle/zvec_oracle.c: IVFSearcher::search_impl loops, the
     reference's own AVX-512 distance kernels from oracle/_ref when that library travelled), on the
     host cores of this box, searching THE SAME index (exported centroids / list order) with the same
@@ -439,7 +442,22 @@ def cpu_baseline_ivf(torch, ivf, base, q, topk, nprobe, max_scan, args):
     o.ivf_search(cent, offs, vecs, qh[:n1], topk, nprobe, max_scan, keys=rows, threads=1)
     one = n1 / (time.perf_counter() - t1)
     o.use_reference_kernels(False)
-    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": "port", "value_1_thread": one,
+    parity = None
+    if gpu is not None:
+        # the oracle as the checker: the GPU's answers for the same queries at full size (ids as sets per query; scores of
+        # the common ids; the CPU sums in AVX-512 lane order, the GPU refines L2 scores directly: ~1e-6 relative apart)
+        gk, gs, gc = gpu
+        same = rel = 0.0
+        for i in range(nq):
+            a, b = set(gk[i, :gc[i]].astype(np.uint64).tolist()), set(ok[i, :oc[i]].tolist())
+            same += len(a & b) / float(max(len(b), 1))
+            cs = dict(zip(ok[i, :oc[i]].tolist(), os_[i, :oc[i]].tolist()))
+            for key, sc in zip(gk[i, :gc[i]].astype(np.uint64).tolist(), gs[i, :gc[i]].tolist()):
+                if key in cs:
+                    rel = max(rel, abs(sc - cs[key]) / max(abs(cs[key]), 1e-30))
+        parity = {"queries": int(nq), "topk_ids_in_common": same / nq, "max_rel_score_diff": rel}
+        log("parity at full size vs the CPU path: ids in common %.6f, max relative score difference %.3g" % (same / nq, rel))
+    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": "port", "value_1_thread": one, "parity": parity,
             "sample": "%d queries of the timed batch, same IVF index (exported), %d threads across queries, best of %d; "
                       "scan loops = oracle restatement, 1x1 distance kernel = %s" % (
                           nq, threads, reps, "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")}
