@@ -307,7 +307,7 @@ def roaring_portable(ids):
     return bytes(out)
 
 
-def cpu_baseline_flat(torch, base, q, topk, metric_name, args):
+def cpu_baseline_flat(torch, base, q, topk, metric_name, args, gpu=None):
     """Reference CPU flat scan restated (oracle: FlatSearcherContext row-major loops + the reference's AVX-512 1x1
     kernels when oracle/_ref travelled) on a bounded sample of the timed batch, same base rows."""
     from oracle import oracle as O
@@ -321,11 +321,24 @@ def cpu_baseline_flat(torch, base, q, topk, metric_name, args):
     best = None
     for _ in range(2):
         t1 = time.perf_counter()
-        o.flat_search(host, qh, topk, metric, threads=threads)
+        ok, os_, _, oc = o.flat_search(host, qh, topk, metric, threads=threads)
         dt = time.perf_counter() - t1
         best = dt if best is None else min(best, dt)
     o.use_reference_kernels(False)
-    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": "port",
+    parity = None
+    if gpu is not None:        # the oracle as the checker, as in cpu_baseline_ivf
+        gk, gs, gc = gpu
+        same = rel = 0.0
+        for i in range(nq):
+            a, b = set(gk[i, :gc[i]].astype(np.uint64).tolist()), set(ok[i, :oc[i]].tolist())
+            same += len(a & b) / float(max(len(b), 1))
+            cs = dict(zip(ok[i, :oc[i]].tolist(), os_[i, :oc[i]].tolist()))
+            for key, sc in zip(gk[i, :gc[i]].astype(np.uint64).tolist(), gs[i, :gc[i]].tolist()):
+                if key in cs:
+                    rel = max(rel, abs(sc - cs[key]) / max(abs(cs[key]), 1e-30))
+        parity = {"queries": int(nq), "topk_ids_in_common": same / nq, "max_rel_score_diff": rel}
+        log("parity vs the CPU path: ids in common %.6f, max relative score difference %.3g" % (same / nq, rel))
+    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": "port", "parity": parity,
             "sample": "%d queries of the timed batch over the same %d rows, %d threads across queries, best of 2; scan loop = "
                       "oracle restatement, 1x1 distance kernel = %s" % (
                           nq, host.shape[0], threads, "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")}
@@ -363,7 +376,9 @@ def run_flat(torch, dist, zvec_amd, flat, fctx, q, n, dim, topk, args, dev, stre
 
     cpu = None
     if not args.no_cpu_baseline and world == 1 and doc_filter is None and n <= 2_000_000:
-        cpu = cpu_baseline_flat(torch, base, q, topk, metric_name, args)
+        step()
+        torch.cuda.synchronize()
+        cpu = cpu_baseline_flat(torch, base, q, topk, metric_name, args, gpu=(ok.cpu().numpy(), os_.cpu().numpy(), oc.cpu().numpy()))
     for _ in range(args.warmup):
         step()
     fctx.profile(True)
