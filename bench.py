@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--gt-queries", type=int, default=256)
     ap.add_argument("--intrinsic-dim", type=int, default=12)
     ap.add_argument("--target-recall", type=float, default=0.99)
+    ap.add_argument("--nprobe-step", type=int, default=2, help="widening step of the recall sweep")
     ap.add_argument("--keep", type=float, default=0.1, help="filter workloads: fraction of rows the bitmap keeps")
     ap.add_argument("--flat-threshold", type=float, default=None,
                     help="diagnostic: RNN radius for the flat workloads (a huge negative value admits nothing => distance-only time)")
@@ -195,7 +196,7 @@ def main():
         nprobe_base = nprobe
         log("recall@%d = %.4f (nprobe=%d, %d queries)" % (topk, recall, nprobe, ngt))
         while recall < args.target_recall and nprobe < nlist:
-            nprobe = min(nlist, nprobe + max(8, nprobe // 4))
+            nprobe = min(nlist, nprobe + max(args.nprobe_step, 1))
             recall = recall_at(nprobe)
             log("recall@%d = %.4f (nprobe=%d)" % (topk, recall, nprobe))
         scanned, probes = ivf.last_stats(ctx, ngt)
