@@ -357,4 +357,8 @@ class HipIVFSearcher {
   std::vector<uint64_t> keys_;
 };
 
+// "IVFStreamer" is what the product instantiates (indexes/ivf_index.cc:38-39); in the reference it is the same read-only
+// operator over a dumped index as the searcher (ivf_streamer.h:28-85: open / search / unload, no add_impl)
+using HipIVFStreamer = HipIVFSearcher;
+
 }  // namespace zvec_hip_host

@@ -585,6 +585,11 @@ class HipIVFSearcher:
         return scanned, probes
 
 
+# "IVFStreamer" (what the product instantiates, indexes/ivf_index.cc:38-39) is a read-only operator over a dumped index
+# in the reference too (ivf_streamer.h:28-85): same class
+HipIVFStreamer = HipIVFSearcher
+
+
 def merge_topk(ctx, keys, scores, counts, topk):
     """host form of the shard merge: inputs [nparts][count][topk] / [nparts][count]."""
     keys = np.ascontiguousarray(keys, np.uint64)
