@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--intrinsic-dim", type=int, default=12)
     ap.add_argument("--target-recall", type=float, default=0.99)
     ap.add_argument("--nprobe-step", type=int, default=2, help="widening step of the recall sweep")
+    ap.add_argument("--streams", type=int, default=1, help="IVF workloads: alternate consecutive batches over this many streams (1 or 2)")
     ap.add_argument("--keep", type=float, default=0.1, help="filter workloads: fraction of rows the bitmap keeps")
     ap.add_argument("--flat-threshold", type=float, default=None,
                     help="diagnostic: RNN radius for the flat workloads (a huge negative value admits nothing => distance-only time)")
@@ -213,16 +214,33 @@ def main():
         torch.cuda.empty_cache()
 
         # ---------------- timed region ----------------
-        for _ in range(args.warmup):
-            sh.search(q, topk, nprobe, max_scan, stream_ptr)
+        # --streams 2: consecutive (independent) batches alternate between two contexts on two HIP streams, so the
+        # coarse pass / plan of batch i+1 runs under the tail of batch i's list scan (serving-style concurrency);
+        # every step is still one complete pass over one batch and all K steps complete inside the timed region
+        lanes = [(sh, stream_ptr, None)]
+        if args.streams > 1 and world == 1:
+            s2 = torch.cuda.Stream(device=dev)
+            ctx2 = ivf.create_context()
+            ctx2.set_stream(s2.cuda_stream)
+            lanes.append((ShardedIVF(ivf, ctx2, rank, world), s2.cuda_stream, s2))
+        def run_step(i):
+            sh_i, sp, ts = lanes[i % len(lanes)]
+            if ts is None:
+                sh_i.search(q, topk, nprobe, max_scan, sp)
+            else:
+                with torch.cuda.stream(ts):
+                    sh_i.search(q, topk, nprobe, max_scan, sp)
+        for i in range(args.warmup * len(lanes)):
+            run_step(i)
+        torch.cuda.synchronize()
         ctx.profile(True)
         ctx.profile_read(reset=True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
-        for _ in range(args.steps):
-            sh.search(q, topk, nprobe, max_scan, stream_ptr)
+        for i in range(args.steps):
+            run_step(i)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
