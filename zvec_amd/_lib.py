@@ -106,7 +106,7 @@ def lib():
         # "No HIP GPUs").  So when torch is installed it is imported first.  Not needed for C/C++ callers.
         try:
             import torch  # noqa: F401
-        except ImportError:
+        except Exception:  # noqa: BLE001 - torch absent or unusable: the library then owns the only HIP runtime
             pass
         # ZVEC_HIP_LIBRARY: another build of the same library (kernel A/B experiments on one GPU box)
         path = os.environ.get("ZVEC_HIP_LIBRARY") or _build.build()
