@@ -94,6 +94,7 @@ def main():
                     help="diagnostic: on ONE GPU, hold and time only shard 0 of an N-way list sharding (no exchange; "
                          "recall is not computed) — the per-rank compute time of an N-GPU run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
     ap.add_argument("--cpu-queries", type=int, default=0, help="0 = one whole batch")
     args = ap.parse_args()
 
@@ -252,6 +253,28 @@ def main():
             elapsed = float(t.item())
         prof = ctx.profile_read(reset=True)
         ctx.profile(False)
+        # the boundary's HOST-pointer entry (what IndexRunner::search_impl hands over: queries in host memory, results
+        # back into host buffers) on the same batch: H2D of the queries + D2H of the lists per call.  Reported next to
+        # `value`, never as it.
+        host_qps = None
+        if world == 1 and not args.no_host_path:
+            hctx = ivf.create_context()
+            qh = np.ascontiguousarray(q.cpu().numpy())
+            hk = np.zeros((batch, topk), np.uint64)
+            hs = np.zeros((batch, topk), np.float32)
+            hc = np.zeros(batch, np.uint32)
+            L = zvec_amd._lib.lib()
+
+            def host_call():      # zvec_hip_ivf_search: the C ABI entry itself (no Python result objects)
+                zvec_amd._lib.check(L.zvec_hip_ivf_search(ivf._h, hctx._h, qh.ctypes.data, batch, topk, 3.4028234663852886e38,
+                                                          nprobe, n - 1, None, hk.ctypes.data, hs.ctypes.data, hc.ctypes.data),
+                                    "zvec_hip_ivf_search")
+            host_call()
+            th = time.perf_counter()
+            for _ in range(5):
+                host_call()
+            host_qps = 5 * batch / (time.perf_counter() - th)
+            log("host-pointer entry zvec_hip_ivf_search (PCIe-inclusive): %.0f QPS" % host_qps)
         per_launch_ms = prof["scan_ms"] / max(prof["launches"], 1)
         bytes_per_launch = prof["bytes"] / max(prof["launches"], 1)
         flops_per_launch = prof["flops"] / max(prof["launches"], 1)
@@ -275,6 +298,7 @@ def main():
                          "algorithmic_flops": flops_per_launch,
                          "mfma_tflops": flops_per_launch / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0},
             "cpu_baseline": cpu,
+            "host_pointer_qps": host_qps,
         }
 
     if rank == 0:
@@ -288,6 +312,7 @@ def main():
                 (" nlist=%d nprobe=%d" % (nlist, nprobe)) if kind == "ivf" else "", batch, topk),
                 "recall_at_10": recall, "nprobe_timed": nprobe if kind == "ivf" else None, "sharding": "inverted lists l %% %d, all-gather of candidates" % world if world > 1 else "single GPU"},
             "roofline": result["roofline"], "cpu_baseline": result.get("cpu_baseline"),
+            "host_pointer_qps": result.get("host_pointer_qps"),
         }
         print(json.dumps(line), flush=True)
     if world > 1:
