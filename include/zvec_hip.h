@@ -86,6 +86,9 @@ int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n,
 int zvec_hip_flat_count(zvec_hip_flat_t h, uint64_t *count);
 /* IndexRunner::get_vector_by_id (index_runner.h:450-453): copy row `pos` (dim elements) to out. */
 int zvec_hip_flat_get_vector(zvec_hip_flat_t h, uint64_t pos, void *out);
+/* the same for a list of positions in one launch + one copy (IndexContext::set_fetch_vector, index_context.h:139:
+ * the vectors of a result list, index.cc:635-647); out = n rows of the element type, row-major */
+int zvec_hip_flat_get_vectors(zvec_hip_flat_t h, const uint64_t *positions, uint64_t n, void *out);
 /* search_impl / search_bf_impl(query, qmeta, count, ctx) (index_runner.h:490-531).
  * exclude_bitset: nullable, 1 bit per storage position (bit i of word i/64), set = filter(key)
  * returned true = excluded (IndexFilter, index_filter.h:48-50).
@@ -136,6 +139,7 @@ int zvec_hip_ivf_info(zvec_hip_ivf_t h, uint64_t *count, uint32_t *nlist);
 int zvec_hip_ivf_export(zvec_hip_ivf_t h, void *centroids, uint64_t *list_offsets,
                         uint64_t *row_ids);
 int zvec_hip_ivf_get_vector(zvec_hip_ivf_t h, uint64_t list_pos, void *out);
+int zvec_hip_ivf_get_vectors(zvec_hip_ivf_t h, const uint64_t *list_positions, uint64_t n, void *out);
 /* IVFSearcher::search_impl(query, qmeta, count, ctx):
  *   nprobe         = max(round(nlist*scan_ratio),1)          ivf_searcher_context.h:70-74
  *   max_scan_count = max(bf_threshold, ceil(N*scan_ratio))    ivf_searcher_context.h:75-78

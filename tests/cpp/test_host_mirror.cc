@@ -111,6 +111,20 @@ static int TestFilter() {
   EXPECT(99 == results2[0].key());
   EXPECT(102 == results2[1].key());
   EXPECT(98 == results2[2].key());
+  // fetch_vector: documents carry their stored rows (index_context.h:139, index.cc:635-647)
+  ctx->reset_filter();
+  ctx->set_fetch_vector(true);
+  ASSERT(0 == streamer.search_impl(vec.data(), qmeta, ctx));
+  {
+    auto &rf = ctx->result();
+    ASSERT(10 == rf.size());
+    for (auto &d : rf) {
+      ASSERT(d.vector().size() == dim * sizeof(float));
+      const float *v = reinterpret_cast<const float *>(d.vector().data());
+      for (size_t j = 0; j < dim; ++j) EXPECT(v[j] == (float)d.key());
+    }
+  }
+  ctx->set_fetch_vector(false);
   // the same predicate as data: a delete store holding {100, 101} in roaring portable form
   // (cookie 12346, 1 container; key 0, cardinality-1 = 1; offset 16; values) — materialised on the GPU
   const uint8_t deleted[20] = {0x3a, 0x30, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 16, 0, 0, 0, 100, 0, 101, 0};

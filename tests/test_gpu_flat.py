@@ -357,3 +357,37 @@ def test_flat_load_features_segment(zv, dtype, column_major, n, dim):
     ra, rb = _search(a, q, 7), _search(b, q, 7)
     assert all(np.array_equal(x, y) for x, y in zip(ra[:3], rb[:3]))
     assert a.load_features(bytes(blob)[: n * dim * base.itemsize - 1], n, column_major=column_major) == zv.IndexError_.InvalidArgument
+
+
+def test_fetch_vector_results_carry_stored_rows(zv):
+    """IndexContext::set_fetch_vector (index_context.h:139, index.cc:635-647): documents come back with their vectors;
+    flat (fp32, cosine rows with the norm column) and IVF, through one gather launch per search."""
+    rng = np.random.default_rng(4)
+    n, dim, nq, k = 3000, 19, 6, 5
+    base = rng.integers(-9, 10, (n, dim)).astype(np.float32)
+    keys = rng.permutation(7 * n)[:n].astype(np.uint64)
+    key2row = {int(kk): i for i, kk in enumerate(keys)}
+    se = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert se.load(base, keys) == 0
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    q = base[:nq] + 0.25
+    assert se.search_impl(q, nq, ctx) == 0 and ctx.result(0)[0].vector() is None
+    ctx.set_fetch_vector(True)
+    assert se.search_impl(q, nq, ctx) == 0
+    for qi in range(nq):
+        assert len(ctx.result(qi)) == k
+        for doc in ctx.result(qi):
+            assert np.array_equal(doc.vector(), base[key2row[doc.key()]])
+    assert np.array_equal(se.get_vectors_by_ids([5, 0, n - 1, 5]), base[[5, 0, n - 1, 5]])
+    with pytest.raises(zv._lib.ZvecHipError):
+        se.get_vectors_by_ids([n])
+    ivf = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=0.5, brute_force_threshold=10)
+    assert ivf.build(base, 8, keys=keys, kmeans_iters=3) == 0
+    ictx = ivf.create_context()
+    ictx.set_topk(k)
+    ictx.set_fetch_vector(True)
+    assert ivf.search_impl(q, nq, ictx) == 0
+    for qi in range(nq):
+        for doc in ictx.result(qi):
+            assert np.array_equal(doc.vector(), base[key2row[doc.key()]])

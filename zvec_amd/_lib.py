@@ -38,6 +38,7 @@ SYMBOLS = {
     "zvec_hip_flat_append_dev": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p, C.c_void_p]),
     "zvec_hip_flat_count": (C.c_int, [_h, C.POINTER(C.c_uint64)]),
     "zvec_hip_flat_get_vector": (C.c_int, [_h, C.c_uint64, C.c_void_p]),
+    "zvec_hip_flat_get_vectors": (C.c_int, [_h, _u64p, C.c_uint64, C.c_void_p]),
     "zvec_hip_flat_search": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, _u64p,
                                        _u64p, _f32p, _u32p]),
     "zvec_hip_flat_search_by_ids": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, _u32p, _u32p, C.c_uint32, C.c_float,
@@ -57,6 +58,7 @@ SYMBOLS = {
     "zvec_hip_ivf_info": (C.c_int, [_h, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "zvec_hip_ivf_export": (C.c_int, [_h, C.c_void_p, _u64p, _u64p]),
     "zvec_hip_ivf_get_vector": (C.c_int, [_h, C.c_uint64, C.c_void_p]),
+    "zvec_hip_ivf_get_vectors": (C.c_int, [_h, _u64p, C.c_uint64, C.c_void_p]),
     "zvec_hip_ivf_search": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float,
                                       C.c_uint32, C.c_uint32, _u64p, _u64p, _f32p, _u32p]),
     "zvec_hip_ivf_search_dev": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float,

@@ -166,6 +166,18 @@ int zvec_hip_flat_get_vector(zvec_hip_flat_t h, uint64_t pos, void *out) {
   return 0;
 }
 
+int zvec_hip_flat_get_vectors(zvec_hip_flat_t h, const uint64_t *positions, uint64_t n, void *out) {
+  if (!h || (n && (!positions || !out))) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return 0;
+  if (n > 0x7fffffffull) return ZVEC_HIP_ERR_OUT_OF_RANGE;
+  std::lock_guard<std::mutex> g(h->mu);
+  std::vector<uint64_t> pos(positions, positions + n);
+  for (uint64_t p : pos)
+    if (p >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
+  ZCHK(hipSetDevice(h->device));
+  return store_get_rows(h->defctx, h->st, pos, out);
+}
+
 int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count,
                              uint32_t topk, float threshold, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys,
                              float *d_out_scores, uint32_t *d_out_counts, void *stream) {

@@ -429,6 +429,23 @@ int zvec_hip_ivf_get_vector(zvec_hip_ivf_t h, uint64_t list_pos, void *out) {
   return 0;
 }
 
+int zvec_hip_ivf_get_vectors(zvec_hip_ivf_t h, const uint64_t *list_positions, uint64_t n, void *out) {
+  if (!h || (n && (!list_positions || !out))) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  if (n == 0) return 0;
+  if (n > 0x7fffffffull) return ZVEC_HIP_ERR_OUT_OF_RANGE;
+  std::lock_guard<std::mutex> g(h->mu);
+  std::vector<uint64_t> pos(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t lp = list_positions[i];
+    if (lp >= h->count_local) return ZVEC_HIP_ERR_NO_EXIST;
+    const uint32_t l = (uint32_t)(std::upper_bound(h->h_dense0.begin(), h->h_dense0.end(), lp) - h->h_dense0.begin()) - 1;
+    pos[i] = (uint64_t)h->h_tile0[l] * TILE_N + (lp - h->h_dense0[l]);
+  }
+  ZCHK(hipSetDevice(h->device));
+  return store_get_rows(h->defctx, h->lists, pos, out);
+}
+
 static int ivf_search_dev_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count,
                                uint32_t topk, float threshold, uint32_t nprobe, uint32_t max_scan_count,
                                int brute_force, const uint64_t *d_exclude, uint64_t *d_out_keys, float *d_out_scores,

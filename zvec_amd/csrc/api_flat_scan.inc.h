@@ -479,6 +479,25 @@ int launch_unpack(const Store &st, uint64_t pos, void *d_out, hipStream_t stream
   return 0;
 }
 
+// rows at `n` padded positions (host array) -> host buffer, one gather launch + one copy back
+int store_get_rows(zvec_hip_ctx_s *c, const Store &st, const std::vector<uint64_t> &pos, void *out) {
+  const size_t n = pos.size();
+  if (n == 0) return 0;
+  const size_t rb = st.row_bytes();
+  Scoped<uint64_t> d_pos;
+  ZRET(d_pos.alloc(n));
+  ZRET(c->io_q.ensure(n * rb));
+  ZCHK(hipMemcpyAsync(d_pos, pos.data(), n * 8, hipMemcpyHostToDevice, c->own));
+  if (st.f16)
+    hipLaunchKernelGGL(unpack_rows_kernel<true>, dim3((unsigned)n), dim3(256), 0, c->own, st.base, st.extra, d_pos, st.dscan, st.dim_in, st.dpad, c->io_q.p);
+  else
+    hipLaunchKernelGGL(unpack_rows_kernel<false>, dim3((unsigned)n), dim3(256), 0, c->own, st.base, st.extra, d_pos, st.dscan, st.dim_in, st.dpad, c->io_q.p);
+  ZCHK(hipGetLastError());
+  ZCHK(hipMemcpyAsync(out, c->io_q.p, n * rb, hipMemcpyDeviceToHost, c->own));
+  ZCHK(hipStreamSynchronize(c->own));
+  return 0;
+}
+
 int store_append_dev(Store &st, const void *d_vecs, uint64_t n, const uint64_t *d_keys, hipStream_t stream) {
   if (n == 0) return 0;
   if (st.n + n >= 0xfffffff0ull) return ZVEC_HIP_ERR_OUT_OF_RANGE;   // positions are 32-bit (IDX_NONE reserved)

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <unordered_map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -86,10 +87,15 @@ class IndexDocument {
   IndexDocument(uint64_t k, float s) : key_(k), score_(s) {}
   uint64_t key() const { return key_; }
   float score() const { return score_; }
+  // the stored row, present when the context has fetch_vector on (index_document.h:207-216 carries a MemoryBlock;
+  // here the bytes are owned by the document and stay valid as long as the result list does)
+  const std::vector<char> &vector() const { return vector_; }
+  void set_vector(const char *p, size_t bytes) { vector_.assign(p, p + bytes); }
   bool operator<(const IndexDocument &rhs) const { return score_ < rhs.score_; }   // index_document.h:143
  private:
   uint64_t key_{0};
   float score_{0.f};
+  std::vector<char> vector_;
 };
 using IndexDocumentList = std::vector<IndexDocument>;
 
@@ -120,6 +126,8 @@ class Context {
   void set_topk(uint32_t k) { topk_ = k; }
   uint32_t topk() const { return topk_; }
   void set_threshold(float v) { threshold_ = v; }
+  void set_fetch_vector(bool v) { fetch_vector_ = v; }                       // index_context.h:139
+  bool fetch_vector() const { return fetch_vector_; }
   float threshold() const { return threshold_; }
   template <typename T> void set_filter(T &&fn) { filter_.set(std::forward<T>(fn)); }
   void reset_filter() { filter_.reset(); has_doc_ = false; has_bits_ = false; }
@@ -167,8 +175,36 @@ class Context {
   bool has_bits_{false};
   zvec_hip_doc_filter_t doc_{};
   bool has_doc_{false};
+  bool fetch_vector_{false};
   std::vector<IndexDocumentList> results_{1};
 };
+
+// fetch_vector: one gather of the stored rows of every result document (key -> position through `pos_of_key`,
+// built lazily from the keys the index holds), then the rows are attached to the documents
+template <typename GetRows>
+inline int attach_result_vectors(Context *ctx, uint32_t count, size_t row_bytes, const std::vector<uint64_t> &keys_by_pos,
+                                 std::unordered_map<uint64_t, uint64_t> *pos_of_key, GetRows &&get_rows) {
+  if (pos_of_key->size() != keys_by_pos.size()) {
+    pos_of_key->clear();
+    pos_of_key->reserve(keys_by_pos.size());
+    for (uint64_t i = 0; i < keys_by_pos.size(); ++i) pos_of_key->emplace(keys_by_pos[i], i);
+  }
+  std::vector<uint64_t> pos;
+  for (uint32_t q = 0; q < count; ++q)
+    for (const auto &d : ctx->result(q)) {
+      auto it = pos_of_key->find(d.key());
+      if (it == pos_of_key->end()) return IndexError_NoExist;
+      pos.push_back(it->second);
+    }
+  if (pos.empty()) return 0;
+  std::vector<char> rows(pos.size() * row_bytes);
+  int rc = get_rows(pos.data(), pos.size(), rows.data());
+  if (rc != 0) return rc;
+  size_t o = 0;
+  for (uint32_t q = 0; q < count; ++q)
+    for (auto &d : *ctx->mutable_result(q)) d.set_vector(rows.data() + (o++) * row_bytes, row_bytes);
+  return 0;
+}
 
 // ---- flat: one class body serves the "FlatStreamer" and "FlatSearcher" registrations -------------
 class HipFlatStreamer {
@@ -235,7 +271,7 @@ class HipFlatStreamer {
                                   keys.data(), scores.data(), counts.data());
     if (rc != 0) return rc;
     ctx->take(count, k, keys, scores, counts);
-    return 0;
+    return ctx->fetch_vector() ? attach_vectors(ctx, count) : 0;
   }
   //! Similarity brute force search (index_runner.h:520-531): the flat scan is the brute force
   int search_bf_impl(const void *query, const IndexQueryMeta &qmeta, Context::Pointer &context) const {
@@ -258,6 +294,12 @@ class HipFlatStreamer {
   uint32_t magic_{0};
   zvec_hip_flat_t h_{nullptr};
   std::vector<uint64_t> keys_;
+  mutable std::unordered_map<uint64_t, uint64_t> pos_of_key_;
+  int attach_vectors(Context *ctx, uint32_t count) const {
+    zvec_hip_flat_t h = h_;
+    return attach_result_vectors(ctx, count, meta_.element_size(), keys_, &pos_of_key_,
+                                 [h](const uint64_t *p, size_t n, void *out) { return zvec_hip_flat_get_vectors(h, p, n, out); });
+  }
 };
 using HipFlatSearcher = HipFlatStreamer;
 
@@ -344,8 +386,12 @@ class HipIVFSearcher {
                                       bits, keys.data(), scores.data(), counts.data());
     if (rc != 0) return rc;
     ctx->take(count, k, keys, scores, counts);
-    return 0;
+    if (!ctx->fetch_vector()) return 0;
+    zvec_hip_ivf_t h = h_;
+    return attach_result_vectors(ctx, count, meta_.element_size(), keys_, &pos_of_key_,
+                                 [h](const uint64_t *p, size_t n, void *out) { return zvec_hip_ivf_get_vectors(h, p, n, out); });
   }
+  mutable std::unordered_map<uint64_t, uint64_t> pos_of_key_;
   IndexMeta meta_;
   int device_{0};
   uint32_t magic_{0};

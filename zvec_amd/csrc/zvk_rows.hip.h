@@ -111,6 +111,28 @@ __global__ void unpack_row_kernel(const float *base, const float *extra, uint64_
   }
 }
 
+// blocked rows -> plain rows for a list of positions (fetch_vector: the vectors of a result list in one launch);
+// one work-group per position
+template <bool F16>
+__global__ void unpack_rows_kernel(const float *base, const float *extra, const uint64_t *pos, uint32_t dscan,
+                                   uint32_t dim_out, uint32_t dpadw, void *out) {
+  const uint64_t p = pos[blockIdx.x];
+  const size_t row_bytes = (size_t)dim_out * (F16 ? 2u : 4u);
+  char *o = reinterpret_cast<char *>(out) + (size_t)blockIdx.x * row_bytes;
+  for (uint32_t c = threadIdx.x; c < dim_out; c += blockDim.x) {
+    if constexpr (F16) {
+      if (c < dscan) {
+        reinterpret_cast<_Float16 *>(o)[c] = (_Float16)load_elem<F16>(base, p, c, dpadw);
+      } else {
+        const uint32_t bits = extra ? __builtin_bit_cast(uint32_t, extra[p]) : 0u;
+        reinterpret_cast<uint16_t *>(o)[c] = (uint16_t)(c == dscan ? bits : bits >> 16);
+      }
+    } else {
+      reinterpret_cast<float *>(o)[c] = (c < dscan) ? load_elem<F16>(base, p, c, dpadw) : (extra ? extra[p] : 0.f);
+    }
+  }
+}
+
 // one launch instead of two memsets + fill_gtau before the IVF plan: zero `nzero` plan words (list_count, list_fill),
 // zero the 4 work-queue words, reset the shared bounds of `nq` queries to the threshold
 // ... and set this search's chunk length of every list: `tpc` tiles, a quarter of that for the lists flagged as the tail

@@ -53,18 +53,22 @@ class IndexError_:
 
 
 class IndexDocument:
-    """key / score / index triple (index_document.h:69-218)."""
-    __slots__ = ("_key", "_score")
+    """key + score (+ the stored vector when the context asked for it) — index_document.h:207-216 subset"""
 
-    def __init__(self, key, score):
+    def __init__(self, key, score, vector=None):
         self._key = int(key)
         self._score = float(score)
+        self._vector = vector
 
     def key(self):
         return self._key
 
     def score(self):
         return self._score
+
+    def vector(self):
+        """the stored row (fetch_vector contexts only, index.cc:635-647), else None"""
+        return self._vector
 
     def __repr__(self):
         return "IndexDocument(key=%d, score=%r)" % (self._key, self._score)
@@ -120,6 +124,7 @@ class IndexContext:
         self._exclude = None      # numpy uint64 words (host) — materialised IndexFilter
         self._filter_fn = None
         self._doc_filter = None   # DocFilter: materialised by zvec_hip_*_build_filter
+        self._fetch_vector = False
         self._results = []
         self.keys = None
         self.scores = None
@@ -139,6 +144,13 @@ class IndexContext:
 
     def topk(self):
         return self._topk
+
+    def set_fetch_vector(self, enable):
+        """IndexContext::set_fetch_vector (index_context.h:139): result documents carry their stored vectors."""
+        self._fetch_vector = bool(enable)
+
+    def fetch_vector(self):
+        return self._fetch_vector
 
     def set_threshold(self, val):
         self._threshold = float(val)
@@ -187,12 +199,19 @@ class IndexContext:
         np.bitwise_or.at(words, idx // 64, np.uint64(1) << (idx % 64).astype(np.uint64))
         return words
 
-    def _set_results(self, keys, scores, counts):
+    def _set_results(self, keys, scores, counts, vectors_of=None):
+        """vectors_of: callable(keys 1-D uint64) -> rows, used when fetch_vector is on"""
         self.keys, self.scores, self.counts = keys, scores, counts
-        self._results = [
-            [IndexDocument(keys[q, j], scores[q, j]) for j in range(int(counts[q]))]
-            for q in range(keys.shape[0])
-        ]
+        vecs = None
+        if self._fetch_vector and vectors_of is not None:
+            flat = np.concatenate([keys[q, :int(counts[q])] for q in range(keys.shape[0])]) if keys.shape[0] else np.zeros(0, np.uint64)
+            vecs = vectors_of(flat)
+        self._results = []
+        o = 0
+        for q in range(keys.shape[0]):
+            c = int(counts[q])
+            self._results.append([IndexDocument(keys[q, j], scores[q, j], None if vecs is None else vecs[o + j]) for j in range(c)])
+            o += c
 
     def reform_queries_dev(self, d_in, count, dim, d_out, cosine=False, out_dtype="fp32", stream=None):
         """CosineReformer / HalfFloatReformer on raw fp32 queries already in HBM (device pointers)."""
@@ -290,6 +309,19 @@ class _FlatBase:
         rc = _lib.lib().zvec_hip_flat_get_vector(self._h, int(pos), _np_ptr(out))
         return out if rc == 0 else None
 
+    def get_vectors_by_ids(self, positions):
+        pos = np.ascontiguousarray(positions, np.uint64)
+        out = np.zeros((pos.size, self.dim), self.np_dtype)
+        _lib.check(_lib.lib().zvec_hip_flat_get_vectors(self._h, _np_ptr(pos), pos.size, _np_ptr(out)), "zvec_hip_flat_get_vectors")
+        return out
+
+    def _vectors_of_keys(self, keys):
+        """stored rows of the documents with these keys (fetch_vector); key -> position through a sorted view of the keys"""
+        allk = self._all_keys()
+        order = np.argsort(allk, kind="stable")
+        pos = order[np.searchsorted(allk[order], keys)]
+        return self.get_vectors_by_ids(pos)
+
     def build_filter(self, doc_filter, ctx=None, d_out=None, stream=None):
         """DocFilter -> exclude bitset over this index's storage positions, built on the GPU.  Returns numpy
         uint64 words, or fills the device buffer `d_out` ((count+63)//64 uint64) and returns None."""
@@ -320,7 +352,7 @@ class _FlatBase:
         rc = _lib.lib().zvec_hip_flat_search(self._h, ctx._h, _np_ptr(q), count, k, ctx.threshold(),
                                              _np_ptr(ex), _np_ptr(keys), _np_ptr(scores), _np_ptr(counts))
         if rc == 0:
-            ctx._set_results(keys, scores, counts)
+            ctx._set_results(keys, scores, counts, self._vectors_of_keys)
         return rc
 
     # brute force == the flat scan itself (flat_streamer.cc:304-344)
@@ -355,7 +387,7 @@ class _FlatBase:
                                                     ctx.threshold(), _np_ptr(ctx._exclude), _np_ptr(keys_o),
                                                     _np_ptr(scores), _np_ptr(counts))
         if rc == 0:
-            ctx._set_results(keys_o, scores, counts)
+            ctx._set_results(keys_o, scores, counts, self._vectors_of_keys)
         return rc
 
     def search_dev(self, d_queries, count, topk, d_out_keys, d_out_scores, d_out_counts, ctx,
@@ -496,6 +528,17 @@ class HipIVFSearcher:
         rc = _lib.lib().zvec_hip_ivf_get_vector(self._h, int(list_pos), _np_ptr(out))
         return out if rc == 0 else None
 
+    def get_vectors_by_ids(self, list_positions):
+        pos = np.ascontiguousarray(list_positions, np.uint64)
+        out = np.zeros((pos.size, self.dim), self.np_dtype)
+        _lib.check(_lib.lib().zvec_hip_ivf_get_vectors(self._h, _np_ptr(pos), pos.size, _np_ptr(out)), "zvec_hip_ivf_get_vectors")
+        return out
+
+    def _vectors_of_keys(self, keys):
+        lk = self.keys_in_list_order()
+        order = np.argsort(lk, kind="stable")
+        return self.get_vectors_by_ids(order[np.searchsorted(lk[order], keys)])
+
     # IVFSearcherContext::update (ivf_searcher_context.h:61-79)
     def probe_params(self):
         n, nlist = self.total_count, self.info()[1]
@@ -550,7 +593,7 @@ class HipIVFSearcher:
                                             max_scan, _np_ptr(ex), _np_ptr(keys), _np_ptr(scores),
                                             _np_ptr(counts))
         if rc == 0:
-            ctx._set_results(keys, scores, counts)
+            ctx._set_results(keys, scores, counts, self._vectors_of_keys)
         return rc
 
     def search_bf_impl(self, query, count, ctx):
@@ -567,7 +610,7 @@ class HipIVFSearcher:
         rc = _lib.lib().zvec_hip_ivf_search_bf(self._h, ctx._h, _np_ptr(q), count, k, ctx.threshold(),
                                                _np_ptr(ex), _np_ptr(keys), _np_ptr(scores), _np_ptr(counts))
         if rc == 0:
-            ctx._set_results(keys, scores, counts)
+            ctx._set_results(keys, scores, counts, self._vectors_of_keys)
         return rc
 
     def search_dev(self, d_queries, count, topk, nprobe, max_scan, d_out_keys, d_out_scores, d_out_counts,
