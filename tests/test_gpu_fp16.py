@@ -151,3 +151,31 @@ def test_device_reformers_bit_exact(zv, oracle, dim):
     assert np.array_equal(out16.cpu().numpy().view(np.uint16), oracle.cosine_transform16(q).view(np.uint16))
     with np.errstate(over="ignore"):
         assert np.array_equal(half.cpu().numpy().view(np.uint16), q.astype(np.float16).view(np.uint16))
+
+
+def test_ivf_fp16_cosine(zv, oracle):
+    """IVF over fp16 cosine rows (d halves + the fp32 norm in two half slots): coarse assign and list scan use 1 - ip over
+    the first d halves on both sides; same index on both sides."""
+    rng = np.random.default_rng(91)
+    n, dim, nlist, nq, k = 5000, 40, 24, 50, 10
+    raw = rng.standard_normal((n, dim)).astype(np.float32)
+    base = oracle.cosine_transform16(raw)
+    q = oracle.cosine_transform16(rng.standard_normal((nq, dim)).astype(np.float32))
+    lab = rng.integers(0, nlist, n)
+    order = np.argsort(lab, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(lab, minlength=nlist))]).astype(np.uint64)
+    cent = oracle.cosine_transform16(np.stack([raw[lab == l].mean(0) for l in range(nlist)]).astype(np.float32))
+    vecs, keys = base[order], order.astype(np.uint64)
+    se = zv.HipIVFSearcher(dim + 2, "Cosine", scan_ratio=0.3, brute_force_threshold=100, dtype="fp16")
+    assert se.load(cent, offs, vecs, keys) == 0
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, metric=O.METRIC_COSINE, keys=keys)
+    c32, q32 = cent[:, :dim].astype(np.float32), q[:, :dim].astype(np.float32)
+    cs = np.sort(1.0 - q32 @ c32.T, 1)
+    sel = np.nonzero(cs[:, nprobe] - cs[:, nprobe - 1] > 1e-4)[0]
+    assert len(sel) > nq // 2
+    tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel], atol=3e-6, what="ivf fp16 cosine")
+    assert np.array_equal(se.get_vector_by_id(7).view(np.uint16), vecs[7].view(np.uint16))
