@@ -194,3 +194,24 @@ def test_wide_batch_sparse_filter_gathers_kept_rows(zv, oracle, metric_name, met
     tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="gather keep=%g %s" % (keep, metric_name))
     kept = set(keys[~drop].tolist())
     assert all(int(x) in kept for qi in range(nq) for x in ctx.keys[qi, : ctx.counts[qi]])
+
+
+@pytest.mark.parametrize("kept", [0, 1, 5, 127, 129])
+def test_wide_batch_filter_with_a_handful_of_kept_rows(zv, oracle, kept):
+    """edge of the gather path: fewer kept rows than one tile / than topk, and none at all"""
+    rng = np.random.default_rng(kept)
+    n, dim, nq, k = 66_000, 16, 130, 10
+    base = rng.integers(-5, 6, (n, dim)).astype(np.float32)
+    q = rng.integers(-5, 6, (nq, dim)).astype(np.float32)
+    drop = np.ones(n, bool)
+    drop[rng.choice(n, kept, replace=False)] = False
+    ex = O.pack_bits(drop)
+    se = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert se.load(base) == 0
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    ctx.set_exclude_bitset(ex)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc = oracle.flat_search(base, q, k, O.METRIC_L2, exclude_bits=ex)
+    assert np.array_equal(ctx.counts, oc) and int(oc.max(initial=0)) == min(k, kept)
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="gather kept=%d" % kept)
