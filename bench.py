@@ -39,6 +39,7 @@ WORKLOADS = {
     "ivf10m_fp16": ("ivf", 10_000_000, 768, 4096, 32, 1024, "fp16"),  # BASELINE configs[3]'s storage type at 1-GPU size
     "ivf100m_fp16": ("ivf", 100_000_000, 768, 16384, 64, 1024, "fp16"),  # BASELINE configs[3] (needs 8 GPUs' HBM for the build)
     "filter10m": ("flat", 10_000_000, 768, 0, 0, 512, "fp32"),        # BASELINE configs[4]: bitmap-gated scan, keep 10 %
+    "flat1m_fp16": ("flat", 1_000_000, 768, 0, 0, 256, "fp16"),       # (not a BASELINE config: fp16 rows through the wide flat tile)
 }
 
 

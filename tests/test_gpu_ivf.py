@@ -294,3 +294,34 @@ def test_ivf_load_from_reference_segments(zv, oracle, dtype, column_major, dim):
                                np.zeros((nlist, dim + 1), dtype)) == zv.IndexError_.Mismatch
     assert a.load_segments(seg["ivf.inverted_header"], seg["ivf.inverted_meta"][40:] + seg["ivf.inverted_meta"][:40],
                            seg["ivf.inverted_body"], seg["hc.keys"], cent) == zv.IndexError_.InvalidArgument
+
+
+def test_same_value_rows_all_ties(zv):
+    """ivf_searcher_test.cc:3301-3420 (TestSameValue): every stored vector is the same point, so every score ties.
+    Counts and scores are determined, the ids only as a set of distinct stored keys; the GPU k-means build must
+    survive a corpus with one distinct point (all but one cluster empty)."""
+    n, dim = 33, 8
+    base = np.zeros((n, dim), np.float32)
+    keys = np.arange(100, 100 + n, dtype=np.uint64)
+    q1 = np.full((1, dim), 32.0, np.float32)
+    qb = np.repeat(np.arange(33, dtype=np.float32)[:, None], dim, 1)
+    flat = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert flat.load(base, keys) == 0
+    ivf = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=1.0, brute_force_threshold=1)
+    assert ivf.build(base, 2, keys=keys, kmeans_iters=5) == 0
+    assert ivf.info() == (n, 2)
+    for se, fns in ((flat, (flat.search_impl,)), (ivf, (ivf.search_impl, ivf.search_bf_impl))):
+        for fn in fns:
+            ctx = se.create_context()
+            for k in (33, 10, 40):
+                ctx.set_topk(k)
+                assert fn(q1, 1, ctx) == 0
+                r = ctx.result(0)
+                assert len(r) == min(k, n)
+                assert all(d.score() == 32.0 * 32.0 * dim for d in r)
+                got = [d.key() for d in r]
+                assert len(set(got)) == len(got) and set(got) <= set(keys.tolist())
+            ctx.set_topk(1)
+            assert fn(qb, 33, ctx) == 0
+            for qi in range(33):
+                assert len(ctx.result(qi)) == 1 and ctx.result(qi)[0].score() == float(qi * qi * dim)

@@ -113,3 +113,101 @@ def test_concurrent_contexts_on_one_index(oracle):
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errors, errors
+
+
+def test_shared_context_across_indexes(oracle):
+    """ivf_searcher_test.cc:2700-2830 (TestSharedContext): a context created by one index is handed to other index
+    instances (different sizes, dimensions and types), from several threads, in random order.  The context here is an
+    index-agnostic workspace (stream + buffers), so every search must return what a private context returns."""
+    import threading
+    import zvec_amd as zv
+    rng = np.random.default_rng(77)
+    specs = [("flat", 900, 8), ("flat", 5000, 40), ("ivf", 7000, 24)]
+    idx, data = [], []
+    for kind, n, dim in specs:
+        base = rng.integers(-9, 10, (n, dim)).astype(np.float32)
+        if kind == "flat":
+            se = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+            assert se.load(base) == 0
+        else:
+            se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=0.3, brute_force_threshold=10)
+            assert se.build(base, 16, kmeans_iters=3) == 0
+        q = rng.integers(-9, 10, (20, dim)).astype(np.float32)
+        own = se.create_context()
+        own.set_topk(7)
+        assert se.search_impl(q, 20, own) == 0
+        idx.append(se)
+        data.append((q, own.keys.copy(), own.scores.copy()))
+    errors = []
+
+    def worker(seed):
+        try:
+            r = np.random.default_rng(seed)
+            ctx = idx[seed % 3].create_context()          # created by one index ...
+            ctx.set_topk(7)
+            for _ in range(40):
+                j = int(r.integers(0, 3))                 # ... used with any of them
+                q, wk, ws = data[j]
+                assert idx[j].search_impl(q, 20, ctx) == 0
+                assert np.array_equal(ctx.keys, wk) and np.array_equal(ctx.scores, ws)
+        except Exception as e:   # noqa: BLE001 - reported below
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+
+
+def test_concurrent_add_and_search(oracle):
+    """flat_streamer_test.cc TestConcurrentAddAndSearch: the streamer is searched while another thread keeps adding
+    (growth reallocations included: the store starts empty and grows 1.5x at a time).  Every search must see a
+    consistent prefix of the rows: the planted nearest neighbour (added first) is always rank 0 with score 0, every
+    returned key exists, and at the end the index equals one built in a single call."""
+    import threading
+    import zvec_amd as zv
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    dim, batches, per = 24, 60, 700
+    base = rng.integers(-9, 10, (batches * per, dim)).astype(np.float32)
+    base[0] = 40.0                                           # far from everything else: a unique nearest neighbour
+    q = np.repeat(base[:1], 8, 0)
+    st = zv.HipFlatStreamer(dim, "SquaredEuclidean")
+    assert st.add_batch(base[:per]) == 0
+    errors, done = [], threading.Event()
+
+    def adder():
+        try:
+            for b in range(1, batches):
+                assert st.add_batch(base[b * per:(b + 1) * per]) == 0
+        except Exception as e:   # noqa: BLE001
+            errors.append(("add", repr(e)))
+        finally:
+            done.set()
+
+    def searcher(seed):
+        try:
+            ctx = st.create_context()
+            ctx.set_topk(5)
+            n_seen = 0
+            while not done.is_set() or n_seen == 0:
+                assert st.search_impl(q, 8, ctx) == 0
+                hi = st.count()
+                assert (ctx.counts == 5).all()
+                assert (ctx.keys[:, 0] == 0).all() and (ctx.scores[:, 0] == 0).all()
+                assert int(ctx.keys.max()) < hi
+                n_seen += 1
+        except Exception as e:   # noqa: BLE001
+            errors.append(("search", seed, repr(e)))
+
+    ts = [threading.Thread(target=adder)] + [threading.Thread(target=searcher, args=(s,)) for s in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    assert st.count() == batches * per
+    qq = rng.integers(-9, 10, (30, dim)).astype(np.float32)
+    ctx = st.create_context()
+    ctx.set_topk(10)
+    assert st.search_impl(qq, 30, ctx) == 0
+    ok, os_, _, oc = oracle.flat_search(base, qq, 10, O.METRIC_L2)
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="after concurrent adds")

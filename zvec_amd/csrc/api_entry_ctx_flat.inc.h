@@ -74,6 +74,7 @@ int zvec_hip_flat_destroy(zvec_hip_flat_t h) {
 int zvec_hip_flat_reserve(zvec_hip_flat_t h, uint64_t capacity) {
   if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
+  std::unique_lock<std::shared_mutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   return h->st.reserve(capacity, h->defctx->own);
 }
@@ -81,6 +82,7 @@ int zvec_hip_flat_reserve(zvec_hip_flat_t h, uint64_t capacity) {
 int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n, const uint64_t *d_keys, void *stream) {
   if (!h || (!d_vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
+  std::unique_lock<std::shared_mutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(h->defctx, stream);
   return store_append_dev(h->st, d_vecs, n, d_keys, s);
@@ -96,6 +98,7 @@ int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_
   const uint64_t elem = h->st.row_bytes();
   if (bytes < count * elem) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
+  std::unique_lock<std::shared_mutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
   Scoped<uint8_t> d_body;
@@ -126,6 +129,7 @@ int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const 
   if (!h || (!vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (n == 0) return 0;
   std::lock_guard<std::mutex> g(h->mu);
+  std::unique_lock<std::shared_mutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
   // stage through the device in slices of <= 1 GiB
@@ -156,6 +160,7 @@ int zvec_hip_flat_count(zvec_hip_flat_t h, uint64_t *count) {
 int zvec_hip_flat_get_vector(zvec_hip_flat_t h, uint64_t pos, void *out) {
   if (!h || !out) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
+  std::shared_lock<std::shared_mutex> r(h->rw);
   if (pos >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
   ZCHK(hipSetDevice(h->device));
   zvec_hip_ctx_s *c = h->defctx;
@@ -171,6 +176,7 @@ int zvec_hip_flat_get_vectors(zvec_hip_flat_t h, const uint64_t *positions, uint
   if (n == 0) return 0;
   if (n > 0x7fffffffull) return ZVEC_HIP_ERR_OUT_OF_RANGE;
   std::lock_guard<std::mutex> g(h->mu);
+  std::shared_lock<std::shared_mutex> r(h->rw);
   std::vector<uint64_t> pos(positions, positions + n);
   for (uint64_t p : pos)
     if (p >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
@@ -197,6 +203,7 @@ int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *
     return 0;
   }
   std::lock_guard<std::mutex> g(c->mu);
+  std::shared_lock<std::shared_mutex> r(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(c, stream);
   ZRET(prep_queries(c, h->st, d_queries, count, threshold, s));
@@ -232,6 +239,7 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
   if ((size_t)topk * 12 + 16 > 60 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
   zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
   std::lock_guard<std::mutex> g(c->mu);
+  std::shared_lock<std::shared_mutex> r(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = c->cur;
   const Store &st = h->st;

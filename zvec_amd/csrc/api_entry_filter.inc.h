@@ -223,6 +223,7 @@ extern "C" uint32_t zvec_hip_crc32c(const void *data, uint64_t len, uint32_t crc
 extern "C" int zvec_hip_flat_build_filter(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const zvec_hip_doc_filter_t *filter,
                                           uint64_t *out_words, int out_on_device, void *stream) {
   if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::shared_lock<std::shared_mutex> r(h->rw);
   return build_filter(ctx ? ctx : h->defctx, h->device, h->st.keys, h->st.n, nullptr, nullptr, 0, filter, out_words,
                       out_on_device, stream);
 }

@@ -141,7 +141,12 @@ struct zvec_hip_flat_s {
   int dtype = 0;
   Store st;
   zvec_hip_ctx_s *defctx = nullptr;
-  std::mutex mu;
+  std::mutex mu;            // serialises the calls that use defctx's workspace (appends, get_vector)
+  // The streamer is searched while it grows (flat_streamer_test.cc TestConcurrentAddAndSearch): searches hold `rw`
+  // shared while they read the store's pointers / row count and enqueue their kernels; anything that may move or
+  // extend the store holds it exclusive.  A growth reallocation frees the old arrays with hipFree, which waits for
+  // the device, so kernels enqueued by earlier searches have finished with them.
+  std::shared_mutex rw;
 };
 
 struct zvec_hip_ivf_s {
