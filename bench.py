@@ -35,6 +35,7 @@ WORKLOADS = {
     # name: (kind, n, dim, nlist, nprobe, batch, dtype)
     "ivf10m": ("ivf", 10_000_000, 768, 4096, 32, 1024, "fp32"),       # BASELINE configs[2]  (headline)
     "ivf1m": ("ivf", 1_000_000, 768, 1024, 16, 1024, "fp32"),         # small rehearsal
+    "flat_sift1m": ("flat", 1_000_000, 128, 0, 0, 1, "fp32"),         # BASELINE configs[0] shape: 1M x 128-d, one query at a time
     "flat1m": ("flat", 1_000_000, 768, 0, 0, 256, "fp32"),            # BASELINE configs[1]
     "ivf10m_fp16": ("ivf", 10_000_000, 768, 4096, 32, 1024, "fp16"),  # BASELINE configs[3]'s storage type at 1-GPU size
     "ivf100m_fp16": ("ivf", 100_000_000, 768, 16384, 64, 1024, "fp16"),  # BASELINE configs[3] (needs 8 GPUs' HBM for the build)
