@@ -95,6 +95,7 @@ struct Knobs {
   bool no_seed = false;       // ZVEC_HIP_NO_SEED     no prefix scan to seed the admission bounds
   bool no_gather = false;     // ZVEC_HIP_NO_GATHER   sparse filters: compact the kept rows instead of gathering them
   int ivf_tpc = 0;            // ZVEC_HIP_IVF_TPC     fixed tiles per IVF chunk (0 = adaptive)
+  bool m16_small = true;      // ZVEC_HIP_NO_M16_SMALL  keep flat scans of <= 16 queries on the 32-row MFMA shape
   Knobs() {
     if (const char *e = getenv("ZVEC_HIP_MAX_NG")) max_ng = std::max(1, std::min(4, atoi(e)));
     no_wide = getenv("ZVEC_HIP_NO_WIDE") != nullptr;
@@ -102,6 +103,7 @@ struct Knobs {
     no_seed = getenv("ZVEC_HIP_NO_SEED") != nullptr;
     no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;
     if (const char *e = getenv("ZVEC_HIP_IVF_TPC")) ivf_tpc = std::max(1, atoi(e));
+    m16_small = getenv("ZVEC_HIP_NO_M16_SMALL") == nullptr;
   }
 };
 const Knobs &knobs() {
@@ -371,6 +373,10 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   const bool cache_resident = (double)st.n * st.dpad * 4.0 <= 64.0 * 1024 * 1024;
   if (cache_resident && ng > 1) ng = 1;
   if (ng < 1) return ZVEC_HIP_ERR_UNSUPPORTED;
+  // a handful of queries (the product's count = 1): the 16-row MFMA shape (the IVF list-scan kernel in flat mode) does
+  // half the matrix work and half the epilogue of the 32-row one, and streams the base around the L2
+  // (1 query over 1M x 768: scan 0.64 -> 0.50 ms = 6.1 TB/s; 1M x 128: 0.155 -> 0.126 ms)
+  const bool m16_small = knobs().m16_small && ng == 1 && count <= 16;
   const int cus = device_cus(ctx);
   // wide batches over a streamed base: the 8-wave 128x128 tile (two work-groups per CU while its lists fit)
   const bool wide = !knobs().no_wide && (!cache_resident || knobs().force_wide) && pick_ng(count, topk) == 4 && count > 2 * QGROUP && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
@@ -409,7 +415,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     pi = prof_begin(ctx, stream, bytes, flops, 0);
   }
   if (wide) ZRET(launch_scan8(a, st.f16, ((nchunks + 7) / 8) * 8 * nqtiles, cus, stream));   // ids padded to whole XCD groups
-  else ZRET(launch_scan_ng(ng, a, st.f16, nchunks * nqtiles, cus, stream));
+  else ZRET(launch_scan_ng(m16_small ? 0 : ng, a, st.f16, nchunks * nqtiles, cus, stream));
   prof_end(ctx, stream, pi);
 
   MergeArgs m{};
