@@ -106,7 +106,10 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     const uint64_t lists_touched = std::min<uint64_t>(nlist, (uint64_t)count * (brute_force ? nlist : nprobe));
     const uint64_t est_tiles = std::max<uint64_t>(1, h->local_tiles * lists_touched / std::max<uint32_t>(nlist, 1));
     const uint64_t t = est_tiles / (4ull * (uint64_t)device_cus(ctx) * 3ull);
-    tpc = (uint32_t)std::min<uint64_t>(h->tiles_per_chunk, std::max<uint64_t>(1, t));
+    // never one-tile items: they double the slots the merge has to fold for nothing (measured, 10M x 768, nprobe 38:
+    // batch 1 best at 2 tiles, batch 8 at 4, batch 32 at 4-8, batch 1024 at the index default)
+    const uint64_t lo = est_tiles >= 4096 ? 4 : 2;
+    tpc = (uint32_t)std::min<uint64_t>(h->tiles_per_chunk, std::max<uint64_t>(lo, t));
     if (knobs().ivf_tpc) tpc = (uint32_t)knobs().ivf_tpc;
   }
   {
