@@ -84,6 +84,22 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
     // upper bound of the final k-th score; nothing above it can be in the result
     tau = fminf(tau, fkey_inv(a.bound_keys[q]));
   }
+  // Contiguous partial lists ([slots][k], each ascending): the HEADS of the slots are distinct candidates, so the k-th
+  // smallest of 64 lane-wise minima over the heads bounds the final k-th score from above — with hundreds of slots
+  // this is far tighter than the scan's shared bound (the k-th of ONE slot), which lets through a few candidates
+  // of every slot (768 slots x ~3 survivors overflowed the gather and sent single-query merges down the slow path).
+  if (a.part_i != nullptr && a.part_keys == nullptr && a.part_counts == nullptr && a.packed_stride == 0 &&
+      a.slot_stride == 1 && nslots >= 64 && k <= 64) {
+    float mn = __builtin_inff();
+    for (uint32_t j = lane; j < nslots; j += 64) mn = fminf(mn, a.part_s[((size_t)sb + j) * sl]);
+    uint32_t rank = 0;
+    for (int m = 0; m < 64; ++m) {
+      const float o = bcast_f(mn, m);
+      rank += (o < mn || (o == mn && m < lane)) ? 1u : 0u;
+    }
+    const uint64_t hit = __ballot(rank == k - 1);
+    tau = fminf(tau, bcast_f(mn, __builtin_ctzll(hit)));
+  }
 
   // Survivors: usually only a few dozen candidates are at or below the bound.  Gather them (ballot compaction, no
   // ordering yet), sort the <= 128 survivors once by (score, slot, index) with a bitonic network in LDS and emit the
@@ -104,8 +120,15 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
     __syncthreads();
     uint32_t ns = 0;       // uniform per wave: survivors seen so far (single wave) / at the last append (several waves)
     const bool dense_row = a.part_i == nullptr && a.part_keys == nullptr && a.part_counts == nullptr && nslots == 1;
-    auto gather = [&](auto dense_tag) {
-      constexpr bool DENSE = decltype(dense_tag)::value;
+    // three shapes of the candidate stream: 1 = one dense row of scores (element e is candidate e); 2 = contiguous
+    // partial lists of one query ([slots][k], the scans' output: scores are read linearly, slot number and index only
+    // for the survivors); 0 = anything else (strided / packed shard lists with per-slot counts)
+    const bool linear_lists = !dense_row && a.part_i != nullptr && a.part_keys == nullptr && a.part_counts == nullptr &&
+                              a.packed_stride == 0 && a.slot_stride == 1;
+    auto gather = [&](auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
+      constexpr bool DENSE = MODE == 1;
+      constexpr bool LINEAR = MODE == 2;
       for (uint32_t base = wave * 64 * U; base < tot && ns <= GATHER; base += nwaves * 64 * U) {
         float sv[U];
         uint32_t iv[U], jv[U];
@@ -113,8 +136,8 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
         for (int u = 0; u < U; ++u) {
           const uint32_t e = base + (uint32_t)u * 64 + lane;
           bool valid = e < tot;
-          if constexpr (DENSE) {                  // one row of scores: element e is candidate e
-            sv[u] = valid ? a.part_s[(size_t)sb * sl + e] : __builtin_inff();
+          if constexpr (DENSE || LINEAR) {
+            sv[u] = valid ? a.part_s[(size_t)sb * sl + e] : __builtin_inff();    // (unused list entries hold +inf)
             iv[u] = e;
             jv[u] = 0;
           } else {
@@ -150,15 +173,22 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
             }
             const uint32_t pos = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (in && pos < GATHER) {
-              surv_hi[pos] = ((unsigned long long)fkey(sv[u] + 0.f) << 32) | jv[u];
-              surv_lo[pos] = iv[u];
+              uint32_t sj = jv[u], si = iv[u];
+              if constexpr (LINEAR) {                // survivors only: which slot, which stored position
+                sj = iv[u] / sl;
+                si = a.part_i[(size_t)sb * sl + iv[u]];
+              }
+              surv_hi[pos] = ((unsigned long long)fkey(sv[u] + 0.f) << 32) | sj;
+              surv_lo[pos] = si;
             }
             ns = first + add;
           }
         }
       }
     };
-    if (dense_row) gather(std::true_type{}); else gather(std::false_type{});
+    if (dense_row) gather(std::integral_constant<int, 1>{});
+    else if (linear_lists) gather(std::integral_constant<int, 2>{});
+    else gather(std::integral_constant<int, 0>{});
     if (nwaves > 1) {
       __syncthreads();
       if (wave != 0) return;                       // (no work-group barrier below this point)
