@@ -4,7 +4,10 @@
 //   tests/core/algorithm/ivf/ivf_searcher_test.cc:200-321 (TestSimple), :2830-2886 (TestRnnSearch shape)
 // Needs a GPU.  Exit code 0 = all checks passed.
 #include <cstdio>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "../../zvec_amd/csrc/host/hip_index.h"
@@ -204,11 +207,84 @@ static int TestIVFSimple() {
   return 0;
 }
 
+// Single-query callers on many threads, with and without the micro-batcher: identical result lists, and (printed) the
+// searches per second of both — the product drives the boundary exactly like this (index.cc:617).
+static int TestMicroBatcher() {
+  const bool big = getenv("ZVEC_MIRROR_BIG") != nullptr;       // a larger index for a meaningful searches/s figure
+  const uint32_t dim = big ? 128 : 32, nlist = big ? 256 : 24, per_list = big ? 4000 : 700, n = nlist * per_list;
+  const uint32_t threads = big ? 64 : 32, per_thread = 100, topk = 10;
+  IndexMeta meta(IndexMeta::DT_FP32, dim);
+  meta.set_metric("SquaredEuclidean");
+  std::vector<float> base((size_t)n * dim), cent((size_t)nlist * dim);
+  std::vector<uint64_t> keys(n), offs(nlist + 1);
+  uint32_t seed = 12345;
+  auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)((seed >> 9) & 1023) / 64.0f; };
+  for (uint32_t l = 0; l < nlist; ++l) {
+    offs[l] = (uint64_t)l * per_list;
+    for (uint32_t j = 0; j < dim; ++j) cent[(size_t)l * dim + j] = (float)(l * 20);
+    for (uint32_t i = 0; i < per_list; ++i) {
+      const size_t r = (size_t)l * per_list + i;
+      keys[r] = 7 * r + 1;
+      for (uint32_t j = 0; j < dim; ++j) base[r * dim + j] = (float)(l * 20) + rnd();
+    }
+  }
+  offs[nlist] = n;
+  Params pa, pb;
+  pa.set(PARAM_IVF_SEARCHER_SCAN_RATIO, 0.25);
+  pa.set(PARAM_IVF_SEARCHER_BRUTE_FORCE_THRESHOLD, 10);
+  pb = pa;
+  pb.set(PARAM_HIP_SEARCHER_BATCH_WINDOW_US, 2000);
+  pb.set(PARAM_HIP_SEARCHER_MAX_BATCH, 64);
+  pb.set(PARAM_HIP_SEARCHER_BATCH_LINGER_US, 40);
+  HipIVFSearcher plain, batched;
+  ASSERT(0 == plain.init(pa) && 0 == batched.init(pb));
+  ASSERT(0 == plain.load(meta, cent.data(), nlist, offs.data(), base.data(), keys.data()));
+  ASSERT(0 == batched.load(meta, cent.data(), nlist, offs.data(), base.data(), keys.data()));
+  IndexQueryMeta qmeta(IndexMeta::DT_FP32, dim);
+  std::vector<float> queries((size_t)threads * per_thread * dim);
+  for (auto &v : queries) v = rnd() + 20.0f * (float)((seed >> 20) % nlist);
+  std::vector<IndexDocumentList> want((size_t)threads * per_thread);
+  {
+    auto ctx = plain.create_context();
+    ctx->set_topk(topk);
+    for (size_t i = 0; i < want.size(); ++i) {
+      ASSERT(0 == plain.search_impl(&queries[i * dim], qmeta, ctx));
+      want[i] = ctx->result();
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    HipIVFSearcher &se = pass ? batched : plain;
+    std::atomic<int> bad{0};
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < threads; ++t)
+      th.emplace_back([&, t]() {
+        auto ctx = se.create_context();
+        ctx->set_topk(topk);
+        for (uint32_t i = 0; i < per_thread; ++i) {
+          const size_t qi = (size_t)t * per_thread + i;
+          if (se.search_impl(&queries[qi * dim], qmeta, ctx) != 0) { ++bad; continue; }
+          const auto &r = ctx->result();
+          if (r.size() != want[qi].size()) { ++bad; continue; }
+          for (size_t j = 0; j < r.size(); ++j)
+            if (r[j].key() != want[qi][j].key() || r[j].score() != want[qi][j].score()) { ++bad; break; }
+        }
+      });
+    for (auto &x : th) x.join();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("  %u threads x %u single queries, %s: %.0f searches/s\n", threads, per_thread, pass ? "micro-batched" : "direct",
+           threads * per_thread / dt);
+    EXPECT(bad.load() == 0);
+  }
+  return 0;
+}
+
 int main() {
   int rc = 0;
   rc |= TestLinearSearch();
   rc |= TestFilter();
   rc |= TestIVFSimple();
+  rc |= TestMicroBatcher();
   if (rc == 0 && g_fail == 0) { printf("host mirror: all tests passed\n"); return 0; }
   printf("host mirror: %d failures (rc=%d)\n", g_fail, rc);
   return 1;

@@ -17,11 +17,14 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <functional>
 #include <map>
 #include <unordered_map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -80,6 +83,10 @@ class Params {
 };
 static const char *const PARAM_IVF_SEARCHER_SCAN_RATIO = "proxima.ivf.searcher.scan_ratio";
 static const char *const PARAM_IVF_SEARCHER_BRUTE_FORCE_THRESHOLD = "proxima.ivf.searcher.brute_force_threshold";
+// not a reference parameter: > 0 turns on the micro-batcher for single-query searches (see MicroBatcher below)
+static const char *const PARAM_HIP_SEARCHER_BATCH_WINDOW_US = "proxima.hip.searcher.batch_window_us";
+static const char *const PARAM_HIP_SEARCHER_MAX_BATCH = "proxima.hip.searcher.max_batch";
+static const char *const PARAM_HIP_SEARCHER_BATCH_LINGER_US = "proxima.hip.searcher.batch_linger_us";
 
 class IndexDocument {
  public:
@@ -138,6 +145,8 @@ class Context {
   // buffer; the index materialises it on the GPU (zvec_hip_*_build_filter) instead of sweeping a callback
   void set_doc_filter(const zvec_hip_doc_filter_t &f) { doc_ = f; has_doc_ = true; has_bits_ = false; }
   bool has_doc_filter() const { return has_doc_; }
+  bool has_any_filter() const { return has_doc_ || has_bits_ || filter_.is_valid(); }
+  void take_single(IndexDocumentList &&list) { results_.assign(1, IndexDocumentList()); results_[0] = std::move(list); }
   const zvec_hip_doc_filter_t &doc_filter() const { return doc_; }
   std::vector<uint64_t> &bits() { return bits_; }
   const IndexDocumentList &result() const { return results_.at(0); }
@@ -205,6 +214,90 @@ inline int attach_result_vectors(Context *ctx, uint32_t count, size_t row_bytes,
     for (auto &d : *ctx->mutable_result(q)) d.set_vector(rows.data() + (o++) * row_bytes, row_bytes);
   return 0;
 }
+
+// ---- micro-batcher -------------------------------------------------------------------------------
+// The product drives boundary B with ONE query per call from many threads (index.cc:617), which leaves the GPU at a
+// few thousand searches per second, while one batched call answers 1024 queries in 5 ms.  The batcher turns the
+// former into the latter behind the same single-query entry point: concurrent callers with the same topk join an open
+// batch; the first one in becomes its leader, keeps the batch open while an earlier batch is still searching (at most
+// until it is full or `window_us` has passed), runs ONE batched search and hands every caller its own result list.
+// A lone caller on an idle index is not delayed at all; under load the batches grow by themselves.  Callers with a filter / threshold / fetch_vector bypass it (their searches are not interchangeable).
+class MicroBatcher {
+ public:
+  // runs a batched search of `count` queries (row-major, row_bytes each) and fills keys/scores [count][topk] + counts
+  using RunFn = std::function<int(const void *queries, uint32_t count, uint32_t topk, std::vector<uint64_t> *keys,
+                                  std::vector<float> *scores, std::vector<uint32_t> *counts)>;
+  // linger_us: how long a leader keeps its batch open even when nothing else is searching (0 = a lone caller is never
+  // delayed; a few tens of microseconds let callers that arrive in a burst share the first batch too)
+  MicroBatcher(size_t row_bytes, uint32_t max_batch, uint32_t window_us, uint32_t linger_us, RunFn fn)
+      : row_bytes_(row_bytes), max_batch_(std::max<uint32_t>(1, max_batch)), window_us_(window_us),
+        linger_us_(std::min(linger_us, window_us)), fn_(std::move(fn)) {}
+
+  int search(const void *query, uint32_t topk, IndexDocumentList *out) {
+    std::unique_lock<std::mutex> lk(mu_);
+    // join the open batch if it takes this topk and has room; otherwise wait for it to close and open a new one
+    while (open_ && (open_->topk != topk || open_->n >= max_batch_ || open_->closed)) cv_.wait(lk);
+    std::shared_ptr<Batch> b = open_;
+    bool leader = false;
+    if (!b) {
+      b = std::make_shared<Batch>();
+      b->topk = topk;
+      b->deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us_);
+      b->linger = std::chrono::steady_clock::now() + std::chrono::microseconds(linger_us_);
+      open_ = b;
+      leader = true;
+    }
+    const uint32_t slot = b->n++;
+    b->queries.insert(b->queries.end(), static_cast<const char *>(query), static_cast<const char *>(query) + row_bytes_);
+    if (b->n >= max_batch_) cv_.notify_all();
+    if (leader) {
+      // collect while an earlier batch is still searching (no added latency on an idle index: a lone caller goes at
+      // once), at most until the batch is full or the window has passed
+      while (b->n < max_batch_) {
+        const auto now = std::chrono::steady_clock::now();
+        const auto until = inflight_ > 0 ? b->deadline : b->linger;
+        if (now >= until) break;
+        cv_.wait_until(lk, until);
+      }
+      b->closed = true;
+      open_.reset();                    // the next arrival opens (and leads) the next batch
+      ++inflight_;
+      cv_.notify_all();
+      lk.unlock();
+      b->rc = fn_(b->queries.data(), b->n, topk, &b->keys, &b->scores, &b->counts);
+      lk.lock();
+      --inflight_;
+      b->done = true;
+      cv_.notify_all();
+    } else {
+      while (!b->done) cv_.wait(lk);
+    }
+    if (b->rc != 0) return b->rc;
+    out->clear();
+    for (uint32_t j = 0; j < b->counts[slot]; ++j)
+      out->emplace_back(b->keys[(size_t)slot * topk + j], b->scores[(size_t)slot * topk + j]);
+    return 0;
+  }
+
+ private:
+  struct Batch {
+    uint32_t topk = 0, n = 0;
+    bool closed = false, done = false;
+    int rc = 0;
+    std::chrono::steady_clock::time_point deadline, linger;
+    std::vector<char> queries;
+    std::vector<uint64_t> keys;
+    std::vector<float> scores;
+    std::vector<uint32_t> counts;
+  };
+  size_t row_bytes_;
+  uint32_t max_batch_, window_us_, linger_us_;
+  RunFn fn_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::shared_ptr<Batch> open_;
+  uint32_t inflight_ = 0;      // batches currently searching
+};
 
 // ---- flat: one class body serves the "FlatStreamer" and "FlatSearcher" registrations -------------
 class HipFlatStreamer {
@@ -311,6 +404,9 @@ class HipIVFSearcher {
     double v;
     if (params.get(PARAM_IVF_SEARCHER_SCAN_RATIO, &v)) scan_ratio_ = (float)v;
     if (params.get(PARAM_IVF_SEARCHER_BRUTE_FORCE_THRESHOLD, &v)) bruteforce_threshold_ = (uint32_t)v;
+    if (params.get(PARAM_HIP_SEARCHER_BATCH_WINDOW_US, &v)) batch_window_us_ = (uint32_t)v;
+    if (params.get(PARAM_HIP_SEARCHER_MAX_BATCH, &v)) max_batch_ = (uint32_t)v;
+    if (params.get(PARAM_HIP_SEARCHER_BATCH_LINGER_US, &v)) batch_linger_us_ = (uint32_t)v;
     if (scan_ratio_ <= 0.0f) return IndexError_InvalidArgument;   // ivf_searcher_context.h:65-69
     return 0;
   }
@@ -333,9 +429,31 @@ class HipIVFSearcher {
     count_ = list_offsets[nlist];
     keys_.resize(count_);
     for (uint64_t i = 0; i < count_; ++i) keys_[i] = keys ? keys[i] : i;
+    if (batch_window_us_ > 0) {
+      batcher_.reset(new MicroBatcher(meta_.element_size(), max_batch_, batch_window_us_, batch_linger_us_,
+          [this](const void *q, uint32_t n, uint32_t k, std::vector<uint64_t> *ks, std::vector<float> *sc, std::vector<uint32_t> *cn) {
+            // a small pool of workspaces shared by the leaders (any thread may lead a batch; creating a context —
+            // a stream plus its buffers — per thread would cost more than the searches)
+            std::unique_ptr<Context> c;
+            {
+              std::lock_guard<std::mutex> g(pool_mu_);
+              if (!pool_.empty()) { c = std::move(pool_.back()); pool_.pop_back(); }
+            }
+            if (!c) c.reset(new Context(device_, magic_));
+            if (!c->ok()) return (int)IndexError_Runtime;
+            ks->assign((size_t)n * k, 0);
+            sc->assign((size_t)n * k, 0.f);
+            cn->assign(n, 0);
+            int rc = zvec_hip_ivf_search(h_, c->handle(), q, n, k, FLT_MAX, nprobe(), max_scan_count(), nullptr, ks->data(),
+                                         sc->data(), cn->data());
+            std::lock_guard<std::mutex> g(pool_mu_);
+            pool_.push_back(std::move(c));
+            return rc;
+          }));
+    }
     return 0;
   }
-  int unload() { int rc = h_ ? zvec_hip_ivf_destroy(h_) : 0; h_ = nullptr; return rc; }
+  int unload() { batcher_.reset(); pool_.clear(); int rc = h_ ? zvec_hip_ivf_destroy(h_) : 0; h_ = nullptr; return rc; }
   Context::Pointer create_context() const {
     if (!h_) return nullptr;                                   // "Load the index first" ivf_searcher.cc:257-260
     Context::Pointer c(new Context(device_, magic_));
@@ -352,6 +470,14 @@ class HipIVFSearcher {
   }
   int search_impl(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context) const {
     if (h_ && count_ <= bruteforce_threshold_) return search_bf_impl(query, qmeta, count, context);   // ivf_searcher.cc:188-190
+    Context *ctx = context.get();
+    if (batcher_ && count == 1 && h_ && query && ctx && ctx->topk() != 0 && qmeta.element_size() == meta_.element_size() &&
+        !ctx->has_any_filter() && !ctx->fetch_vector() && ctx->threshold() == FLT_MAX) {
+      IndexDocumentList r;                       // single plain query: ride a shared batch (MicroBatcher)
+      int rc = batcher_->search(query, ctx->topk(), &r);
+      if (rc == 0) ctx->take_single(std::move(r));
+      return rc;
+    }
     return run(query, qmeta, count, context, false);
   }
   int search_bf_impl(const void *query, const IndexQueryMeta &qmeta, Context::Pointer &context) const {
@@ -392,6 +518,10 @@ class HipIVFSearcher {
                                  [h](const uint64_t *p, size_t n, void *out) { return zvec_hip_ivf_get_vectors(h, p, n, out); });
   }
   mutable std::unordered_map<uint64_t, uint64_t> pos_of_key_;
+  std::unique_ptr<MicroBatcher> batcher_;
+  mutable std::mutex pool_mu_;
+  mutable std::vector<std::unique_ptr<Context>> pool_;
+  uint32_t batch_window_us_{0}, max_batch_{1024}, batch_linger_us_{0};
   IndexMeta meta_;
   int device_{0};
   uint32_t magic_{0};
