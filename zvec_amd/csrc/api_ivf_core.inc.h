@@ -202,10 +202,17 @@ __global__ void ivf_work_stats_kernel(const uint32_t *list_count, const uint32_t
   atomicAdd(&out2[1], pairs);
 }
 
+constexpr size_t PIN_LIMIT = 8u << 20;    // staging through pinned memory up to 8 MiB per direction
+
 int host_search_wrap_begin(zvec_hip_ctx_s *ctx, const void *queries, size_t qbytes, const uint64_t *exclude,
                            uint64_t nbits, uint32_t count, uint32_t topk, hipStream_t stream) {
   ZRET(ctx->io_q.ensure(qbytes));
-  ZCHK(hipMemcpyAsync(ctx->io_q.p, queries, qbytes, hipMemcpyHostToDevice, stream));
+  if (qbytes <= PIN_LIMIT && ctx->pin_in.ensure(qbytes) == 0) {
+    memcpy(ctx->pin_in.p, queries, qbytes);              // (the previous call's transfer has been waited for)
+    ZCHK(hipMemcpyAsync(ctx->io_q.p, ctx->pin_in.p, qbytes, hipMemcpyHostToDevice, stream));
+  } else {
+    ZCHK(hipMemcpyAsync(ctx->io_q.p, queries, qbytes, hipMemcpyHostToDevice, stream));
+  }
   if (exclude) {
     size_t words = (size_t)((nbits + 63) / 64);
     ZRET(ctx->io_ex.ensure(words * 8 + 8));
@@ -219,9 +226,21 @@ int host_search_wrap_begin(zvec_hip_ctx_s *ctx, const void *queries, size_t qbyt
 
 int host_search_wrap_end(zvec_hip_ctx_s *ctx, uint32_t count, uint32_t topk, uint64_t *out_keys, float *out_scores,
                          uint32_t *out_counts, hipStream_t stream) {
-  ZCHK(hipMemcpyAsync(out_keys, ctx->io_keys.p, (size_t)count * topk * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-  ZCHK(hipMemcpyAsync(out_scores, ctx->io_scores.p, (size_t)count * topk * sizeof(float), hipMemcpyDeviceToHost, stream));
-  ZCHK(hipMemcpyAsync(out_counts, ctx->io_counts.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  const size_t kb = (size_t)count * topk * sizeof(uint64_t), sb = (size_t)count * topk * sizeof(float), cb = (size_t)count * sizeof(uint32_t);
+  if (kb + sb + cb <= PIN_LIMIT && ctx->pin_out.ensure(kb + sb + cb) == 0) {
+    char *h = static_cast<char *>(ctx->pin_out.p);
+    ZCHK(hipMemcpyAsync(h, ctx->io_keys.p, kb, hipMemcpyDeviceToHost, stream));
+    ZCHK(hipMemcpyAsync(h + kb, ctx->io_scores.p, sb, hipMemcpyDeviceToHost, stream));
+    ZCHK(hipMemcpyAsync(h + kb + sb, ctx->io_counts.p, cb, hipMemcpyDeviceToHost, stream));
+    ZCHK(hipStreamSynchronize(stream));
+    memcpy(out_keys, h, kb);
+    memcpy(out_scores, h + kb, sb);
+    memcpy(out_counts, h + kb + sb, cb);
+    return 0;
+  }
+  ZCHK(hipMemcpyAsync(out_keys, ctx->io_keys.p, kb, hipMemcpyDeviceToHost, stream));
+  ZCHK(hipMemcpyAsync(out_scores, ctx->io_scores.p, sb, hipMemcpyDeviceToHost, stream));
+  ZCHK(hipMemcpyAsync(out_counts, ctx->io_counts.p, cb, hipMemcpyDeviceToHost, stream));
   ZCHK(hipStreamSynchronize(stream));
   return 0;
 }

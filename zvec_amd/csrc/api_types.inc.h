@@ -37,6 +37,22 @@ struct DevBuf {
   template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// pinned host staging (small transfers of the host-pointer entry points: a copy from / to pageable memory is staged
+// and synchronised by the runtime, a pinned one is a plain asynchronous DMA)
+struct PinnedBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    ZCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 // scope-owned device temporary: freed on every exit path of the enclosing function
 template <typename T>
 struct Scoped {
@@ -122,6 +138,7 @@ struct zvec_hip_ctx_s {
   DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
   DevBuf plan;        // all u32 plan arrays
   DevBuf io_q, io_ex, io_keys, io_scores, io_counts;   // staging for host-pointer entry points
+  PinnedBuf pin_in, pin_out;                           // (batches up to PIN_LIMIT bytes go through pinned memory)
   DevBuf stats;       // per-launch {distinct_rows, pair_rows} u64 x PROFILE_MAX
   uint32_t *q_scanned = nullptr, *q_nprobe = nullptr;  // inside plan
   uint32_t *last_list_count = nullptr;                 // inside plan
