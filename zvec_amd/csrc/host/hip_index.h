@@ -234,43 +234,56 @@ class MicroBatcher {
         linger_us_(std::min(linger_us, window_us)), fn_(std::move(fn)) {}
 
   int search(const void *query, uint32_t topk, IndexDocumentList *out) {
-    std::unique_lock<std::mutex> lk(mu_);
-    // join the open batch if it takes this topk and has room; otherwise wait for it to close and open a new one
-    while (open_ && (open_->topk != topk || open_->n >= max_batch_ || open_->closed)) cv_.wait(lk);
-    std::shared_ptr<Batch> b = open_;
+    std::shared_ptr<Batch> b;
     bool leader = false;
-    if (!b) {
-      b = std::make_shared<Batch>();
-      b->topk = topk;
-      b->deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us_);
-      b->linger = std::chrono::steady_clock::now() + std::chrono::microseconds(linger_us_);
-      open_ = b;
-      leader = true;
-    }
-    const uint32_t slot = b->n++;
-    b->queries.insert(b->queries.end(), static_cast<const char *>(query), static_cast<const char *>(query) + row_bytes_);
-    if (b->n >= max_batch_) cv_.notify_all();
-    if (leader) {
-      // collect while an earlier batch is still searching (no added latency on an idle index: a lone caller goes at
-      // once), at most until the batch is full or the window has passed
-      while (b->n < max_batch_) {
+    uint32_t slot = 0;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      // join the open batch if it takes this topk and has room; otherwise wait for it to close and open a new one
+      while (open_ && (open_->topk != topk || open_->n >= max_batch_)) cv_.wait(lk);
+      b = open_;
+      if (!b) {
+        b = std::make_shared<Batch>();
+        b->topk = topk;
         const auto now = std::chrono::steady_clock::now();
-        const auto until = inflight_ > 0 ? b->deadline : b->linger;
-        if (now >= until) break;
-        cv_.wait_until(lk, until);
+        b->deadline = now + std::chrono::microseconds(window_us_);
+        b->linger = now + std::chrono::microseconds(linger_us_);
+        open_ = b;
+        leader = true;
       }
-      b->closed = true;
-      open_.reset();                    // the next arrival opens (and leads) the next batch
-      ++inflight_;
-      cv_.notify_all();
-      lk.unlock();
-      b->rc = fn_(b->queries.data(), b->n, topk, &b->keys, &b->scores, &b->counts);
-      lk.lock();
-      --inflight_;
-      b->done = true;
-      cv_.notify_all();
+      slot = b->n++;
+      b->queries.insert(b->queries.end(), static_cast<const char *>(query), static_cast<const char *>(query) + row_bytes_);
+      if (b->n >= max_batch_) cv_.notify_all();
+      if (leader) {
+        // collect while an earlier batch is still searching (no added latency on an idle index: a lone caller goes
+        // at once unless a linger is configured), at most until the batch is full or the window has passed
+        while (b->n < max_batch_) {
+          const auto now = std::chrono::steady_clock::now();
+          const auto until = inflight_ > 0 ? b->deadline : b->linger;
+          if (now >= until) break;
+          cv_.wait_until(lk, until);
+        }
+        open_.reset();                    // the next arrival opens (and leads) the next batch
+        ++inflight_;
+        cv_.notify_all();
+      }
+    }
+    if (leader) {
+      const int rc = fn_(b->queries.data(), b->n, topk, &b->keys, &b->scores, &b->counts);
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        --inflight_;
+        cv_.notify_all();                 // a leader that was collecting behind this batch may go now
+      }
+      {
+        std::lock_guard<std::mutex> g(b->mu); // the members of THIS batch wait on its own lock: no stampede on mu_
+        b->rc = rc;
+        b->done = true;
+      }
+      b->cv.notify_all();
     } else {
-      while (!b->done) cv_.wait(lk);
+      std::unique_lock<std::mutex> bl(b->mu);
+      while (!b->done) b->cv.wait(bl);
     }
     if (b->rc != 0) return b->rc;
     out->clear();
@@ -282,8 +295,10 @@ class MicroBatcher {
  private:
   struct Batch {
     uint32_t topk = 0, n = 0;
-    bool closed = false, done = false;
+    bool done = false;
     int rc = 0;
+    std::mutex mu;
+    std::condition_variable cv;
     std::chrono::steady_clock::time_point deadline, linger;
     std::vector<char> queries;
     std::vector<uint64_t> keys;
