@@ -160,13 +160,22 @@ class Oracle:
     def block_dist(self, metric, m_block, q_block, use_ref=False):
         """M x N block kernel: m_block [dim][M] (column-major block of M vectors), q_block [dim][N] (N interleaved
         queries) -> out [N][M].  metric L2 or IP (minus inner product).  M in {8, 16, 32}."""
-        m = np.ascontiguousarray(m_block, np.float32)
-        q = np.ascontiguousarray(q_block, np.float32)
+        half = np.asarray(m_block).dtype == np.float16
+        m = np.ascontiguousarray(m_block, np.float16 if half else np.float32)
+        q = np.ascontiguousarray(q_block, np.float16 if half else np.float32)
         dim, M = m.shape
         N = q.shape[1]
         assert q.shape[0] == dim and M in (8, 16, 32)
         out = np.zeros((N, M), np.float32)
         name = "sqeuclid" if metric == METRIC_L2 else "minus_ip"
+        if np.asarray(m_block).dtype == np.float16:                 # fp16 blocks
+            m = np.ascontiguousarray(m_block, np.float16)
+            q = np.ascontiguousarray(q_block, np.float16)
+            fn = getattr(self.ref if use_ref else self.lib, ("zref_%s_block_f16" if use_ref else "zo_%s_block_f16") % name)
+            fn.restype = C.c_int if use_ref else None
+            rc = fn(M, N, m.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), C.c_size_t(dim), _ptr(out, _f32p))
+            assert not use_ref or rc == 0
+            return out
         if use_ref:
             fn = getattr(self.ref, "zref_%s_block_f32" % name)
             fn.restype = C.c_int

@@ -105,6 +105,22 @@ int zref_minus_ip_block_f32(int M, int N, const float *m, const float *q, size_t
   ZREF_BLOCK_ALL(MinusInnerProductMatrix)
   return -1;
 }
+// fp16 blocks (euclidean_distance_matrix_fp16.cc / inner_product_matrix_fp16.cc; distance_matrix_accum_fp16.i)
+#define ZREF_BLOCK16(KERNEL, M_, N_) \
+  if (M == M_ && N == N_) { KERNEL<Float16, M_, N_>::Compute(reinterpret_cast<const Float16 *>(m), reinterpret_cast<const Float16 *>(q), dim, out); return 0; }
+#define ZREF_BLOCK16_ALL(KERNEL)                                                                              \
+  ZREF_BLOCK16(KERNEL, 8, 1) ZREF_BLOCK16(KERNEL, 8, 2) ZREF_BLOCK16(KERNEL, 8, 4) ZREF_BLOCK16(KERNEL, 8, 8)     \
+  ZREF_BLOCK16(KERNEL, 16, 1) ZREF_BLOCK16(KERNEL, 16, 2) ZREF_BLOCK16(KERNEL, 16, 4) ZREF_BLOCK16(KERNEL, 16, 8) \
+  ZREF_BLOCK16(KERNEL, 16, 16) ZREF_BLOCK16(KERNEL, 32, 1) ZREF_BLOCK16(KERNEL, 32, 2) ZREF_BLOCK16(KERNEL, 32, 4) \
+  ZREF_BLOCK16(KERNEL, 32, 8) ZREF_BLOCK16(KERNEL, 32, 16) ZREF_BLOCK16(KERNEL, 32, 32)
+int zref_sqeuclid_block_f16(int M, int N, const uint16_t *m, const uint16_t *q, size_t dim, float *out) {
+  ZREF_BLOCK16_ALL(SquaredEuclideanDistanceMatrix)
+  return -1;
+}
+int zref_minus_ip_block_f16(int M, int N, const uint16_t *m, const uint16_t *q, size_t dim, float *out) {
+  ZREF_BLOCK16_ALL(MinusInnerProductMatrix)
+  return -1;
+}
 
 // Replays n emplace() calls through the reference Heap and returns the heap array as laid out.
 size_t zref_heap_replay(const float *scores, size_t n, size_t limit, float threshold,

@@ -123,6 +123,27 @@ void zo_minus_ip_block_f32(int M, int N, const float *m, const float *q, size_t 
     }
 }
 
+static float half_to_float(uint16_t h);   /* defined with the fp16 1x1 kernels below */
+void zo_sqeuclid_block_f16(int M, int N, const uint16_t *m, const uint16_t *q, size_t dim, float *out) {
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i < M; ++i) {
+      float acc = 0.0f;
+      for (size_t k = 0; k < dim; ++k) {
+        const float d = half_to_float(m[k * (size_t)M + i]) - half_to_float(q[k * (size_t)N + j]);
+        acc = fmaf(d, d, acc);
+      }
+      out[(size_t)j * M + i] = acc;
+    }
+}
+void zo_minus_ip_block_f16(int M, int N, const uint16_t *m, const uint16_t *q, size_t dim, float *out) {
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i < M; ++i) {
+      float acc = 0.0f;
+      for (size_t k = 0; k < dim; ++k) acc = fmaf(half_to_float(m[k * (size_t)M + i]), half_to_float(q[k * (size_t)N + j]), acc);
+      out[(size_t)j * M + i] = -acc;
+    }
+}
+
 /* CosineDistanceMatrix<float,1,1>::Compute  cosine_distance_matrix.h:32-50 */
 float zo_cosine_f32(const float *m, const float *q, size_t dim_with_norm) {
   size_t d = dim_with_norm - 1; /* extra_dim = sizeof(float)/sizeof(float) */

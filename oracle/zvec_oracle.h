@@ -60,6 +60,10 @@ float zo_distance(int metric, const float *m, const float *q, size_t dim);
  * several k into one vector and are NOT restated. */
 void zo_sqeuclid_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out);
 void zo_minus_ip_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out);
+/* fp16 blocks (euclidean_distance_matrix_fp16.cc, inner_product_matrix_fp16.cc, distance_matrix_accum_fp16.i): halves are
+ * widened to fp32 and accumulated by the same per-pair sequential FMA chain (M in {8, 16, 32}; pinned bit for bit). */
+void zo_sqeuclid_block_f16(int M, int N, const uint16_t *m, const uint16_t *q, size_t dim, float *out);
+void zo_minus_ip_block_f16(int M, int N, const uint16_t *m, const uint16_t *q, size_t dim, float *out);
 
 /* fp16 rows (DT_FP16): halves as uint16_t; restated AVX-512 (no FP16 ISA) order, fp32 accumulation */
 float zo_sqeuclid_f16(const uint16_t *m, const uint16_t *q, size_t dim);

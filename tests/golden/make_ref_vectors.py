@@ -90,6 +90,22 @@ out["block_m"] = np.concatenate(BM)
 out["block_q"] = np.concatenate(BQ)
 out["block_l2"] = np.concatenate(BL2)
 out["block_minus_ip"] = np.concatenate(BIP)
+# fp16 blocks (again drawn last)
+HM, HQ, HL2, HIP, HSHAPE = [], [], [], [], []
+for M, N in ((8, 2), (16, 16), (32, 1), (32, 32)):
+    for d in (1, 17, 128, 769):
+        mb = (rng.standard_normal((d, M)) * 2).astype(np.float16)
+        qb = (rng.standard_normal((d, N)) * 2).astype(np.float16)
+        HM.append(mb.ravel().view(np.uint16))
+        HQ.append(qb.ravel().view(np.uint16))
+        HL2.append(o.block_dist(O.METRIC_L2, mb, qb, use_ref=True).ravel())
+        HIP.append(o.block_dist(O.METRIC_IP, mb, qb, use_ref=True).ravel())
+        HSHAPE.append((M, N, d))
+out["hblock_shapes"] = np.array(HSHAPE, np.int32)
+out["hblock_m"] = np.concatenate(HM)
+out["hblock_q"] = np.concatenate(HQ)
+out["hblock_l2"] = np.concatenate(HL2)
+out["hblock_minus_ip"] = np.concatenate(HIP)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_kernel_vectors.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes")

@@ -103,6 +103,21 @@ def test_block_kernels_bit_exact_vs_reference_vectors(oracle, golden_dir):
         oo += M * N
 
 
+def test_fp16_block_kernels_bit_exact_vs_reference_vectors(oracle, golden_dir):
+    """fp16 M x N blocks (euclidean_distance_matrix_fp16.cc, inner_product_matrix_fp16.cc): outputs of the compiled
+    reference for seeded half blocks"""
+    z = np.load(os.path.join(golden_dir, "ref_kernel_vectors.npz"))
+    om = oq = oo = 0
+    for M, N, d in z["hblock_shapes"]:
+        m = z["hblock_m"][om:om + d * M].view(np.float16).reshape(d, M)
+        q = z["hblock_q"][oq:oq + d * N].view(np.float16).reshape(d, N)
+        assert np.array_equal(oracle.block_dist(O.METRIC_L2, m, q).ravel().view(np.uint32), z["hblock_l2"][oo:oo + M * N].view(np.uint32)), (M, N, d)
+        assert np.array_equal(oracle.block_dist(O.METRIC_IP, m, q).ravel().view(np.uint32), z["hblock_minus_ip"][oo:oo + M * N].view(np.uint32)), (M, N, d)
+        om += d * M
+        oq += d * N
+        oo += M * N
+
+
 def test_live_vs_compiled_reference(oracle):
     if oracle.ref is None:
         pytest.skip("oracle/_ref/libzvec_ref.so not present (or CPU lacks AVX-512)")
@@ -130,6 +145,9 @@ def test_live_vs_compiled_reference(oracle):
                 for m in (O.METRIC_L2, O.METRIC_IP):
                     assert np.array_equal(oracle.block_dist(m, mb, qb).view(np.uint32),
                                           oracle.block_dist(m, mb, qb, use_ref=True).view(np.uint32)), (M, N, d, m)
+                    hm, hq = mb.astype(np.float16), qb.astype(np.float16)
+                    assert np.array_equal(oracle.block_dist(m, hm, hq).view(np.uint32),
+                                          oracle.block_dist(m, hm, hq, use_ref=True).view(np.uint32)), ("fp16", M, N, d, m)
     for _ in range(100):
         n, k = int(rng.integers(1, 400)), int(rng.integers(1, 64))
         s = rng.integers(0, 9, n).astype(np.float32)
