@@ -159,9 +159,42 @@ int zvec_hip_ivf_search_bf(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *que
                            uint32_t count, uint32_t topk, float threshold,
                            const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
                            uint32_t *out_counts);
-/* shard: keep only the lists l with l % nshards == shard (centroids stay replicated), the
- * multi-GPU partition of SURVEY §8(e).  Call after load/build, before searching. */
+/* shard: keep only the lists this shard owns (centroids stay replicated), the multi-GPU partition of
+ * SURVEY §8(e) ("whole inverted lists assigned to GPUs, balanced by bytes").  The list -> shard map is the greedy
+ * largest-first assignment of zvec_hip_ivf_shard_map over the GLOBAL list sizes, so every rank derives the same map
+ * without communicating.  Call before load / build / begin_lists. */
 int zvec_hip_ivf_keep_shard(zvec_hip_ivf_t h, uint32_t shard, uint32_t nshards);
+/* the map itself (pure host arithmetic, no GPU needed): lists ordered by (128-row tiles desc, id asc), each given to the
+ * shard holding the fewest tiles so far (lowest shard on ties).  owner_out[nlist]; shard_rows_out[nshards] nullable. */
+int zvec_hip_ivf_shard_map(const uint32_t *list_sizes, uint32_t nlist, uint32_t nshards, uint32_t *owner_out,
+                           uint64_t *shard_rows_out);
+/* owner of every list of a loaded / filling index (owner_out[nlist]) */
+int zvec_hip_ivf_list_owners(zvec_hip_ivf_t h, uint32_t *owner_out);
+
+/* ---- streamed IVF build ---------------------------------------------------------------------
+ * IVFBuilder's three phases as separate calls, so that a (sharded) index far larger than one chunk of raw rows can be
+ * built without ever holding the corpus: train (ivf_builder.cc:212-267) on a sample; label chunks of rows with their
+ * nearest centroid (ivf_builder.h:253-274, ivf_builder.cc:607-650); announce the global list sizes, then hand the chunks
+ * over again with their labels — rows of lists this shard owns are appended to those lists in arrival order (the
+ * dump step, ivf_builder.cc:652-729 / ivf_dumper.h:33-160).  zvec_hip_ivf_build[_dev] is exactly
+ * train(strided sample) + label(all) + begin + add(all) + end. */
+int zvec_hip_ivf_train_dev(zvec_hip_ivf_t h, const void *d_sample, uint64_t n_sample, uint32_t nlist,
+                           uint32_t kmeans_iters, uint64_t seed, void *stream);
+/* centroids trained elsewhere (e.g. broadcast from rank 0): [nlist][dim] host rows of the index element type */
+int zvec_hip_ivf_set_centroids(zvec_hip_ivf_t h, const void *centroids, uint32_t nlist);
+int zvec_hip_ivf_get_centroids(zvec_hip_ivf_t h, void *centroids, uint32_t *nlist);   /* either pointer nullable */
+/* d_labels[i] = id of the centroid nearest to d_rows[i] under the index metric (DEVICE array, n entries);
+ * returns after the labels are complete.  NoTrained (-205) before train / set_centroids / load. */
+int zvec_hip_ivf_label_dev(zvec_hip_ivf_t h, const void *d_rows, uint64_t n, uint32_t *d_labels, void *stream);
+/* list_sizes[nlist]: GLOBAL row count of every list (all shards).  Allocates the lists this shard owns. */
+int zvec_hip_ivf_begin_lists(zvec_hip_ivf_t h, const uint32_t *list_sizes);
+/* labels / keys: HOST arrays for the n rows of this call (keys NULL -> key = first_row + i); first_row = global row
+ * number of d_rows[0] (what zvec_hip_ivf_export reports as row_ids).  InvalidArgument if a list overflows its
+ * announced size. */
+int zvec_hip_ivf_add_dev(zvec_hip_ivf_t h, const void *d_rows, uint64_t n, const uint32_t *labels,
+                         const uint64_t *keys, uint64_t first_row, void *stream);
+/* NoReady (-21) while any owned list is short of its announced size; the index is searchable afterwards */
+int zvec_hip_ivf_end_lists(zvec_hip_ivf_t h);
 /* per-query statistics of the last search on ctx (IndexContext::Stats, index_context.h:67-111):
  * scanned[q] = total_scan_count, probes[q] = lists actually probed.  Host arrays, nullable. */
 int zvec_hip_ivf_last_stats(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, uint32_t count,

@@ -283,6 +283,24 @@ class Oracle:
             return ok, os_, oi, oc, osc, op
         return ok, os_, oi, oc, osc
 
+    def ivf_label_and_pack(self, centroids, rows, metric=METRIC_L2, threads=1):
+        """IVFBuilder::label + the dump order restated (test infrastructure).
+        label: every row goes to the top-1 result of the centroid index for that row (ivf_builder.h:253-274 ->
+        IVFCentroidIndex::search, ivf_centroid_index.cc:273-297, i.e. the flat scan over the centroids with topk = 1:
+        ties keep the first centroid in id order, heap.h:103-114); pack: rows are written list by list, inside a list in
+        the order they were labelled (ivf_builder.cc:607-650 appends to `labels_[cid]` under a lock per task of 10
+        vectors and sorts nothing; the single-threaded order is ascending row number, which is what the dumper walks:
+        ivf_builder.cc:652-729).  Returns (labels[n], list_offsets[nlist+1], order[n] = row of each list position)."""
+        cent = np.ascontiguousarray(centroids)
+        ok, _, oi, oc = self.flat_search(cent, rows, 1, metric, threads=threads)
+        assert (oc == 1).all()
+        labels = oi[:, 0].astype(np.uint32)
+        nlist = cent.shape[0]
+        sizes = np.bincount(labels, minlength=nlist)
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        order = np.argsort(labels, kind="stable").astype(np.uint64)
+        return labels, offs, order
+
     def merge_topk(self, keys, scores, counts, topk):
         """keys/scores [nparts][nq][topk], counts [nparts][nq]."""
         keys = np.ascontiguousarray(keys, np.uint64)

@@ -60,3 +60,22 @@ def test_product_package_never_imports_oracle():
                 assert "oracle" not in src.replace("oracle/", "ORACLE_DIR_MENTION").replace("import oracle", "X") or \
                     "import oracle" not in src, f
                 assert "from oracle" not in src and "import oracle" not in src and "liboracle" not in src, f
+
+
+def test_shard_map_is_byte_balanced_and_matches_restatement():
+    """zvec_hip_ivf_shard_map is pure host arithmetic (no HIP call): greedy largest-first by 128-row tiles."""
+    import numpy as np
+    import zvec_amd
+    from tests.util import lpt_owner
+    rng = np.random.default_rng(3)
+    for nlist, nshards in ((48, 3), (4096, 8), (16384, 8), (7, 8), (100, 1)):
+        sizes = (rng.gamma(2.0, 1200.0, nlist)).astype(np.uint32)
+        sizes[rng.integers(0, nlist, max(1, nlist // 50))] = 0          # some empty lists
+        owner, rows = zvec_amd.shard_map(sizes, nshards)
+        assert np.array_equal(owner, lpt_owner(sizes, nshards))
+        assert int(rows.sum()) == int(sizes.astype(np.uint64).sum())
+        for g in range(nshards):
+            assert int(rows[g]) == int(sizes[owner == g].astype(np.uint64).sum())
+        if nlist >= 64 * nshards:
+            tiles = np.array([((sizes[owner == g].astype(np.int64) + 127) // 128).sum() for g in range(nshards)])
+            assert tiles.max() <= 1.01 * tiles.mean()                   # balanced by bytes

@@ -1,8 +1,8 @@
 """N>1 plumbing on CPU: 2 processes over gloo exchange their per-shard candidate lists with the same
 pack / all_gather_into_tensor / unpack code the GPU path uses (zvec_amd/dist.py); the merged result is
 checked with the oracle's concat-sort-truncate merge (combined_vector_column_indexer.cc:172-232) against
-the single-index answer.  The shards are produced by the oracle scanning the lists `l % world == rank`
-(the same partition zvec_hip_ivf_keep_shard applies on the GPU)."""
+the single-index answer.  The shards are produced by the oracle scanning the lists the byte-balanced list -> shard map gives each
+rank (tests/util.py::lpt_owner, the restatement of zvec_hip_ivf_shard_map that zvec_hip_ivf_keep_shard applies on the GPU)."""
 import os
 import socket
 
@@ -28,7 +28,7 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as O
-    from tests.util import kmeans_lists
+    from tests.util import kmeans_lists, lpt_owner
     from zvec_amd.dist import all_gather_candidates, packed_bytes, pack_candidates
     o = O.get()
     rng = np.random.default_rng(41)                      # same data on every rank
@@ -39,10 +39,11 @@ def _worker(rank, world, port, out):
     vecs, keys = base[order], order.astype(np.uint64)
     # full answer (every rank computes it for the check)
     fk, fs, _, fc, _, probes = o.ivf_search(cent, offs, vecs, q, k, nprobe, n, keys=keys, want_probes=True)
-    # this rank's shard: keep only lists l % world == rank (others become empty), same centroids
+    # this rank's shard: keep only the lists it owns (others become empty), same centroids
     sizes = np.diff(offs.astype(np.int64))
-    keep = np.concatenate([np.arange(offs[l], offs[l + 1]) for l in range(nlist) if l % world == rank]).astype(np.int64)
-    soffs = np.concatenate([[0], np.cumsum([sizes[l] if l % world == rank else 0 for l in range(nlist)])]).astype(np.uint64)
+    owner = lpt_owner(sizes, world)
+    keep = np.concatenate([np.arange(offs[l], offs[l + 1]) for l in range(nlist) if owner[l] == rank]).astype(np.int64)
+    soffs = np.concatenate([[0], np.cumsum([sizes[l] if owner[l] == rank else 0 for l in range(nlist)])]).astype(np.uint64)
     sk, ss, _, sc, _ = o.ivf_search(cent, soffs, vecs[keep], q, k, nprobe, n, keys=keys[keep])
     tk = torch.from_numpy(sk.astype(np.int64))
     ts = torch.from_numpy(ss)

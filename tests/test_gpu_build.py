@@ -1,0 +1,154 @@
+"""GPU IVF build against the oracle — run with -m gpu.
+
+* labelling: every row of a GPU-built index sits in the list of its nearest centroid as the oracle's restatement of
+  IVFBuilder::label finds it (ivf_builder.h:253-274: top-1 of the centroid index), exactly on integer data, up to the
+  stated selection band on real data;
+* packing: the list order equals the oracle's stable grouping (rows of a list in ascending row number);
+* the streamed build (train / label / begin_lists / add / end_lists) equals the one-call build, for 1 and 3 shards,
+  and a shard holds exactly the lists the byte-balanced map gives it.
+k-means itself (OptKmeansCluster) is NOT compared: the reference's trainer is a different algorithm with its own
+random initialisation (parity unpinned for the centroids; both sides then search the same exported centroids)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import lpt_owner
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zv():
+    import zvec_amd
+    return zvec_amd
+
+
+def _labels_of_export(offs, rows, n):
+    lab = np.empty(n, np.uint32)
+    sizes = np.diff(offs.astype(np.int64))
+    lab[rows.astype(np.int64)] = np.repeat(np.arange(sizes.size, dtype=np.uint32), sizes)
+    return lab
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_labelling_and_packing_integer_data_exact(zv, oracle, dtype):
+    rng = np.random.default_rng(11)
+    n, dim, nlist = 20000, 48, 64
+    npdt = np.float16 if dtype == "fp16" else np.float32
+    base = rng.integers(-8, 9, (n, dim)).astype(npdt)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", dtype=dtype)
+    assert se.build(base, nlist, kmeans_iters=3, sample_per_list=64, seed=3) == 0
+    cent, offs, rows = se.export()
+    got = _labels_of_export(offs, rows, n)
+    want, woffs, worder = oracle.ivf_label_and_pack(cent, base)
+    # centroids are means (not integers): L2 scores are selected on |q|^2+|b|^2-2qb, so a row may legitimately sit in
+    # another list only if that centroid is within the selection band of the nearest one
+    bad = np.nonzero(got != want)[0]
+    for i in bad:
+        d_got = oracle.dist16(O.METRIC_L2, cent[got[i]], base[i]) if dtype == "fp16" else oracle.dist(O.METRIC_L2, cent[got[i]], base[i])
+        d_want = oracle.dist16(O.METRIC_L2, cent[want[i]], base[i]) if dtype == "fp16" else oracle.dist(O.METRIC_L2, cent[want[i]], base[i])
+        norms = float((base[i].astype(np.float64) ** 2).sum() + (cent[want[i]].astype(np.float64) ** 2).sum())
+        assert abs(d_got - d_want) <= 4e-6 * norms, (i, d_got, d_want)
+    assert bad.size <= n // 1000
+    # packing = stable grouping by label: inside every list the rows ascend
+    assert np.array_equal(rows, np.argsort(got, kind="stable").astype(np.uint64))
+    if bad.size == 0:
+        assert np.array_equal(offs, woffs) and np.array_equal(rows, worder)
+
+
+def test_labelling_exact_when_centroids_are_lattice_points(zv, oracle):
+    """integer rows AND integer centroids (set_centroids): every score is exact, so labels / offsets / order must equal
+    the oracle's bit for bit, ties included (first centroid in id order wins, heap.h:103-114)."""
+    import torch
+    rng = np.random.default_rng(12)
+    n, dim, nlist = 30000, 32, 40
+    base = rng.integers(-6, 7, (n, dim)).astype(np.float32)
+    cent = rng.integers(-6, 7, (nlist, dim)).astype(np.float32)
+    cent[7] = cent[3]                                    # duplicate centroid: list 7 must stay empty
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean")
+    assert se.set_centroids(cent) == 0
+    d_base = torch.from_numpy(base).cuda()
+    d_lab = torch.empty(n, dtype=torch.int32, device="cuda")
+    assert se.label_dev(d_base.data_ptr(), n, d_lab.data_ptr()) == 0
+    got = d_lab.cpu().numpy().astype(np.uint32)
+    want, woffs, worder = oracle.ivf_label_and_pack(cent, base)
+    assert np.array_equal(got, want)
+    assert (got != 7).all()
+    assert se.begin_lists(np.bincount(got, minlength=nlist)) == 0
+    for o in range(0, n, 7001):                          # ragged chunks
+        m = min(7001, n - o)
+        assert se.add_dev(d_base[o:o + m].data_ptr(), m, got[o:o + m], o) == 0
+    assert se.end_lists() == 0
+    c2, offs, rows = se.export()
+    assert np.array_equal(c2, cent) and np.array_equal(offs, woffs) and np.array_equal(rows, worder)
+    # and the index answers like the oracle on that very structure
+    q = rng.integers(-6, 7, (50, dim)).astype(np.float32)
+    se.scan_ratio, se.brute_force_threshold = 8 / 40., 10
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(10)
+    assert se.search_impl(q, 50, ctx) == 0
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, woffs, base[worder.astype(np.int64)], q, 10, nprobe, max_scan, keys=worder)
+    from tests.util import tie_tolerant_compare, exact_l2
+    cd = np.sort(exact_l2(cent, q), 1)
+    sel = np.nonzero(cd[:, nprobe - 1] != cd[:, nprobe])[0]
+    tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel], what="streamed-built index")
+
+
+@pytest.mark.parametrize("nshards", [1, 3])
+def test_streamed_build_equals_one_call_build(zv, nshards):
+    import torch
+    rng = np.random.default_rng(13)
+    n, dim, nlist, spl = 24000, 40, 48, 64
+    base = (rng.standard_normal((n, 6)) @ rng.standard_normal((6, dim))).astype(np.float32)
+    d_base = torch.from_numpy(base).cuda()
+    S = min(n, spl * nlist)
+    sample_ids = (np.arange(S, dtype=np.uint64) * np.uint64(n)) // np.uint64(S)       # the one-call build's strided sample
+    d_sample = d_base[torch.from_numpy(sample_ids.astype(np.int64)).cuda()].contiguous()
+    # labels once (any shard can do it: centroids are replicated)
+    tr = zv.HipIVFSearcher(dim, "SquaredEuclidean")
+    assert tr.train_dev(d_sample.data_ptr(), S, nlist, kmeans_iters=5, seed=5) == 0
+    cent = tr.get_centroids()
+    d_lab = torch.empty(n, dtype=torch.int32, device="cuda")
+    for o in range(0, n, 5000):
+        m = min(5000, n - o)
+        assert tr.label_dev(d_base[o:o + m].data_ptr(), m, d_lab[o:o + m].data_ptr()) == 0
+    labels = d_lab.cpu().numpy().astype(np.uint32)
+    sizes = np.bincount(labels, minlength=nlist)
+    owner = lpt_owner(sizes, nshards)
+    for r in range(nshards):
+        one = zv.HipIVFSearcher(dim, "SquaredEuclidean")
+        assert one.set_shard(r, nshards) == 0
+        assert one.build_dev(d_base.data_ptr(), n, nlist, kmeans_iters=5, sample_per_list=spl, seed=5) == 0
+        st = zv.HipIVFSearcher(dim, "SquaredEuclidean")
+        assert st.set_shard(r, nshards) == 0
+        assert st.set_centroids(cent) == 0                      # (as a rank that received rank 0's centroids would)
+        assert st.begin_lists(sizes) == 0
+        assert st.end_lists() == zv.IndexError_.NoReady         # lists still short
+        for o in range(0, n, 5000):
+            m = min(5000, n - o)
+            assert st.add_dev(d_base[o:o + m].data_ptr(), m, labels[o:o + m], o) == 0
+        assert st.end_lists() == 0
+        c1, o1, r1 = one.export()
+        c2, o2, r2 = st.export()
+        assert np.array_equal(c1, c2) and np.array_equal(o1, o2) and np.array_equal(r1, r2)
+        assert np.array_equal(st.list_owners(), owner)
+        assert np.array_equal(np.diff(o2.astype(np.int64)), np.where(owner == r, sizes, 0))
+        pos = rng.integers(0, st.info()[0], 50)
+        assert np.array_equal(one.get_vectors_by_ids(pos), st.get_vectors_by_ids(pos))
+        assert np.array_equal(st.get_vectors_by_ids(pos), base[r2[pos].astype(np.int64)])
+
+
+def test_streamed_build_errors(zv):
+    import torch
+    se = zv.HipIVFSearcher(8)
+    d = torch.zeros((16, 8), device="cuda")
+    lab = torch.zeros(16, dtype=torch.int32, device="cuda")
+    assert se.label_dev(d.data_ptr(), 16, lab.data_ptr()) == zv.IndexError_.NoTrained
+    assert se.begin_lists(np.array([16], np.uint32)) == zv.IndexError_.NoTrained
+    assert se.add_dev(d.data_ptr(), 16, np.zeros(16, np.uint32), 0) == zv.IndexError_.NoReady
+    assert se.end_lists() == zv.IndexError_.NoReady
+    assert se.set_centroids(np.zeros((2, 8), np.float32)) == 0
+    assert se.begin_lists(np.array([4, 0], np.uint32)) == 0
+    assert se.add_dev(d.data_ptr(), 16, np.zeros(16, np.uint32), 0) == zv.IndexError_.InvalidArgument    # list 0 overflows
+    assert se.add_dev(d.data_ptr(), 1, np.array([5], np.uint32), 0) == zv.IndexError_.InvalidArgument     # no such list

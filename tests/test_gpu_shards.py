@@ -1,5 +1,5 @@
 """Sharded IVF on the GPU, single process: the index is cut into `world` shards by inverted list
-(zvec_hip_ivf_keep_shard, the partition bench.py uses across ranks), every shard answers the whole
+(zvec_hip_ivf_keep_shard: the byte-balanced list -> shard map bench.py uses across ranks), every shard answers the whole
 batch, the candidate lists are merged with zvec_hip_merge_topk_dev — the result must equal the
 unsharded search and the oracle.  Covers everything of the N>1 path except the RCCL transport
 (which tests/test_dist_cpu.py covers over gloo)."""
@@ -61,7 +61,7 @@ def test_sharded_build_is_deterministic_across_shards():
     rng = np.random.default_rng(7)
     n, dim, nlist = 12000, 32, 48
     base = (rng.standard_normal((n, 6)) @ rng.standard_normal((6, dim))).astype(np.float32)
-    cents, rows_all = [], []
+    cents, rows_all, sizes_all, owners = [], [], [], []
     for r in range(3):
         se = zvec_amd.HipIVFSearcher(dim, "SquaredEuclidean")
         assert se.set_shard(r, 3) == 0
@@ -69,9 +69,18 @@ def test_sharded_build_is_deterministic_across_shards():
         c, offs, rows = se.export()
         cents.append(c)
         rows_all.append(rows)
-        sizes = np.diff(offs.astype(np.int64))
-        assert all(sizes[l] == 0 for l in range(nlist) if l % 3 != r)
+        sizes_all.append(np.diff(offs.astype(np.int64)))
+        owners.append(se.list_owners())
     assert np.array_equal(cents[0], cents[1]) and np.array_equal(cents[1], cents[2])
+    # every rank derives the same byte-balanced list -> shard map from the global list sizes
+    from tests.util import lpt_owner
+    sizes_global = sizes_all[0] + sizes_all[1] + sizes_all[2]
+    want = lpt_owner(sizes_global, 3)
+    for r in range(3):
+        assert np.array_equal(owners[r], want)
+        assert np.array_equal(sizes_all[r], np.where(want == r, sizes_global, 0))
+    tiles = np.array([((sizes_all[r] + 127) // 128).sum() for r in range(3)])
+    assert tiles.max() - tiles.min() <= max(2, ((sizes_global + 127) // 128).max())
     allrows = np.sort(np.concatenate(rows_all))
     assert np.array_equal(allrows, np.arange(n, dtype=np.uint64))
 

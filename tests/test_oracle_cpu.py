@@ -265,3 +265,21 @@ def test_multithreaded_matches_single(oracle):
     a = oracle.flat_search(base, q, 10, O.METRIC_IP)
     b = oracle.flat_search(base, q, 10, O.METRIC_IP, threads=4)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_label_and_pack_restatement_on_exact_data(oracle):
+    """IVFBuilder::label restated (oracle.ivf_label_and_pack): on integer data every distance is exact, so the label is
+    the fp64 argmin with the FIRST centroid winning ties (heap.h:103-114), and the pack order is the stable grouping."""
+    rng = np.random.default_rng(8)
+    n, dim, nlist = 3000, 12, 20
+    base = rng.integers(-5, 6, (n, dim)).astype(np.float32)
+    cent = rng.integers(-5, 6, (nlist, dim)).astype(np.float32)
+    cent[11] = cent[2]
+    lab, offs, order = oracle.ivf_label_and_pack(cent, base)
+    d = ((base[:, None, :].astype(np.float64) - cent[None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(lab, d.argmin(1).astype(np.uint32))      # numpy argmin: first minimum, like the heap
+    assert (lab != 11).all()
+    assert np.array_equal(np.diff(offs.astype(np.int64)), np.bincount(lab, minlength=nlist))
+    for l in range(nlist):
+        seg = order[int(offs[l]):int(offs[l + 1])]
+        assert (lab[seg.astype(np.int64)] == l).all() and (np.diff(seg.astype(np.int64)) > 0).all()

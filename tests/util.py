@@ -63,3 +63,18 @@ def kmeans_lists(rng, base, nlist):
     sizes = np.bincount(lab, minlength=nlist)
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
     return cent, offs, order
+
+
+def lpt_owner(sizes, nshards, tile=128):
+    """the list -> shard map of zvec_hip_ivf_shard_map restated: lists by (tiles desc, id asc), each to the shard
+    with the fewest 128-row tiles so far (lowest shard on ties).  SURVEY §8(e): whole lists, balanced by bytes."""
+    sizes = np.asarray(sizes, np.int64)
+    owner = np.zeros(sizes.size, np.uint32)
+    if nshards <= 1:
+        return owner
+    load = [0] * nshards
+    for l in np.argsort(-sizes, kind="stable"):
+        g = min(range(nshards), key=lambda j: (load[j], j))
+        owner[l] = g
+        load[g] += (int(sizes[l]) + tile - 1) // tile
+    return owner

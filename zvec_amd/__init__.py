@@ -9,5 +9,5 @@ Package layout (only what the hot path needs):
 """
 from .index import (  # noqa: F401
     DocFilter, HipFlatSearcher, HipFlatStreamer, HipIVFSearcher, HipIVFStreamer, IndexContext, IndexDocument, IndexError_,
-    METRIC_L2, METRIC_IP, METRIC_COSINE, metric_from_name,
+    METRIC_L2, METRIC_IP, METRIC_COSINE, metric_from_name, shard_map,
 )

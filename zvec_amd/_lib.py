@@ -67,6 +67,15 @@ SYMBOLS = {
     "zvec_hip_ivf_search_bf": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, _u64p,
                                          _u64p, _f32p, _u32p]),
     "zvec_hip_ivf_keep_shard": (C.c_int, [_h, C.c_uint32, C.c_uint32]),
+    "zvec_hip_ivf_shard_map": (C.c_int, [_u32p, C.c_uint32, C.c_uint32, _u32p, _u64p]),
+    "zvec_hip_ivf_list_owners": (C.c_int, [_h, _u32p]),
+    "zvec_hip_ivf_train_dev": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "zvec_hip_ivf_set_centroids": (C.c_int, [_h, C.c_void_p, C.c_uint32]),
+    "zvec_hip_ivf_get_centroids": (C.c_int, [_h, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "zvec_hip_ivf_label_dev": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u32p, C.c_void_p]),
+    "zvec_hip_ivf_begin_lists": (C.c_int, [_h, _u32p]),
+    "zvec_hip_ivf_add_dev": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u32p, _u64p, C.c_uint64, C.c_void_p]),
+    "zvec_hip_ivf_end_lists": (C.c_int, [_h]),
     "zvec_hip_ivf_last_stats": (C.c_int, [_h, _h, C.c_uint32, _u32p, _u32p]),
     "zvec_hip_merge_topk": (C.c_int, [_h, _u64p, _f32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                       _u64p, _f32p, _u32p]),

@@ -28,7 +28,7 @@ static void ivf_release(zvec_hip_ivf_s *h) {
   if (h->d_tail) (void)hipFree(h->d_tail);
   if (h->d_dense0) (void)hipFree(h->d_dense0);
   h->d_size = h->d_size_global = h->d_tile0 = h->d_order = h->d_tail = nullptr; h->d_dense0 = nullptr;
-  h->loaded = false;
+  h->loaded = false; h->trained = false; h->filling = false;
 }
 
 int zvec_hip_ivf_destroy(zvec_hip_ivf_t h) {
@@ -41,24 +41,81 @@ int zvec_hip_ivf_destroy(zvec_hip_ivf_t h) {
   return 0;
 }
 
+// Greedy largest-first (LPT) assignment of inverted lists to shards, weighted by the 128-row tiles a list occupies in
+// HBM (= the bytes a scan streams).  Deterministic: lists ordered by (tiles desc, list id asc), each given to the shard
+// with the least tiles so far (lowest shard id on ties) — every rank computes the same map from the global list sizes.
+// "whole inverted lists assigned to GPUs (balanced by bytes, list->GPU map)".
+static void ivf_lpt_owner(const uint32_t *sizes, uint32_t nlist, uint32_t nshards, uint32_t *owner, uint64_t *rows_out) {
+  std::vector<uint64_t> load(nshards, 0), rows(nshards, 0);
+  if (nshards <= 1) {
+    for (uint32_t l = 0; l < nlist; ++l) { owner[l] = 0; rows[0] += sizes[l]; }
+  } else {
+    std::vector<uint32_t> order(nlist);
+    for (uint32_t l = 0; l < nlist; ++l) order[l] = l;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return sizes[x] > sizes[y]; });
+    for (uint32_t i = 0; i < nlist; ++i) {
+      const uint32_t l = order[i];
+      uint32_t best = 0;
+      for (uint32_t g = 1; g < nshards; ++g)
+        if (load[g] < load[best]) best = g;
+      owner[l] = best;
+      load[best] += (sizes[l] + TILE_N - 1) / TILE_N;
+      rows[best] += sizes[l];
+    }
+  }
+  if (rows_out) for (uint32_t g = 0; g < nshards; ++g) rows_out[g] = rows[g];
+}
+
+int zvec_hip_ivf_shard_map(const uint32_t *list_sizes, uint32_t nlist, uint32_t nshards, uint32_t *owner_out,
+                           uint64_t *shard_rows_out) {
+  if (!list_sizes || !owner_out || nlist == 0 || nshards == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  ivf_lpt_owner(list_sizes, nlist, nshards, owner_out, shard_rows_out);
+  return 0;
+}
+
 int zvec_hip_ivf_keep_shard(zvec_hip_ivf_t h, uint32_t shard, uint32_t nshards) {
   if (!h || nshards == 0 || shard >= nshards) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
-  if (h->loaded) return ZVEC_HIP_ERR_NO_READY;   // must be set before load/build
+  if (h->loaded || h->filling) return ZVEC_HIP_ERR_NO_READY;   // must be set before load/build
   h->shard = shard; h->nshards = nshards;
   return 0;
 }
 
-// pack rows (device, row-major [n][dim]) given per-row labels (host) into the inverted-list store
-static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uint64_t *keys,
-                    const std::vector<uint32_t> &labels, const void *h_centroids, uint32_t nlist, hipStream_t s) {
+int zvec_hip_ivf_list_owners(zvec_hip_ivf_t h, uint32_t *owner_out) {
+  if (!h || !owner_out) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->loaded && !h->filling) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  memcpy(owner_out, h->h_owner.data(), (size_t)h->nlist * 4);
+  return 0;
+}
+
+// (re)build the centroid store from host rows; the index is "trained" afterwards
+static int ivf_set_centroids(zvec_hip_ivf_s *h, const void *h_centroids, uint32_t nlist, hipStream_t s) {
   const size_t rb = h->lists.row_bytes();
   h->nlist = nlist;
-  h->h_centroids.assign(reinterpret_cast<const char *>(h_centroids), reinterpret_cast<const char *>(h_centroids) + (size_t)nlist * rb);
-  h->h_size_global.assign(nlist, 0);
-  for (uint64_t i = 0; i < n; ++i) h->h_size_global[labels[i]] += 1;
+  if (h_centroids != h->h_centroids.data())
+    h->h_centroids.assign(reinterpret_cast<const char *>(h_centroids), reinterpret_cast<const char *>(h_centroids) + (size_t)nlist * rb);
+  h->cent.n = 0;
+  Scoped<char> d_c;
+  ZRET(d_c.alloc((size_t)nlist * rb));
+  ZCHK(hipMemcpyAsync(d_c, h->h_centroids.data(), (size_t)nlist * rb, hipMemcpyHostToDevice, s));
+  ZRET(store_append_dev(h->cent, d_c, nlist, nullptr, s));
+  ZCHK(hipStreamSynchronize(s));
+  h->trained = true;
+  return 0;
+}
+
+// IVFDumper's job, step 1 (ivf_dumper.h:33-160: every list's extent is known before its blocks are written): lay out
+// the lists this shard owns from the GLOBAL list sizes, allocate the blocked store, reset the per-list cursors.
+static int ivf_begin_lists(zvec_hip_ivf_s *h, const uint32_t *sizes_global, hipStream_t s) {
+  const uint32_t nlist = h->nlist;
+  h->h_size_global.assign(sizes_global, sizes_global + nlist);
+  h->h_owner.assign(nlist, 0);
+  ivf_lpt_owner(sizes_global, nlist, h->nshards, h->h_owner.data(), nullptr);
   h->h_size.assign(nlist, 0);
-  for (uint32_t l = 0; l < nlist; ++l)
-    if (l % h->nshards == h->shard) h->h_size[l] = h->h_size_global[l];
+  uint64_t total = 0;
+  for (uint32_t l = 0; l < nlist; ++l) {
+    total += sizes_global[l];
+    if (h->h_owner[l] == h->shard) h->h_size[l] = sizes_global[l];
+  }
   h->h_tile0.assign(nlist, 0);
   h->h_dense0.assign(nlist + 1, 0);
   uint64_t tiles = 0, dense = 0;
@@ -70,50 +127,63 @@ static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uin
   }
   h->h_dense0[nlist] = dense;
   h->count_local = dense;
-  h->count_global = n;
+  h->count_global = total;
+  h->local_tiles = tiles;
   if (tiles * TILE_N >= 0xffffffffull) return ZVEC_HIP_ERR_OUT_OF_RANGE;
-  // stable counting sort of the owned rows into list order
-  std::vector<uint64_t> cursor(nlist);
-  for (uint32_t l = 0; l < nlist; ++l) cursor[l] = h->h_dense0[l];
+  h->h_cursor.assign(h->h_dense0.begin(), h->h_dense0.end() - 1);
   h->h_row_ids.assign(dense, 0);
-  for (uint64_t i = 0; i < n; ++i) {
-    uint32_t l = labels[i];
-    if (l % h->nshards == h->shard) h->h_row_ids[cursor[l]++] = i;
-  }
-  std::vector<uint64_t> dst(dense), hkeys((size_t)tiles * TILE_N, ~0ull);
-  for (uint32_t l = 0; l < nlist; ++l) {
-    uint64_t pos0 = (uint64_t)h->h_tile0[l] * TILE_N;
-    for (uint64_t j = 0; j < h->h_size[l]; ++j) {
-      uint64_t d = h->h_dense0[l] + j;
-      dst[d] = pos0 + j;
-      hkeys[pos0 + j] = keys ? keys[h->h_row_ids[d]] : h->h_row_ids[d];
-    }
-  }
-  // device side
   h->lists.n = 0;
   ZRET(h->lists.reserve(std::max<uint64_t>(tiles * TILE_N, 1), s));
   h->lists.n = tiles * TILE_N;
-  if (dense) {
-    Scoped<uint64_t> d_src, d_dst;
-    ZRET(d_src.alloc(dense));
-    ZRET(d_dst.alloc(dense));
-    ZCHK(hipMemcpyAsync(d_src, h->h_row_ids.data(), dense * 8, hipMemcpyHostToDevice, s));
-    ZCHK(hipMemcpyAsync(d_dst, dst.data(), dense * 8, hipMemcpyHostToDevice, s));
-    ZRET(launch_pack(h->lists, d_rows, dense, d_src, 0, d_dst, s));
-    ZCHK(hipMemcpyAsync(h->lists.keys, hkeys.data(), hkeys.size() * 8, hipMemcpyHostToDevice, s));
-    ZCHK(hipStreamSynchronize(s));
+  if (tiles) ZCHK(hipMemsetAsync(h->lists.keys, 0xff, (size_t)tiles * TILE_N * 8, s));   // padding rows: invalid key
+  h->filling = true;
+  return 0;
+}
+
+// step 2: rows (device, row-major [n][dim]) with their labels (host); the rows of owned lists are appended to those
+// lists in arrival order (stable, like the reference's per-list append).  `first_row` = global number of d_rows[0];
+// keys: host, per row of this call, NULL -> global row number.
+static int ivf_add_rows(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uint32_t *labels, const uint64_t *keys,
+                        uint64_t first_row, hipStream_t s) {
+  if (n == 0) return 0;
+  std::vector<uint64_t> src, dst, kv;
+  src.reserve(n / h->nshards + 16); dst.reserve(n / h->nshards + 16); kv.reserve(n / h->nshards + 16);
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint32_t l = labels[i];
+    if (l >= h->nlist) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+    if (h->h_owner[l] != h->shard) continue;
+    const uint64_t d = h->h_cursor[l];
+    if (d >= h->h_dense0[l + 1]) return ZVEC_HIP_ERR_INVALID_ARGUMENT;   // more rows than begin_lists was told
+    h->h_cursor[l] = d + 1;
+    h->h_row_ids[d] = first_row + i;
+    src.push_back(i);
+    dst.push_back((uint64_t)h->h_tile0[l] * TILE_N + (d - h->h_dense0[l]));
+    kv.push_back(keys ? keys[i] : first_row + i);
   }
-  // centroids as a flat store
-  h->cent.n = 0;
-  {
-    Scoped<char> d_c;
-    ZRET(d_c.alloc((size_t)nlist * rb));
-    ZCHK(hipMemcpyAsync(d_c, h_centroids, (size_t)nlist * rb, hipMemcpyHostToDevice, s));
-    ZRET(store_append_dev(h->cent, d_c, nlist, nullptr, s));
-    ZCHK(hipStreamSynchronize(s));
-  }
-  // list tables
-  if (h->d_size) { (void)hipFree(h->d_size); (void)hipFree(h->d_size_global); (void)hipFree(h->d_tile0); (void)hipFree(h->d_dense0); (void)hipFree(h->d_order); (void)hipFree(h->d_tail); }
+  const uint64_t kept = src.size();
+  if (kept == 0) return 0;
+  Scoped<uint64_t> d_src, d_dst, d_kv;
+  ZRET(d_src.alloc(kept));
+  ZRET(d_dst.alloc(kept));
+  ZRET(d_kv.alloc(kept));
+  ZCHK(hipMemcpyAsync(d_src, src.data(), kept * 8, hipMemcpyHostToDevice, s));
+  ZCHK(hipMemcpyAsync(d_dst, dst.data(), kept * 8, hipMemcpyHostToDevice, s));
+  ZCHK(hipMemcpyAsync(d_kv, kv.data(), kept * 8, hipMemcpyHostToDevice, s));
+  ZRET(launch_pack(h->lists, d_rows, kept, d_src, 0, d_dst, s));
+  hipLaunchKernelGGL(scatter_keys_kernel, dim3((unsigned)((kept + 255) / 256)), dim3(256), 0, s, h->lists.keys,
+                     (const uint64_t *)d_dst, (const uint64_t *)d_kv, kept);
+  ZCHK(hipGetLastError());
+  ZCHK(hipStreamSynchronize(s));     // the staged arrays are freed on return
+  return 0;
+}
+
+// step 3: every list must be complete; upload the list tables and the deal order of the scan's work queue
+static int ivf_end_lists(zvec_hip_ivf_s *h) {
+  const uint32_t nlist = h->nlist;
+  for (uint32_t l = 0; l < nlist; ++l)
+    if (h->h_cursor[l] != h->h_dense0[l + 1]) return ZVEC_HIP_ERR_NO_READY;   // fewer rows than announced
+  const uint64_t tiles = h->local_tiles;
+  if (h->d_size) { (void)hipFree(h->d_size); (void)hipFree(h->d_size_global); (void)hipFree(h->d_tile0); (void)hipFree(h->d_dense0); (void)hipFree(h->d_order); (void)hipFree(h->d_tail); h->d_size = nullptr; }
   // largest lists are dealt first by the scan's work queue; chunk length adapts to the index size so
   // that a search has a few items per resident work-group yet long runs per top-k warm-up
   std::vector<uint32_t> order(nlist);
@@ -128,7 +198,6 @@ static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uin
     // tail of such items leaves most of the chip idle.  The last quarter of the tiles is therefore cut into chunks
     // a quarter as long (guided self-scheduling: coarse items first, fine items last).
     h->h_tail.assign(nlist, 0);
-    h->local_tiles = tiles;
     uint64_t acc = 0;
     for (uint32_t i = nlist; i-- > 0;) {
       const uint32_t l = order[i];
@@ -149,8 +218,23 @@ static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uin
   ZCHK(hipMemcpy(h->d_size_global, h->h_size_global.data(), nlist * 4, hipMemcpyHostToDevice));
   ZCHK(hipMemcpy(h->d_tile0, h->h_tile0.data(), nlist * 4, hipMemcpyHostToDevice));
   ZCHK(hipMemcpy(h->d_dense0, h->h_dense0.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
+  h->filling = false;
   h->loaded = true;
   return 0;
+}
+
+// all rows at once (load, load_segments, the one-call build): centroids + layout + rows + tables
+static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uint64_t *keys,
+                    const std::vector<uint32_t> &labels, const void *h_centroids, uint32_t nlist, hipStream_t s) {
+  ZRET(ivf_set_centroids(h, h_centroids, nlist, s));
+  std::vector<uint32_t> sizes(nlist, 0);
+  for (uint64_t i = 0; i < n; ++i) {
+    if (labels[i] >= nlist) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+    sizes[labels[i]] += 1;
+  }
+  ZRET(ivf_begin_lists(h, sizes.data(), s));
+  ZRET(ivf_add_rows(h, d_rows, n, labels.data(), keys, 0, s));
+  return ivf_end_lists(h);
 }
 
 int zvec_hip_ivf_load(zvec_hip_ivf_t h, const void *centroids, uint32_t nlist, const uint64_t *list_offsets,
@@ -171,7 +255,7 @@ int zvec_hip_ivf_load(zvec_hip_ivf_t h, const void *centroids, uint32_t nlist, c
     ZRET(d_rows.alloc((size_t)n * h->lists.row_bytes()));
     ZCHK(hipMemcpyAsync(d_rows, vecs, (size_t)n * h->lists.row_bytes(), hipMemcpyHostToDevice, s));
   }
-  if (h->loaded) ivf_release(h);
+  if (h->loaded || h->filling) ivf_release(h);
   return ivf_pack(h, d_rows, n, keys, labels, centroids, nlist, s);
 }
 
@@ -260,37 +344,44 @@ int zvec_hip_ivf_load_segments(zvec_hip_ivf_t h, const void *inverted_header, ui
   std::vector<uint32_t> labels(total);
   for (uint32_t l = 0; l < nlist; ++l)
     for (uint64_t i = list_offsets[l]; i < list_offsets[l + 1]; ++i) labels[i] = l;
-  if (h->loaded) ivf_release(h);
+  if (h->loaded || h->filling) ivf_release(h);
   return ivf_pack(h, d_rows, total, static_cast<const uint64_t *>(keys), labels, centroids, nlist, s);
 }
 
-int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, const uint64_t *keys, uint32_t nlist,
-                           uint32_t kmeans_iters, uint32_t sample_per_list, uint64_t seed, void *stream) {
-  if (!h || !d_vecs || n == 0 || nlist == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
-  if (nlist > n) nlist = (uint32_t)n;
-  std::lock_guard<std::mutex> g(h->mu);
-  ZCHK(hipSetDevice(h->device));
-  zvec_hip_ctx_s *c = h->defctx;
-  hipStream_t s = pick_stream(c, stream);
-  const char *rows = reinterpret_cast<const char *>(d_vecs);
+// nearest centroid of every row (IVFBuilder::label, ivf_builder.h:253-274: top-1 of the centroid index): device rows ->
+// device labels, in batches through the flat scan over the centroid store
+static int ivf_label_rows(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const Store &cs, const char *d_rows, uint64_t n,
+                          uint32_t *d_labels, hipStream_t s) {
+  const size_t rb = cs.row_bytes();
+  const uint64_t BATCH = 1u << 18;
+  const uint64_t maxq = std::min<uint64_t>(n, BATCH);
+  Scoped<uint64_t> d_lab_keys; Scoped<float> d_lab_scores; Scoped<uint32_t> d_lab_cnt;
+  ZRET(d_lab_keys.alloc(maxq));
+  ZRET(d_lab_scores.alloc(maxq));
+  ZRET(d_lab_cnt.alloc(maxq));
+  for (uint64_t o = 0; o < n; o += BATCH) {
+    const uint32_t m = (uint32_t)std::min<uint64_t>(BATCH, n - o);
+    ZRET(prep_queries(c, cs, d_rows + (size_t)o * rb, m, FLT_MAX, s));
+    SearchOut out{d_lab_keys.p, d_lab_scores.p, d_labels + o, d_lab_cnt.p};
+    ZRET(flat_scan_prepared(c, cs, m, 1, FLT_MAX, nullptr, out, s, false));
+  }
+  ZCHK(hipStreamSynchronize(s));      // the scratch lists are freed on return
+  (void)h;
+  return 0;
+}
+
+// Lloyd's k-means over `S` device rows (IVFBuilder::train, ivf_builder.cc:212-267; the reference's trainer is
+// OptKmeansCluster, opt_kmeans_cluster.cc): seeded choice of nlist distinct rows, `iters` assign / mean rounds, empty
+// clusters re-seeded by splitting the largest.  Result -> h->h_centroids + the centroid store (h->trained).
+static int ivf_train(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const char *d_sample, uint64_t S, uint32_t nlist,
+                     uint32_t kmeans_iters, uint64_t seed, hipStream_t s) {
   const uint32_t dim = h->dim;
   const bool f16 = h->lists.f16;
   const size_t rb = h->lists.row_bytes();
-  if (sample_per_list == 0) sample_per_list = 256;
-  if (h->loaded) ivf_release(h);
-
-  // ---- sample (deterministic stride) ----
-  uint64_t S = std::min<uint64_t>(n, (uint64_t)sample_per_list * nlist);
-  std::vector<uint64_t> sample_ids(S);
-  for (uint64_t i = 0; i < S; ++i) sample_ids[i] = (uint64_t)(((unsigned __int128)i * n) / S);
   Scoped<uint64_t> d_ids;
-  Scoped<char> d_sample, d_cent;
-  ZRET(d_ids.alloc(S));
-  ZRET(d_sample.alloc((size_t)S * rb));
+  Scoped<char> d_cent;
+  ZRET(d_ids.alloc(std::max<uint64_t>(nlist, 1)));
   ZRET(d_cent.alloc((size_t)nlist * rb));
-  ZCHK(hipMemcpyAsync(d_ids, sample_ids.data(), S * 8, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)S), dim3(256), 0, s, (const void *)rows, (uint32_t)rb, d_ids, S, (void *)d_sample);
-  ZCHK(hipGetLastError());
   // ---- initial centroids: nlist distinct sample rows picked by a seeded partial shuffle ----
   {
     std::vector<uint64_t> perm(S);
@@ -310,32 +401,17 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
   Store cs;
   struct StoreGuard { Store &s; ~StoreGuard() { s.release(); } } cs_guard{cs};   // the k-means codebook store
   cs.configure(dim, h->metric, h->dtype);
-  Scoped<uint64_t> d_lab_keys; Scoped<float> d_lab_scores; Scoped<uint32_t> d_lab_idx, d_lab_cnt;
-  const uint64_t BATCH = 1u << 18;
-  uint64_t maxq = std::max<uint64_t>(std::min<uint64_t>(S, BATCH), std::min<uint64_t>(n, BATCH));
-  ZRET(d_lab_keys.alloc(maxq));
-  ZRET(d_lab_scores.alloc(maxq));
-  ZRET(d_lab_idx.alloc(maxq));
-  ZRET(d_lab_cnt.alloc(maxq));
+  Scoped<uint32_t> d_lab;
+  ZRET(d_lab.alloc(S));
   Scoped<uint64_t> d_moff, d_members;
   ZRET(d_moff.alloc((size_t)nlist + 1));
   ZRET(d_members.alloc(S));
-  std::vector<uint32_t> lab(std::max<uint64_t>(S, n));
-  auto assign = [&](const char *q, uint64_t nq, uint32_t *host_labels) -> int {
-    for (uint64_t o = 0; o < nq; o += BATCH) {
-      uint32_t m = (uint32_t)std::min<uint64_t>(BATCH, nq - o);
-      ZRET(prep_queries(c, cs, q + (size_t)o * rb, m, FLT_MAX, s));
-      SearchOut out{d_lab_keys.p, d_lab_scores.p, d_lab_idx.p, d_lab_cnt.p};
-      ZRET(flat_scan_prepared(c, cs, m, 1, FLT_MAX, nullptr, out, s, false));
-      ZCHK(hipMemcpyAsync(host_labels + o, d_lab_idx, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-      ZCHK(hipStreamSynchronize(s));
-    }
-    return 0;
-  };
+  std::vector<uint32_t> lab(S);
   for (uint32_t it = 0; it < kmeans_iters; ++it) {
     cs.n = 0;
     ZRET(store_append_dev(cs, d_cent, nlist, nullptr, s));
-    ZRET(assign(d_sample, S, lab.data()));
+    ZRET(ivf_label_rows(h, c, cs, d_sample, S, d_lab, s));
+    ZCHK(hipMemcpy(lab.data(), d_lab, S * 4, hipMemcpyDeviceToHost));
     std::vector<uint64_t> moff(nlist + 1, 0), members(S);
     for (uint64_t i = 0; i < S; ++i) moff[(lab[i] < nlist ? lab[i] : 0) + 1] += 1;
     for (uint32_t l = 0; l < nlist; ++l) moff[l + 1] += moff[l];
@@ -357,17 +433,17 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
       for (uint32_t e : empties) {
         uint32_t b = (uint32_t)(std::max_element(sizes.begin(), sizes.end()) - sizes.begin());
         if (sizes[b] < 2) break;
-        for (uint32_t c = 0; c < dim; ++c) {
+        for (uint32_t col = 0; col < dim; ++col) {
           if (f16) {
             _Float16 *hp = reinterpret_cast<_Float16 *>(hcb.data());
-            float v = (float)hp[(size_t)b * dim + c];
-            hp[(size_t)e * dim + c] = (_Float16)(v * (1.0f + 1.0f / 256.0f));
-            hp[(size_t)b * dim + c] = (_Float16)(v * (1.0f - 1.0f / 256.0f));
+            float v = (float)hp[(size_t)b * dim + col];
+            hp[(size_t)e * dim + col] = (_Float16)(v * (1.0f + 1.0f / 256.0f));
+            hp[(size_t)b * dim + col] = (_Float16)(v * (1.0f - 1.0f / 256.0f));
           } else {
             float *hp = reinterpret_cast<float *>(hcb.data());
-            float v = hp[(size_t)b * dim + c];
-            hp[(size_t)e * dim + c] = v * (1.0f + 1.0f / 1024.0f);
-            hp[(size_t)b * dim + c] = v * (1.0f - 1.0f / 1024.0f);
+            float v = hp[(size_t)b * dim + col];
+            hp[(size_t)e * dim + col] = v * (1.0f + 1.0f / 1024.0f);
+            hp[(size_t)b * dim + col] = v * (1.0f - 1.0f / 1024.0f);
           }
         }
         sizes[e] = sizes[b] / 2;
@@ -376,15 +452,53 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
       ZCHK(hipMemcpy(d_cent, hcb.data(), hcb.size(), hipMemcpyHostToDevice));
     }
   }
-  // ---- label every row with its nearest centroid (ivf_builder.h:253-274) ----
-  cs.n = 0;
-  ZRET(store_append_dev(cs, d_cent, nlist, nullptr, s));
-  ZRET(assign(rows, n, lab.data()));
   std::vector<char> hc((size_t)nlist * rb);
   ZCHK(hipMemcpy(hc.data(), d_cent, hc.size(), hipMemcpyDeviceToHost));
-  lab.resize(n);
+  return ivf_set_centroids(h, hc.data(), nlist, s);
+}
+
+int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, const uint64_t *keys, uint32_t nlist,
+                           uint32_t kmeans_iters, uint32_t sample_per_list, uint64_t seed, void *stream) {
+  if (!h || !d_vecs || n == 0 || nlist == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (nlist > n) nlist = (uint32_t)n;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  zvec_hip_ctx_s *c = h->defctx;
+  std::lock_guard<std::mutex> gc(c->mu);
+  hipStream_t s = pick_stream(c, stream);
+  const char *rows = reinterpret_cast<const char *>(d_vecs);
+  const size_t rb = h->lists.row_bytes();
+  if (sample_per_list == 0) sample_per_list = 256;
+  if (h->loaded || h->filling) ivf_release(h);
+
+  // ---- sample (deterministic stride) ----
+  uint64_t S = std::min<uint64_t>(n, (uint64_t)sample_per_list * nlist);
+  {
+    std::vector<uint64_t> sample_ids(S);
+    for (uint64_t i = 0; i < S; ++i) sample_ids[i] = (uint64_t)(((unsigned __int128)i * n) / S);
+    Scoped<uint64_t> d_ids;
+    Scoped<char> d_sample;
+    ZRET(d_ids.alloc(S));
+    ZRET(d_sample.alloc((size_t)S * rb));
+    ZCHK(hipMemcpyAsync(d_ids, sample_ids.data(), S * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)S), dim3(256), 0, s, (const void *)rows, (uint32_t)rb, d_ids, S, (void *)d_sample);
+    ZCHK(hipGetLastError());
+    ZRET(ivf_train(h, c, d_sample, S, nlist, kmeans_iters, seed, s));
+  }
+  // ---- label every row with its nearest centroid (ivf_builder.h:253-274), then pack the lists ----
+  std::vector<uint32_t> lab(n);
+  {
+    Scoped<uint32_t> d_lab;
+    ZRET(d_lab.alloc(n));
+    ZRET(ivf_label_rows(h, c, h->cent, rows, n, d_lab, s));
+    ZCHK(hipMemcpy(lab.data(), d_lab, n * 4, hipMemcpyDeviceToHost));
+  }
   for (uint64_t i = 0; i < n; ++i) if (lab[i] >= nlist) lab[i] = 0;
-  return ivf_pack(h, rows, n, keys, lab, hc.data(), nlist, s);
+  std::vector<uint32_t> sizes(nlist, 0);
+  for (uint64_t i = 0; i < n; ++i) sizes[lab[i]] += 1;
+  ZRET(ivf_begin_lists(h, sizes.data(), s));
+  ZRET(ivf_add_rows(h, rows, n, lab.data(), keys, 0, s));
+  return ivf_end_lists(h);
 }
 
 int zvec_hip_ivf_build(zvec_hip_ivf_t h, const void *vecs, uint64_t n, const uint64_t *keys, uint32_t nlist,
@@ -395,6 +509,80 @@ int zvec_hip_ivf_build(zvec_hip_ivf_t h, const void *vecs, uint64_t n, const uin
   ZRET(d_rows.alloc((size_t)n * h->lists.row_bytes()));
   ZCHK(hipMemcpy(d_rows, vecs, (size_t)n * h->lists.row_bytes(), hipMemcpyHostToDevice));
   return zvec_hip_ivf_build_dev(h, d_rows, n, keys, nlist, kmeans_iters, sample_per_list, seed, nullptr);
+}
+
+// ---- streamed build: train / label / begin_lists / add / end_lists ---------------------------------------------------
+// The one-call build needs the whole corpus resident next to the store; a rank of a sharded index (100M x 768 fp16 over
+// 8 GPUs: 153.6 GB of raw rows) only ever holds a chunk of raw rows, the labels, and the lists it owns.
+int zvec_hip_ivf_train_dev(zvec_hip_ivf_t h, const void *d_sample, uint64_t n_sample, uint32_t nlist, uint32_t kmeans_iters,
+                           uint64_t seed, void *stream) {
+  if (!h || !d_sample || n_sample == 0 || nlist == 0 || nlist > n_sample) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  zvec_hip_ctx_s *c = h->defctx;
+  std::lock_guard<std::mutex> gc(c->mu);
+  if (h->loaded || h->filling) ivf_release(h);
+  return ivf_train(h, c, reinterpret_cast<const char *>(d_sample), n_sample, nlist, kmeans_iters, seed, pick_stream(c, stream));
+}
+
+int zvec_hip_ivf_set_centroids(zvec_hip_ivf_t h, const void *centroids, uint32_t nlist) {
+  if (!h || !centroids || nlist == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  if (h->loaded || h->filling) ivf_release(h);
+  return ivf_set_centroids(h, centroids, nlist, h->defctx->own);
+}
+
+int zvec_hip_ivf_get_centroids(zvec_hip_ivf_t h, void *centroids, uint32_t *nlist) {
+  if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->trained) return ZVEC_HIP_ERR_NO_TRAINED;
+  if (nlist) *nlist = h->nlist;
+  if (centroids) memcpy(centroids, h->h_centroids.data(), h->h_centroids.size());
+  return 0;
+}
+
+int zvec_hip_ivf_label_dev(zvec_hip_ivf_t h, const void *d_rows, uint64_t n, uint32_t *d_labels, void *stream) {
+  if (!h || (n && (!d_rows || !d_labels))) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->trained) return ZVEC_HIP_ERR_NO_TRAINED;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  zvec_hip_ctx_s *c = h->defctx;
+  std::lock_guard<std::mutex> gc(c->mu);
+  return ivf_label_rows(h, c, h->cent, reinterpret_cast<const char *>(d_rows), n, d_labels, pick_stream(c, stream));
+}
+
+int zvec_hip_ivf_begin_lists(zvec_hip_ivf_t h, const uint32_t *list_sizes) {
+  if (!h || !list_sizes) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->trained) return ZVEC_HIP_ERR_NO_TRAINED;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  if (h->loaded) {                       // a new fill replaces the lists, the centroids stay
+    std::vector<char> keep(h->h_centroids);
+    const uint32_t nl = h->nlist;
+    ivf_release(h);
+    ZRET(ivf_set_centroids(h, keep.data(), nl, h->defctx->own));
+  }
+  int rc = ivf_begin_lists(h, list_sizes, h->defctx->own);
+  if (rc == 0) ZCHK(hipStreamSynchronize(h->defctx->own));
+  return rc;
+}
+
+int zvec_hip_ivf_add_dev(zvec_hip_ivf_t h, const void *d_rows, uint64_t n, const uint32_t *labels, const uint64_t *keys,
+                         uint64_t first_row, void *stream) {
+  if (!h || (n && (!d_rows || !labels))) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->filling) return ZVEC_HIP_ERR_NO_READY;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  return ivf_add_rows(h, d_rows, n, labels, keys, first_row, pick_stream(h->defctx, stream));
+}
+
+int zvec_hip_ivf_end_lists(zvec_hip_ivf_t h) {
+  if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->filling) return ZVEC_HIP_ERR_NO_READY;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  return ivf_end_lists(h);
 }
 
 int zvec_hip_ivf_info(zvec_hip_ivf_t h, uint64_t *count, uint32_t *nlist) {

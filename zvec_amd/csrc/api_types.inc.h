@@ -174,6 +174,10 @@ struct zvec_hip_ivf_s {
   uint32_t nlist = 0;
   uint32_t shard = 0, nshards = 1;
   bool loaded = false;
+  bool trained = false;                // centroids present (h_centroids + cent store): labelling possible
+  bool filling = false;                // between begin_lists and end_lists of a streamed build
+  std::vector<uint32_t> h_owner;       // list -> shard (byte-balanced, identical on every rank)
+  std::vector<uint64_t> h_cursor;      // streamed build: next dense position of each list
   Store cent;     // centroids as a flat store
   Store lists;    // inverted lists, each padded to whole tiles
   uint64_t count_local = 0, count_global = 0;

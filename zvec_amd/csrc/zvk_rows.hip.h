@@ -161,6 +161,12 @@ __global__ void fill_keys_kernel(uint64_t *keys, uint64_t pos0, uint64_t n, cons
   if (i < n) keys[pos0 + i] = src ? src[i] : pos0 + i;
 }
 
+// keys of rows packed at scattered positions (streamed IVF build: a chunk's kept rows land in their lists)
+__global__ void scatter_keys_kernel(uint64_t *keys, const uint64_t *dst_pos, const uint64_t *src, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[dst_pos[i]] = src[i];
+}
+
 // bitset widening is not needed: the API bitset is uint64 words, bit i of word i/64 == bit (i&31) of
 // 32-bit word i/32 on a little-endian host/device, so the kernel reads it as uint32 words directly.
 

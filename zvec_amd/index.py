@@ -508,6 +508,53 @@ class HipIVFSearcher:
             self._list_keys = None
         return rc
 
+    # ---- streamed build (IVFBuilder train / label / dump as separate steps; see include/zvec_hip.h) ----
+    def train_dev(self, d_sample, n_sample, nlist, kmeans_iters=10, seed=20260320, stream=None):
+        return _lib.lib().zvec_hip_ivf_train_dev(self._h, C.c_void_p(d_sample), int(n_sample), int(nlist), int(kmeans_iters),
+                                                 int(seed), C.c_void_p(stream) if stream else None)
+
+    def set_centroids(self, centroids):
+        cent = np.ascontiguousarray(centroids, self.np_dtype)
+        return _lib.lib().zvec_hip_ivf_set_centroids(self._h, _np_ptr(cent), cent.shape[0])
+
+    def get_centroids(self):
+        nl = C.c_uint32(0)
+        _lib.check(_lib.lib().zvec_hip_ivf_get_centroids(self._h, None, C.byref(nl)), "zvec_hip_ivf_get_centroids")
+        cent = np.zeros((int(nl.value), self.dim), self.np_dtype)
+        _lib.check(_lib.lib().zvec_hip_ivf_get_centroids(self._h, _np_ptr(cent), None), "zvec_hip_ivf_get_centroids")
+        return cent
+
+    def label_dev(self, d_rows, n, d_labels, stream=None):
+        """d_labels: device uint32[n]; complete when the call returns."""
+        return _lib.lib().zvec_hip_ivf_label_dev(self._h, C.c_void_p(d_rows), int(n), C.c_void_p(d_labels),
+                                                 C.c_void_p(stream) if stream else None)
+
+    def begin_lists(self, list_sizes):
+        sz = np.ascontiguousarray(list_sizes, np.uint32)
+        rc = _lib.lib().zvec_hip_ivf_begin_lists(self._h, _np_ptr(sz))
+        if rc == 0:
+            self.total_count = int(sz.astype(np.uint64).sum())
+            self._orig_keys = None
+            self._list_keys = None
+            self._streamed_keys = False
+        return rc
+
+    def add_dev(self, d_rows, n, labels, first_row, keys=None, stream=None):
+        lab = np.ascontiguousarray(labels, np.uint32)
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        if k is not None:
+            self._streamed_keys = True     # explicit keys arrive per chunk: keys_in_list_order() is not tracked for them
+        return _lib.lib().zvec_hip_ivf_add_dev(self._h, C.c_void_p(d_rows), int(n), _np_ptr(lab), _np_ptr(k), int(first_row),
+                                               C.c_void_p(stream) if stream else None)
+
+    def end_lists(self):
+        return _lib.lib().zvec_hip_ivf_end_lists(self._h)
+
+    def list_owners(self):
+        own = np.zeros(self.info()[1], np.uint32)
+        _lib.check(_lib.lib().zvec_hip_ivf_list_owners(self._h, _np_ptr(own)), "zvec_hip_ivf_list_owners")
+        return own
+
     def info(self):
         n = C.c_uint64(0)
         nl = C.c_uint32(0)
@@ -631,6 +678,16 @@ class HipIVFSearcher:
 # "IVFStreamer" (what the product instantiates, indexes/ivf_index.cc:38-39) is a read-only operator over a dumped index
 # in the reference too (ivf_streamer.h:28-85): same class
 HipIVFStreamer = HipIVFSearcher
+
+
+def shard_map(list_sizes, nshards):
+    """list -> shard map of zvec_hip_ivf_shard_map (pure host arithmetic): (owner[nlist], rows per shard)."""
+    sz = np.ascontiguousarray(list_sizes, np.uint32)
+    owner = np.zeros(sz.size, np.uint32)
+    rows = np.zeros(nshards, np.uint64)
+    _lib.check(_lib.lib().zvec_hip_ivf_shard_map(_np_ptr(sz), sz.size, int(nshards), _np_ptr(owner), _np_ptr(rows)),
+               "zvec_hip_ivf_shard_map")
+    return owner, rows
 
 
 def merge_topk(ctx, keys, scores, counts, topk):
