@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X zvec scan core (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher (no WORLD_SIZE in the environment): this process starts the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a child, before
+anything here touches the GPU), relays their output and exits with their status.  Under a launcher
+(`torch.distributed.run ... bench.py --gpus N`) each process is one rank; WORLD_SIZE != --gpus is an error.
 
 A "step" = one pass of the hot path over one batch of synthetic queries already resident in HBM:
 coarse assign -> plan -> list-major IVF scan (MFMA distance + fused top-k) -> merge [-> all-gather of
 the candidate lists over RCCL + shard merge when N>1].  Workload at N=1 = BASELINE.json configs[2]:
 IVF-Flat nlist=4096 nprobe=32, 10M x 768 fp32, batch=1024, k=10 (the configuration the metric
 "QPS @ recall@10 >= 0.99, 10M x 768 fp32, batch=1024" is quoted on).  With N GPUs the SAME 10M index
-is sharded by inverted list (strong scaling).
+is sharded by inverted list, byte-balanced (strong scaling).
+
+The corpus is never resident as a whole: it is generated chunk by chunk (counter-based generator, identical on
+every rank) three times — (A) ground-truth flat shard + k-means sample, (B) nearest-centroid labels (chunks dealt
+round-robin to the ranks, labels summed over RCCL), (C) list fill (every rank keeps the rows of the lists it owns).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the list scan, timed with HIP events
 on its launch stream inside the library) and `cpu_baseline` (the oracle's restated reference loops on
 the host cores, same index / queries; N=1 only).  oracle/ is used ONLY for that baseline and the
-recall cross-check — never on the timed GPU path.
+parity cross-check — never on the timed GPU path.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +41,8 @@ sys.path.insert(0, ROOT)
 SEED = 20260320
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA peak (no xf32 on gfx950)
+MFMA_F16_PEAK_TF = 2500.0    # dense fp16 MFMA peak (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
+CHUNK = 1 << 20
 
 WORKLOADS = {
     # name: (kind, n, dim, nlist, nprobe, batch, dtype)
@@ -38,7 +51,7 @@ WORKLOADS = {
     "flat_sift1m": ("flat", 1_000_000, 128, 0, 0, 1, "fp32"),         # BASELINE configs[0] shape: 1M x 128-d, one query at a time
     "flat1m": ("flat", 1_000_000, 768, 0, 0, 256, "fp32"),            # BASELINE configs[1]
     "ivf10m_fp16": ("ivf", 10_000_000, 768, 4096, 32, 1024, "fp16"),  # BASELINE configs[3]'s storage type at 1-GPU size
-    "ivf100m_fp16": ("ivf", 100_000_000, 768, 16384, 64, 1024, "fp16"),  # BASELINE configs[3] (needs 8 GPUs' HBM for the build)
+    "ivf100m_fp16": ("ivf", 100_000_000, 768, 16384, 64, 1024, "fp16"),  # BASELINE configs[3]: 8 ranks, or --shard-of 8 for one rank's share
     "filter10m": ("flat", 10_000_000, 768, 0, 0, 512, "fp32"),        # BASELINE configs[4]: bitmap-gated scan, keep 10 %
     "flat1m_fp16": ("flat", 1_000_000, 768, 0, 0, 256, "fp16"),       # (not a BASELINE config: fp16 rows through the wide flat tile)
 }
@@ -49,31 +62,7 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def gen_corpus(torch, n, dim, device, seed, intrinsic_dim=12, noise=0.02, chunk=1 << 20, proj=None, out_dtype=None):
-    """Seeded synthetic corpus with realistic neighbourhood structure: a Gaussian of low intrinsic
-    dimension embedded in R^dim by a fixed random projection, plus small isotropic noise
-    (x = z A + noise, z ~ N(0, I_r)).  i.i.d. Gaussians in 768-d have no cluster structure at all
-    (no IVF can reach recall 0.99 at nprobe 32/4096) and a mixture of a few thousand
-    well separated blobs makes recall trivially 1 at nprobe 1; a low-rank Gaussian gives k-means cells
-    of moderate imbalance and true neighbours that spill into adjacent cells, like embedding data.
-    Counter-based generator (torch Philox), identical on every rank."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    if proj is None:
-        pg = torch.Generator(device=device)
-        pg.manual_seed(SEED + 7)
-        proj = torch.randn((intrinsic_dim, dim), generator=pg, device=device, dtype=torch.float32)
-    out = torch.empty((n, dim), device=device, dtype=out_dtype or torch.float32)
-    for o in range(0, n, chunk):
-        m = min(chunk, n - o)
-        z = torch.randn((m, proj.shape[0]), generator=g, device=device, dtype=torch.float32)
-        x = torch.mm(z, proj)
-        x += torch.randn((m, dim), generator=g, device=device, dtype=torch.float32) * noise
-        out[o:o + m] = x          # (fp16 workloads: round to nearest even here)
-    return out, proj
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -82,9 +71,10 @@ def main():
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--nprobe", type=int, default=0)
+    ap.add_argument("--nlist", type=int, default=0)
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--kmeans-iters", type=int, default=10)
-    ap.add_argument("--gt-queries", type=int, default=256)
+    ap.add_argument("--gt-queries", type=int, default=0, help="queries recall is measured on (0 = the timed batch)")
     ap.add_argument("--intrinsic-dim", type=int, default=12)
     ap.add_argument("--target-recall", type=float, default=0.99)
     ap.add_argument("--nprobe-step", type=int, default=2, help="widening step of the recall sweep")
@@ -93,12 +83,111 @@ def main():
     ap.add_argument("--flat-threshold", type=float, default=None,
                     help="diagnostic: RNN radius for the flat workloads (a huge negative value admits nothing => distance-only time)")
     ap.add_argument("--shard-of", type=int, default=0,
-                    help="diagnostic: on ONE GPU, hold and time only shard 0 of an N-way list sharding (no exchange; "
-                         "recall is not computed) — the per-rank compute time of an N-GPU run")
+                    help="on ONE GPU, hold and time only shard 0 of an N-way byte-balanced list sharding (no exchange; "
+                         "recall is not computed) — the per-rank compute of an N-GPU run; with --workload ivf100m_fp16 "
+                         "--shard-of 8 this is one rank's real share of BASELINE configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
     ap.add_argument("--cpu-queries", type=int, default=0, help="0 = one whole batch")
-    args = ap.parse_args()
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, form the process group (backend: $ZVEC_BENCH_BACKEND, default nccl = RCCL), "
+                         "all-gather the rank ids and print the JSON line; no GPU work (the CPU test of the launcher path)")
+    return ap.parse_args()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_launch(args):
+    """--gpus N > 1 and no launcher: become the launcher.  Nothing in this process has touched torch / HIP yet; the
+    ranks are fresh children of a torch.distributed.run child (never an exec of a process that initialised the GPU)."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            print("bench.py: WORLD_SIZE=%s but --gpus %d; launch with `python -m torch.distributed.run --nnodes=1 "
+                  "--nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...` or run "
+                  "`python bench.py --gpus %d` and let it start the ranks" % (env_world, args.gpus, args.gpus, args.gpus, args.gpus),
+                  file=sys.stderr, flush=True)
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def corpus_proj(torch, dim, device, intrinsic_dim):
+    pg = torch.Generator(device=device)
+    pg.manual_seed(SEED + 7)
+    return torch.randn((intrinsic_dim, dim), generator=pg, device=device, dtype=torch.float32)
+
+
+def corpus_chunks(torch, n, dim, device, seed, proj, out_dtype, noise=0.02, chunk=CHUNK):
+    """Seeded synthetic corpus with realistic neighbourhood structure, one chunk at a time: a Gaussian of low intrinsic
+    dimension embedded in R^dim by a fixed random projection, plus small isotropic noise (x = z A + noise,
+    z ~ N(0, I_r)).  i.i.d. Gaussians in 768-d have no cluster structure at all (no IVF can reach recall 0.99 at
+    nprobe 32/4096) and a mixture of a few thousand well separated blobs makes recall trivially 1 at
+    nprobe 1; a low-rank Gaussian gives k-means cells of moderate imbalance and true neighbours that spill into
+    adjacent cells, like embedding data.  Counter-based generator (torch Philox), identical on every rank and on every
+    pass; yields (first_row, rows[m][dim]) with fp16 workloads rounded to nearest even (HalfFloatConverter)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    for o in range(0, n, chunk):
+        m = min(chunk, n - o)
+        z = torch.randn((m, proj.shape[0]), generator=g, device=device, dtype=torch.float32)
+        x = torch.mm(z, proj)
+        x += torch.randn((m, dim), generator=g, device=device, dtype=torch.float32) * noise
+        yield o, (x if out_dtype == torch.float32 else x.to(out_dtype))
+
+
+def gen_corpus(torch, n, dim, device, seed, proj, out_dtype):
+    out = torch.empty((n, dim), device=device, dtype=out_dtype)
+    for o, x in corpus_chunks(torch, n, dim, device, seed, proj, out_dtype):
+        out[o:o + x.shape[0]] = x
+    return out
+
+
+def launch_check(args):
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("ZVEC_BENCH_BACKEND", "nccl")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group(backend)
+    mine = torch.tensor([rank, local_rank], dtype=torch.int64, device=dev)
+    got = torch.zeros((dist.get_world_size(), 2), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(got.view(-1), mine)
+    ranks = sorted(int(r) for r in got[:, 0].cpu().tolist())
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks": len(set(ranks)), "ranks": ranks,
+                          "backend": dist.get_backend()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if (len(set(ranks)) == world == args.gpus) else 3)
+
+
+def main():
+    args = parse_args()
+    maybe_launch(args)
+    if args.launch_check:
+        launch_check(args)
 
     import torch
     import torch.distributed as dist
@@ -113,13 +202,22 @@ def main():
     # stream has handle 0, which the C ABI would read as "the context's own stream"
     work_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(work_stream)
+    rccl = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        # proof that RCCL sees every rank: one all-gather of (rank, device) over the process group
+        mine = torch.tensor([rank, local_rank], dtype=torch.int64, device=dev)
+        got = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(got.view(-1), mine)
+        torch.cuda.synchronize()
+        rows = got.cpu().tolist()
+        rccl = {"ranks": len(set(int(r[0]) for r in rows)), "devices": [int(r[1]) for r in rows], "backend": dist.get_backend()}
+        if rccl["ranks"] != args.gpus:
+            raise SystemExit("RCCL process group has %d ranks, --gpus %d" % (rccl["ranks"], args.gpus))
 
     import zvec_amd
-    from zvec_amd.dist import ShardedIVF
+    from zvec_amd.dist import ShardedIVF, ShardedFlat, flat_row_range
 
     kind, n, dim, nlist, nprobe, batch, dtype = WORKLOADS[args.workload]
     tdtype = torch.float16 if dtype == "fp16" else torch.float32
@@ -127,94 +225,160 @@ def main():
     batch = args.batch or batch
     nprobe = args.nprobe or nprobe
     topk = args.topk
-    if args.n and kind == "ivf":
+    if args.nlist and kind == "ivf":
+        nlist = args.nlist
+    elif args.n and kind == "ivf":
         nlist = max(16, min(nlist, int(round(math.sqrt(n) * 1.3))))
     t0 = time.time()
     log("workload %s: n=%d dim=%d nlist=%d nprobe=%d batch=%d k=%d world=%d" % (args.workload, n, dim, nlist, nprobe, batch, topk, world))
-
-    # ---------------- synthetic corpus + queries (identical on every rank) ----------------
-    base, proj = gen_corpus(torch, n, dim, dev, SEED, intrinsic_dim=args.intrinsic_dim, out_dtype=tdtype)
-    nqueries = max(batch, args.gt_queries)
-    queries, _ = gen_corpus(torch, nqueries, dim, dev, SEED + 1, intrinsic_dim=args.intrinsic_dim, proj=proj,
-                            out_dtype=tdtype)   # held-out draws; fp16 workloads: HalfFloatConverter/Reformer = RNE cast
-    torch.cuda.synchronize()
-    log("data generated in %.1fs" % (time.time() - t0))
     stream_ptr = torch.cuda.current_stream().cuda_stream
-
-    # ---------------- exact ground truth for recall (flat scan on the GPU, rank-local) ----------------
-    ngt = min(args.gt_queries, nqueries)
+    proj = corpus_proj(torch, dim, dev, args.intrinsic_dim)
+    shard_mode = args.shard_of > 1 and world == 1 and kind == "ivf"
+    if shard_mode:
+        args.no_cpu_baseline = True
+    ngt = 0 if shard_mode else max(batch, args.gt_queries or batch)
+    nqueries = max(batch, ngt)
+    queries = gen_corpus(torch, nqueries, dim, dev, SEED + 1, proj, tdtype)   # held-out draws (fp16: HalfFloatReformer = RNE cast)
     # BASELINE configs[1] is a flat INNER-PRODUCT scan; every other workload is L2
     flat_metric = "InnerProduct" if args.workload == "flat1m" else "SquaredEuclidean"
-    flat = zvec_amd.HipFlatSearcher(dim, flat_metric, device=local_rank, dtype=dtype)
-    t1 = time.time()
-    zvec_amd._lib.check(flat.add_batch_dev(base.data_ptr(), n, stream=stream_ptr), "flat append")
-    torch.cuda.synchronize()
-    log("flat store packed in %.1fs" % (time.time() - t1))
-    fctx = flat.create_context()
-    fctx.set_stream(stream_ptr)
-    gt_keys = torch.empty((ngt, topk), dtype=torch.int64, device=dev)
-    gt_scores = torch.empty((ngt, topk), dtype=torch.float32, device=dev)
-    gt_counts = torch.empty((ngt,), dtype=torch.int32, device=dev)
-    zvec_amd._lib.check(flat.search_dev(queries.data_ptr(), ngt, topk, gt_keys.data_ptr(), gt_scores.data_ptr(),
-                                        gt_counts.data_ptr(), fctx, stream=stream_ptr), "flat gt")
-    torch.cuda.synchronize()
-    gt = gt_keys.cpu().numpy()
+    extra_cfg = {}
 
-    result = {}
     if kind == "flat":
-        result = run_flat(torch, dist, zvec_amd, flat, fctx, queries[:batch].contiguous(), n, dim, topk, args, dev, stream_ptr, world,
-                          base, flat_metric)
+        # ---------------- flat workloads: rank g holds the contiguous row range g ----------------
+        lo, hi = flat_row_range(n, rank, world)
+        flat = zvec_amd.HipFlatSearcher(dim, flat_metric, device=local_rank, dtype=dtype)
+        base = None
+        keep_base = world == 1 and n <= 2_000_000 and not args.no_cpu_baseline
+        parts = []
+        for o, x in corpus_chunks(torch, n, dim, dev, SEED, proj, tdtype):
+            a, b = max(o, lo), min(o + x.shape[0], hi)
+            if a < b:
+                rows = x[a - o:b - o].contiguous()
+                keys = None if world == 1 else torch.arange(a, b, dtype=torch.int64, device=dev)
+                zvec_amd._lib.check(flat.add_batch_dev(rows.data_ptr(), b - a, d_keys_ptr=keys.data_ptr() if keys is not None else None,
+                                                       stream=stream_ptr), "flat append")
+                torch.cuda.synchronize()
+                if keep_base:
+                    parts.append(rows)
+        if keep_base:
+            base = torch.cat(parts)
+            del parts
+        log("flat rows [%d, %d) packed in %.1fs" % (lo, hi, time.time() - t0))
+        fctx = flat.create_context()
+        fctx.set_stream(stream_ptr)
+        result = run_flat(torch, dist, zvec_amd, ShardedFlat(flat, fctx, rank, world), flat, fctx, queries[:batch].contiguous(), n, hi - lo,
+                          dim, topk, args, dev, stream_ptr, world, rank, base, flat_metric)
         recall = 1.0
+        nprobe_base = recall_base = None
     else:
-        del fctx
-        del flat
-        torch.cuda.synchronize()
-        # ---------------- IVF build on the GPU (same seed on every rank => same centroids) ----------------
-        t1 = time.time()
+        nshards = args.shard_of if shard_mode else world
+        shard = 0 if shard_mode else rank
         ivf = zvec_amd.HipIVFSearcher(dim, "SquaredEuclidean", device=local_rank, dtype=dtype)
-        if args.shard_of > 1 and world == 1:
-            zvec_amd._lib.check(ivf.set_shard(0, args.shard_of), "set_shard")
-            args.target_recall = 0.0
-            args.no_cpu_baseline = True
-            nprobe = args.nprobe or 40
-        else:
-            zvec_amd._lib.check(ivf.set_shard(rank, world), "set_shard")
-        zvec_amd._lib.check(ivf.build_dev(base.data_ptr(), n, nlist, kmeans_iters=args.kmeans_iters, seed=SEED,
-                                          stream=stream_ptr), "ivf build")
+        zvec_amd._lib.check(ivf.set_shard(shard, nshards), "set_shard")
+        # ---------------- pass A: ground-truth flat shard + the k-means sample ----------------
+        S = min(n, 256 * nlist)
+        sample_ids = (np.arange(S, dtype=np.uint64) * np.uint64(n)) // np.uint64(S)    # the strided sample of zvec_hip_ivf_build
+        sample = torch.empty((S, dim), device=dev, dtype=tdtype)
+        flat = None
+        lo, hi = flat_row_range(n, rank, world)
+        if ngt:
+            flat = zvec_amd.HipFlatSearcher(dim, flat_metric, device=local_rank, dtype=dtype)
+        t1 = time.time()
+        for o, x in corpus_chunks(torch, n, dim, dev, SEED, proj, tdtype):
+            m = x.shape[0]
+            i0, i1 = np.searchsorted(sample_ids, [o, o + m])
+            if i1 > i0:
+                sample[i0:i1] = x[torch.from_numpy((sample_ids[i0:i1] - np.uint64(o)).astype(np.int64)).to(dev)]
+            a, b = max(o, lo), min(o + m, hi)
+            if flat is not None and a < b:
+                rows = x[a - o:b - o].contiguous()
+                keys = None if world == 1 else torch.arange(a, b, dtype=torch.int64, device=dev)
+                zvec_amd._lib.check(flat.add_batch_dev(rows.data_ptr(), b - a, d_keys_ptr=keys.data_ptr() if keys is not None else None,
+                                                       stream=stream_ptr), "flat append")
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
-        log("ivf build (k-means %d iters, %d lists, shard %d/%d) in %.1fs" % (args.kmeans_iters, nlist, rank, world, time.time() - t1))
+        log("pass A (sample%s) in %.1fs" % (", ground-truth flat rows [%d, %d)" % (lo, hi) if flat is not None else "", time.time() - t1))
+        # exact ground truth for recall: the flat path over the same corpus (sharded by row range when N > 1)
+        gt = None
+        if flat is not None:
+            fctx = flat.create_context()
+            fctx.set_stream(stream_ptr)
+            gk, _, _ = ShardedFlat(flat, fctx, rank, world).search(queries[:ngt].contiguous(), topk, stream_ptr)
+            torch.cuda.synchronize()
+            gt = gk.cpu().numpy()
+            del fctx, flat
+            torch.cuda.empty_cache()
+        # ---------------- train: k-means on the sample (same seed, same rows on every rank) ----------------
+        t1 = time.time()
+        zvec_amd._lib.check(ivf.train_dev(sample.data_ptr(), S, nlist, kmeans_iters=args.kmeans_iters, seed=SEED, stream=stream_ptr), "ivf train")
+        del sample
+        if world > 1:      # one set of centroids for everybody: rank 0's, bit for bit
+            cent = torch.from_numpy(ivf.get_centroids().view(np.uint8)).to(dev)
+            dist.broadcast(cent, 0)
+            if rank != 0:
+                zvec_amd._lib.check(ivf.set_centroids(cent.cpu().numpy().view(np.float16 if dtype == "fp16" else np.float32)), "set_centroids")
+        log("k-means (%d iters, %d lists, %d sample rows) in %.1fs" % (args.kmeans_iters, nlist, S, time.time() - t1))
+        # ---------------- pass B: nearest-centroid labels (chunks dealt round-robin to the ranks) ----------------
+        t1 = time.time()
+        labels = torch.zeros((n,), dtype=torch.int32, device=dev)
+        for ci, (o, x) in enumerate(corpus_chunks(torch, n, dim, dev, SEED, proj, tdtype)):
+            if ci % world == rank:
+                zvec_amd._lib.check(ivf.label_dev(x.data_ptr(), x.shape[0], labels[o:o + x.shape[0]].data_ptr(), stream=stream_ptr), "label")
+        if world > 1:
+            dist.all_reduce(labels)        # every row was labelled by exactly one rank, the others hold 0
+        torch.cuda.synchronize()
+        labels_h = labels.cpu().numpy().astype(np.uint32)
+        del labels
+        sizes = np.bincount(labels_h, minlength=nlist).astype(np.uint32)
+        log("pass B (labels) in %.1fs; list sizes min %d / mean %.0f / max %d" % (time.time() - t1, sizes.min(), sizes.mean(), sizes.max()))
+        # ---------------- pass C: fill the lists this rank owns ----------------
+        t1 = time.time()
+        zvec_amd._lib.check(ivf.begin_lists(sizes), "begin_lists")
+        for o, x in corpus_chunks(torch, n, dim, dev, SEED, proj, tdtype):
+            zvec_amd._lib.check(ivf.add_dev(x.data_ptr(), x.shape[0], labels_h[o:o + x.shape[0]], o, stream=stream_ptr), "add")
+        zvec_amd._lib.check(ivf.end_lists(), "end_lists")
+        del labels_h
+        torch.cuda.empty_cache()
+        _, shard_rows = zvec_amd.shard_map(sizes, nshards)
+        local_rows = ivf.info()[0]
+        assert local_rows == int(shard_rows[shard])
+        extra_cfg["shard_rows_max_over_mean"] = float(shard_rows.max() / shard_rows.mean())
+        log("pass C (lists of shard %d/%d: %d rows = %.2f GB; max/mean over shards %.4f) in %.1fs" % (
+            shard, nshards, local_rows, local_rows * dim * (2 if dtype == "fp16" else 4) / 1e9, extra_cfg["shard_rows_max_over_mean"],
+            time.time() - t1))
         ctx = ivf.create_context()
         ctx.set_stream(stream_ptr)
         sh = ShardedIVF(ivf, ctx, rank, world)
         max_scan = n        # brute_force_threshold = N-1 => exactly nprobe lists are probed
         q = queries[:batch].contiguous()
 
-        # recall@10 of the configuration being timed; the metric demands >= 0.99: if nprobe (BASELINE: 32) does
-        # not reach it on this corpus, widen nprobe until it does and time THAT (the nprobe=32 recall is reported too)
+        # recall@10 of the configuration being timed, measured on the timed queries; the metric demands >= 0.99: if
+        # nprobe (BASELINE: 32) does not reach it on this corpus, widen nprobe until it does and time THAT (the
+        # nprobe=32 recall and QPS are reported too)
         def recall_at(np_):
             k_, s_, c_ = sh.search(queries[:ngt].contiguous(), topk, np_, max_scan, stream_ptr)
             torch.cuda.synchronize()
             got = k_.cpu().numpy()
             return float(np.mean([len(set(got[i].tolist()) & set(gt[i].tolist())) / float(topk) for i in range(ngt)]))
-        recall_base = recall = recall_at(nprobe)
         nprobe_base = nprobe
-        log("recall@%d = %.4f (nprobe=%d, %d queries)" % (topk, recall, nprobe, ngt))
-        while recall < args.target_recall and nprobe < nlist:
-            nprobe = min(nlist, nprobe + max(args.nprobe_step, 1))
-            recall = recall_at(nprobe)
-            log("recall@%d = %.4f (nprobe=%d)" % (topk, recall, nprobe))
-        scanned, probes = ivf.last_stats(ctx, ngt)
-        log("rows scanned per query: mean %.0f (%.3f%% of the shard), lists probed %.1f" % (
-            scanned.mean(), 100.0 * scanned.mean() / n, probes.mean()))
+        recall_base = recall = None
+        if gt is not None:
+            recall_base = recall = recall_at(nprobe)
+            log("recall@%d = %.4f (nprobe=%d, %d queries)" % (topk, recall, nprobe, ngt))
+            while recall < args.target_recall and nprobe < nlist:
+                nprobe = min(nlist, nprobe + max(args.nprobe_step, 1))
+                recall = recall_at(nprobe)
+                log("recall@%d = %.4f (nprobe=%d)" % (topk, recall, nprobe))
+            scanned, probes = ivf.last_stats(ctx, ngt)
+            log("rows scanned per query: mean %.0f (%.3f%% of the corpus), lists probed %.1f" % (
+                scanned.mean(), 100.0 * scanned.mean() / n, probes.mean()))
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             gk, gs, gc = sh.search(q, topk, nprobe, max_scan, stream_ptr)
             torch.cuda.synchronize()
-            cpu = cpu_baseline_ivf(torch, ivf, base, q, topk, nprobe, max_scan, args,
+            cpu = cpu_baseline_ivf(torch, ivf, q, topk, nprobe, max_scan, args, dtype,
                                    gpu=(gk.cpu().numpy(), gs.cpu().numpy(), gc.cpu().numpy()))
-        del base
-        torch.cuda.empty_cache()
 
         # ---------------- timed region ----------------
         # --streams 2: consecutive (independent) batches alternate between two contexts on two HIP streams, so the
@@ -226,35 +390,44 @@ def main():
             ctx2 = ivf.create_context()
             ctx2.set_stream(s2.cuda_stream)
             lanes.append((ShardedIVF(ivf, ctx2, rank, world), s2.cuda_stream, s2))
-        def run_step(i):
+
+        def run_step(i, np_):
             sh_i, sp, ts = lanes[i % len(lanes)]
             if ts is None:
-                sh_i.search(q, topk, nprobe, max_scan, sp)
+                sh_i.search(q, topk, np_, max_scan, sp)
             else:
                 with torch.cuda.stream(ts):
-                    sh_i.search(q, topk, nprobe, max_scan, sp)
-        for i in range(args.warmup * len(lanes)):
-            run_step(i)
-        torch.cuda.synchronize()
-        ctx.profile(True)
-        ctx.profile_read(reset=True)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t_start = time.perf_counter()
-        for i in range(args.steps):
-            run_step(i)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t_start
-        if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        prof = ctx.profile_read(reset=True)
-        ctx.profile(False)
+                    sh_i.search(q, topk, np_, max_scan, sp)
+
+        def timed(np_, steps, warmup):
+            for i in range(warmup * len(lanes)):
+                run_step(i, np_)
+            torch.cuda.synchronize()
+            ctx.profile(True)
+            ctx.profile_read(reset=True)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t_start = time.perf_counter()
+            for i in range(steps):
+                run_step(i, np_)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t_start
+            if world > 1:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            pr = ctx.profile_read(reset=True)
+            ctx.profile(False)
+            return el, pr
+        elapsed, prof = timed(nprobe, args.steps, args.warmup)
+        qps_base = None
+        if nprobe != nprobe_base:      # the BASELINE nprobe as well (outside the reported region)
+            el32, _ = timed(nprobe_base, max(3, min(args.steps, 10)), 1)
+            qps_base = batch * max(3, min(args.steps, 10)) / el32
         # the boundary's HOST-pointer entry (what IndexRunner::search_impl hands over: queries in host memory, results
         # back into host buffers) on the same batch: H2D of the queries + D2H of the lists per call.  Reported next to
         # `value`, never as it.
@@ -281,38 +454,46 @@ def main():
         bytes_per_launch = prof["bytes"] / max(prof["launches"], 1)
         flops_per_launch = prof["flops"] / max(prof["launches"], 1)
         achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-        # HBM traffic of one launch from the PMC counters: rocprofv3 cannot run inside this process, so the value
-        # is the one measured by separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command
-        # (profiles/README.md) and corrected as MI355X_MICROARCH.md §HBM prescribes; null for other workloads
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if world == 1 and not args.n and not args.batch and not args.nprobe:
-                traffic = pmc.get(args.workload)
-        except (OSError, ValueError):
-            pass
+        traffic, traffic_source = committed_traffic(args, world, shard_mode)
+        ms_per_step = elapsed / args.steps * 1e3
         result = {
             "value": batch * args.steps / elapsed,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "roofline": {"bound": "hbm", "kernel": "zvk::scan_kernel<1> (IVF list scan)", "achieved": achieved,
+            "ms_per_step": ms_per_step,
+            "roofline": {"bound": "hbm", "kernel": "zvk::scan_kernel<1> (IVF list scan%s)" % (", rank 0's shard" if world > 1 or shard_mode else ""),
+                         "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": per_launch_ms, "algorithmic_bytes": bytes_per_launch,
+                         "traffic_source": traffic_source,
+                         "kernel_ms": per_launch_ms, "fixed_ms_per_step": ms_per_step - per_launch_ms,
+                         "algorithmic_bytes": bytes_per_launch,
                          "algorithmic_flops": flops_per_launch,
                          "mfma_tflops": flops_per_launch / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0},
             "cpu_baseline": cpu,
             "host_pointer_qps": host_qps,
         }
+        extra_cfg.update({"recall_at_nprobe%d" % nprobe_base: recall_base, "qps_nprobe%d" % nprobe_base: qps_base if qps_base else
+                          (result["value"] if nprobe == nprobe_base else None), "recall_queries": ngt})
+        if shard_mode:
+            extra_cfg["shard_of"] = args.shard_of
 
     if rank == 0:
+        sharding = "single GPU"
+        if world > 1:
+            sharding = ("inverted lists dealt to %d ranks by bytes (largest first), one all-gather of the candidate lists" % world
+                        if kind == "ivf" else "contiguous row ranges over %d ranks, one all-gather of the candidate lists" % world)
+        elif shard_mode:
+            sharding = "shard 0 of %d (byte-balanced list map), no exchange: one rank's share" % args.shard_of
+        cfg = {"workload": "%s: %s n=%d dim=%d%s batch=%d k=%d" % (
+            args.workload, "IVF-Flat L2" if kind == "ivf" else ("Flat IP" if args.workload == "flat1m" else "Flat L2"), n, dim,
+            (" nlist=%d nprobe=%d" % (nlist, nprobe)) if kind == "ivf" else "", batch, topk),
+            "recall_at_10": recall, "nprobe_timed": nprobe if kind == "ivf" else None, "sharding": sharding}
+        cfg.update(extra_cfg)
         line = {
             "metric": "QPS @ recall@10>=0.99, 10Mx768 fp32, batch=1024" if args.workload == "ivf10m" else "QPS (%s)" % args.workload,
             "value": result["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": result["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if dtype == "fp32" else "f16 rows, f32 accumulate", "data": "synthetic",
-            "config": {"workload": "%s: %s n=%d dim=%d%s batch=%d k=%d" % (
-                args.workload, "IVF-Flat L2" if kind == "ivf" else ("Flat IP" if args.workload == "flat1m" else "Flat L2"), n, dim,
-                (" nlist=%d nprobe=%d" % (nlist, nprobe)) if kind == "ivf" else "", batch, topk),
-                "recall_at_10": recall, "nprobe_timed": nprobe if kind == "ivf" else None, "sharding": "inverted lists l %% %d, all-gather of candidates" % world if world > 1 else "single GPU"},
+            "config": cfg,
+            "rccl_ranks": rccl["ranks"] if rccl else 1, "rccl": rccl,
             "roofline": result["roofline"], "cpu_baseline": result.get("cpu_baseline"),
             "host_pointer_qps": result.get("host_pointer_qps"),
         }
@@ -320,6 +501,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def committed_traffic(args, world, shard_mode):
+    """HBM traffic of one launch from the PMC counters: rocprofv3 cannot run inside this process, so the value is the one
+    measured by separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (profiles/README.md) and
+    corrected as MI355X_MICROARCH.md §HBM prescribes; null for any other configuration."""
+    try:
+        if world == 1 and not shard_mode and not args.n and not args.batch and not args.nprobe and not args.nlist:
+            v = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+            if v is not None:
+                return v, "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, not this run)"
+    except (OSError, ValueError):
+        pass
+    return None, None
 
 
 def roaring_portable(ids):
@@ -353,6 +548,22 @@ def roaring_portable(ids):
     return bytes(out)
 
 
+def parity_vs_cpu(gpu, ok, os_, oc, nq):
+    """the oracle as the checker: the GPU's answers for the same queries at full size (ids as sets per query; scores of
+    the common ids; the CPU sums in AVX-512 lane order, the GPU refines L2 scores directly: ~1e-6 relative apart)"""
+    gk, gs, gc = gpu
+    same = rel = 0.0
+    for i in range(nq):
+        a, b = set(gk[i, :gc[i]].astype(np.uint64).tolist()), set(ok[i, :oc[i]].tolist())
+        same += len(a & b) / float(max(len(b), 1))
+        cs = dict(zip(ok[i, :oc[i]].tolist(), os_[i, :oc[i]].tolist()))
+        for key, sc in zip(gk[i, :gc[i]].astype(np.uint64).tolist(), gs[i, :gc[i]].tolist()):
+            if key in cs:
+                rel = max(rel, abs(sc - cs[key]) / max(abs(cs[key]), 1e-30))
+    log("parity vs the CPU path: ids in common %.6f, max relative score difference %.3g" % (same / nq, rel))
+    return {"queries": int(nq), "topk_ids_in_common": same / nq, "max_rel_score_diff": rel}
+
+
 def cpu_baseline_flat(torch, base, q, topk, metric_name, args, gpu=None):
     """Reference CPU flat scan restated (oracle: FlatSearcherContext row-major loops + the reference's AVX-512 1x1
     kernels when oracle/_ref travelled) on a bounded sample of the timed batch, same base rows."""
@@ -371,87 +582,81 @@ def cpu_baseline_flat(torch, base, q, topk, metric_name, args, gpu=None):
         dt = time.perf_counter() - t1
         best = dt if best is None else min(best, dt)
     o.use_reference_kernels(False)
-    parity = None
-    if gpu is not None:        # the oracle as the checker, as in cpu_baseline_ivf
-        gk, gs, gc = gpu
-        same = rel = 0.0
-        for i in range(nq):
-            a, b = set(gk[i, :gc[i]].astype(np.uint64).tolist()), set(ok[i, :oc[i]].tolist())
-            same += len(a & b) / float(max(len(b), 1))
-            cs = dict(zip(ok[i, :oc[i]].tolist(), os_[i, :oc[i]].tolist()))
-            for key, sc in zip(gk[i, :gc[i]].astype(np.uint64).tolist(), gs[i, :gc[i]].tolist()):
-                if key in cs:
-                    rel = max(rel, abs(sc - cs[key]) / max(abs(cs[key]), 1e-30))
-        parity = {"queries": int(nq), "topk_ids_in_common": same / nq, "max_rel_score_diff": rel}
-        log("parity vs the CPU path: ids in common %.6f, max relative score difference %.3g" % (same / nq, rel))
+    parity = parity_vs_cpu(gpu, ok, os_, oc, nq) if gpu is not None else None
     return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": "port", "parity": parity,
             "sample": "%d queries of the timed batch over the same %d rows, %d threads across queries, best of 2; scan loop = "
                       "oracle restatement, 1x1 distance kernel = %s" % (
                           nq, host.shape[0], threads, "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")}
 
 
-def run_flat(torch, dist, zvec_amd, flat, fctx, q, n, dim, topk, args, dev, stream_ptr, world, base, metric_name):
+def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, topk, args, dev, stream_ptr, world, rank, base, metric_name):
     batch = q.shape[0]
-    ok = torch.empty((batch, topk), dtype=torch.int64, device=dev)
-    os_ = torch.empty((batch, topk), dtype=torch.float32, device=dev)
-    oc = torch.empty((batch,), dtype=torch.int32, device=dev)
-
     excl = None
     doc_filter = None
     if args.workload.startswith("filter"):
         # BASELINE configs[4]: CRoaring bitmap predicate.  Bernoulli keep-mask p = --keep as the result
         # bitmap of an inverted-index condition (ids that MATCH, InvertedSearchResult) in roaring portable form; every
         # step materialises it on the GPU into the 1-bit-per-position exclude set (zvec_hip_flat_build_filter) and
-        # runs the gated scan — both inside the timed region
+        # runs the gated scan — both inside the timed region.  (N > 1: every rank draws the mask of the whole corpus and
+        # hands its own row range's keys to the predicate; the bitmap is over KEYS = global row numbers.)
         g = torch.Generator(device=dev)
         g.manual_seed(SEED + 2)
         keep = (torch.rand((n,), generator=g, device=dev) < args.keep).cpu().numpy()
         blob = roaring_portable(np.nonzero(keep)[0])
         doc_filter = zvec_amd.DocFilter(invert=blob)
-        excl = torch.zeros(((n + 63) // 64,), dtype=torch.int64, device=dev)
+        excl = torch.zeros(((n_local + 63) // 64,), dtype=torch.int64, device=dev)
         log("filter: keep %.3f of %d rows; predicate = %d bytes of roaring" % (keep.mean(), n, len(blob)))
 
-    thr = {} if args.flat_threshold is None else {"threshold": args.flat_threshold}
+    thr = None if args.flat_threshold is None else args.flat_threshold
 
     def step():
         if doc_filter is not None:
             flat.build_filter(doc_filter, fctx, d_out=excl.data_ptr(), stream=stream_ptr)
-        zvec_amd._lib.check(flat.search_dev(q.data_ptr(), batch, topk, ok.data_ptr(), os_.data_ptr(), oc.data_ptr(), fctx,
-                                            d_exclude=excl.data_ptr() if excl is not None else None,
-                                            stream=stream_ptr, **thr), "flat search")
+        return sharded.search(q, topk, stream_ptr, d_exclude=excl.data_ptr() if excl is not None else None, threshold=thr)
 
     cpu = None
-    if not args.no_cpu_baseline and world == 1 and doc_filter is None and n <= 2_000_000:
-        step()
+    if not args.no_cpu_baseline and world == 1 and doc_filter is None and base is not None:
+        ok, os_, oc = step()
         torch.cuda.synchronize()
         cpu = cpu_baseline_flat(torch, base, q, topk, metric_name, args, gpu=(ok.cpu().numpy(), os_.cpu().numpy(), oc.cpu().numpy()))
     for _ in range(args.warmup):
         step()
     fctx.profile(True)
     fctx.profile_read(reset=True)
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
     prof = fctx.profile_read(reset=True)
     ms = prof["scan_ms"] / max(prof["launches"], 1)
     fl = prof["flops"] / max(prof["launches"], 1)
     by = prof["bytes"] / max(prof["launches"], 1)
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    traffic = None          # HBM bytes per launch from separate PMC passes over this same command (profiles/README.md)
-    try:
-        if world == 1 and not args.n and not args.batch:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
-    except (OSError, ValueError):
-        pass
-    return {"value": batch * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
-            "roofline": {"bound": "mfma", "kernel": "zvk::scan8_kernel (flat scan)", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": traffic, "kernel_ms": ms,
-                         "algorithmic_bytes": by, "algorithmic_flops": fl,
-                         "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0},
-            "cpu_baseline": cpu}
+    traffic, traffic_source = committed_traffic(args, world, False)
+    ms_per_step = elapsed / args.steps * 1e3
+    f16 = args.workload.endswith("fp16")
+    small = batch <= 16         # a handful of queries: the scan streams the base once => HBM-bound
+    peak = MFMA_F16_PEAK_TF if f16 else MFMA_F32_PEAK_TF
+    roof = {"bound": "mfma", "kernel": "zvk::scan8_kernel (flat scan)", "achieved": tf, "peak": peak,
+            "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": ms,
+            "fixed_ms_per_step": ms_per_step - ms, "algorithmic_bytes": by, "algorithmic_flops": fl,
+            "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
+    if small:
+        gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        roof.update({"bound": "hbm", "kernel": "zvk::scan_kernel<1, M16> (flat scan, <= 16 queries)", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "mfma_tflops": tf})
+    return {"value": batch * args.steps / elapsed, "ms_per_step": ms_per_step, "roofline": roof, "cpu_baseline": cpu}
 
 
 def host_threads():
@@ -466,21 +671,22 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("ZVEC_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline_ivf(torch, ivf, base, q, topk, nprobe, max_scan, args, gpu=None):
+def cpu_baseline_ivf(torch, ivf, q, topk, nprobe, max_scan, args, dtype, gpu=None):
     """The reference's CPU path restated (oracle/zvec_oracle.c: IVFSearcher::search_impl loops, the
     reference's own AVX-512 distance kernels from oracle/_ref when that library travelled), on the
-    host cores of this box, searching THE SAME index (exported centroids / list order) with the same
-    queries.  Parallel across queries, one query per thread at a time (tools/core/bench.cc:145-245)."""
+    host cores of this box, searching THE SAME index (exported centroids / list order, rows read back from
+    the HBM store) with the same queries.  Parallel across queries, one query per thread at a time
+    (tools/core/bench.cc:145-245)."""
     from oracle import oracle as O
     o = O.get()
     t0 = time.time()
     cent, offs, rows = ivf.export()
-    n, dim = base.shape
-    vecs = np.empty((n, dim), np.float16 if base.dtype == torch.float16 else np.float32)
-    rows_t = torch.from_numpy(rows.astype(np.int64)).to(base.device)
+    n, dim = rows.shape[0], cent.shape[1]
+    vecs = np.empty((n, dim), np.float16 if dtype == "fp16" else np.float32)
     step = 1 << 20
     for s in range(0, n, step):
-        vecs[s:s + step] = base.index_select(0, rows_t[s:s + step]).cpu().numpy()
+        e = min(n, s + step)
+        vecs[s:e] = ivf.get_vectors_by_ids(np.arange(s, e, dtype=np.uint64))
     qh = q.cpu().numpy()
     nq = args.cpu_queries or qh.shape[0]
     qh = qh[:nq]
@@ -503,21 +709,7 @@ def cpu_baseline_ivf(torch, ivf, base, q, topk, nprobe, max_scan, args, gpu=None
     o.ivf_search(cent, offs, vecs, qh[:n1], topk, nprobe, max_scan, keys=rows, threads=1)
     one = n1 / (time.perf_counter() - t1)
     o.use_reference_kernels(False)
-    parity = None
-    if gpu is not None:
-        # the oracle as the checker: the GPU's answers for the same queries at full size (ids as sets per query; scores of
-        # the common ids; the CPU sums in AVX-512 lane order, the GPU refines L2 scores directly: ~1e-6 relative apart)
-        gk, gs, gc = gpu
-        same = rel = 0.0
-        for i in range(nq):
-            a, b = set(gk[i, :gc[i]].astype(np.uint64).tolist()), set(ok[i, :oc[i]].tolist())
-            same += len(a & b) / float(max(len(b), 1))
-            cs = dict(zip(ok[i, :oc[i]].tolist(), os_[i, :oc[i]].tolist()))
-            for key, sc in zip(gk[i, :gc[i]].astype(np.uint64).tolist(), gs[i, :gc[i]].tolist()):
-                if key in cs:
-                    rel = max(rel, abs(sc - cs[key]) / max(abs(cs[key]), 1e-30))
-        parity = {"queries": int(nq), "topk_ids_in_common": same / nq, "max_rel_score_diff": rel}
-        log("parity at full size vs the CPU path: ids in common %.6f, max relative score difference %.3g" % (same / nq, rel))
+    parity = parity_vs_cpu(gpu, ok, os_, oc, nq) if gpu is not None else None
     return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": "port", "value_1_thread": one, "parity": parity,
             "sample": "%d queries of the timed batch, same IVF index (exported), %d threads across queries, best of %d; "
                       "scan loops = oracle restatement, 1x1 distance kernel = %s" % (

@@ -1,6 +1,7 @@
 """One-process-per-GPU sharding of the IVF scan + the candidate-list exchange.
 
-The index shards by inverted list (list l lives on rank l % world; centroids are replicated), every
+The IVF index shards by inverted list (whole lists, dealt to ranks by the byte-balanced map of
+zvec_hip_ivf_shard_map; centroids are replicated), a flat index by contiguous row ranges; every
 rank sees the whole query batch, scans only the probed lists it owns and produces a partial top-k per
 query.  The only exchange on the path is ONE all-gather of the small candidate lists
 ([count][topk] keys u64 + scores f32 + counts u32 per rank; 1024x10 => 124 KiB per rank) over RCCL
@@ -51,8 +52,8 @@ def all_gather_candidates(keys, scores, counts, group=None):
     return unpack_candidates(out, world, count, topk)
 
 
-class ShardedIVF:
-    """rank-local shard of an IVF index + the exchange/merge step.
+class _Sharded:
+    """rank-local shard + the exchange/merge step.
 
     The scan writes keys / scores / counts straight into one packed per-rank buffer (zvec_hip_packed_bytes
     layout), that buffer is all-gathered as is, and the merge kernel reads the gathered buffer with a part
@@ -82,7 +83,10 @@ class ShardedIVF:
                 ocounts=torch.empty((count,), dtype=torch.int32, device=device))
         return self._buf[key]
 
-    def search(self, d_queries, topk, nprobe, max_scan, stream_ptr):
+    def _local_search(self, d_queries, count, topk, b, stream_ptr, **kw):
+        raise NotImplementedError
+
+    def search(self, d_queries, topk, *args, stream_ptr=None, **kw):
         """d_queries: torch tensor [count][dim] (index element type) on this rank's GPU.  Returns
         (keys, scores, counts) tensors of the GLOBAL top-k (identical on every rank)."""
         from . import _lib
@@ -95,9 +99,7 @@ class ShardedIVF:
         legacy = not stream_ptr
         if legacy:
             torch.cuda.current_stream().synchronize()
-        rc = self.searcher.search_dev(d_queries.data_ptr(), count, topk, nprobe, max_scan, b["keys"].data_ptr(),
-                                      b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx, stream=stream_ptr)
-        _lib.check(rc, "zvec_hip_ivf_search_dev")
+        self._local_search(d_queries, count, topk, b, stream_ptr, *args, **kw)
         if legacy:
             self.ctx.synchronize()
         if self.world == 1:
@@ -119,3 +121,39 @@ class ShardedIVF:
         if legacy:
             self.ctx.synchronize()
         return b["okeys"], b["oscores"], b["ocounts"]
+
+
+class ShardedIVF(_Sharded):
+    """IVF: the shard holds the inverted lists the byte-balanced list -> shard map gives this rank
+    (zvec_hip_ivf_keep_shard / zvec_hip_ivf_shard_map), centroids replicated; probe sets are global."""
+
+    def _local_search(self, d_queries, count, topk, b, stream_ptr, nprobe, max_scan):
+        from . import _lib
+        rc = self.searcher.search_dev(d_queries.data_ptr(), count, topk, nprobe, max_scan, b["keys"].data_ptr(),
+                                      b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx, stream=stream_ptr)
+        _lib.check(rc, "zvec_hip_ivf_search_dev")
+
+    def search(self, d_queries, topk, nprobe, max_scan, stream_ptr):
+        return super().search(d_queries, topk, nprobe, max_scan, stream_ptr=stream_ptr)
+
+
+def flat_row_range(n, rank, world):
+    """rows [rank*n/world, (rank+1)*n/world) — SURVEY §8(e): contiguous row ranges, key = local + offset
+    (combined_vector_column_indexer.cc:140-145)."""
+    return (rank * n) // world, ((rank + 1) * n) // world
+
+
+class ShardedFlat(_Sharded):
+    """Flat: rank g holds the contiguous row range flat_row_range(n, g, world) with GLOBAL keys (the caller appends its
+    range with keys = global row numbers, i.e. local position + range start), every rank scans the whole batch over its
+    rows, same exchange + merge.  Part order = rank order = ascending row ranges, so ties resolve as in one scan."""
+
+    def _local_search(self, d_queries, count, topk, b, stream_ptr, d_exclude=None, threshold=None):
+        from . import _lib
+        kw = {} if threshold is None else {"threshold": threshold}
+        rc = self.searcher.search_dev(d_queries.data_ptr(), count, topk, b["keys"].data_ptr(), b["scores"].data_ptr(),
+                                      b["counts"].data_ptr(), self.ctx, d_exclude=d_exclude, stream=stream_ptr, **kw)
+        _lib.check(rc, "zvec_hip_flat_search_dev")
+
+    def search(self, d_queries, topk, stream_ptr, d_exclude=None, threshold=None):
+        return super().search(d_queries, topk, stream_ptr=stream_ptr, d_exclude=d_exclude, threshold=threshold)
