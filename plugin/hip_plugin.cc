@@ -1,0 +1,620 @@
+// hip_plugin.cc — the zvec-side binding of the MI355X scan core: IndexStreamer / IndexSearcher subclasses that forward
+// to the C ABI of include/zvec_hip.h and register themselves with the reference's factory.
+//
+// This file is meant to be compiled INSIDE a zvec checkout (e.g. as src/core/algorithm/hip/hip_plugin.cc, or into
+// libzvec_hip_plugin.so loaded with IndexPluginBroker::emplace, index_plugin.h:73-101) against zvec's own headers:
+//     g++ -std=c++17 -fsyntax-only -I<zvec>/src/include -I<zvec>/src -I<this repo>/include plugin/hip_plugin.cc
+// (__graft_entry__.build() runs exactly this when /root/reference is present; nothing of the reference is copied or
+// shipped.)  Interfaces implemented, all pure virtuals included:
+//   IndexStreamer   src/include/zvec/core/framework/index_streamer.h:29-53   init/open/flush/close/meta
+//   IndexSearcher   src/include/zvec/core/framework/index_searcher.h:30-54   init/meta/params/load
+//   IndexRunner     src/include/zvec/core/framework/index_runner.h:400-740   stats/cleanup/unload/create_context/
+//                   create_provider/get_vector*/add_impl/search_impl x2/search_bf_impl x2/search_bf_by_p_keys_impl
+//   IndexContext    src/include/zvec/core/framework/index_context.h:57-262   set_topk/topk/result/mutable_result/
+//                   update/magic/reset/set_fetch_vector (+ inherited filter(), threshold())
+//   registration    src/include/zvec/core/framework/index_factory.h:237-250
+//
+// Division of labour: persistence stays with the reference's own operators and storage engine (out of scope for the
+// GPU core) — the mutable flat streamer WRAPS the registered "FlatStreamer" for open / add / flush / get_vector and
+// mirrors the rows into HBM; the immutable searchers read the dumped segments through IndexStorage exactly as
+// FlatSearcher::load / IVFSearcher::load do and hand the payloads to the loaders of the C ABI.  Every search goes to
+// the GPU; there is no CPU fallback (a missing device makes open / load fail with the ABI's error).
+#include <zvec/core/framework/index_factory.h>
+#include <zvec/core/framework/index_helper.h>
+#include <zvec/core/framework/index_searcher.h>
+#include <zvec/core/framework/index_segment_storage.h>
+#include <zvec/core/framework/index_streamer.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <type_traits>
+#include <unordered_map>
+#include <vector>
+
+#include "zvec_hip.h"
+
+namespace zvec {
+namespace core {
+
+namespace {
+
+// parameter keys of the operators this plugin stands in for
+const std::string kParamScanRatio("proxima.ivf.searcher.scan_ratio");                       // ivf_params.h:44-45
+const std::string kParamBruteForceThreshold("proxima.ivf.searcher.brute_force_threshold");  // ivf_params.h:46-47
+const std::string kParamHipDevice("proxima.hip.device");                                    // new: HIP device ordinal
+
+// segment ids (flat_utility.h:32-34, ivf_index_format.h:152-164)
+const std::string kFlatKeys("flat.keys"), kFlatFeatures("flat.features");
+const std::string kIvfCentroid("ivf.centroid"), kIvfBody("ivf.inverted_body"), kIvfHeader("ivf.inverted_header"),
+    kIvfMeta("ivf.inverted_meta"), kIvfKeys("hc.keys");
+
+int metric_of(const IndexMeta &meta) {          // names chosen in src/core/interface/index.cc:47-106
+  const std::string &m = meta.metric_name();
+  if (m == "SquaredEuclidean") return ZVEC_HIP_METRIC_L2;
+  if (m == "InnerProduct") return ZVEC_HIP_METRIC_IP;
+  if (m == "Cosine") return ZVEC_HIP_METRIC_COSINE;
+  return -1;
+}
+
+int dtype_of(const IndexMeta &meta) {
+  if (meta.data_type() == IndexMeta::DT_FP32) return ZVEC_HIP_DT_FP32;
+  if (meta.data_type() == IndexMeta::DT_FP16) return ZVEC_HIP_DT_FP16;
+  return -1;
+}
+
+// whole payload of a segment as one contiguous host buffer
+int read_segment(IndexStorage *stg, const std::string &id, std::string *out, int level = -1) {
+  auto seg = stg->get(id, level);
+  if (!seg) return IndexError_NoExist;
+  out->resize(seg->data_size());
+  if (seg->fetch(0, &(*out)[0], out->size()) != out->size()) return IndexError_ReadData;
+  return 0;
+}
+
+}  // namespace
+
+/*! Search context: one per caller thread (index.cc:24-45 caches it thread-local per index type and may hand it to
+ *  another index instance of that type => magic re-binding, flat_streamer.cc:319-321 / ivf_streamer.cc:198-202).
+ *  The HIP side (stream + workspace, zvec_hip_ctx_t) is index-agnostic, so re-binding is only bookkeeping. */
+class HipContext : public IndexContext {
+ public:
+  HipContext(int device, uint32_t magic) : magic_(magic) { rc_ = zvec_hip_ctx_create(device, &h_); }
+  ~HipContext() override { if (h_) zvec_hip_ctx_destroy(h_); }
+
+  void set_topk(uint32_t k) override { topk_ = k; }
+  uint32_t topk() const override { return topk_; }
+  void set_fetch_vector(bool on) override { fetch_vector_ = on; }
+  bool fetch_vector() const override { return fetch_vector_; }
+  const IndexDocumentList &result() const override { return results_[0]; }
+  const IndexDocumentList &result(size_t i) const override { return results_[i]; }
+  IndexDocumentList *mutable_result(size_t i) override { return &results_[i]; }
+  uint32_t magic() const override { return magic_; }
+  void reset() override { results_.assign(1, IndexDocumentList()); }
+  //! IVFSearcherContext::update (ivf_searcher_context.h:61-79); flat contexts ignore it (flat_searcher_context.h)
+  int update(const ailego::Params &params) override {
+    params.get(kParamBruteForceThreshold, &bruteforce_threshold_);
+    params.get(kParamScanRatio, &scan_ratio_);
+    if (scan_ratio_ <= 0.0f) return IndexError_InvalidArgument;
+    return 0;
+  }
+  void set_bruteforce_threshold(uint32_t v) override { bruteforce_threshold_ = v; }
+
+  //! key/score arrays of one batched call -> per-query IndexDocumentList (topk_to_result: lists end at the
+  //! RNN threshold, which the device gate already applied)
+  void fill(uint32_t count, uint32_t k, const uint64_t *keys, const float *scores, const uint32_t *n) {
+    results_.assign(count, IndexDocumentList());
+    for (uint32_t q = 0; q < count; ++q) {
+      results_[q].reserve(n[q]);
+      for (uint32_t j = 0; j < n[q]; ++j) results_[q].emplace_back(keys[size_t(q) * k + j], scores[size_t(q) * k + j]);
+    }
+  }
+
+  zvec_hip_ctx_t h_{nullptr};
+  int rc_{0};
+  uint32_t topk_{0}, magic_{0};
+  bool fetch_vector_{false};
+  float scan_ratio_{0.1f};                  // ivf_searcher_context.h:211-213 defaults
+  uint32_t bruteforce_threshold_{1000};
+  std::vector<IndexDocumentList> results_{1};
+  std::vector<uint64_t> bits_, keys_;
+  std::vector<float> scores_;
+  std::vector<uint32_t> counts_;
+  std::string vectors_;                     // fetch_vector payload the documents point into (valid until the next search)
+};
+
+namespace {
+
+//! H4: IndexFilter is an opaque std::function<bool(uint64_t)> (index_filter.h:48-50, true = exclude); swept once over
+//! the keys in storage order into the 1-bit-per-position exclude set the scan kernels gate on
+const uint64_t *sweep_filter(HipContext *ctx, const uint64_t *keys, size_t n) {
+  if (!ctx->filter().is_valid()) return nullptr;
+  ctx->bits_.assign((n + 63) / 64, 0);
+  for (size_t i = 0; i < n; ++i)
+    if (ctx->filter()(keys[i])) ctx->bits_[i >> 6] |= 1ull << (i & 63);
+  return ctx->bits_.data();
+}
+
+HipContext *bind(IndexContext::Pointer &c, uint32_t magic) {
+  auto *ctx = dynamic_cast<HipContext *>(c.get());
+  if (!ctx || ctx->rc_ != 0 || ctx->topk() == 0) return nullptr;   // "Invalid context or topk not set yet"
+  if (ctx->magic_ != magic) { ctx->magic_ = magic; ctx->reset(); }
+  return ctx;
+}
+
+void size_outputs(HipContext *ctx, uint32_t count) {
+  const size_t k = ctx->topk();
+  ctx->keys_.resize(size_t(count) * k);
+  ctx->scores_.resize(size_t(count) * k);
+  ctx->counts_.resize(count);
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// flat, shared by the searcher and the streamer
+// =====================================================================================================================
+class HipFlatCore {
+ public:
+  ~HipFlatCore() { destroy(); }
+  int create(const IndexMeta &meta, int device) {
+    destroy();
+    const int metric = metric_of(meta), dtype = dtype_of(meta);
+    if (metric < 0 || dtype < 0) return IndexError_Unsupported;
+    device_ = device;
+    elem_size_ = meta.element_size();
+    return zvec_hip_flat_create(meta.dimension(), dtype, metric, device, &h_);
+  }
+  void destroy() {
+    if (h_) zvec_hip_flat_destroy(h_);
+    h_ = nullptr;
+    keys_.clear();
+    pos_of_key_.clear();
+  }
+  int append(const void *rows, size_t n, const uint64_t *keys) {
+    std::unique_lock<std::shared_mutex> w(mu_);
+    int rc = zvec_hip_flat_append(h_, rows, n, keys);
+    if (rc != 0) return rc;
+    for (size_t i = 0; i < n; ++i) {
+      pos_of_key_.emplace(keys[i], (uint32_t)keys_.size());
+      keys_.push_back(keys[i]);
+    }
+    return 0;
+  }
+  int search(const void *q, const IndexQueryMeta &qm, uint32_t count, HipContext *ctx) const {
+    if (!q || qm.element_size() != elem_size_) return IndexError_InvalidArgument;
+    std::shared_lock<std::shared_mutex> r(mu_);
+    size_outputs(ctx, count);
+    const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());
+    int rc = zvec_hip_flat_search(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), bits, ctx->keys_.data(),
+                                  ctx->scores_.data(), ctx->counts_.data());
+    if (rc != 0) return rc;
+    ctx->fill(count, ctx->topk(), ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+    return attach_vectors(ctx, count);
+  }
+  //! search_bf_by_p_keys_impl (flat_streamer.cc:346-389): unknown keys are skipped, as get_vector_by_key != 0 -> continue
+  int search_by_keys(const void *q, const std::vector<std::vector<uint64_t>> &p_keys, const IndexQueryMeta &qm,
+                     uint32_t count, HipContext *ctx) const {
+    if (!q || qm.element_size() != elem_size_ || p_keys.size() != count) return IndexError_InvalidArgument;
+    std::shared_lock<std::shared_mutex> r(mu_);
+    std::vector<uint32_t> ids, offs(count + 1, 0);
+    for (uint32_t i = 0; i < count; ++i) {
+      for (uint64_t key : p_keys[i]) {
+        auto it = pos_of_key_.find(key);
+        if (it != pos_of_key_.end()) ids.push_back(it->second);
+      }
+      offs[i + 1] = (uint32_t)ids.size();
+    }
+    if (ids.empty()) ids.push_back(0);
+    size_outputs(ctx, count);
+    const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());
+    int rc = zvec_hip_flat_search_by_ids(h_, ctx->h_, q, count, ids.data(), offs.data(), ctx->topk(), ctx->threshold(), bits,
+                                         ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+    if (rc != 0) return rc;
+    ctx->fill(count, ctx->topk(), ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+    return attach_vectors(ctx, count);
+  }
+  int vector_of_key(uint64_t key, void *out) const {
+    std::shared_lock<std::shared_mutex> r(mu_);
+    auto it = pos_of_key_.find(key);
+    return it == pos_of_key_.end() ? (int)IndexError_NoExist : zvec_hip_flat_get_vector(h_, it->second, out);
+  }
+  int vector_of_pos(uint32_t pos, void *out) const { return zvec_hip_flat_get_vector(h_, pos, out); }
+  zvec_hip_flat_t handle() const { return h_; }
+  size_t count() const { return keys_.size(); }
+  void adopt_keys(const uint64_t *keys, size_t n) {
+    keys_.assign(keys, keys + n);
+    for (size_t i = 0; i < n; ++i) pos_of_key_.emplace(keys[i], (uint32_t)i);
+  }
+
+ private:
+  //! IndexContext::set_fetch_vector (index.cc:635-647): the stored vectors of the result documents, one gather launch
+  int attach_vectors(HipContext *ctx, uint32_t count) const {
+    if (!ctx->fetch_vector()) return 0;
+    std::vector<uint64_t> pos;
+    for (uint32_t q = 0; q < count; ++q)
+      for (auto &d : ctx->results_[q]) pos.push_back(pos_of_key_.at(d.key()));
+    ctx->vectors_.resize(pos.size() * elem_size_);
+    if (pos.empty()) return 0;
+    int rc = zvec_hip_flat_get_vectors(h_, pos.data(), pos.size(), &ctx->vectors_[0]);
+    if (rc != 0) return rc;
+    size_t j = 0;
+    for (uint32_t q = 0; q < count; ++q)
+      for (auto &d : ctx->results_[q]) {
+        d = IndexDocument(d.key(), d.score(), (uint32_t)pos[j], ctx->vectors_.data() + j * elem_size_);
+        ++j;
+      }
+    return 0;
+  }
+
+  zvec_hip_flat_t h_{nullptr};
+  int device_{0};
+  uint32_t elem_size_{0};
+  mutable std::shared_mutex mu_;          // add (exclusive) vs search (shared): flat_streamer.cc:236-242
+  std::vector<uint64_t> keys_;            // key of every storage position
+  std::unordered_map<uint64_t, uint32_t> pos_of_key_;
+};
+
+/*! "HipFlatSearcher": stands where FlatSearcher<32> is registered (flat_searcher.cc:247-250). */
+class HipFlatSearcher : public IndexSearcher {
+ public:
+  int init(const ailego::Params &params) override {
+    params_ = params;
+    params.get(kParamHipDevice, &device_);
+    return 0;
+  }
+  int cleanup() override { return this->unload(); }
+  //! FlatSearcher::load (flat_searcher.cc:68-157): meta + "flat.keys" + "flat.features" (row-major, or 32-row blocks
+  //! transposed for a column-major index, flat_builder.cc:188-276) -> HBM
+  int load(IndexStorage::Pointer stg, IndexMetric::Pointer /*metric*/) override {
+    if (!stg) return IndexError_InvalidArgument;
+    int rc = IndexHelper::DeserializeFromStorage(stg.get(), &meta_);
+    if (rc != 0) return rc;
+    std::string keys, features;
+    if ((rc = read_segment(stg.get(), kFlatKeys, &keys)) != 0) return rc;
+    if ((rc = read_segment(stg.get(), kFlatFeatures, &features)) != 0) return rc;
+    if (keys.size() % sizeof(uint64_t) != 0) return IndexError_InvalidLength;
+    const size_t n = keys.size() / sizeof(uint64_t);
+    if (n * meta_.element_size() != features.size()) return IndexError_Mismatch;
+    if ((rc = core_.create(meta_, device_)) != 0) return rc;
+    rc = zvec_hip_flat_load_features(core_.handle(), features.data(), features.size(), n,
+                                     meta_.major_order() == IndexMeta::MO_COLUMN, 32,
+                                     reinterpret_cast<const uint64_t *>(keys.data()));
+    if (rc != 0) return rc;
+    core_.adopt_keys(reinterpret_cast<const uint64_t *>(keys.data()), n);
+    magic_ = IndexContext::GenerateMagic();
+    stats_.set_loaded_count(n);
+    return 0;
+  }
+  int unload() override { core_.destroy(); return 0; }
+  const Stats &stats() const override { return stats_; }
+  const IndexMeta &meta() const override { return meta_; }
+  const ailego::Params &params() const override { return params_; }
+  Context::Pointer create_context() const override { return Context::Pointer(new HipContext(device_, magic_)); }
+  int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
+  int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
+    HipContext *ctx = bind(c, magic_);
+    return ctx ? core_.search(q, qm, count, ctx) : (int)IndexError_InvalidArgument;
+  }
+  int search_bf_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
+  int search_bf_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
+    return search_impl(q, qm, count, c);
+  }
+  int search_bf_by_p_keys_impl(const void *q, const std::vector<std::vector<uint64_t>> &p_keys, const IndexQueryMeta &qm,
+                               Context::Pointer &c) const override {
+    return search_bf_by_p_keys_impl(q, p_keys, qm, 1, c);
+  }
+  int search_bf_by_p_keys_impl(const void *q, const std::vector<std::vector<uint64_t>> &p_keys, const IndexQueryMeta &qm,
+                               uint32_t count, Context::Pointer &c) const override {
+    HipContext *ctx = bind(c, magic_);
+    return ctx ? core_.search_by_keys(q, p_keys, qm, count, ctx) : (int)IndexError_InvalidArgument;
+  }
+
+ private:
+  IndexMeta meta_;
+  ailego::Params params_;
+  Stats stats_;
+  int device_{0};
+  uint32_t magic_{0};
+  HipFlatCore core_;
+};
+
+/*! "HipFlatStreamer": stands where FlatStreamer<32> is registered (flat_streamer.cc:486-489).  Persistence (linked
+ *  32-vector blocks in the storage, flat_streamer_entity.cc:43-47) stays with the wrapped reference streamer; its rows
+ *  are mirrored in HBM, where every search runs. */
+class HipFlatStreamer : public IndexStreamer {
+ public:
+  int init(const IndexMeta &meta, const ailego::Params &params) override {
+    meta_ = meta;
+    params.get(kParamHipDevice, &device_);
+    if (metric_of(meta) < 0 || dtype_of(meta) < 0) return IndexError_Unsupported;
+    store_ = IndexFactory::CreateStreamer("FlatStreamer");
+    if (!store_) return IndexError_NoExist;
+    return store_->init(meta, params);
+  }
+  int cleanup() override { core_.destroy(); return store_ ? store_->cleanup() : 0; }
+  int open(IndexStorage::Pointer stg) override {
+    int rc = store_->open(std::move(stg));
+    if (rc != 0) return rc;
+    if ((rc = core_.create(meta_, device_)) != 0) return rc;
+    // rows already persisted: walk the reference streamer's provider (key, vector) in storage order
+    auto provider = store_->create_provider();
+    if (provider) {
+      const size_t es = meta_.element_size(), chunk = 16384;
+      std::string rows;
+      std::vector<uint64_t> keys;
+      for (auto it = provider->create_iterator(); it && it->is_valid(); it->next()) {
+        rows.append(static_cast<const char *>(it->data()), es);
+        keys.push_back(it->key());
+        if (keys.size() == chunk) {
+          if ((rc = core_.append(rows.data(), keys.size(), keys.data())) != 0) return rc;
+          rows.clear();
+          keys.clear();
+        }
+      }
+      if (!keys.empty() && (rc = core_.append(rows.data(), keys.size(), keys.data())) != 0) return rc;
+    }
+    magic_ = IndexContext::GenerateMagic();
+    return 0;
+  }
+  int flush(uint64_t check_point) override { return store_->flush(check_point); }
+  int close() override { core_.destroy(); return store_->close(); }
+  const IndexMeta &meta() const override { return meta_; }
+  const Stats &stats() const override { return store_->stats(); }
+  int dump(const IndexDumper::Pointer &dumper) override { return store_->dump(dumper); }
+  Context::Pointer create_context() const override { return Context::Pointer(new HipContext(device_, magic_)); }
+  Provider::Pointer create_provider() const override { return store_->create_provider(); }
+  const void *get_vector(uint64_t key) const override { return store_->get_vector(key); }
+  int get_vector(const uint64_t key, IndexStorage::MemoryBlock &block) const override { return store_->get_vector(key, block); }
+  int get_vector_by_key(const uint64_t key, IndexStorage::MemoryBlock &block) const override {
+    return store_->get_vector_by_key(key, block);
+  }
+  int get_vector_by_id(const uint32_t id, IndexStorage::MemoryBlock &block) const override {
+    return store_->get_vector_by_id(id, block);
+  }
+  //! add_impl / add_with_id_impl (index_runner.h:476-487): persist through the reference streamer, then mirror
+  int add_impl(uint64_t key, const void *vec, const IndexQueryMeta &qm, Context::Pointer &c) override {
+    if (!vec || qm.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
+    Context::Pointer none;
+    int rc = store_->add_impl(key, vec, qm, none);
+    (void)c;
+    return rc != 0 ? rc : core_.append(vec, 1, &key);
+  }
+  int add_with_id_impl(uint32_t id, const void *vec, const IndexQueryMeta &qm, Context::Pointer &c) override {
+    if (!vec || qm.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
+    Context::Pointer none;
+    int rc = store_->add_with_id_impl(id, vec, qm, none);
+    (void)c;
+    const uint64_t key = id;
+    return rc != 0 ? rc : core_.append(vec, 1, &key);
+  }
+  int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
+  int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
+    HipContext *ctx = bind(c, magic_);
+    return ctx ? core_.search(q, qm, count, ctx) : (int)IndexError_InvalidArgument;
+  }
+  int search_bf_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
+  int search_bf_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
+    return search_impl(q, qm, count, c);
+  }
+  int search_bf_by_p_keys_impl(const void *q, const std::vector<std::vector<uint64_t>> &p_keys, const IndexQueryMeta &qm,
+                               Context::Pointer &c) const override {
+    return search_bf_by_p_keys_impl(q, p_keys, qm, 1, c);
+  }
+  int search_bf_by_p_keys_impl(const void *q, const std::vector<std::vector<uint64_t>> &p_keys, const IndexQueryMeta &qm,
+                               uint32_t count, Context::Pointer &c) const override {
+    HipContext *ctx = bind(c, magic_);
+    return ctx ? core_.search_by_keys(q, p_keys, qm, count, ctx) : (int)IndexError_InvalidArgument;
+  }
+
+ private:
+  IndexMeta meta_;
+  int device_{0};
+  uint32_t magic_{0};
+  IndexStreamer::Pointer store_;          // the reference's FlatStreamer: storage engine side
+  HipFlatCore core_;
+};
+
+// =====================================================================================================================
+// IVF-Flat
+// =====================================================================================================================
+class HipIVFCore {
+ public:
+  ~HipIVFCore() { destroy(); }
+  void destroy() {
+    if (h_) zvec_hip_ivf_destroy(h_);
+    h_ = nullptr;
+    keys_.clear();
+  }
+  //! IVFSearcher::load (ivf_searcher.cc:43-103) + IVFEntity::load (ivf_entity.cc:443-570): the centroid index is a
+  //! nested flat index inside the "ivf.centroid" segment; the inverted lists come as header / meta / body / keys
+  int load(IndexStorage *stg, IndexMeta *meta, int device) {
+    destroy();
+    int rc = IndexHelper::DeserializeFromStorage(stg, meta);
+    if (rc != 0) return rc;
+    const int metric = metric_of(*meta), dtype = dtype_of(*meta);
+    if (metric < 0 || dtype < 0) return IndexError_Unsupported;
+    elem_size_ = meta->element_size();
+    // centroid rows: features of the nested FlatSearcher index, put in centroid-id order
+    auto cseg = stg->get(kIvfCentroid, 0);
+    if (!cseg) return IndexError_InvalidFormat;
+    IndexStorage::Pointer nested = std::make_shared<IndexSegmentStorage>(cseg);
+    if ((rc = nested->open(std::string(), false)) != 0) return rc;
+    IndexMeta cmeta;
+    if ((rc = IndexHelper::DeserializeFromStorage(nested.get(), &cmeta)) != 0) return rc;
+    if (cmeta.element_size() != elem_size_) return IndexError_Unsupported;   // (converted / quantised centroid index)
+    std::string ckeys, cfeat;
+    if ((rc = read_segment(nested.get(), kFlatKeys, &ckeys)) != 0) return rc;
+    if ((rc = read_segment(nested.get(), kFlatFeatures, &cfeat)) != 0) return rc;
+    const size_t nlist = ckeys.size() / sizeof(uint64_t);
+    if (nlist == 0 || nlist * elem_size_ != cfeat.size()) return IndexError_Mismatch;
+    std::string centroids(cfeat.size(), '\0');
+    const uint64_t *ck = reinterpret_cast<const uint64_t *>(ckeys.data());
+    const size_t unit = IndexMeta::AlignSizeof(cmeta.data_type()), cols = elem_size_ / unit;
+    const bool colmajor = cmeta.major_order() == IndexMeta::MO_COLUMN;
+    for (size_t i = 0; i < nlist; ++i) {
+      if (ck[i] >= nlist) return IndexError_InvalidFormat;
+      char *dst = &centroids[ck[i] * elem_size_];
+      const size_t blk = i / 32, r = i % 32;
+      if (colmajor && (blk + 1) * 32 <= nlist) {             // full 32-row block, transposed in units (flat_builder.cc:231-262)
+        const char *b0 = cfeat.data() + blk * 32 * elem_size_;
+        for (size_t u = 0; u < cols; ++u) memcpy(dst + u * unit, b0 + (u * 32 + r) * unit, unit);
+      } else {
+        memcpy(dst, cfeat.data() + i * elem_size_, elem_size_);
+      }
+    }
+    std::string header, lmeta, body, keys;
+    if ((rc = read_segment(stg, kIvfHeader, &header)) != 0) return rc;
+    if ((rc = read_segment(stg, kIvfMeta, &lmeta)) != 0) return rc;
+    if ((rc = read_segment(stg, kIvfBody, &body)) != 0) return rc;
+    if ((rc = read_segment(stg, kIvfKeys, &keys)) != 0) return rc;
+    if ((rc = zvec_hip_ivf_create(meta->dimension(), dtype, metric, device, &h_)) != 0) return rc;
+    rc = zvec_hip_ivf_load_segments(h_, header.data(), header.size(), lmeta.data(), lmeta.size(), body.data(), body.size(),
+                                    keys.data(), keys.size(), centroids.data());
+    if (rc != 0) return rc;
+    keys_.assign(reinterpret_cast<const uint64_t *>(keys.data()),
+                 reinterpret_cast<const uint64_t *>(keys.data()) + keys.size() / sizeof(uint64_t));
+    nlist_ = (uint32_t)nlist;
+    return 0;
+  }
+  //! IVFSearcher::search_impl / search_bf_impl (ivf_searcher.cc:106-250)
+  int search(const void *q, const IndexQueryMeta &qm, uint32_t count, HipContext *ctx, bool brute_force) const {
+    if (!q || qm.element_size() != elem_size_) return IndexError_InvalidArgument;
+    size_outputs(ctx, count);
+    const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());    // keys in list order (ivf_entity.cc:612)
+    int rc;
+    if (brute_force || keys_.size() <= ctx->bruteforce_threshold_) {         // ivf_searcher.cc:188-190
+      rc = zvec_hip_ivf_search_bf(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), bits, ctx->keys_.data(),
+                                  ctx->scores_.data(), ctx->counts_.data());
+    } else {
+      // IVFSearcherContext::update (ivf_searcher_context.h:70-78): float arithmetic, std::round / std::ceil
+      const uint32_t nprobe = std::max(static_cast<uint32_t>(std::round(nlist_ * ctx->scan_ratio_)), 1u);
+      uint32_t max_scan = static_cast<uint32_t>(std::ceil(keys_.size() * ctx->scan_ratio_));
+      max_scan = std::max(ctx->bruteforce_threshold_, max_scan);
+      rc = zvec_hip_ivf_search(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits,
+                               ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+    }
+    if (rc != 0) return rc;
+    ctx->fill(count, ctx->topk(), ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+    return 0;
+  }
+  size_t count() const { return keys_.size(); }
+  zvec_hip_ivf_t handle() const { return h_; }
+
+ private:
+  zvec_hip_ivf_t h_{nullptr};
+  uint32_t elem_size_{0}, nlist_{0};
+  std::vector<uint64_t> keys_;
+};
+
+/*! "HipIVFSearcher": stands where IVFSearcher is registered (ivf_searcher.cc). */
+class HipIVFSearcher : public IndexSearcher {
+ public:
+  int init(const ailego::Params &params) override {
+    params_ = params;
+    params.get(kParamHipDevice, &device_);
+    return 0;
+  }
+  int cleanup() override { return this->unload(); }
+  int load(IndexStorage::Pointer stg, IndexMetric::Pointer /*metric*/) override {
+    if (!stg) return IndexError_InvalidArgument;
+    int rc = core_.load(stg.get(), &meta_, device_);
+    if (rc != 0) return rc;
+    magic_ = IndexContext::GenerateMagic();
+    stats_.set_loaded_count(core_.count());
+    return 0;
+  }
+  int unload() override { core_.destroy(); return 0; }
+  const Stats &stats() const override { return stats_; }
+  const IndexMeta &meta() const override { return meta_; }
+  const ailego::Params &params() const override { return params_; }
+  Context::Pointer create_context() const override {
+    auto *ctx = new HipContext(device_, magic_);
+    ctx->update(params_);
+    return Context::Pointer(ctx);
+  }
+  int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
+  int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
+    HipContext *ctx = bind(c, magic_);
+    return ctx ? core_.search(q, qm, count, ctx, false) : (int)IndexError_InvalidArgument;
+  }
+  int search_bf_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_bf_impl(q, qm, 1, c); }
+  int search_bf_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
+    HipContext *ctx = bind(c, magic_);
+    return ctx ? core_.search(q, qm, count, ctx, true) : (int)IndexError_InvalidArgument;
+  }
+
+ private:
+  IndexMeta meta_;
+  ailego::Params params_;
+  Stats stats_;
+  int device_{0};
+  uint32_t magic_{0};
+  HipIVFCore core_;
+};
+
+/*! "HipIVFStreamer": what the product instantiates (indexes/ivf_index.cc:38-39).  Like the reference's IVFStreamer
+ *  (ivf_streamer.h:28-85) it only opens, searches and closes a dumped index: no add_impl. */
+class HipIVFStreamer : public IndexStreamer {
+ public:
+  int init(const IndexMeta &meta, const ailego::Params &params) override {
+    meta_ = meta;
+    params_ = params;
+    params.get(kParamHipDevice, &device_);
+    return 0;
+  }
+  int cleanup() override { core_.destroy(); return 0; }
+  int open(IndexStorage::Pointer stg) override {
+    if (!stg) return IndexError_InvalidArgument;
+    int rc = core_.load(stg.get(), &meta_, device_);
+    if (rc != 0) return rc;
+    magic_ = IndexContext::GenerateMagic();
+    stats_.set_loaded_count(core_.count());
+    return 0;
+  }
+  int flush(uint64_t /*check_point*/) override { return 0; }      // immutable: nothing to persist
+  int close() override { core_.destroy(); return 0; }
+  const IndexMeta &meta() const override { return meta_; }
+  const Stats &stats() const override { return stats_; }
+  Context::Pointer create_context() const override {
+    auto *ctx = new HipContext(device_, magic_);
+    ctx->update(params_);
+    return Context::Pointer(ctx);
+  }
+  int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
+  int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
+    HipContext *ctx = bind(c, magic_);
+    return ctx ? core_.search(q, qm, count, ctx, false) : (int)IndexError_InvalidArgument;
+  }
+  int search_bf_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_bf_impl(q, qm, 1, c); }
+  int search_bf_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
+    HipContext *ctx = bind(c, magic_);
+    return ctx ? core_.search(q, qm, count, ctx, true) : (int)IndexError_InvalidArgument;
+  }
+
+ private:
+  IndexMeta meta_;
+  ailego::Params params_;
+  Stats stats_;
+  int device_{0};
+  uint32_t magic_{0};
+  HipIVFCore core_;
+};
+
+static_assert(!std::is_abstract<HipContext>::value && !std::is_abstract<HipFlatStreamer>::value &&
+                  !std::is_abstract<HipFlatSearcher>::value && !std::is_abstract<HipIVFSearcher>::value &&
+                  !std::is_abstract<HipIVFStreamer>::value,
+              "every pure virtual of IndexContext / IndexStreamer / IndexSearcher / IndexRunner is implemented");
+
+// New names keep the CPU classes selectable; registering under "FlatStreamer" / "IVFStreamer" instead would shadow
+// them (the factory map insert overwrites, src/include/zvec/ailego/pattern/factory.h:120-122).
+INDEX_FACTORY_REGISTER_STREAMER_ALIAS(HipFlatStreamer, HipFlatStreamer);
+INDEX_FACTORY_REGISTER_SEARCHER_ALIAS(HipFlatSearcher, HipFlatSearcher);
+INDEX_FACTORY_REGISTER_SEARCHER_ALIAS(HipIVFSearcher, HipIVFSearcher);
+INDEX_FACTORY_REGISTER_STREAMER_ALIAS(HipIVFStreamer, HipIVFStreamer);
+
+}  // namespace core
+}  // namespace zvec

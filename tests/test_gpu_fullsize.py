@@ -4,6 +4,9 @@ cannot scan 10M x 768 for hundreds of queries in seconds) plus oracle spot check
   configs[0]  Flat L2, SIFT-1M-shaped (1M x 128, uint8-valued fp32), batch 1      -> bit-exact vs oracle
   configs[1]  Flat IP, 1M x 768 fp32, batch 256                                   -> self-query / order / oracle spot
   configs[2]  IVF-Flat nlist 4096, 10M x 768 fp32, batch 1024                     -> bf==flat, shard union, self-query
+  configs[3]  IVF-Flat nlist 16384, 100M x 768 fp16 over 8 GPUs: ONE rank's share  -> shard 0 of 8 (12.5M rows, 19.2 GB)
+              held on this GPU, built streamed (the corpus is never resident): byte balance, self-query, keys stay
+              inside the shard, oracle spot check on the probed lists
   configs[4]  filtered scan, 10M x 768 + bitmap, batch 512                        -> gate respected, equals unfiltered∖mask
 Data is generated on the GPU with torch (seeded), indexes are built through the C ABI."""
 import numpy as np
@@ -180,3 +183,82 @@ def test_config4_filtered_scan_10m_bitmap_batch512(zv, ten_million):
             if len(allowed) >= k:
                 assert [kk for _, kk in allowed[:k]] == fk[i].tolist() or np.array_equal(
                     np.array([s for s, _ in allowed[:k]], np.float32), fs[i])
+
+
+def test_config3_ivf_100m_768_fp16_one_rank_share(zv, oracle):
+    """BASELINE configs[3] at one rank's real share: shard 0 of 8 of a 100M x 768 fp16, nlist-16384 index on ONE GPU.
+    The corpus (153.6 GB) is generated chunk by chunk three times and never held: sample -> k-means, labels of all 100M
+    rows (ivf_builder.h:253-274 on the GPU), then only the rows of the lists the byte-balanced map gives shard 0 are
+    kept.  Arithmetic under test: fp16 rows, fp32 accumulation (euclidean_distance_matrix_fp16.cc:137,
+    distance_matrix_accum_fp16.i:554-594); search loop ivf_searcher.cc:217-247."""
+    from tests.util import lpt_owner
+    stream = _stream()
+    dev = torch.device("cuda", 0)
+    n, dim, r, nlist, nshards, nq, k, nprobe = 100_000_000, 768, 12, 16384, 8, 1024, 10, 64
+    chunk = 1 << 21
+    pg = torch.Generator(device=dev)
+    pg.manual_seed(20260324)
+    proj = torch.randn((r, dim), generator=pg, device=dev)
+
+    def chunks():
+        g = torch.Generator(device=dev)
+        g.manual_seed(20260325)
+        for o in range(0, n, chunk):
+            m = min(chunk, n - o)
+            x = torch.mm(torch.randn((m, r), generator=g, device=dev), proj)
+            x += torch.randn((m, dim), generator=g, device=dev) * 0.02
+            yield o, x.half()
+
+    ivf = zv.HipIVFSearcher(dim, "SquaredEuclidean", dtype="fp16")
+    assert ivf.set_shard(0, nshards) == 0
+    S = 64 * nlist                                            # the first 1M rows (i.i.d. rows: any subset is a sample)
+    sample = torch.cat([x for o, x in chunks() if o < S])[:S].contiguous()
+    assert ivf.train_dev(sample.data_ptr(), S, nlist, kmeans_iters=4, seed=3, stream=stream) == 0
+    del sample
+    labels = torch.empty((n,), dtype=torch.int32, device=dev)
+    for o, x in chunks():
+        assert ivf.label_dev(x.data_ptr(), x.shape[0], labels[o:o + x.shape[0]].data_ptr(), stream=stream) == 0
+    lab = labels.cpu().numpy().astype(np.uint32)
+    del labels
+    sizes = np.bincount(lab, minlength=nlist).astype(np.uint32)
+    assert ivf.begin_lists(sizes) == 0
+    for o, x in chunks():
+        assert ivf.add_dev(x.data_ptr(), x.shape[0], lab[o:o + x.shape[0]], o, stream=stream) == 0
+    assert ivf.end_lists() == 0
+    # ---- the shard is what the byte-balanced map says, and the map is balanced ----
+    owner, shard_rows = zv.shard_map(sizes, nshards)
+    assert np.array_equal(owner, lpt_owner(sizes, nshards)) and np.array_equal(ivf.list_owners(), owner)
+    cnt, nl = ivf.info()
+    assert nl == nlist and cnt == int(shard_rows[0]) == int(sizes[owner == 0].sum())
+    assert shard_rows.max() <= 1.001 * shard_rows.mean()
+    assert 12_000_000 < cnt < 13_000_000                      # one eighth of 100M: 19.2 GB of fp16 rows in HBM
+    cent, offs, rows = ivf.export()
+    assert (lab[rows[::997].astype(np.int64)] == np.repeat(np.arange(nlist), np.diff(offs.astype(np.int64)))[::997]).all()
+    # ---- self-query: stored rows of the shard come back first with distance exactly 0 ----
+    rng = np.random.default_rng(5)
+    pos = np.sort(rng.choice(cnt, nq, replace=False)).astype(np.uint64)
+    hq = ivf.get_vectors_by_ids(pos)
+    q = torch.from_numpy(hq).to(dev)
+    ctx = ivf.create_context()
+    ctx.set_stream(stream)
+    gk, gs, gc = _search_dev(ivf, ctx, q, k, stream, args=(nprobe, n))
+    assert (gc == k).all() and np.all(np.diff(gs, axis=1) >= 0)
+    assert (gs[:, 0] == 0).all()
+    assert (gk[:, 0] == rows[pos.astype(np.int64)]).mean() > 0.999           # (exact duplicates aside)
+    # ---- every returned key lives in a list this shard owns ----
+    assert (owner[lab[gk.astype(np.int64).reshape(-1)]] == 0).all()
+    scanned, probes = ivf.last_stats(ctx, nq)
+    assert (probes == nprobe).all()
+    # ---- oracle spot check: 2 queries against the probed lists of the exported shard (same centroids, same order) ----
+    pk, _, _, pc = oracle.flat_search(cent, hq[:2], nprobe)                   # IVFCentroidIndex::search: top-nprobe centroids
+    need = np.unique(pk[:, :nprobe].astype(np.int64))
+    lsz = np.diff(offs.astype(np.int64))
+    sub_offs = np.zeros(nlist + 1, np.int64)
+    sub_offs[1:][need] = lsz[need]
+    sub_offs = np.cumsum(sub_offs)
+    idx = np.concatenate([np.arange(offs[l], offs[l + 1]) for l in need]).astype(np.uint64)
+    sub_vecs = ivf.get_vectors_by_ids(idx)
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, sub_offs.astype(np.uint64), sub_vecs, hq[:2], k, nprobe, n, keys=rows[idx.astype(np.int64)])
+    qn = (hq[:2].astype(np.float64) ** 2).sum(1)
+    tie_tolerant_compare(gk[:2], gs[:2], gc[:2], ok, os_, oc, rtol=2e-6, atol=1e-6, select_band=4e-6 * (2 * qn.max() + 1),
+                         what="100M fp16 shard oracle spot")
