@@ -279,11 +279,116 @@ static int TestMicroBatcher() {
   return 0;
 }
 
+// ctx == NULL from several threads (include/zvec_hip.h: "uses the handle's built-in context under a mutex"): the staged
+// queries / results of the built-in context must not be overwritten between upload, search and copy-out.  Flat and IVF,
+// every thread its own queries, compared with what a private context returns.
+static int TestNullContextFromManyThreads() {
+  const uint32_t dim = 24, n = 6000, nq = 40, topk = 8, threads = 6, rounds = 30, nlist = 12;
+  std::vector<float> base((size_t)n * dim);
+  uint32_t seed = 777;
+  auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)((int)((seed >> 10) % 41) - 20); };
+  for (auto &v : base) v = rnd();
+  zvec_hip_flat_t flat = nullptr;
+  ASSERT(0 == zvec_hip_flat_create(dim, ZVEC_HIP_DT_FP32, ZVEC_HIP_METRIC_L2, 0, &flat));
+  ASSERT(0 == zvec_hip_flat_append(flat, base.data(), n, nullptr));
+  // IVF over the same rows: centroids = the first nlist rows, lists = contiguous ranges
+  std::vector<uint64_t> offs(nlist + 1);
+  for (uint32_t l = 0; l <= nlist; ++l) offs[l] = (uint64_t)l * (n / nlist);
+  zvec_hip_ivf_t ivf = nullptr;
+  ASSERT(0 == zvec_hip_ivf_create(dim, ZVEC_HIP_DT_FP32, ZVEC_HIP_METRIC_L2, 0, &ivf));
+  ASSERT(0 == zvec_hip_ivf_load(ivf, base.data(), nlist, offs.data(), base.data(), nullptr));
+  std::vector<std::vector<float>> q(threads, std::vector<float>((size_t)nq * dim));
+  for (auto &v : q) for (auto &x : v) x = rnd();
+  struct Out { std::vector<uint64_t> k; std::vector<float> s; std::vector<uint32_t> c; };
+  auto mk = [&]() { Out o; o.k.assign((size_t)nq * topk, 0); o.s.assign((size_t)nq * topk, 0.f); o.c.assign(nq, 0); return o; };
+  std::vector<Out> want_f, want_i;
+  zvec_hip_ctx_t own = nullptr;
+  ASSERT(0 == zvec_hip_ctx_create(0, &own));
+  for (uint32_t t = 0; t < threads; ++t) {
+    Out a = mk(), b = mk();
+    ASSERT(0 == zvec_hip_flat_search(flat, own, q[t].data(), nq, topk, FLT_MAX, nullptr, a.k.data(), a.s.data(), a.c.data()));
+    ASSERT(0 == zvec_hip_ivf_search(ivf, own, q[t].data(), nq, topk, FLT_MAX, 4, n, nullptr, b.k.data(), b.s.data(), b.c.data()));
+    want_f.push_back(a); want_i.push_back(b);
+  }
+  std::atomic<int> bad{0};
+  std::vector<std::thread> th;
+  for (uint32_t t = 0; t < threads; ++t)
+    th.emplace_back([&, t]() {
+      for (uint32_t r = 0; r < rounds; ++r) {
+        Out a = mk(), b = mk();
+        if (zvec_hip_flat_search(flat, nullptr, q[t].data(), nq, topk, FLT_MAX, nullptr, a.k.data(), a.s.data(), a.c.data()) != 0 ||
+            zvec_hip_ivf_search(ivf, nullptr, q[t].data(), nq, topk, FLT_MAX, 4, n, nullptr, b.k.data(), b.s.data(), b.c.data()) != 0) { ++bad; continue; }
+        if (a.k != want_f[t].k || a.s != want_f[t].s || a.c != want_f[t].c) ++bad;
+        if (b.k != want_i[t].k || b.s != want_i[t].s || b.c != want_i[t].c) ++bad;
+        std::vector<float> row(dim);                         // get_vector shares the built-in context's staging buffer
+        if (zvec_hip_flat_get_vector(flat, (t * 37 + r) % n, row.data()) != 0 ||
+            memcmp(row.data(), &base[(size_t)((t * 37 + r) % n) * dim], dim * 4) != 0) ++bad;
+      }
+    });
+  for (auto &x : th) x.join();
+  EXPECT(bad.load() == 0);
+  zvec_hip_ctx_destroy(own);
+  zvec_hip_ivf_destroy(ivf);
+  zvec_hip_flat_destroy(flat);
+  return 0;
+}
+
+// add_impl from one thread while others search WITH a filter callback and fetch_vector (the mirror's host state —
+// the keys of the storage positions, the lazily built key -> position map — is shared between them)
+static int TestConcurrentAddWithFilterAndFetch() {
+  const uint32_t dim = 16, n0 = 2000, n1 = 6000, topk = 6;
+  IndexMeta meta(IndexMeta::DT_FP32, dim);
+  meta.set_metric("SquaredEuclidean");
+  HipFlatStreamer st;
+  ASSERT(0 == st.init(meta, Params()));
+  ASSERT(0 == st.open());
+  IndexQueryMeta qmeta(IndexMeta::DT_FP32, dim);
+  auto row = [&](uint64_t i) { std::vector<float> v(dim); for (uint32_t j = 0; j < dim; ++j) v[j] = (float)(i % 997) + (float)j; return v; };
+  Context::Pointer none;
+  for (uint64_t i = 0; i < n0; ++i) { auto v = row(i); ASSERT(0 == st.add_impl(i, v.data(), qmeta, none)); }
+  std::atomic<int> bad{0};
+  std::atomic<bool> done{false};
+  std::thread adder([&]() {
+    Context::Pointer c;
+    for (uint64_t i = n0; i < n1; ++i) { auto v = row(i); if (st.add_impl(i, v.data(), qmeta, c) != 0) ++bad; }
+    done = true;
+  });
+  std::vector<std::thread> th;
+  for (int t = 0; t < 3; ++t)
+    th.emplace_back([&, t]() {
+      auto ctx = st.create_context();
+      ctx->set_topk(topk);
+      ctx->set_fetch_vector(true);
+      ctx->set_filter([](uint64_t key) { return key % 2 == 1; });          // odd keys are filtered OUT
+      std::vector<float> q = row(100 + t);
+      int loops = 0;
+      while (!done.load() || loops < 3) {
+        ++loops;
+        if (st.search_impl(q.data(), qmeta, ctx) != 0) { ++bad; continue; }
+        const auto &r = ctx->result();
+        if (r.size() != topk) { ++bad; continue; }
+        for (const auto &d : r) {
+          if (d.key() % 2 == 1) ++bad;                                     // gate respected
+          auto want = row(d.key());                                        // the fetched vector is the document's row
+          if (d.vector().size() != dim * 4 || memcmp(d.vector().data(), want.data(), dim * 4) != 0) ++bad;
+        }
+        if (r[0].score() != 0.0f) ++bad;                                   // an even key with the query's row exists
+      }
+    });
+  adder.join();
+  for (auto &x : th) x.join();
+  EXPECT(bad.load() == 0);
+  EXPECT(st.count() == n1);
+  return 0;
+}
+
 int main() {
   int rc = 0;
   rc |= TestLinearSearch();
   rc |= TestFilter();
   rc |= TestIVFSimple();
+  rc |= TestNullContextFromManyThreads();
+  rc |= TestConcurrentAddWithFilterAndFetch();
   rc |= TestMicroBatcher();
   if (rc == 0 && g_fail == 0) { printf("host mirror: all tests passed\n"); return 0; }
   printf("host mirror: %d failures (rc=%d)\n", g_fail, rc);

@@ -391,3 +391,38 @@ def test_fetch_vector_results_carry_stored_rows(zv):
     for qi in range(nq):
         for doc in ictx.result(qi):
             assert np.array_equal(doc.vector(), base[key2row[doc.key()]])
+
+
+@pytest.mark.parametrize("metric", ["SquaredEuclidean", "InnerProduct"])
+def test_seeded_bounds_survive_large_common_offset(zv, oracle, metric):
+    """Seeded admission bounds (the main scan starts every query's bound at the k-th score of a 4096-row prefix scan):
+    with a large common offset the norms dwarf the distances, so the selection score of one row differs between the
+    prefix scan and the main scan (different tile shapes) by far more than 1e-6 of the SCORE.  All true neighbours sit
+    in the prefix (rows 0..k-1): a bound that is only score-relative drops them and the query comes back short.
+    Batch of 128 over a streamed base => the wide 128x128 path."""
+    rng = np.random.default_rng(31)
+    n, dim, nq, k = 300_000, 64, 128, 10
+    base = (1000.0 + rng.integers(0, 8, (n, dim))).astype(np.float32)
+    c = (1000.0 + rng.integers(0, 8, dim)).astype(np.float32)
+    if metric == "InnerProduct":
+        c += 8.0                                           # the largest inner products: rows closest to the biggest vector
+    for i in range(k):                                     # the k true neighbours, all inside the 4096-row prefix
+        base[i] = c
+        base[i, i % dim] += 1.0 if metric == "InnerProduct" else (i % 2) * 1.0
+    q = np.repeat(c[None, :], nq, 0)
+    q[np.arange(nq), rng.integers(0, dim, nq)] += 1.0      # 128 different queries around c
+    flat = zv.HipFlatSearcher(dim, metric)
+    assert flat.load(base) == 0
+    ctx = flat.create_context()
+    ctx.set_topk(k)
+    assert flat.search_impl(q, nq, ctx) == 0
+    assert (ctx.counts == k).all(), ctx.counts.min()
+    assert all(set(ctx.keys[i].tolist()) == set(range(k)) for i in range(nq))
+    m = O.METRIC_IP if metric == "InnerProduct" else O.METRIC_L2
+    ok, os_, _, oc = oracle.flat_search(base, q[:8], k, m, threads=8)
+    qn = (q[:8].astype(np.float64) ** 2).sum(1)
+    band = 4e-6 * (qn + (base[:k].astype(np.float64) ** 2).sum(1).max())
+    if metric == "InnerProduct":
+        tie_tolerant_compare(ctx.keys[:8], ctx.scores[:8], ctx.counts[:8], ok, os_, oc, rtol=4e-6, scale=float(qn.max()), what="offset ip")
+    else:
+        tie_tolerant_compare(ctx.keys[:8], ctx.scores[:8], ctx.counts[:8], ok, os_, oc, rtol=2e-6, atol=1e-6, select_band=band, what="offset l2")

@@ -66,6 +66,7 @@ int zvec_hip_flat_destroy(zvec_hip_flat_t h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   h->st.release();
+  if (h->append_ev) (void)hipEventDestroy(h->append_ev);
   ctx_free(h->defctx);
   delete h;
   return 0;
@@ -85,7 +86,16 @@ int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n, 
   std::unique_lock<std::shared_mutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(h->defctx, stream);
-  return store_append_dev(h->st, d_vecs, n, d_keys, s);
+  if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));   // (an earlier append on another stream)
+  int rc = store_append_dev(h->st, d_vecs, n, d_keys, s);
+  if (rc == 0 && n) {
+    // the row count is published now, the pack kernels are only enqueued on `s`: searches on other streams wait for
+    // this event before they read the store (flat_search_dev_locked)
+    if (!h->append_ev) ZCHK(hipEventCreateWithFlags(&h->append_ev, hipEventDisableTiming));
+    ZCHK(hipEventRecord(h->append_ev, s));
+    h->append_pending = true;
+  }
+  return rc;
 }
 
 // FlatSearcher::load of a dumped "flat.features"-style segment (FlatBuilder<32>::write_row_index / write_column_index,
@@ -160,10 +170,12 @@ int zvec_hip_flat_count(zvec_hip_flat_t h, uint64_t *count) {
 int zvec_hip_flat_get_vector(zvec_hip_flat_t h, uint64_t pos, void *out) {
   if (!h || !out) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
+  zvec_hip_ctx_s *c = h->defctx;
+  std::lock_guard<std::mutex> gc(c->mu);             // io_q is the built-in context's staging buffer
   std::shared_lock<std::shared_mutex> r(h->rw);
   if (pos >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
   ZCHK(hipSetDevice(h->device));
-  zvec_hip_ctx_s *c = h->defctx;
+  if (h->append_pending) ZCHK(hipStreamWaitEvent(c->own, h->append_ev, 0));
   ZRET(c->io_q.ensure(h->st.row_bytes()));
   ZRET(launch_unpack(h->st, pos, c->io_q.p, c->own));
   ZCHK(hipMemcpyAsync(out, c->io_q.p, h->st.row_bytes(), hipMemcpyDeviceToHost, c->own));
@@ -176,12 +188,31 @@ int zvec_hip_flat_get_vectors(zvec_hip_flat_t h, const uint64_t *positions, uint
   if (n == 0) return 0;
   if (n > 0x7fffffffull) return ZVEC_HIP_ERR_OUT_OF_RANGE;
   std::lock_guard<std::mutex> g(h->mu);
+  std::lock_guard<std::mutex> gc(h->defctx->mu);
   std::shared_lock<std::shared_mutex> r(h->rw);
   std::vector<uint64_t> pos(positions, positions + n);
   for (uint64_t p : pos)
     if (p >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
   ZCHK(hipSetDevice(h->device));
+  if (h->append_pending) ZCHK(hipStreamWaitEvent(h->defctx->own, h->append_ev, 0));
   return store_get_rows(h->defctx, h->st, pos, out);
+}
+
+// the flat search proper; the caller holds c->mu and h->rw (shared) and has validated the arguments
+static int flat_search_dev_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, const void *d_queries, uint32_t count, uint32_t topk,
+                                  float threshold, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys, float *d_out_scores,
+                                  uint32_t *d_out_counts, hipStream_t s) {
+  // rows appended through the asynchronous device-pointer form may still be in flight on another stream
+  if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));
+  // the kernels address the padded query matrix with 32-bit word offsets: very large batches go in slices
+  const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(h->st.dpad, 1u));
+  for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
+    const uint32_t m = std::min(maxq, count - q0);
+    ZRET(prep_queries(c, h->st, reinterpret_cast<const char *>(d_queries) + (size_t)q0 * h->st.row_bytes(), m, threshold, s));
+    SearchOut out{d_out_keys + (size_t)q0 * topk, d_out_scores + (size_t)q0 * topk, nullptr, d_out_counts + q0};
+    ZRET(flat_scan_prepared(c, h->st, m, topk, threshold, d_exclude_bitset, out, s, true));
+  }
+  return 0;
 }
 
 int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count,
@@ -191,24 +222,11 @@ int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *
   if (count == 0) return 0;
   if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;   // "Invalid context or topk not set yet" flat_searcher.cc:194
   zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
-  // the kernels address the padded query matrix with 32-bit word offsets: very large batches go in slices
-  const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(h->st.dpad, 1u));
-  if (count > maxq) {
-    for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
-      const uint32_t m = std::min(maxq, count - q0);
-      ZRET(zvec_hip_flat_search_dev(h, ctx, reinterpret_cast<const char *>(d_queries) + (size_t)q0 * h->st.row_bytes(), m, topk,
-                                    threshold, d_exclude_bitset, d_out_keys + (size_t)q0 * topk, d_out_scores + (size_t)q0 * topk,
-                                    d_out_counts + q0, stream));
-    }
-    return 0;
-  }
   std::lock_guard<std::mutex> g(c->mu);
   std::shared_lock<std::shared_mutex> r(h->rw);
   ZCHK(hipSetDevice(h->device));
-  hipStream_t s = pick_stream(c, stream);
-  ZRET(prep_queries(c, h->st, d_queries, count, threshold, s));
-  SearchOut out{d_out_keys, d_out_scores, nullptr, d_out_counts};
-  return flat_scan_prepared(c, h->st, count, topk, threshold, d_exclude_bitset, out, s, true);
+  return flat_search_dev_locked(h, c, d_queries, count, topk, threshold, d_exclude_bitset, d_out_keys, d_out_scores,
+                                d_out_counts, pick_stream(c, stream));
 }
 
 int zvec_hip_flat_search(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count, uint32_t topk,
@@ -218,14 +236,16 @@ int zvec_hip_flat_search(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *quer
   if (count == 0) return 0;
   if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
-  {
-    std::lock_guard<std::mutex> g(c->mu);
-    ZCHK(hipSetDevice(h->device));
-    ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->st.row_bytes(), exclude_bitset, h->st.n, count, topk, c->cur));
-  }
-  ZRET(zvec_hip_flat_search_dev(h, c, c->io_q.p, count, topk, threshold, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr,
-                                c->io_keys.as<uint64_t>(), c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
+  // ONE critical section from the upload to the copy-out: the staging buffers belong to the context, and a NULL ctx
+  // means several threads share the handle's built-in one (include/zvec_hip.h: "under a mutex")
   std::lock_guard<std::mutex> g(c->mu);
+  ZCHK(hipSetDevice(h->device));
+  {
+    std::shared_lock<std::shared_mutex> r(h->rw);      // the row count the bitset is sized for == the rows scanned
+    ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->st.row_bytes(), exclude_bitset, h->st.n, count, topk, c->cur));
+    ZRET(flat_search_dev_locked(h, c, c->io_q.p, count, topk, threshold, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr,
+                                c->io_keys.as<uint64_t>(), c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
+  }
   return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, c->cur);
 }
 
@@ -243,6 +263,7 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = c->cur;
   const Store &st = h->st;
+  if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));
   // host-side sanitising: positions out of range or excluded by the filter bitset become holes
   const uint32_t total = offsets[count];
   uint32_t maxlen = 1;

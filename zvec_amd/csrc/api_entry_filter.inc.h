@@ -167,8 +167,7 @@ int upload_roaring(const void *data, uint64_t len, int kind, DeviceRoaring &out,
 int build_filter(zvec_hip_ctx_s *c, int device, const uint64_t *d_keys, uint64_t n, const uint64_t *d_dense0,
                  const uint32_t *d_tile0, uint32_t nlist, const zvec_hip_doc_filter_t *f, uint64_t *out_words,
                  int out_on_device, void *stream) {
-  if (!c || !f || !out_words) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> g(c->mu);
+  if (!c || !f || !out_words) return ZVEC_HIP_ERR_INVALID_ARGUMENT;   // (the caller holds c->mu)
   ZCHK(hipSetDevice(device));
   hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : c->cur;
   const uint64_t words = (n + 63) / 64;
@@ -223,8 +222,14 @@ extern "C" uint32_t zvec_hip_crc32c(const void *data, uint64_t len, uint32_t crc
 extern "C" int zvec_hip_flat_build_filter(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const zvec_hip_doc_filter_t *filter,
                                           uint64_t *out_words, int out_on_device, void *stream) {
   if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);              // lock order everywhere: context, then the store's rw lock
   std::shared_lock<std::shared_mutex> r(h->rw);
-  return build_filter(ctx ? ctx : h->defctx, h->device, h->st.keys, h->st.n, nullptr, nullptr, 0, filter, out_words,
+  if (h->append_pending) {
+    ZCHK(hipSetDevice(h->device));
+    ZCHK(hipStreamWaitEvent(stream ? reinterpret_cast<hipStream_t>(stream) : c->cur, h->append_ev, 0));
+  }
+  return build_filter(c, h->device, h->st.keys, h->st.n, nullptr, nullptr, 0, filter, out_words,
                       out_on_device, stream);
 }
 
@@ -232,6 +237,8 @@ extern "C" int zvec_hip_ivf_build_filter(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, c
                                          uint64_t *out_words, int out_on_device, void *stream) {
   if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
-  return build_filter(ctx ? ctx : h->defctx, h->device, h->lists.keys, h->count_local, h->d_dense0, h->d_tile0, h->nlist,
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  return build_filter(c, h->device, h->lists.keys, h->count_local, h->d_dense0, h->d_tile0, h->nlist,
                       filter, out_words, out_on_device, stream);
 }

@@ -606,6 +606,7 @@ int zvec_hip_ivf_get_vector(zvec_hip_ivf_t h, uint64_t list_pos, void *out) {
   if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
   if (list_pos >= h->count_local) return ZVEC_HIP_ERR_NO_EXIST;
   std::lock_guard<std::mutex> g(h->mu);
+  std::lock_guard<std::mutex> gc(h->defctx->mu);     // io_q is the built-in context's staging buffer
   ZCHK(hipSetDevice(h->device));
   uint32_t l = (uint32_t)(std::upper_bound(h->h_dense0.begin(), h->h_dense0.end(), list_pos) - h->h_dense0.begin()) - 1;
   uint64_t pos = (uint64_t)h->h_tile0[l] * TILE_N + (list_pos - h->h_dense0[l]);
@@ -623,6 +624,7 @@ int zvec_hip_ivf_get_vectors(zvec_hip_ivf_t h, const uint64_t *list_positions, u
   if (n == 0) return 0;
   if (n > 0x7fffffffull) return ZVEC_HIP_ERR_OUT_OF_RANGE;
   std::lock_guard<std::mutex> g(h->mu);
+  std::lock_guard<std::mutex> gc(h->defctx->mu);
   std::vector<uint64_t> pos(n);
   for (uint64_t i = 0; i < n; ++i) {
     const uint64_t lp = list_positions[i];
@@ -634,50 +636,43 @@ int zvec_hip_ivf_get_vectors(zvec_hip_ivf_t h, const uint64_t *list_positions, u
   return store_get_rows(h->defctx, h->lists, pos, out);
 }
 
-static int ivf_search_dev_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count,
-                               uint32_t topk, float threshold, uint32_t nprobe, uint32_t max_scan_count,
-                               int brute_force, const uint64_t *d_exclude, uint64_t *d_out_keys, float *d_out_scores,
-                               uint32_t *d_out_counts, void *stream) {
-  if (!h || !d_queries || !d_out_keys || !d_out_scores || !d_out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
-  if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
-  if (count == 0) return 0;
-  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;   // ivf_searcher.cc:197-200
-  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
-  {
-    const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(h->lists.dpad, 1u));
-    if (count > maxq) {   // 32-bit word offsets into the padded query matrix: slice very large batches
-      for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
-        const uint32_t m = std::min(maxq, count - q0);
-        ZRET(ivf_search_dev_impl(h, ctx, reinterpret_cast<const char *>(d_queries) + (size_t)q0 * h->lists.row_bytes(), m, topk,
-                                 threshold, nprobe, max_scan_count, brute_force, d_exclude, d_out_keys + (size_t)q0 * topk,
-                                 d_out_scores + (size_t)q0 * topk, d_out_counts + q0, stream));
+// the IVF search proper; the caller holds c->mu and has validated the arguments
+static int ivf_search_dev_locked(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const void *d_queries, uint32_t count, uint32_t topk,
+                                 float threshold, uint32_t nprobe, uint32_t max_scan_count, int brute_force,
+                                 const uint64_t *d_exclude, uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts,
+                                 hipStream_t s) {
+  // 32-bit word offsets into the padded query matrix: very large batches go in slices
+  const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(h->lists.dpad, 1u));
+  for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
+    const uint32_t m = std::min(maxq, count - q0);
+    SearchOut out{d_out_keys + (size_t)q0 * topk, d_out_scores + (size_t)q0 * topk, nullptr, d_out_counts + q0};
+    ZRET(ivf_search_core(h, c, reinterpret_cast<const char *>(d_queries) + (size_t)q0 * h->lists.row_bytes(), m, topk, threshold,
+                         nprobe, max_scan_count, brute_force, d_exclude, out, s));
+    if (c->profile && c->nprof > 0 && c->nprof <= PROFILE_MAX && c->stats.p) {
+      int i = c->nprof - 1;
+      if (c->launch_is_ivf[i]) {
+        unsigned long long *st = c->stats.as<unsigned long long>() + 2 * (size_t)i;
+        ZCHK(hipMemsetAsync(st, 0, 16, s));
+        hipLaunchKernelGGL(ivf_work_stats_kernel, dim3(16), dim3(256), 0, s, c->last_list_count, h->d_size, h->nlist, st);
+        ZCHK(hipGetLastError());
       }
-      return 0;
     }
   }
-  std::lock_guard<std::mutex> g(c->mu);
-  ZCHK(hipSetDevice(h->device));
-  hipStream_t s = pick_stream(c, stream);
-  SearchOut out{d_out_keys, d_out_scores, nullptr, d_out_counts};
-  int rc = ivf_search_core(h, c, d_queries, count, topk, threshold, nprobe,
-                           max_scan_count, brute_force, d_exclude, out, s);
-  if (rc == 0 && c->profile && c->nprof > 0 && c->nprof <= PROFILE_MAX && c->stats.p) {
-    int i = c->nprof - 1;
-    if (c->launch_is_ivf[i]) {
-      unsigned long long *st = c->stats.as<unsigned long long>() + 2 * (size_t)i;
-      ZCHK(hipMemsetAsync(st, 0, 16, s));
-      hipLaunchKernelGGL(ivf_work_stats_kernel, dim3(16), dim3(256), 0, s, c->last_list_count, h->d_size, h->nlist, st);
-      ZCHK(hipGetLastError());
-    }
-  }
-  return rc;
+  return 0;
 }
 
 int zvec_hip_ivf_search_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,
                             float threshold, uint32_t nprobe, uint32_t max_scan_count, const uint64_t *d_exclude_bitset,
                             uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts, void *stream) {
-  return ivf_search_dev_impl(h, ctx, d_queries, count, topk, threshold, nprobe, max_scan_count, 0, d_exclude_bitset,
-                             d_out_keys, d_out_scores, d_out_counts, stream);
+  if (!h || !d_queries || !d_out_keys || !d_out_scores || !d_out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  if (count == 0) return 0;
+  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;   // ivf_searcher.cc:197-200
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  ZCHK(hipSetDevice(h->device));
+  return ivf_search_dev_locked(h, c, d_queries, count, topk, threshold, nprobe, max_scan_count, 0, d_exclude_bitset,
+                               d_out_keys, d_out_scores, d_out_counts, pick_stream(c, stream));
 }
 
 static int ivf_search_host_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count, uint32_t topk,
@@ -689,15 +684,13 @@ static int ivf_search_host_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void
   if (count == 0) return 0;
   if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
-  {
-    std::lock_guard<std::mutex> g(c->mu);
-    ZCHK(hipSetDevice(h->device));
-    ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->lists.row_bytes(), exclude_bitset, h->count_local, count, topk, c->cur));
-  }
-  ZRET(ivf_search_dev_impl(h, c, c->io_q.p, count, topk, threshold, nprobe, max_scan_count, brute_force,
-                           exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr, c->io_keys.as<uint64_t>(),
-                           c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
+  // ONE critical section from the upload to the copy-out (see zvec_hip_flat_search)
   std::lock_guard<std::mutex> g(c->mu);
+  ZCHK(hipSetDevice(h->device));
+  ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->lists.row_bytes(), exclude_bitset, h->count_local, count, topk, c->cur));
+  ZRET(ivf_search_dev_locked(h, c, c->io_q.p, count, topk, threshold, nprobe, max_scan_count, brute_force,
+                             exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr, c->io_keys.as<uint64_t>(),
+                             c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
   return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, c->cur);
 }
 

@@ -86,17 +86,19 @@ int launch_scan_ng(int ng, const ScanArgs &a, bool f16, uint32_t max_items, int 
   return ZVEC_HIP_ERR_INVALID_ARGUMENT;
 }
 
-// Tuning / test knobs, read once from the environment.  None is needed in production; they exist so that kernel
-// variants can be A/B-timed on one GPU box (tools/ab_flat.sh) and so that tests can force a path onto small inputs.
+// Tuning knobs.  The shipped library has NONE: every value below is a compile-time constant.  Only a build with
+// -DZVEC_HIP_TUNING (tools/build_variant.sh; kernel A/B timing on one GPU box, tools/ab_flat.sh) reads them from the
+// environment, so a stray variable cannot change the product path.
 struct Knobs {
   int max_ng = 4;             // ZVEC_HIP_MAX_NG      cap of the 4-wave kernel's query-row groups (1, 2, 4)
   bool no_wide = false;       // ZVEC_HIP_NO_WIDE     never take the 8-wave flat tile
-  bool force_wide = false;    // ZVEC_HIP_FORCE_WIDE  take it on cache-resident bases too (tests)
+  bool force_wide = false;    // ZVEC_HIP_FORCE_WIDE  take it on cache-resident bases too
   bool no_seed = false;       // ZVEC_HIP_NO_SEED     no prefix scan to seed the admission bounds
   bool no_gather = false;     // ZVEC_HIP_NO_GATHER   sparse filters: compact the kept rows instead of gathering them
   int ivf_tpc = 0;            // ZVEC_HIP_IVF_TPC     fixed tiles per IVF chunk (0 = adaptive)
   bool m16_small = true;      // ZVEC_HIP_NO_M16_SMALL  keep flat scans of <= 16 queries on the 32-row MFMA shape
   Knobs() {
+#ifdef ZVEC_HIP_TUNING
     if (const char *e = getenv("ZVEC_HIP_MAX_NG")) max_ng = std::max(1, std::min(4, atoi(e)));
     no_wide = getenv("ZVEC_HIP_NO_WIDE") != nullptr;
     force_wide = getenv("ZVEC_HIP_FORCE_WIDE") != nullptr;
@@ -104,6 +106,7 @@ struct Knobs {
     no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;
     if (const char *e = getenv("ZVEC_HIP_IVF_TPC")) ivf_tpc = std::max(1, atoi(e));
     m16_small = getenv("ZVEC_HIP_NO_M16_SMALL") == nullptr;
+#endif
   }
 };
 const Knobs &knobs() {
@@ -187,6 +190,7 @@ int flat_scan_gather(zvec_hip_ctx_s *ctx, const Store &st, const uint32_t *d_pos
     ZRET(ctx->seed_keys.ensure((size_t)count * topk * sizeof(uint64_t)));
     ZRET(ctx->seed_scores.ensure((size_t)count * topk * sizeof(float)));
     ZRET(ctx->seed_counts.ensure((size_t)count * sizeof(uint32_t)));
+    ZRET(ctx->seed_idx.ensure((size_t)count * topk * sizeof(uint32_t)));
     ZRET(ctx->part_s.ensure((size_t)count * SEED_ROWS * sizeof(float)));
     ScanArgs d = a;
     d.k = 1; d.n = SEED_ROWS; d.ndense = SEED_ROWS; d.tiles_per_chunk = 1; d.nchunks = SEED_ROWS / TILE_N; d.nqtiles = nqtiles;
@@ -195,9 +199,10 @@ int flat_scan_gather(zvec_hip_ctx_s *ctx, const Store &st, const uint32_t *d_pos
     MergeArgs m{};
     m.part_s = d.dump; m.slots_per_q = 1; m.slot_stride = 1; m.k = topk; m.slot_len = SEED_ROWS; m.threshold = threshold;
     m.out_keys = ctx->seed_keys.as<uint64_t>(); m.out_scores = ctx->seed_scores.as<float>(); m.out_counts = ctx->seed_counts.as<uint32_t>();
+    m.out_idx = ctx->seed_idx.as<uint32_t>();          // logical (gathered) positions: mapped through d_pos below
     hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
     hipLaunchKernelGGL(seed_gtau_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, ctx->gtau.as<uint32_t>(),
-                       m.out_scores, m.out_counts, count, topk);
+                       m.out_scores, m.out_idx, d_pos, m.out_counts, ctx->qnorm.as<float>(), st.bnorm, st.metric, count, topk);
     ZCHK(hipGetLastError());
   }
   int occ8 = 1;
@@ -356,14 +361,15 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     ZRET(ctx->seed_keys.ensure((size_t)count * topk * sizeof(uint64_t)));
     ZRET(ctx->seed_scores.ensure((size_t)count * topk * sizeof(float)));
     ZRET(ctx->seed_counts.ensure((size_t)count * sizeof(uint32_t)));
+    ZRET(ctx->seed_idx.ensure((size_t)count * topk * sizeof(uint32_t)));
     Store view = st;                      // a view of the first SEED_ROWS rows (whole tiles of the same arrays)
     view.n = SEED_ROWS; view.cap_tiles = SEED_ROWS / TILE_N;
-    SearchOut so{ctx->seed_keys.as<uint64_t>(), ctx->seed_scores.as<float>(), nullptr, ctx->seed_counts.as<uint32_t>()};
+    SearchOut so{ctx->seed_keys.as<uint64_t>(), ctx->seed_scores.as<float>(), ctx->seed_idx.as<uint32_t>(), ctx->seed_counts.as<uint32_t>()};
     int rc = flat_scan_prepared(ctx, view, count, topk, threshold, d_exclude, so, stream, false);
     view.base = nullptr; view.bnorm = nullptr; view.extra = nullptr; view.keys = nullptr;   // the view owns nothing
     ZRET(rc);
     hipLaunchKernelGGL(seed_gtau_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, ctx->gtau.as<uint32_t>(),
-                       so.scores, so.counts, count, topk);
+                       so.scores, so.idx, (const uint32_t *)nullptr, so.counts, ctx->qnorm.as<float>(), st.bnorm, st.metric, count, topk);
     ZCHK(hipGetLastError());
   }
   int ng = pick_ng(count, topk);
@@ -541,7 +547,7 @@ void ctx_free(zvec_hip_ctx_s *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own) (void)hipStreamSynchronize(c->own);
-  c->gtau.release(); c->ridx.release(); c->cmp_base.release(); c->cmp_norm.release(); c->cmp_extra.release(); c->cmp_keys.release(); c->cmp_pos.release(); c->cmp_cnt.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
+  c->gtau.release(); c->ridx.release(); c->seed_keys.release(); c->seed_scores.release(); c->seed_counts.release(); c->seed_idx.release(); c->cmp_base.release(); c->cmp_norm.release(); c->cmp_extra.release(); c->cmp_keys.release(); c->cmp_pos.release(); c->cmp_cnt.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
   c->coarse_keys.release(); c->coarse_scores.release(); c->coarse_idx.release(); c->coarse_cnt.release();
   c->plan.release(); c->io_q.release(); c->io_ex.release(); c->io_keys.release(); c->io_scores.release();
   c->io_counts.release(); c->stats.release(); c->pin_in.release(); c->pin_out.release();

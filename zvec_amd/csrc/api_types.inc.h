@@ -133,7 +133,7 @@ struct zvec_hip_ctx_s {
   std::mutex mu;
   // workspace
   DevBuf gtau, ridx;
-  DevBuf seed_keys, seed_scores, seed_counts;   // sample scan that seeds the shared admission bounds
+  DevBuf seed_keys, seed_scores, seed_counts, seed_idx;   // sample scan that seeds the shared admission bounds
   DevBuf cmp_base, cmp_norm, cmp_extra, cmp_keys, cmp_pos, cmp_cnt;   // compacted keep-set (sparse filters)
   DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
   DevBuf plan;        // all u32 plan arrays
@@ -164,6 +164,10 @@ struct zvec_hip_flat_s {
   // extend the store holds it exclusive.  A growth reallocation frees the old arrays with hipFree, which waits for
   // the device, so kernels enqueued by earlier searches have finished with them.
   std::shared_mutex rw;
+  // zvec_hip_flat_append_dev returns with its pack kernels only enqueued: recorded after them on the append stream,
+  // waited for by every reader of the store on its own stream
+  hipEvent_t append_ev = nullptr;
+  bool append_pending = false;
 };
 
 struct zvec_hip_ivf_s {

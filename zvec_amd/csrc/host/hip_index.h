@@ -24,7 +24,9 @@
 #include <map>
 #include <unordered_map>
 #include <memory>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -192,19 +194,23 @@ class Context {
 // built lazily from the keys the index holds), then the rows are attached to the documents
 template <typename GetRows>
 inline int attach_result_vectors(Context *ctx, uint32_t count, size_t row_bytes, const std::vector<uint64_t> &keys_by_pos,
-                                 std::unordered_map<uint64_t, uint64_t> *pos_of_key, GetRows &&get_rows) {
-  if (pos_of_key->size() != keys_by_pos.size()) {
-    pos_of_key->clear();
-    pos_of_key->reserve(keys_by_pos.size());
-    for (uint64_t i = 0; i < keys_by_pos.size(); ++i) pos_of_key->emplace(keys_by_pos[i], i);
-  }
+                                 std::unordered_map<uint64_t, uint64_t> *pos_of_key, std::mutex *map_mu, GetRows &&get_rows) {
   std::vector<uint64_t> pos;
-  for (uint32_t q = 0; q < count; ++q)
-    for (const auto &d : ctx->result(q)) {
-      auto it = pos_of_key->find(d.key());
-      if (it == pos_of_key->end()) return IndexError_NoExist;
-      pos.push_back(it->second);
+  {
+    // searches are const and run concurrently (index_runner.h:490-531): the lazily built map is shared mutable state
+    std::lock_guard<std::mutex> g(*map_mu);
+    if (pos_of_key->size() != keys_by_pos.size()) {
+      pos_of_key->clear();
+      pos_of_key->reserve(keys_by_pos.size());
+      for (uint64_t i = 0; i < keys_by_pos.size(); ++i) pos_of_key->emplace(keys_by_pos[i], i);
     }
+    for (uint32_t q = 0; q < count; ++q)
+      for (const auto &d : ctx->result(q)) {
+        auto it = pos_of_key->find(d.key());
+        if (it == pos_of_key->end()) return IndexError_NoExist;
+        pos.push_back(it->second);
+      }
+  }
   if (pos.empty()) return 0;
   std::vector<char> rows(pos.size() * row_bytes);
   int rc = get_rows(pos.data(), pos.size(), rows.data());
@@ -326,8 +332,8 @@ class HipFlatStreamer {
   }
   int open(int device = 0) {
     device_ = device;
-    static uint32_t next_magic = 0x48495031u;
-    magic_ = next_magic++;
+    static std::atomic<uint32_t> next_magic{0x48495031u};    // IndexContext::GenerateMagic (index_context.cc:22-25)
+    magic_ = next_magic.fetch_add(1);
     return zvec_hip_flat_create(meta_.dimension(), meta_.data_type() == IndexMeta::DT_FP16 ? ZVEC_HIP_DT_FP16 : ZVEC_HIP_DT_FP32,
                                 metric_, device, &h_);
   }
@@ -342,6 +348,7 @@ class HipFlatStreamer {
   //! Add a vector into index (index_runner.h:476-480)
   int add_impl(uint64_t key, const void *query, const IndexQueryMeta &qmeta, Context::Pointer & /*context*/) {
     if (!h_ || !query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
+    std::unique_lock<std::shared_mutex> w(keys_mu_);    // add vs search: flat_streamer.cc:236-242, flat_streamer_entity.cc:150
     int rc = zvec_hip_flat_append(h_, query, 1, &key);
     if (rc == 0) keys_.push_back(key);
     return rc;
@@ -349,6 +356,7 @@ class HipFlatStreamer {
   //! bulk form used by FlatBuilder::build / FlatSearcher::load (flat_builder.cc:188-276)
   int add_batch(const void *vecs, uint64_t n, const uint64_t *keys) {
     if (!h_) return IndexError_InvalidArgument;
+    std::unique_lock<std::shared_mutex> w(keys_mu_);
     int rc = zvec_hip_flat_append(h_, vecs, n, keys);
     if (rc == 0) for (uint64_t i = 0; i < n; ++i) keys_.push_back(keys ? keys[i] : keys_.size());
     return rc;
@@ -362,6 +370,7 @@ class HipFlatStreamer {
     Context *ctx = context.get();
     if (!ctx || ctx->topk() == 0) return IndexError_InvalidArgument;    // flat_searcher.cc:194-198
     if (ctx->magic() != magic_) ctx->set_magic(magic_);                 // context made by another index: re-bind
+    std::shared_lock<std::shared_mutex> r(keys_mu_);    // keys_ (filter sweep, bitset size, fetch_vector) vs add
     const uint32_t k = ctx->topk();
     std::vector<uint64_t> keys((size_t)count * k);
     std::vector<float> scores((size_t)count * k);
@@ -402,10 +411,12 @@ class HipFlatStreamer {
   uint32_t magic_{0};
   zvec_hip_flat_t h_{nullptr};
   std::vector<uint64_t> keys_;
+  mutable std::shared_mutex keys_mu_;
+  mutable std::mutex map_mu_;
   mutable std::unordered_map<uint64_t, uint64_t> pos_of_key_;
   int attach_vectors(Context *ctx, uint32_t count) const {
     zvec_hip_flat_t h = h_;
-    return attach_result_vectors(ctx, count, meta_.element_size(), keys_, &pos_of_key_,
+    return attach_result_vectors(ctx, count, meta_.element_size(), keys_, &pos_of_key_, &map_mu_,
                                  [h](const uint64_t *p, size_t n, void *out) { return zvec_hip_flat_get_vectors(h, p, n, out); });
   }
 };
@@ -433,8 +444,8 @@ class HipIVFSearcher {
     int metric = metric_from_name(meta.metric_name());
     if (metric < 0 || (meta.data_type() != IndexMeta::DT_FP32 && meta.data_type() != IndexMeta::DT_FP16)) return IndexError_Unsupported;
     device_ = device;
-    static uint32_t next_magic = 0x49564631u;
-    magic_ = next_magic++;
+    static std::atomic<uint32_t> next_magic{0x49564631u};
+    magic_ = next_magic.fetch_add(1);
     int rc = zvec_hip_ivf_create(meta.dimension(), meta.data_type() == IndexMeta::DT_FP16 ? ZVEC_HIP_DT_FP16 : ZVEC_HIP_DT_FP32,
                                  metric, device, &h_);
     if (rc != 0) return rc;
@@ -529,9 +540,10 @@ class HipIVFSearcher {
     ctx->take(count, k, keys, scores, counts);
     if (!ctx->fetch_vector()) return 0;
     zvec_hip_ivf_t h = h_;
-    return attach_result_vectors(ctx, count, meta_.element_size(), keys_, &pos_of_key_,
+    return attach_result_vectors(ctx, count, meta_.element_size(), keys_, &pos_of_key_, &map_mu_,
                                  [h](const uint64_t *p, size_t n, void *out) { return zvec_hip_ivf_get_vectors(h, p, n, out); });
   }
+  mutable std::mutex map_mu_;
   mutable std::unordered_map<uint64_t, uint64_t> pos_of_key_;
   std::unique_ptr<MicroBatcher> batcher_;
   mutable std::mutex pool_mu_;

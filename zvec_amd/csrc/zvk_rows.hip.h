@@ -145,14 +145,28 @@ __global__ void ivf_reset_kernel(uint32_t *zero0, uint32_t nzero, uint32_t *queu
   if (i < nlist) list_tpc[i] = list_tail[i] ? max(1u, tpc >> 2) : tpc;
 }
 
-// gtau[q] = min(gtau[q], k-th score of a sample scan, nudged up by ~1e-6 relative) — only for full sample lists.
+// gtau[q] = min(gtau[q], k-th score of a sample scan + slack) — only for full sample lists.
 // The k-th best score of ANY subset of the rows bounds the final k-th score from above, so starting every
 // work-group of the main scan at that bound drops nothing it could keep; it only spares the list warm-up.
-__global__ void seed_gtau_kernel(uint32_t *gtau, const float *scores, const uint32_t *counts, uint32_t n, uint32_t k) {
+// Slack: the sample scan and the main scan may sum the same row's dot product in different orders (different tile
+// shapes), and the rounding error of a selection score scales with the operands' NORMS, not with the score
+// (L2: |q|^2 + |b|^2 - 2 q.b; IP / cosine: |q||b|) — so the bound is lifted by 8e-6 of that magnitude, taken over the k
+// sample rows (one of which is the row the bound must still admit), plus 1e-6 relative.  `idx`: positions of the
+// sample's winners (through `pos_map` when the sample was a gathered view).
+__global__ void seed_gtau_kernel(uint32_t *gtau, const float *scores, const uint32_t *idx, const uint32_t *pos_map,
+                                 const uint32_t *counts, const float *qnorm, const float *bnorm, int metric, uint32_t n,
+                                 uint32_t k) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || counts[i] < k) return;
   const float s = scores[(size_t)i * k + (k - 1)];
-  const float b = s + fabsf(s) * 1e-6f + 1e-30f;
+  float bmax = 0.f;
+  for (uint32_t j = 0; j < k; ++j) {
+    uint32_t p = idx[(size_t)i * k + j];
+    if (pos_map) p = pos_map[p];
+    bmax = fmaxf(bmax, bnorm[p]);
+  }
+  const float mag = (metric == 0) ? qnorm[i] + bmax : sqrtf(qnorm[i] * bmax);
+  const float b = s + 8e-6f * mag + fabsf(s) * 1e-6f + 1e-30f;
   if (b == b) atomicMin(&gtau[i], fkey(b));
 }
 

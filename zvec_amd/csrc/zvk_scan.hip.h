@@ -384,9 +384,7 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : (NG == 2 && !M16 ? 3 : 1))
               const float tn = st.tq[nrow];
               if ((uint32_t)row < nrows) {
                 if (a.dump) *reinterpret_cast<f32x2 *>(a.dump + (size_t)qrow_s[row] * a.dump_stride + pos0 + 2 * lane) = v;
-#ifndef ZVK_M16_NOEPI
                 else owner_row(st, row, v.x, v.y, t0, pos0, lane);
-#endif
               }
               v = vn;
               t0 = tn;
