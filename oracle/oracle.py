@@ -165,7 +165,7 @@ class Oracle:
         q = np.ascontiguousarray(q_block, np.float16 if half else np.float32)
         dim, M = m.shape
         N = q.shape[1]
-        assert q.shape[0] == dim and M in (8, 16, 32)
+        assert q.shape[0] == dim and M in (2, 4, 8, 16, 32)
         out = np.zeros((N, M), np.float32)
         name = "sqeuclid" if metric == METRIC_L2 else "minus_ip"
         if np.asarray(m_block).dtype == np.float16:                 # fp16 blocks
@@ -239,6 +239,30 @@ class Oracle:
                                           _ptr(oc, _u32p), threads)
         if rc != 0:
             raise RuntimeError("zo_flat_search rc=%d" % rc)
+        return ok, os_, oi, oc
+
+    def flat_search_column(self, base, queries, topk, metric=METRIC_L2, keys=None, threshold=FLT_MAX, exclude_bits=None):
+        """the column-major dense path (FlatSearcherContext::batch_search_column_*, flat_searcher_context.h:682-845):
+        32-row transposed blocks x query groups of 32/16/8/4/2/1 through the M x N block kernels.  `base` row-major."""
+        half = np.asarray(base).dtype == np.float16
+        dt = np.float16 if half else np.float32
+        base = np.ascontiguousarray(base, dt)
+        queries = np.ascontiguousarray(np.atleast_2d(queries), dt)
+        n, dim = base.shape
+        nq = queries.shape[0]
+        keys = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        ex = None if exclude_bits is None else np.ascontiguousarray(exclude_bits, np.uint64)
+        ok = np.zeros((nq, topk), np.uint64)
+        os_ = np.full((nq, topk), np.inf, np.float32)
+        oi = np.zeros((nq, topk), np.uint32)
+        oc = np.zeros(nq, np.uint32)
+        fn = self.lib.zo_flat_search_column_t
+        fn.restype = C.c_int
+        rc = fn(int(half), C.c_void_p(base.ctypes.data), _ptr(keys, _u64p), C.c_uint64(n), C.c_uint32(dim), C.c_int(metric),
+                C.c_void_p(queries.ctypes.data), C.c_uint32(nq), C.c_uint32(topk), C.c_float(threshold), _ptr(ex, _u64p),
+                _ptr(ok, _u64p), _ptr(os_, _f32p), _ptr(oi, _u32p), _ptr(oc, _u32p))
+        if rc != 0:
+            raise RuntimeError("zo_flat_search_column rc=%d" % rc)
         return ok, os_, oi, oc
 
     def ivf_search(self, centroids, list_offsets, vecs, queries, topk, nprobe, max_scan_count,

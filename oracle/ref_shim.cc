@@ -109,6 +109,8 @@ int zref_minus_ip_block_f32(int M, int N, const float *m, const float *q, size_t
 #define ZREF_BLOCK16(KERNEL, M_, N_) \
   if (M == M_ && N == N_) { KERNEL<Float16, M_, N_>::Compute(reinterpret_cast<const Float16 *>(m), reinterpret_cast<const Float16 *>(q), dim, out); return 0; }
 #define ZREF_BLOCK16_ALL(KERNEL)                                                                              \
+  ZREF_BLOCK16(KERNEL, 2, 1) ZREF_BLOCK16(KERNEL, 2, 2) ZREF_BLOCK16(KERNEL, 4, 1) ZREF_BLOCK16(KERNEL, 4, 2)     \
+  ZREF_BLOCK16(KERNEL, 4, 4)                                                                                  \
   ZREF_BLOCK16(KERNEL, 8, 1) ZREF_BLOCK16(KERNEL, 8, 2) ZREF_BLOCK16(KERNEL, 8, 4) ZREF_BLOCK16(KERNEL, 8, 8)     \
   ZREF_BLOCK16(KERNEL, 16, 1) ZREF_BLOCK16(KERNEL, 16, 2) ZREF_BLOCK16(KERNEL, 16, 4) ZREF_BLOCK16(KERNEL, 16, 8) \
   ZREF_BLOCK16(KERNEL, 16, 16) ZREF_BLOCK16(KERNEL, 32, 1) ZREF_BLOCK16(KERNEL, 32, 2) ZREF_BLOCK16(KERNEL, 32, 4) \

@@ -100,49 +100,62 @@ float zo_ip_f32(const float *m, const float *q, size_t dim) {
 float zo_minus_ip_f32(const float *m, const float *q, size_t dim) {
   return -lane_ip(m, q, dim);
 }
-/* SquaredEuclideanDistanceMatrix<float,M,N> / MinusInnerProductMatrix<float,M,N> (M >= 2): the AVX-512 / AVX / SSE
- * bodies (distance_matrix_accum_fp32.i) keep one accumulator lane per (vector i, query j) and step k sequentially:
- * sum = fma(m - q, m - q, sum)  resp.  sum = fma(m, q, sum); minus-ip negates at the end. */
-void zo_sqeuclid_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out) {
-  for (int j = 0; j < N; ++j)
-    for (int i = 0; i < M; ++i) {
-      float acc = 0.0f;
-      for (size_t k = 0; k < dim; ++k) {
-        const float d = m[k * (size_t)M + i] - q[k * (size_t)N + j];
-        acc = fmaf(d, d, acc);
-      }
-      out[(size_t)j * M + i] = acc;
-    }
+/* SquaredEuclideanDistanceMatrix<T,M,N> / MinusInnerProductMatrix<T,M,N> (M >= 2), T = float or Float16 (converted to
+ * fp32 first, distance_matrix_accum_fp16.i): one accumulator per (vector i, query j); the step is
+ *     sum = fma(m - q, m - q, sum)   resp.   sum = fma(m, q, sum)        (minus-ip negates at the end).
+ * How the k steps of one pair are chained depends on M (AVX-512 build, distance_matrix_accum_fp32.i):
+ *   M >= 8   one vector per SIMD lane, k sequential: a single chain over k = 0 .. dim-1;
+ *   M == 4   a 256-bit register holds TWO k steps of the 4 vectors (ACCUM_FP32_4X1/4X2/4X4_AVX, :573-680): an even-k
+ *            chain and an odd-k chain over the first dim & ~1 steps, added (low + high half), then the odd tail step
+ *            is folded into the sum;
+ *   M == 2   FOUR k steps per register (ACCUM_FP32_2X1/2X2_AVX, :496-571): chains c0..c3 over k = t mod 4 for the first
+ *            dim & ~3 steps; x = c0 + c2, y = c1 + c3 (low + high half); a tail of >= 2 steps goes x <- k, y <- k+1;
+ *            r = x + y (movehl); a last single step is folded into r. */
+static inline float blk_step(int l2, float a, float b, float acc) {
+  if (l2) { const float d = a - b; return fmaf(d, d, acc); }
+  return fmaf(a, b, acc);
 }
-void zo_minus_ip_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out) {
-  for (int j = 0; j < N; ++j)
-    for (int i = 0; i < M; ++i) {
-      float acc = 0.0f;
-      for (size_t k = 0; k < dim; ++k) acc = fmaf(m[k * (size_t)M + i], q[k * (size_t)N + j], acc);
-      out[(size_t)j * M + i] = -acc;
-    }
-}
-
 static float half_to_float(uint16_t h);   /* defined with the fp16 1x1 kernels below */
-void zo_sqeuclid_block_f16(int M, int N, const uint16_t *m, const uint16_t *q, size_t dim, float *out) {
+static inline float blk_elem(int half, const void *p, size_t idx) {
+  return half ? half_to_float(((const uint16_t *)p)[idx]) : ((const float *)p)[idx];
+}
+static float blk_pair(int l2, int half, int M, int N, const void *m, const void *q, int i, int j, size_t dim) {
+#define BLK_TERM(k, acc) blk_step(l2, blk_elem(half, m, (k) * (size_t)M + i), blk_elem(half, q, (k) * (size_t)N + j), (acc))
+  if (M == 4) {
+    float e = 0.0f, o = 0.0f;
+    const size_t al = dim & ~(size_t)1;
+    for (size_t k = 0; k < al; k += 2) { e = BLK_TERM(k, e); o = BLK_TERM(k + 1, o); }
+    float r = e + o;
+    if (al != dim) r = BLK_TERM(al, r);
+    return r;
+  }
+  if (M == 2) {
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+    const size_t al = dim & ~(size_t)3;
+    for (size_t k = 0; k < al; k += 4) { c0 = BLK_TERM(k, c0); c1 = BLK_TERM(k + 1, c1); c2 = BLK_TERM(k + 2, c2); c3 = BLK_TERM(k + 3, c3); }
+    float x = c0 + c2, y = c1 + c3;
+    size_t k = al;
+    if (dim >= al + 2) { x = BLK_TERM(k, x); y = BLK_TERM(k + 1, y); k += 2; }
+    float r = x + y;
+    if (k != dim) r = BLK_TERM(k, r);
+    return r;
+  }
+  float acc = 0.0f;
+  for (size_t k = 0; k < dim; ++k) acc = BLK_TERM(k, acc);
+  return acc;
+#undef BLK_TERM
+}
+static void blk_all(int l2, int half, int M, int N, const void *m, const void *q, size_t dim, float *out) {
   for (int j = 0; j < N; ++j)
     for (int i = 0; i < M; ++i) {
-      float acc = 0.0f;
-      for (size_t k = 0; k < dim; ++k) {
-        const float d = half_to_float(m[k * (size_t)M + i]) - half_to_float(q[k * (size_t)N + j]);
-        acc = fmaf(d, d, acc);
-      }
-      out[(size_t)j * M + i] = acc;
+      const float v = blk_pair(l2, half, M, N, m, q, i, j, dim);
+      out[(size_t)j * M + i] = l2 ? v : -v;
     }
 }
-void zo_minus_ip_block_f16(int M, int N, const uint16_t *m, const uint16_t *q, size_t dim, float *out) {
-  for (int j = 0; j < N; ++j)
-    for (int i = 0; i < M; ++i) {
-      float acc = 0.0f;
-      for (size_t k = 0; k < dim; ++k) acc = fmaf(half_to_float(m[k * (size_t)M + i]), half_to_float(q[k * (size_t)N + j]), acc);
-      out[(size_t)j * M + i] = -acc;
-    }
-}
+void zo_sqeuclid_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out) { blk_all(1, 0, M, N, m, q, dim, out); }
+void zo_minus_ip_block_f32(int M, int N, const float *m, const float *q, size_t dim, float *out) { blk_all(0, 0, M, N, m, q, dim, out); }
+void zo_sqeuclid_block_f16(int M, int N, const uint16_t *m, const uint16_t *q, size_t dim, float *out) { blk_all(1, 1, M, N, m, q, dim, out); }
+void zo_minus_ip_block_f16(int M, int N, const uint16_t *m, const uint16_t *q, size_t dim, float *out) { blk_all(0, 1, M, N, m, q, dim, out); }
 
 /* CosineDistanceMatrix<float,1,1>::Compute  cosine_distance_matrix.h:32-50 */
 float zo_cosine_f32(const float *m, const float *q, size_t dim_with_norm) {
@@ -439,6 +452,110 @@ int zo_flat_search(const float *base, const uint64_t *keys, uint64_t n, uint32_t
                    uint32_t *out_index, uint32_t *out_counts) {
   return flat_search_range(0, base, keys, n, dim, metric, queries, 0, nq, topk, threshold,
                            exclude_bits, out_keys, out_scores, out_index, out_counts);
+}
+
+/* ---------------------------------------------------------------------------------------- *
+ * Column-major flat scan: FlatSearcherContext<32>::batch_search_column_{nofilter,filter}
+ * (flat_searcher_context.h:682-752, :754-845) — the reference's dense "32 x K tile" path for
+ * indexes with d <= 512 (flat_builder.cc:27-66).  Restated with its own loop structure:
+ *   - the features segment = full 32-row blocks TRANSPOSED ([dim][32], flat_builder.cc:188-276)
+ *     followed by the n % 32 left-over rows row-major;
+ *   - TransposeQueries<32> (flat_utility.h:106-158): the batch is cut greedily into groups of
+ *     K = 32, 16, 8, 4, 2, 1 queries, each group interleaved ([dim][K]);
+ *   - a full block against a group: the M=32 x N=K block kernel (batch_enqueue_*, :236-330),
+ *     scores_[k*32 + j]; every query of the group then emplaces rows j = 0..31 in order
+ *     (with a filter: only rows whose block_mask bit is set, mask bit = !filter(key), and a
+ *     block whose mask is 0 is skipped entirely, :785-796);
+ *   - a left-over row against a group of K > 1: the M=K x N=1 block kernel with the GROUP as the
+ *     matrix and the row as the query (single_enqueue_nofilter, :336-357); against the K = 1
+ *     tail query: the 1x1 kernel (:360-370) — the only place the lane-ordered 1x1 sum appears;
+ *   - keys are mapped from the row index after the scan, then heap.sort() (:745-750).
+ * The block kernels are the pinned zo_*_block_* restatements (one sequential FMA chain per pair).
+ * `base` is given ROW-major here; the transposition is done inside, as FlatBuilder would.
+ * ---------------------------------------------------------------------------------------- */
+static void column_block_scores(int dtype, int metric, int M, int N, const void *m, const void *q, uint32_t dim, float *out) {
+  if (dtype) {
+    if (metric == ZO_METRIC_L2) zo_sqeuclid_block_f16(M, N, (const uint16_t *)m, (const uint16_t *)q, dim, out);
+    else zo_minus_ip_block_f16(M, N, (const uint16_t *)m, (const uint16_t *)q, dim, out);
+  } else {
+    if (metric == ZO_METRIC_L2) zo_sqeuclid_block_f32(M, N, (const float *)m, (const float *)q, dim, out);
+    else zo_minus_ip_block_f32(M, N, (const float *)m, (const float *)q, dim, out);
+  }
+}
+
+int zo_flat_search_column_t(int dtype, const void *base_v, const uint64_t *keys, uint64_t n, uint32_t dim, int metric,
+                            const void *queries_v, uint32_t nq, uint32_t topk, float threshold,
+                            const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores,
+                            uint32_t *out_index, uint32_t *out_counts) {
+  if (topk == 0) return -31;
+  if (metric != ZO_METRIC_L2 && metric != ZO_METRIC_IP) return -12;    /* the metrics with M x N tables restated here */
+  const size_t es = dtype ? 2 : 4, rb = (size_t)dim * es;
+  const char *base = (const char *)base_v, *queries = (const char *)queries_v;
+  enum { B = 32 };
+  /* TransposeQueries<32>: groups of 32, 16, ..., 1 */
+  char *tq = (char *)malloc((size_t)nq * rb + 1);
+  uint32_t *gstart = (uint32_t *)malloc(sizeof(uint32_t) * (nq + 1)), *gk = (uint32_t *)malloc(sizeof(uint32_t) * (nq + 1));
+  zo_doc *st = (zo_doc *)malloc(sizeof(zo_doc) * (size_t)topk * nq);
+  zo_heap *heaps = (zo_heap *)malloc(sizeof(zo_heap) * nq);
+  char *blk = (char *)malloc((size_t)B * rb + 1);
+  if (!tq || !gstart || !gk || !st || !heaps || !blk) return -2;
+  uint32_t ngroups = 0;
+  {
+    uint32_t qi = 0, left = nq;
+    for (uint32_t K = B; K >= 1; K >>= 1)          /* count / K groups of K, the remainder goes on with K / 2 */
+      while (left >= K) {
+        gstart[ngroups] = qi; gk[ngroups] = K; ++ngroups;
+        for (uint32_t j = 0; j < K; ++j)
+          for (uint32_t c = 0; c < dim; ++c)
+            memcpy(tq + (size_t)qi * rb + ((size_t)c * K + j) * es, queries + (size_t)(qi + j) * rb + (size_t)c * es, es);
+        qi += K; left -= K;
+      }
+  }
+  for (uint32_t q = 0; q < nq; ++q) zo_heap_init(&heaps[q], st + (size_t)q * topk, topk, threshold);
+  float scores[B * B];
+  const uint64_t full = n / B * B;
+  for (uint64_t b0 = 0; b0 < full; b0 += B) {
+    uint32_t mask = 0;
+    for (uint32_t j = 0; j < B; ++j)
+      if (!bit_set(exclude_bits, b0 + j)) mask |= (1u << j);
+    if (exclude_bits && mask == 0) continue;                       /* block skipped entirely */
+    for (uint32_t j = 0; j < B; ++j)                               /* write_column_index: transpose the block */
+      for (uint32_t c = 0; c < dim; ++c)
+        memcpy(blk + ((size_t)c * B + j) * es, base + (size_t)(b0 + j) * rb + (size_t)c * es, es);
+    for (uint32_t g = 0; g < ngroups; ++g) {
+      const uint32_t K = gk[g];
+      column_block_scores(dtype, metric, B, (int)K, blk, tq + (size_t)gstart[g] * rb, dim, scores);
+      for (uint32_t k = 0; k < K; ++k)
+        for (uint32_t j = 0; j < B; ++j)
+          if (mask & (1u << j)) zo_heap_emplace(&heaps[gstart[g] + k], 0, scores[k * B + j], (uint32_t)(b0 + j));
+    }
+  }
+  for (uint64_t r = full; r < n; ++r) {                            /* left-over rows, row-major */
+    if (bit_set(exclude_bits, r)) continue;
+    const char *row = base + (size_t)r * rb;
+    for (uint32_t g = 0; g < ngroups; ++g) {
+      const uint32_t K = gk[g];
+      if (K > 1) {
+        column_block_scores(dtype, metric, (int)K, 1, tq + (size_t)gstart[g] * rb, row, dim, scores);
+        for (uint32_t k = 0; k < K; ++k) zo_heap_emplace(&heaps[gstart[g] + k], 0, scores[k], (uint32_t)r);
+      } else {
+        zo_heap_emplace(&heaps[gstart[g]], 0, zo_distance_t(dtype, metric, row, tq + (size_t)gstart[g] * rb, dim), (uint32_t)r);
+      }
+    }
+  }
+  for (uint32_t q = 0; q < nq; ++q) {
+    zo_heap *h = &heaps[q];
+    for (size_t j = 0; j < h->n; ++j) h->a[j].key = keys ? keys[h->a[j].index] : h->a[j].index;   /* it.set_key(owner_->key(it.index())) */
+    zo_heap_sort(h);
+    for (size_t j = 0; j < h->n; ++j) {
+      out_keys[(size_t)q * topk + j] = h->a[j].key;
+      out_scores[(size_t)q * topk + j] = h->a[j].score;
+      if (out_index) out_index[(size_t)q * topk + j] = h->a[j].index;
+    }
+    out_counts[q] = (uint32_t)h->n;
+  }
+  free(tq); free(gstart); free(gk); free(st); free(heaps); free(blk);
+  return 0;
 }
 
 /* ======================================================================================== *

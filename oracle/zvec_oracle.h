@@ -140,6 +140,14 @@ int zo_ivf_search_mt_t(int dtype, const void *centroids, uint32_t nlist, const u
                        int brute_force, const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores,
                        uint32_t *out_index, uint32_t *out_counts, uint32_t *out_scanned, int threads);
 
+/* FlatSearcherContext<32>::batch_search_column_{nofilter,filter} (flat_searcher_context.h:682-845): the column-major
+ * dense path — 32-row transposed blocks x query groups of 32/16/8/4/2/1 through the M x N block kernels; `base` is
+ * row-major here (transposed inside, as FlatBuilder::write_column_index does).  dtype: 0 fp32, 1 fp16.  L2 / IP. */
+int zo_flat_search_column_t(int dtype, const void *base, const uint64_t *keys, uint64_t n, uint32_t dim, int metric,
+                            const void *queries, uint32_t nq, uint32_t topk, float threshold,
+                            const uint64_t *exclude_bits, uint64_t *out_keys, float *out_scores,
+                            uint32_t *out_index, uint32_t *out_counts);
+
 /* ---- shard merge (CombinedVectorColumnIndexer::Search, combined_vector_column_indexer.cc:172-232)
  * concat partial lists, sort by score, truncate to topk. */
 int zo_merge_topk(const uint64_t *keys, const float *scores, const uint32_t *counts,

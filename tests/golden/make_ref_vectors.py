@@ -106,6 +106,24 @@ out["hblock_m"] = np.concatenate(HM)
 out["hblock_q"] = np.concatenate(HQ)
 out["hblock_l2"] = np.concatenate(HL2)
 out["hblock_minus_ip"] = np.concatenate(HIP)
+# small-M blocks (M = 2, 4: several k steps share one SIMD register, so a pair's sum is NOT one sequential chain;
+# the column-major scan uses them for the left-over rows) — fp32 and fp16, drawn last again
+for tag, dt, scale in (("sblock", np.float32, 2.0), ("hsblock", np.float16, 2.0)):
+    SM, SQ, SL2, SIP, SSHAPE = [], [], [], [], []
+    for M, N in ((2, 1), (2, 2), (4, 1), (4, 2), (4, 4)):
+        for d in (1, 2, 3, 5, 6, 7, 17, 128, 769, 770, 771):
+            mb = (rng.standard_normal((d, M)) * scale).astype(dt)
+            qb = (rng.standard_normal((d, N)) * scale).astype(dt)
+            SM.append(mb.ravel().view(np.uint16) if dt == np.float16 else mb.ravel())
+            SQ.append(qb.ravel().view(np.uint16) if dt == np.float16 else qb.ravel())
+            SL2.append(o.block_dist(O.METRIC_L2, mb, qb, use_ref=True).ravel())
+            SIP.append(o.block_dist(O.METRIC_IP, mb, qb, use_ref=True).ravel())
+            SSHAPE.append((M, N, d))
+    out[tag + "_shapes"] = np.array(SSHAPE, np.int32)
+    out[tag + "_m"] = np.concatenate(SM)
+    out[tag + "_q"] = np.concatenate(SQ)
+    out[tag + "_l2"] = np.concatenate(SL2)
+    out[tag + "_minus_ip"] = np.concatenate(SIP)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_kernel_vectors.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes")

@@ -426,3 +426,59 @@ def test_seeded_bounds_survive_large_common_offset(zv, oracle, metric):
         tie_tolerant_compare(ctx.keys[:8], ctx.scores[:8], ctx.counts[:8], ok, os_, oc, rtol=4e-6, scale=float(qn.max()), what="offset ip")
     else:
         tie_tolerant_compare(ctx.keys[:8], ctx.scores[:8], ctx.counts[:8], ok, os_, oc, rtol=2e-6, atol=1e-6, select_band=band, what="offset l2")
+
+
+def _column_blob(base):
+    """FlatBuilder::write_column_index (flat_builder.cc:188-276): full 32-row blocks transposed, row-major remainder"""
+    blob = bytearray()
+    for b0 in range(0, base.shape[0], 32):
+        blk = base[b0:b0 + 32]
+        blob += (np.ascontiguousarray(blk.T) if blk.shape[0] == 32 else blk).tobytes()
+    return bytes(blob)
+
+
+@pytest.mark.parametrize("metric", ["SquaredEuclidean", "InnerProduct"])
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_flat_vs_column_major_oracle(zv, oracle, metric, dtype):
+    """the reference's dense path — a column-major index (d <= 512) scanned in 32 x K tiles by the
+    M x N block kernels (flat_searcher_context.h:682-752, TransposeQueries flat_utility.h:106-158) — restated in the
+    oracle on top of its pinned block kernels (zo_flat_search_column_t).  The HIP path loads the same column-major
+    features segment and must agree: bit-exact on integer data (every kernel is exact there), within the stated fp32
+    tolerance on real data; batches of 1..45 so that every query-group width 32/16/8/4/2/1 and the left-over rows
+    (n % 32 != 0) are exercised, with and without a filter."""
+    npdt = np.float16 if dtype == "fp16" else np.float32
+    m = O.METRIC_IP if metric == "InnerProduct" else O.METRIC_L2
+    rng = np.random.default_rng(77)
+    for n, dim, k in ((1000 + 13, 64, 10), (95, 300, 7), (4096 + 31, 512, 10)):
+        keys = rng.permutation(4 * n)[:n].astype(np.uint64)
+        for exact in (True, False):
+            base = (rng.integers(-8, 9, (n, dim)) if exact else rng.standard_normal((n, dim))).astype(npdt)
+            se = zv.HipFlatSearcher(dim, metric, dtype=dtype)
+            assert se.load_features(_column_blob(base), n, column_major=True, keys=keys) == 0
+            ctx = se.create_context()
+            ctx.set_topk(k)
+            for nq in (1, 2, 5, 32, 45):
+                q = (rng.integers(-8, 9, (nq, dim)) if exact else rng.standard_normal((nq, dim))).astype(npdt)
+                for filt in (False, True):
+                    bits = None
+                    if filt:
+                        mask = rng.random(n) < 0.4
+                        mask[32:64] = True                   # one whole 32-row block filtered out (block_mask == 0 skip)
+                        bits = O.pack_bits(mask)
+                        ctx.set_exclude_bitset(bits)
+                    else:
+                        ctx.reset_filter()
+                    assert se.search_impl(q, nq, ctx) == 0
+                    ok, os_, _, oc = oracle.flat_search_column(base, q, k, m, keys=keys, exclude_bits=bits)
+                    what = "column %s %s n=%d nq=%d exact=%s filt=%s" % (metric, dtype, n, nq, exact, filt)
+                    if exact:
+                        tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what=what)
+                    else:
+                        qn = (q.astype(np.float64) ** 2).sum(1)
+                        bn = float((base.astype(np.float64) ** 2).sum(1).max())
+                        if m == O.METRIC_IP:
+                            tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, rtol=4e-6,
+                                                 scale=np.sqrt(qn * bn), what=what)
+                        else:
+                            tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, rtol=2e-6, atol=1e-6,
+                                                 select_band=4e-6 * (qn + bn), what=what)

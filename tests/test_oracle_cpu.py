@@ -118,6 +118,23 @@ def test_fp16_block_kernels_bit_exact_vs_reference_vectors(oracle, golden_dir):
         oo += M * N
 
 
+def test_small_m_block_kernels_bit_exact_vs_reference_vectors(oracle, golden_dir):
+    """M = 2 and M = 4 blocks (ACCUM_FP32_2X1 / 2X2 / 4X1 / 4X2 / 4X4_AVX, distance_matrix_accum_fp32.i:496-680, and their
+    fp16 twins): several k steps share one register, so a pair's sum is split into 4 resp. 2 partial chains — the
+    column-major scan reaches them through its left-over rows (single_enqueue_nofilter<4>, <2>)."""
+    z = np.load(os.path.join(golden_dir, "ref_kernel_vectors.npz"))
+    for tag, dt in (("sblock", np.float32), ("hsblock", np.float16)):
+        om = oq = oo = 0
+        for M, N, d in z[tag + "_shapes"]:
+            m = z[tag + "_m"][om:om + d * M].view(dt).reshape(d, M)
+            q = z[tag + "_q"][oq:oq + d * N].view(dt).reshape(d, N)
+            assert np.array_equal(oracle.block_dist(O.METRIC_L2, m, q).ravel().view(np.uint32), z[tag + "_l2"][oo:oo + M * N].view(np.uint32)), (tag, M, N, d)
+            assert np.array_equal(oracle.block_dist(O.METRIC_IP, m, q).ravel().view(np.uint32), z[tag + "_minus_ip"][oo:oo + M * N].view(np.uint32)), (tag, M, N, d)
+            om += d * M
+            oq += d * N
+            oo += M * N
+
+
 def test_live_vs_compiled_reference(oracle):
     if oracle.ref is None:
         pytest.skip("oracle/_ref/libzvec_ref.so not present (or CPU lacks AVX-512)")
@@ -135,7 +152,7 @@ def test_live_vs_compiled_reference(oracle):
             b = (rng.standard_normal(d) * 2).astype(np.float16)
             for m in (O.METRIC_L2, O.METRIC_IP):
                 assert oracle.dist16(m, a, b) == oracle.dist16(m, a, b, use_ref=True), (d, m)
-    for M in (8, 16, 32):                                   # block kernels, every specialised width
+    for M in (2, 4, 8, 16, 32):                             # block kernels, every specialised width
         for N in (1, 2, 4, 8, 16, 32):
             if N > M:
                 continue
@@ -283,3 +300,80 @@ def test_label_and_pack_restatement_on_exact_data(oracle):
     for l in range(nlist):
         seg = order[int(offs[l]):int(offs[l + 1])]
         assert (lab[seg.astype(np.int64)] == l).all() and (np.diff(seg.astype(np.int64)) > 0).all()
+
+
+def _column_replay_with_reference_kernels(oracle, base, q, k, metric):
+    """the column-major batch loop (flat_searcher_context.h:682-752) replayed in Python on top of the REFERENCE's own
+    compiled M x N kernels and heap (oracle/_ref): transposed 32-row blocks x query groups of 32/16/.../1."""
+    n, dim = base.shape
+    nq = q.shape[0]
+    groups, qi, left, K = [], 0, nq, 32
+    while K >= 1:
+        while left >= K:
+            groups.append((qi, K))
+            qi += K
+            left -= K
+        K >>= 1
+    scores = np.zeros((nq, n), np.float32)
+    full = n // 32 * 32
+    for b0 in range(0, full, 32):
+        blk = np.ascontiguousarray(base[b0:b0 + 32].T)                        # [dim][32]
+        for g0, K in groups:
+            out = oracle.block_dist(metric, blk, np.ascontiguousarray(q[g0:g0 + K].T), use_ref=True)   # [K][32]
+            scores[g0:g0 + K, b0:b0 + 32] = out
+    for r in range(full, n):
+        for g0, K in groups:
+            if K > 1:                                                         # the GROUP is the matrix, the row the query
+                out = oracle.block_dist(metric, np.ascontiguousarray(q[g0:g0 + K].T), np.ascontiguousarray(base[r:r + 1].T), use_ref=True)
+                scores[g0:g0 + K, r] = out[0]
+            else:
+                scores[g0, r] = oracle.dist(metric, base[r], q[g0], use_ref=True)
+    res = []
+    for i in range(nq):
+        idx, sc = oracle.heap_replay(scores[i], k, use_ref=True)
+        order = np.argsort(sc, kind="stable")
+        res.append((idx[order], sc[order]))
+    return res
+
+
+@pytest.mark.parametrize("metric", [O.METRIC_L2, O.METRIC_IP])
+def test_column_major_loop_pinned_to_reference_kernels(oracle, metric):
+    """(a)4: the restated column-major dense path (zo_flat_search_column_t) against a replay of the same loop on the
+    reference's OWN block kernels, 1x1 kernel and heap compiled in place — bit for bit, real-valued data, ragged sizes."""
+    if oracle.ref is None:
+        pytest.skip("oracle/_ref/libzvec_ref.so not present (or CPU lacks AVX-512)")
+    rng = np.random.default_rng(19)
+    for n, dim, nq, k in ((70, 20, 45, 7), (32, 9, 1, 5), (31, 33, 3, 4), (200, 64, 63, 10), (97, 128, 32, 10)):
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+        ok, os_, oi, oc = oracle.flat_search_column(base, q, k, metric)
+        want = _column_replay_with_reference_kernels(oracle, base, q, k, metric)
+        for i in range(nq):
+            widx, wsc = want[i]
+            assert oc[i] == len(widx)
+            assert np.array_equal(os_[i, :oc[i]].view(np.uint32), wsc.view(np.uint32)), (n, dim, nq, i)
+            # ids: equal wherever scores are distinct (heap.sort is unstable among equal scores, heap.h:173-175)
+            distinct = np.concatenate([[True], np.diff(wsc) != 0]) & np.concatenate([np.diff(wsc) != 0, [True]])
+            assert np.array_equal(oi[i, :oc[i]][distinct], widx[distinct])
+
+
+def test_column_major_equals_row_major_on_exact_data(oracle):
+    """flat_searcher_test.cpp:93-209 (row == column == filtered) on integer data, where every kernel is exact: the two
+    scan orders give identical lists; filter-all gives 0 results; a block whose 32 rows are all filtered is skipped."""
+    rng = np.random.default_rng(23)
+    for n, dim, nq, k in ((1000, 16, 70, 10), (65, 8, 2, 3), (20, 5, 33, 4)):
+        base = rng.integers(-7, 8, (n, dim)).astype(np.float32)
+        q = rng.integers(-7, 8, (nq, dim)).astype(np.float32)
+        keys = (np.arange(n, dtype=np.uint64) * 3 + 11)
+        for metric in (O.METRIC_L2, O.METRIC_IP):
+            a = oracle.flat_search(base, q, k, metric, keys=keys)
+            b = oracle.flat_search_column(base, q, k, metric, keys=keys)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+            mask = rng.random(n) < 0.6
+            mask[:min(n, 64)] = True                                         # the first two blocks entirely filtered out
+            bits = O.pack_bits(mask)
+            a = oracle.flat_search(base, q, k, metric, keys=keys, exclude_bits=bits)
+            b = oracle.flat_search_column(base, q, k, metric, keys=keys, exclude_bits=bits)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        none = oracle.flat_search_column(base, q, k, exclude_bits=O.pack_bits(np.ones(n, bool)))
+        assert (none[3] == 0).all()
