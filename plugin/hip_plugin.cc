@@ -77,6 +77,20 @@ int read_segment(IndexStorage *stg, const std::string &id, std::string *out, int
 
 }  // namespace
 
+/*! Reader/writer lock that cannot starve the writer (std::shared_mutex on glibc prefers readers; searches that overlap
+ *  continuously would keep add_impl waiting): everybody passes a gate, a writer keeps it while the readers drain. */
+class FairSharedMutex {
+ public:
+  void lock() { gate_.lock(); rw_.lock(); gate_.unlock(); }
+  void unlock() { rw_.unlock(); }
+  void lock_shared() { gate_.lock(); rw_.lock_shared(); gate_.unlock(); }
+  void unlock_shared() { rw_.unlock_shared(); }
+
+ private:
+  std::mutex gate_;
+  std::shared_mutex rw_;
+};
+
 /*! Search context: one per caller thread (index.cc:24-45 caches it thread-local per index type and may hand it to
  *  another index instance of that type => magic re-binding, flat_streamer.cc:319-321 / ivf_streamer.cc:198-202).
  *  The HIP side (stream + workspace, zvec_hip_ctx_t) is index-agnostic, so re-binding is only bookkeeping. */
@@ -175,7 +189,7 @@ class HipFlatCore {
     pos_of_key_.clear();
   }
   int append(const void *rows, size_t n, const uint64_t *keys) {
-    std::unique_lock<std::shared_mutex> w(mu_);
+    std::unique_lock<FairSharedMutex> w(mu_);
     int rc = zvec_hip_flat_append(h_, rows, n, keys);
     if (rc != 0) return rc;
     for (size_t i = 0; i < n; ++i) {
@@ -186,7 +200,7 @@ class HipFlatCore {
   }
   int search(const void *q, const IndexQueryMeta &qm, uint32_t count, HipContext *ctx) const {
     if (!q || qm.element_size() != elem_size_) return IndexError_InvalidArgument;
-    std::shared_lock<std::shared_mutex> r(mu_);
+    std::shared_lock<FairSharedMutex> r(mu_);
     size_outputs(ctx, count);
     const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());
     int rc = zvec_hip_flat_search(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), bits, ctx->keys_.data(),
@@ -199,7 +213,7 @@ class HipFlatCore {
   int search_by_keys(const void *q, const std::vector<std::vector<uint64_t>> &p_keys, const IndexQueryMeta &qm,
                      uint32_t count, HipContext *ctx) const {
     if (!q || qm.element_size() != elem_size_ || p_keys.size() != count) return IndexError_InvalidArgument;
-    std::shared_lock<std::shared_mutex> r(mu_);
+    std::shared_lock<FairSharedMutex> r(mu_);
     std::vector<uint32_t> ids, offs(count + 1, 0);
     for (uint32_t i = 0; i < count; ++i) {
       for (uint64_t key : p_keys[i]) {
@@ -218,7 +232,7 @@ class HipFlatCore {
     return attach_vectors(ctx, count);
   }
   int vector_of_key(uint64_t key, void *out) const {
-    std::shared_lock<std::shared_mutex> r(mu_);
+    std::shared_lock<FairSharedMutex> r(mu_);
     auto it = pos_of_key_.find(key);
     return it == pos_of_key_.end() ? (int)IndexError_NoExist : zvec_hip_flat_get_vector(h_, it->second, out);
   }
@@ -253,7 +267,7 @@ class HipFlatCore {
   zvec_hip_flat_t h_{nullptr};
   int device_{0};
   uint32_t elem_size_{0};
-  mutable std::shared_mutex mu_;          // add (exclusive) vs search (shared): flat_streamer.cc:236-242
+  mutable FairSharedMutex mu_;            // add (exclusive) vs search (shared): flat_streamer.cc:236-242
   std::vector<uint64_t> keys_;            // key of every storage position
   std::unordered_map<uint64_t, uint32_t> pos_of_key_;
 };

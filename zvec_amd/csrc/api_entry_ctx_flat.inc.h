@@ -75,7 +75,7 @@ int zvec_hip_flat_destroy(zvec_hip_flat_t h) {
 int zvec_hip_flat_reserve(zvec_hip_flat_t h, uint64_t capacity) {
   if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
-  std::unique_lock<std::shared_mutex> w(h->rw);
+  std::unique_lock<FairSharedMutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   return h->st.reserve(capacity, h->defctx->own);
 }
@@ -83,7 +83,7 @@ int zvec_hip_flat_reserve(zvec_hip_flat_t h, uint64_t capacity) {
 int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n, const uint64_t *d_keys, void *stream) {
   if (!h || (!d_vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
-  std::unique_lock<std::shared_mutex> w(h->rw);
+  std::unique_lock<FairSharedMutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(h->defctx, stream);
   if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));   // (an earlier append on another stream)
@@ -108,7 +108,7 @@ int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_
   const uint64_t elem = h->st.row_bytes();
   if (bytes < count * elem) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
-  std::unique_lock<std::shared_mutex> w(h->rw);
+  std::unique_lock<FairSharedMutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
   Scoped<uint8_t> d_body;
@@ -139,7 +139,7 @@ int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const 
   if (!h || (!vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (n == 0) return 0;
   std::lock_guard<std::mutex> g(h->mu);
-  std::unique_lock<std::shared_mutex> w(h->rw);
+  std::unique_lock<FairSharedMutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
   // stage through the device in slices of <= 1 GiB
@@ -172,7 +172,7 @@ int zvec_hip_flat_get_vector(zvec_hip_flat_t h, uint64_t pos, void *out) {
   std::lock_guard<std::mutex> g(h->mu);
   zvec_hip_ctx_s *c = h->defctx;
   std::lock_guard<std::mutex> gc(c->mu);             // io_q is the built-in context's staging buffer
-  std::shared_lock<std::shared_mutex> r(h->rw);
+  std::shared_lock<FairSharedMutex> r(h->rw);
   if (pos >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
   ZCHK(hipSetDevice(h->device));
   if (h->append_pending) ZCHK(hipStreamWaitEvent(c->own, h->append_ev, 0));
@@ -189,7 +189,7 @@ int zvec_hip_flat_get_vectors(zvec_hip_flat_t h, const uint64_t *positions, uint
   if (n > 0x7fffffffull) return ZVEC_HIP_ERR_OUT_OF_RANGE;
   std::lock_guard<std::mutex> g(h->mu);
   std::lock_guard<std::mutex> gc(h->defctx->mu);
-  std::shared_lock<std::shared_mutex> r(h->rw);
+  std::shared_lock<FairSharedMutex> r(h->rw);
   std::vector<uint64_t> pos(positions, positions + n);
   for (uint64_t p : pos)
     if (p >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
@@ -223,7 +223,7 @@ int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *
   if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;   // "Invalid context or topk not set yet" flat_searcher.cc:194
   zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
   std::lock_guard<std::mutex> g(c->mu);
-  std::shared_lock<std::shared_mutex> r(h->rw);
+  std::shared_lock<FairSharedMutex> r(h->rw);
   ZCHK(hipSetDevice(h->device));
   return flat_search_dev_locked(h, c, d_queries, count, topk, threshold, d_exclude_bitset, d_out_keys, d_out_scores,
                                 d_out_counts, pick_stream(c, stream));
@@ -241,7 +241,7 @@ int zvec_hip_flat_search(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *quer
   std::lock_guard<std::mutex> g(c->mu);
   ZCHK(hipSetDevice(h->device));
   {
-    std::shared_lock<std::shared_mutex> r(h->rw);      // the row count the bitset is sized for == the rows scanned
+    std::shared_lock<FairSharedMutex> r(h->rw);      // the row count the bitset is sized for == the rows scanned
     ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->st.row_bytes(), exclude_bitset, h->st.n, count, topk, c->cur));
     ZRET(flat_search_dev_locked(h, c, c->io_q.p, count, topk, threshold, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr,
                                 c->io_keys.as<uint64_t>(), c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
@@ -259,7 +259,7 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
   if ((size_t)topk * 12 + 16 > 60 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
   zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
   std::lock_guard<std::mutex> g(c->mu);
-  std::shared_lock<std::shared_mutex> r(h->rw);
+  std::shared_lock<FairSharedMutex> r(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = c->cur;
   const Store &st = h->st;

@@ -224,7 +224,7 @@ extern "C" int zvec_hip_flat_build_filter(zvec_hip_flat_t h, zvec_hip_ctx_t ctx,
   if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
   std::lock_guard<std::mutex> g(c->mu);              // lock order everywhere: context, then the store's rw lock
-  std::shared_lock<std::shared_mutex> r(h->rw);
+  std::shared_lock<FairSharedMutex> r(h->rw);
   if (h->append_pending) {
     ZCHK(hipSetDevice(h->device));
     ZCHK(hipStreamWaitEvent(stream ? reinterpret_cast<hipStream_t>(stream) : c->cur, h->append_ev, 0));

@@ -68,6 +68,19 @@ struct Scoped {
   operator T *() const { return p; }
 };
 
+// reader/writer lock that cannot starve the writer (std::shared_mutex on glibc prefers readers: searches that overlap
+// continuously would keep an append waiting): everybody passes a gate, a writer keeps it while the readers drain
+class FairSharedMutex {
+ public:
+  void lock() { gate_.lock(); rw_.lock(); gate_.unlock(); }
+  void unlock() { rw_.unlock(); }
+  void lock_shared() { gate_.lock(); rw_.lock_shared(); gate_.unlock(); }
+  void unlock_shared() { rw_.unlock_shared(); }
+ private:
+  std::mutex gate_;
+  std::shared_mutex rw_;
+};
+
 // a blocked, HBM-resident set of rows (flat store, IVF centroids, IVF inverted lists)
 struct Store {
   uint32_t dim_in = 0;   // element dimension at the ABI (cosine: d+1)
@@ -163,7 +176,7 @@ struct zvec_hip_flat_s {
   // shared while they read the store's pointers / row count and enqueue their kernels; anything that may move or
   // extend the store holds it exclusive.  A growth reallocation frees the old arrays with hipFree, which waits for
   // the device, so kernels enqueued by earlier searches have finished with them.
-  std::shared_mutex rw;
+  FairSharedMutex rw;
   // zvec_hip_flat_append_dev returns with its pack kernels only enqueued: recorded after them on the append stream,
   // waited for by every reader of the store on its own stream
   hipEvent_t append_ev = nullptr;

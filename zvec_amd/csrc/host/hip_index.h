@@ -118,6 +118,20 @@ class IndexFilter {
   std::function<bool(uint64_t)> fn_;
 };
 
+// reader/writer lock that cannot starve the writer: std::shared_mutex on glibc prefers readers, and searches that
+// overlap continuously (several threads in a loop) would keep an add_impl waiting forever.  Everybody passes a gate
+// first; a writer keeps the gate while the readers in flight drain, so new readers queue behind it.
+class FairSharedMutex {
+ public:
+  void lock() { gate_.lock(); rw_.lock(); gate_.unlock(); }
+  void unlock() { rw_.unlock(); }
+  void lock_shared() { gate_.lock(); rw_.lock_shared(); gate_.unlock(); }
+  void unlock_shared() { rw_.unlock_shared(); }
+ private:
+  std::mutex gate_;
+  std::shared_mutex rw_;
+};
+
 inline int metric_from_name(const std::string &name) {
   if (name == "SquaredEuclidean") return ZVEC_HIP_METRIC_L2;
   if (name == "InnerProduct") return ZVEC_HIP_METRIC_IP;
@@ -348,7 +362,7 @@ class HipFlatStreamer {
   //! Add a vector into index (index_runner.h:476-480)
   int add_impl(uint64_t key, const void *query, const IndexQueryMeta &qmeta, Context::Pointer & /*context*/) {
     if (!h_ || !query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
-    std::unique_lock<std::shared_mutex> w(keys_mu_);    // add vs search: flat_streamer.cc:236-242, flat_streamer_entity.cc:150
+    std::unique_lock<FairSharedMutex> w(keys_mu_);    // add vs search: flat_streamer.cc:236-242, flat_streamer_entity.cc:150
     int rc = zvec_hip_flat_append(h_, query, 1, &key);
     if (rc == 0) keys_.push_back(key);
     return rc;
@@ -356,7 +370,7 @@ class HipFlatStreamer {
   //! bulk form used by FlatBuilder::build / FlatSearcher::load (flat_builder.cc:188-276)
   int add_batch(const void *vecs, uint64_t n, const uint64_t *keys) {
     if (!h_) return IndexError_InvalidArgument;
-    std::unique_lock<std::shared_mutex> w(keys_mu_);
+    std::unique_lock<FairSharedMutex> w(keys_mu_);
     int rc = zvec_hip_flat_append(h_, vecs, n, keys);
     if (rc == 0) for (uint64_t i = 0; i < n; ++i) keys_.push_back(keys ? keys[i] : keys_.size());
     return rc;
@@ -370,7 +384,7 @@ class HipFlatStreamer {
     Context *ctx = context.get();
     if (!ctx || ctx->topk() == 0) return IndexError_InvalidArgument;    // flat_searcher.cc:194-198
     if (ctx->magic() != magic_) ctx->set_magic(magic_);                 // context made by another index: re-bind
-    std::shared_lock<std::shared_mutex> r(keys_mu_);    // keys_ (filter sweep, bitset size, fetch_vector) vs add
+    std::shared_lock<FairSharedMutex> r(keys_mu_);    // keys_ (filter sweep, bitset size, fetch_vector) vs add
     const uint32_t k = ctx->topk();
     std::vector<uint64_t> keys((size_t)count * k);
     std::vector<float> scores((size_t)count * k);
@@ -411,7 +425,7 @@ class HipFlatStreamer {
   uint32_t magic_{0};
   zvec_hip_flat_t h_{nullptr};
   std::vector<uint64_t> keys_;
-  mutable std::shared_mutex keys_mu_;
+  mutable FairSharedMutex keys_mu_;
   mutable std::mutex map_mu_;
   mutable std::unordered_map<uint64_t, uint64_t> pos_of_key_;
   int attach_vectors(Context *ctx, uint32_t count) const {
