@@ -382,6 +382,65 @@ static int TestConcurrentAddWithFilterAndFetch() {
   return 0;
 }
 
+// patches/boundary_a.diff: boundary A's nprobe arrives as scan_ratio = nprobe / nlist (ivf_searcher_context.h:61-79);
+// with brute_force_threshold = N - 1 the operator probes exactly nprobe lists.  The operator-level search
+// must equal the C ABI called with those two numbers.
+static int TestBoundaryAMapping() {
+  const uint32_t dim = 8, nlist = 200, per_list = 30, n = nlist * per_list, nprobe = 7, topk = 5, nq = 20;
+  IndexMeta meta(IndexMeta::DT_FP32, dim);
+  meta.set_metric("SquaredEuclidean");
+  std::vector<float> base((size_t)n * dim), cent((size_t)nlist * dim);
+  std::vector<uint64_t> offs(nlist + 1);
+  uint32_t seed = 99;
+  auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)((seed >> 12) & 255) / 32.0f; };
+  for (uint32_t l = 0; l < nlist; ++l) {
+    offs[l] = (uint64_t)l * per_list;
+    for (uint32_t j = 0; j < dim; ++j) cent[(size_t)l * dim + j] = (float)(l * 10);
+    for (uint32_t i = 0; i < per_list; ++i)
+      for (uint32_t j = 0; j < dim; ++j) base[((size_t)l * per_list + i) * dim + j] = (float)(l * 10) + rnd();
+  }
+  offs[nlist] = n;
+  Params p;
+  p.set(PARAM_IVF_SEARCHER_SCAN_RATIO, (double)((float)nprobe / (float)nlist));
+  p.set(PARAM_IVF_SEARCHER_BRUTE_FORCE_THRESHOLD, (double)(n - 1));
+  HipIVFSearcher se;
+  ASSERT(0 == se.init(p));
+  ASSERT(0 == se.load(meta, cent.data(), nlist, offs.data(), base.data(), nullptr));
+  EXPECT(se.nprobe() == nprobe);
+  EXPECT(se.max_scan_count() == n - 1);
+  std::vector<float> q((size_t)nq * dim);
+  for (uint32_t i = 0; i < nq; ++i)
+    for (uint32_t j = 0; j < dim; ++j) q[(size_t)i * dim + j] = (float)((i * 9) % nlist * 10) + rnd();
+  IndexQueryMeta qmeta(IndexMeta::DT_FP32, dim);
+  auto ctx = se.create_context();
+  ctx->set_topk(topk);
+  ASSERT(0 == se.search_impl(q.data(), qmeta, nq, ctx));
+  // the same search straight through the C ABI with (nprobe, N - 1), plus the per-query probe statistics
+  zvec_hip_ivf_t raw = nullptr;
+  ASSERT(0 == zvec_hip_ivf_create(dim, ZVEC_HIP_DT_FP32, ZVEC_HIP_METRIC_L2, 0, &raw));
+  ASSERT(0 == zvec_hip_ivf_load(raw, cent.data(), nlist, offs.data(), base.data(), nullptr));
+  zvec_hip_ctx_t rc_ctx = nullptr;
+  ASSERT(0 == zvec_hip_ctx_create(0, &rc_ctx));
+  std::vector<uint64_t> keys((size_t)nq * topk);
+  std::vector<float> scores((size_t)nq * topk);
+  std::vector<uint32_t> counts(nq), scanned(nq), probes(nq);
+  ASSERT(0 == zvec_hip_ivf_search(raw, rc_ctx, q.data(), nq, topk, FLT_MAX, nprobe, n - 1, nullptr, keys.data(), scores.data(), counts.data()));
+  ASSERT(0 == zvec_hip_ivf_last_stats(raw, rc_ctx, nq, scanned.data(), probes.data()));
+  for (uint32_t i = 0; i < nq; ++i) {
+    EXPECT(probes[i] == nprobe);
+    EXPECT(scanned[i] == nprobe * per_list);
+    const IndexDocumentList &r = ctx->result(i);
+    ASSERT(r.size() == counts[i]);
+    for (size_t j = 0; j < r.size(); ++j) {
+      EXPECT(r[j].key() == keys[(size_t)i * topk + j]);
+      EXPECT(r[j].score() == scores[(size_t)i * topk + j]);
+    }
+  }
+  zvec_hip_ctx_destroy(rc_ctx);
+  zvec_hip_ivf_destroy(raw);
+  return 0;
+}
+
 int main() {
   int rc = 0;
   rc |= TestLinearSearch();
@@ -389,6 +448,7 @@ int main() {
   rc |= TestIVFSimple();
   rc |= TestNullContextFromManyThreads();
   rc |= TestConcurrentAddWithFilterAndFetch();
+  rc |= TestBoundaryAMapping();
   rc |= TestMicroBatcher();
   if (rc == 0 && g_fail == 0) { printf("host mirror: all tests passed\n"); return 0; }
   printf("host mirror: %d failures (rc=%d)\n", g_fail, rc);

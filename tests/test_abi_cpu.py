@@ -79,3 +79,19 @@ def test_shard_map_is_byte_balanced_and_matches_restatement():
         if nlist >= 64 * nshards:
             tiles = np.array([((sizes[owner == g].astype(np.int64) + 127) // 128).sum() for g in range(nshards)])
             assert tiles.max() <= 1.01 * tiles.mean()                   # balanced by bytes
+
+
+def test_boundary_a_parameter_mapping_arithmetic():
+    """patches/boundary_a.diff hands boundary A's nprobe to IVFSearcherContext::update as scan_ratio = nprobe / nlist
+    (ivf_searcher_context.h:61-79): round(nlist * scan_ratio) must give nprobe back for the BASELINE configurations and
+    for awkward (non power-of-two) list counts; brute_force_threshold = N - 1 pins max_scan_count at N - 1."""
+    import numpy as np
+    from zvec_amd.index import ivf_probe_params
+    for nlist, nprobe, n in ((4096, 32, 10_000_000), (4096, 38, 10_000_000), (16384, 64, 100_000_000), (1000, 7, 123_457),
+                             (1024, 1, 5000), (3, 3, 10), (65536, 1, 1 << 30)):
+        ratio = float(np.float32(nprobe) / np.float32(nlist))
+        got, max_scan = ivf_probe_params(nlist, n, ratio, n - 1)
+        assert got == nprobe and max_scan == max(n - 1, int(np.ceil(np.float32(n) * np.float32(ratio))))
+    # the reference defaults (scan_ratio 0.1, threshold 1000, ivf_searcher_context.h:211-213)
+    assert ivf_probe_params(1024, 50_000, 0.1, 1000) == (102, 5000)
+    assert ivf_probe_params(4, 100, 0.1, 1000) == (1, 1000)

@@ -325,3 +325,33 @@ def test_same_value_rows_all_ties(zv):
             assert fn(qb, 33, ctx) == 0
             for qi in range(33):
                 assert len(ctx.result(qi)) == 1 and ctx.result(qi)[0].score() == float(qi * qi * dim)
+
+
+def test_boundary_a_parameter_mapping_probes_exactly_nprobe(zv):
+    """SURVEY H3 / patches/boundary_a.diff: nlist = 4096 honoured (no clamp to 1024), nprobe = 32 handed over as
+    scan_ratio = 32/4096 with brute_force_threshold = N - 1 => every query probes exactly 32 lists and scans exactly the
+    rows of those lists (BASELINE configs[2]'s probe shape), through the operator-level search_impl."""
+    rng = np.random.default_rng(64)
+    n, dim, nlist, nprobe, nq, k = 200_000, 32, 4096, 32, 64, 10
+    base = (rng.standard_normal((n, 6)) @ rng.standard_normal((6, dim))).astype(np.float32)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean")
+    assert se.build(base, nlist, kmeans_iters=3, sample_per_list=32) == 0
+    assert se.info() == (n, nlist)
+    se.set_nprobe(nprobe)
+    assert se.probe_params() == (nprobe, n - 1)
+    q = base[rng.choice(n, nq, replace=False)]
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    scanned, probes = se.last_stats(ctx, nq)
+    assert (probes == nprobe).all()
+    cent, offs, rows = se.export()
+    sizes = np.diff(offs.astype(np.int64))
+    d = ((q[:, None, :].astype(np.float64) - cent[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    near = np.argsort(d, axis=1, kind="stable")[:, :nprobe]
+    want = sizes[near].sum(1)
+    # (a coarse near-tie at rank 32 may swap one list: compare wherever the 32nd and 33rd centroid are well separated)
+    ds = np.sort(d, axis=1)
+    clear = (ds[:, nprobe] - ds[:, nprobe - 1]) > 1e-4 * ds[:, nprobe]
+    assert clear.sum() > nq // 2 and (scanned[clear] == want[clear]).all()
+    assert (ctx.scores[:, 0] == 0).all()                       # self-queries: found in their own list

@@ -588,12 +588,15 @@ class HipIVFSearcher:
 
     # IVFSearcherContext::update (ivf_searcher_context.h:61-79)
     def probe_params(self):
-        n, nlist = self.total_count, self.info()[1]
-        # float arithmetic and std::round (half away from zero) as in the reference
-        nprobe = max(int(np.floor(np.float32(np.float32(nlist) * np.float32(self.scan_ratio)) + np.float32(0.5))), 1)
-        max_scan = int(np.ceil(np.float32(np.float32(n) * np.float32(self.scan_ratio))))
-        max_scan = max(self.brute_force_threshold, max_scan)
-        return nprobe, max_scan
+        return ivf_probe_params(self.info()[1], self.total_count, self.scan_ratio, self.brute_force_threshold)
+
+    def set_nprobe(self, nprobe, exact=True):
+        """boundary A's `nprobe` as patches/boundary_a.diff hands it to the searcher context: scan_ratio = nprobe / nlist;
+        exact=True also sets brute_force_threshold = N - 1, which makes every query probe exactly nprobe lists
+        (max_scan_count then never cuts the probe loop short)."""
+        self.scan_ratio = float(np.float32(nprobe) / np.float32(max(self.info()[1], 1)))
+        if exact:
+            self.brute_force_threshold = max(self.total_count - 1, 0)
 
     def keys_in_list_order(self):
         """key of every dense list-order position (what IVFEntity::get_keys reads, ivf_entity.cc:612)."""
@@ -678,6 +681,15 @@ class HipIVFSearcher:
 # "IVFStreamer" (what the product instantiates, indexes/ivf_index.cc:38-39) is a read-only operator over a dumped index
 # in the reference too (ivf_streamer.h:28-85): same class
 HipIVFStreamer = HipIVFSearcher
+
+
+def ivf_probe_params(nlist, n, scan_ratio, brute_force_threshold):
+    """IVFSearcherContext::update (ivf_searcher_context.h:61-79) in the reference's float arithmetic:
+    nprobe = max(round(nlist * scan_ratio), 1) (std::round: half away from zero),
+    max_scan_count = max(brute_force_threshold, ceil(N * scan_ratio))."""
+    nprobe = max(int(np.floor(np.float32(np.float32(nlist) * np.float32(scan_ratio)) + np.float32(0.5))), 1)
+    max_scan = int(np.ceil(np.float32(np.float32(n) * np.float32(scan_ratio))))
+    return nprobe, max(int(brute_force_threshold), max_scan)
 
 
 def shard_map(list_sizes, nshards):
