@@ -54,6 +54,7 @@ enum {
 typedef struct zvec_hip_flat_s *zvec_hip_flat_t;
 typedef struct zvec_hip_ivf_s *zvec_hip_ivf_t;
 typedef struct zvec_hip_ctx_s *zvec_hip_ctx_t;
+typedef struct zvec_hip_shards_s *zvec_hip_shards_t;
 
 /* library / device ------------------------------------------------------------------------- */
 int zvec_hip_abi_version(void);
@@ -222,6 +223,39 @@ uint64_t zvec_hip_packed_bytes(uint32_t count, uint32_t topk);
 int zvec_hip_merge_topk_packed_dev(zvec_hip_ctx_t ctx, const void *d_packed, uint64_t part_stride,
                                    uint32_t nparts, uint32_t count, uint32_t topk, uint64_t *d_out_keys,
                                    float *d_out_scores, uint32_t *d_out_counts, void *stream);
+
+/* ---- one index over several GPUs, inside one process ---------------------------------------
+ * zvec is a single-process embedded library: the plugin cannot count on a launcher to use the 8 GPUs of a node.  One
+ * zvec_hip_shards_t owns G device shards of ONE index and does what CombinedVectorColumnIndexer::Search does over
+ * blocks (combined_vector_column_indexer.cc:91-232): fan the batch out, rebase, concatenate in part order, keep the
+ * top-k.  Partition: FLAT = contiguous row ranges (every append is cut into G pieces; key = the caller's
+ * key or the global storage position), IVF = whole inverted lists dealt by zvec_hip_ivf_shard_map, centroids
+ * replicated, probe sets global.  A search runs one worker thread per shard (own device, context and stream); each
+ * writes its candidate lists in the packed layout and peer-copies them (xGMI) to devices[0], which merges them with
+ * the kernel of zvec_hip_merge_topk_packed_dev.  `devices` may repeat a device (several shards on one GPU).
+ * The one-process-per-GPU form of the same partition (RCCL all-gather of the same packed lists) is zvec_amd/dist.py. */
+enum { ZVEC_HIP_SHARDS_FLAT = 0, ZVEC_HIP_SHARDS_IVF = 1 };
+int zvec_hip_shards_create(uint32_t dim, int dtype, int metric, int kind, const int *devices, uint32_t ndev,
+                           zvec_hip_shards_t *out);
+int zvec_hip_shards_destroy(zvec_hip_shards_t h);
+/* rows held in total / per shard (per_shard[ndev] nullable) */
+int zvec_hip_shards_count(zvec_hip_shards_t h, uint64_t *total, uint64_t *per_shard);
+/* FLAT: IndexStreamer::add_impl in bulk (index_runner.h:476-487); keys NULL -> key = global storage position */
+int zvec_hip_shards_flat_append(zvec_hip_shards_t h, const void *vecs, uint64_t n, const uint64_t *keys);
+/* IVF: IVFBuilder::train + build over the shards (ivf_builder.cc:212-403): k-means on devices[0], labels computed in
+ * G pieces, every shard fills the lists it owns.  Same sample / seed rule as zvec_hip_ivf_build, hence the same
+ * centroids and lists as an unsharded build. */
+int zvec_hip_shards_ivf_build(zvec_hip_shards_t h, const void *vecs, uint64_t n, const uint64_t *keys, uint32_t nlist,
+                              uint32_t kmeans_iters, uint32_t sample_per_list, uint64_t seed);
+/* IVF: IVFSearcher::load of host arrays (see zvec_hip_ivf_load); every shard keeps its lists */
+int zvec_hip_shards_ivf_load(zvec_hip_shards_t h, const void *centroids, uint32_t nlist, const uint64_t *list_offsets,
+                             const void *vecs, const uint64_t *keys);
+/* search_impl(query, qmeta, count, ctx) over the shards; host pointers; FLAT ignores nprobe / max_scan_count.
+ * exclude_bitset: 1 bit per GLOBAL storage position (FLAT: append order; IVF: list-order positions of the whole
+ * index), sliced per shard on the host.  Results: the global top-k, as from one unsharded index. */
+int zvec_hip_shards_search(zvec_hip_shards_t h, const void *queries, uint32_t count, uint32_t topk, float threshold,
+                           uint32_t nprobe, uint32_t max_scan_count, const uint64_t *exclude_bitset,
+                           uint64_t *out_keys, float *out_scores, uint32_t *out_counts);
 
 /* ---- measurement hook ---------------------------------------------------------------------
  * Records HIP events around the dominant scan kernel of each search on ctx (on the stream the

@@ -220,3 +220,84 @@ def test_concurrent_add_and_search(oracle):
     assert st.search_impl(qq, 30, ctx) == 0
     ok, os_, _, oc = oracle.flat_search(base, qq, 10, O.METRIC_L2)
     tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="after concurrent adds")
+
+
+@pytest.mark.parametrize("ndev", [1, 2, 5])
+def test_in_process_shards_flat_equals_one_index(oracle, ndev):
+    """zvec_hip_shards_* (one handle, G device shards, worker thread per shard, peer-copied candidate lists, GPU merge) —
+    all shards on device 0 here; the fan-out / merge must reproduce the single-index answer (and the oracle's), with
+    explicit keys, several appends (rows dealt in G pieces each time), a global exclude bitset and an RNN radius."""
+    import zvec_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(500 + ndev)
+    dim, nq, k = 48, 70, 10
+    parts = [rng.integers(-9, 10, (m, dim)).astype(np.float32) for m in (3001, 17, 4999)]
+    base = np.concatenate(parts)
+    n = base.shape[0]
+    keys = (np.arange(n, dtype=np.uint64) * 7 + 3)
+    q = rng.integers(-9, 10, (nq, dim)).astype(np.float32)
+    sh = zvec_amd.HipShardedIndex("flat", dim, "SquaredEuclidean", devices=[0] * ndev)
+    o = 0
+    for p in parts:
+        assert sh.append(p, keys[o:o + p.shape[0]]) == 0
+        o += p.shape[0]
+    total, per = sh.counts()
+    assert total == n and per.sum() == n and (per > 0).all()
+    gk, gs, gc = sh.search(q, k)
+    ok, os_, _, oc = oracle.flat_search(base, q, k, O.METRIC_L2, keys=keys)
+    tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="in-process flat shards")
+    mask = rng.random(n) < 0.5
+    gk, gs, gc = sh.search(q, k, exclude=O.pack_bits(mask), threshold=float(np.median(os_[:, -1])))
+    ok, os_, _, oc = oracle.flat_search(base, q, k, O.METRIC_L2, keys=keys, exclude_bits=O.pack_bits(mask),
+                                        threshold=float(np.median(os_[:, -1])))
+    tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="in-process flat shards, filter + radius")
+    # keys NULL -> global storage positions
+    sh2 = zvec_amd.HipShardedIndex("flat", dim, "SquaredEuclidean", devices=[0] * ndev)
+    for p in parts:
+        assert sh2.append(p) == 0
+    gk, gs, gc = sh2.search(q, k)
+    ok, os_, _, oc = oracle.flat_search(base, q, k, O.METRIC_L2)
+    tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="in-process flat shards, position keys")
+
+
+@pytest.mark.parametrize("ndev", [1, 3])
+def test_in_process_shards_ivf_equals_one_index(oracle, ndev):
+    import zvec_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(600 + ndev)
+    n, dim, nlist, nq, k, nprobe = 30000, 40, 64, 90, 10, 8
+    base = rng.integers(-8, 9, (n, dim)).astype(np.float32)
+    q = rng.integers(-8, 9, (nq, dim)).astype(np.float32)
+    # (1) load of a given structure: compare with the oracle on that structure
+    cent, offs, order = kmeans_lists(rng, base, nlist)
+    cent = np.round(cent)
+    vecs, keys = base[order], order.astype(np.uint64)
+    sh = zvec_amd.HipShardedIndex("ivf", dim, "SquaredEuclidean", devices=[0] * ndev)
+    assert sh.load(cent, offs, vecs, keys) == 0
+    total, per = sh.counts()
+    assert total == n
+    from tests.util import lpt_owner
+    sizes = np.diff(offs.astype(np.int64))
+    owner = lpt_owner(sizes, ndev)
+    assert np.array_equal(per.astype(np.int64), np.array([sizes[owner == g].sum() for g in range(ndev)]))
+    gk, gs, gc = sh.search(q, k, nprobe=nprobe, max_scan=n)
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, n, keys=keys)
+    from tests.util import exact_l2
+    cd = np.sort(exact_l2(cent, q), 1)
+    sel = np.nonzero(cd[:, nprobe - 1] != cd[:, nprobe])[0]
+    tie_tolerant_compare(gk[sel], gs[sel], gc[sel], ok[sel], os_[sel], oc[sel], what="in-process ivf shards vs oracle")
+    mask = rng.random(n) < 0.3                                        # global exclude set over list-order positions
+    gk, gs, gc = sh.search(q, k, nprobe=nprobe, max_scan=n, exclude=O.pack_bits(mask))
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, n, keys=keys, exclude_bits=O.pack_bits(mask))
+    tie_tolerant_compare(gk[sel], gs[sel], gc[sel], ok[sel], os_[sel], oc[sel], what="in-process ivf shards, filter")
+    # (2) sharded build == unsharded build (same sample / seed rule): same answers as one zvec_hip_ivf_build index
+    one = zvec_amd.HipIVFSearcher(dim, "SquaredEuclidean")
+    assert one.build(base, nlist, kmeans_iters=4, sample_per_list=64, seed=11) == 0
+    ctx = one.create_context()
+    ctx.set_topk(k)
+    one.set_nprobe(nprobe)
+    assert one.search_impl(q, nq, ctx) == 0
+    sb = zvec_amd.HipShardedIndex("ivf", dim, "SquaredEuclidean", devices=[0] * ndev)
+    assert sb.build(base, nlist, kmeans_iters=4, sample_per_list=64, seed=11) == 0
+    gk, gs, gc = sb.search(q, k, nprobe=nprobe, max_scan=n - 1)
+    tie_tolerant_compare(gk, gs, gc, ctx.keys, ctx.scores, ctx.counts, what="sharded build vs one-call build")

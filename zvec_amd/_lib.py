@@ -84,6 +84,14 @@ SYMBOLS = {
     "zvec_hip_packed_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32]),
     "zvec_hip_merge_topk_packed_dev": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  _u64p, _f32p, _u32p, C.c_void_p]),
+    "zvec_hip_shards_create": (C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_uint32, C.POINTER(_h)]),
+    "zvec_hip_shards_destroy": (C.c_int, [_h]),
+    "zvec_hip_shards_count": (C.c_int, [_h, C.POINTER(C.c_uint64), _u64p]),
+    "zvec_hip_shards_flat_append": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p]),
+    "zvec_hip_shards_ivf_build": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "zvec_hip_shards_ivf_load": (C.c_int, [_h, C.c_void_p, C.c_uint32, _u64p, C.c_void_p, _u64p]),
+    "zvec_hip_shards_search": (C.c_int, [_h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, _u64p,
+                                         _u64p, _f32p, _u32p]),
     "zvec_hip_flat_build_filter": (C.c_int, [_h, _h, C.POINTER(DocFilterDesc), _u64p, C.c_int, C.c_void_p]),
     "zvec_hip_ivf_build_filter": (C.c_int, [_h, _h, C.POINTER(DocFilterDesc), _u64p, C.c_int, C.c_void_p]),
     "zvec_hip_reform_queries_dev": (C.c_int, [_h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -9,7 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <shared_mutex>
 #include <new>
 #include <vector>
@@ -32,5 +36,6 @@ extern "C" {
 #include "api_entry_ivf.inc.h"
 #include "api_entry_merge_prof.inc.h"
 #include "api_entry_filter.inc.h"
+#include "api_entry_shards.inc.h"
 
 }  // extern "C"

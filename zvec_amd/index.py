@@ -683,6 +683,69 @@ class HipIVFSearcher:
 HipIVFStreamer = HipIVFSearcher
 
 
+class HipShardedIndex:
+    """one index over several GPUs inside ONE process (zvec_hip_shards_*): the in-process counterpart of the
+    one-rank-per-GPU sharding in zvec_amd/dist.py, for embedded callers like zvec itself.  kind: "flat" or "ivf";
+    devices: HIP device ordinals, repeats allowed (several shards on one GPU)."""
+
+    def __init__(self, kind, dim, metric=METRIC_L2, devices=(0,), dtype="fp32"):
+        if isinstance(metric, str):
+            metric = metric_from_name(metric)
+        self.kind = {"flat": 0, "ivf": 1}[kind]
+        self.dim = int(dim)
+        self.dtype, self.np_dtype = _dtype_of(dtype)
+        self.ndev = len(devices)
+        dev = (C.c_int * self.ndev)(*[int(d) for d in devices])
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().zvec_hip_shards_create(self.dim, self.dtype, metric, self.kind, dev, self.ndev, C.byref(self._h)),
+                   "zvec_hip_shards_create")
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().zvec_hip_shards_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def counts(self):
+        total = C.c_uint64(0)
+        per = np.zeros(self.ndev, np.uint64)
+        _lib.check(_lib.lib().zvec_hip_shards_count(self._h, C.byref(total), _np_ptr(per)), "zvec_hip_shards_count")
+        return int(total.value), per
+
+    def append(self, vecs, keys=None):
+        vecs = np.ascontiguousarray(vecs, self.np_dtype)
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        return _lib.lib().zvec_hip_shards_flat_append(self._h, _np_ptr(vecs), vecs.shape[0], _np_ptr(k))
+
+    def build(self, vecs, nlist, keys=None, kmeans_iters=10, sample_per_list=256, seed=20260320):
+        vecs = np.ascontiguousarray(vecs, self.np_dtype)
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        return _lib.lib().zvec_hip_shards_ivf_build(self._h, _np_ptr(vecs), vecs.shape[0], _np_ptr(k), nlist, kmeans_iters,
+                                                    sample_per_list, seed)
+
+    def load(self, centroids, list_offsets, vecs, keys=None):
+        centroids = np.ascontiguousarray(centroids, self.np_dtype)
+        lo = np.ascontiguousarray(list_offsets, np.uint64)
+        vecs = np.ascontiguousarray(vecs, self.np_dtype)
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        return _lib.lib().zvec_hip_shards_ivf_load(self._h, _np_ptr(centroids), centroids.shape[0], _np_ptr(lo), _np_ptr(vecs),
+                                                   _np_ptr(k))
+
+    def search(self, queries, topk, nprobe=1, max_scan=0xffffffff, threshold=FLT_MAX, exclude=None):
+        q = np.ascontiguousarray(queries, self.np_dtype)
+        count = q.shape[0]
+        keys = np.zeros((count, topk), np.uint64)
+        scores = np.zeros((count, topk), np.float32)
+        counts = np.zeros(count, np.uint32)
+        ex = None if exclude is None else np.ascontiguousarray(exclude, np.uint64)
+        rc = _lib.lib().zvec_hip_shards_search(self._h, _np_ptr(q), count, topk, threshold, nprobe, max_scan, _np_ptr(ex),
+                                               _np_ptr(keys), _np_ptr(scores), _np_ptr(counts))
+        _lib.check(rc, "zvec_hip_shards_search")
+        return keys, scores, counts
+
+
 def ivf_probe_params(nlist, n, scan_ratio, brute_force_threshold):
     """IVFSearcherContext::update (ivf_searcher_context.h:61-79) in the reference's float arithmetic:
     nprobe = max(round(nlist * scan_ratio), 1) (std::round: half away from zero),
