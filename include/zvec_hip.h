@@ -113,6 +113,13 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
                                 uint32_t topk, float threshold, const uint64_t *exclude_bitset,
                                 uint64_t *out_keys, float *out_scores, uint32_t *out_counts);
 
+/* IndexMetric::batch_distance (src/include/zvec/core/framework/index_metric.h:85-87; ailego BaseDistance::ComputeBatch,
+ * src/ailego/math_batch/distance_batch.h:29-49): ONE query against n scattered stored rows (storage positions), scores
+ * only, in the listed order — the one-to-many form the graph indexes drive; for L2 / IP the reference's batch form is a
+ * loop of the 1x1 kernel.  Positions beyond the row count score +inf. */
+int zvec_hip_flat_batch_distance(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *query, const uint32_t *positions,
+                                 uint32_t n, float *out_scores);
+
 /* ---- IVF-Flat -----------------------------------------------------------------------------
  * stands behind IVFStreamer / IVFSearcher (src/core/algorithm/ivf/ivf_streamer.cc:183-250,
  * ivf_searcher.cc:183-250) with IVFCentroidIndex (ivf_centroid_index.cc:273-297) and

@@ -482,3 +482,41 @@ def test_flat_vs_column_major_oracle(zv, oracle, metric, dtype):
                         else:
                             tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, rtol=2e-6, atol=1e-6,
                                                  select_band=4e-6 * (qn + bn), what=what)
+
+
+@pytest.mark.parametrize("metric,dtype", [("SquaredEuclidean", "fp32"), ("InnerProduct", "fp32"), ("Cosine", "fp32"),
+                                          ("SquaredEuclidean", "fp16")])
+def test_batch_distance_one_to_many(zv, oracle, metric, dtype):
+    """SURVEY §8(a) row 5: IndexMetric::batch_distance — one query against scattered rows.  BaseDistance::ComputeBatch
+    (distance_batch.h:29-49) is a loop of the 1x1 kernel for L2 / IP, which the oracle restates exactly; the cosine
+    variant sums in another order (inner_product_distance_batch_impl.h), covered by the same stated tolerance."""
+    rng = np.random.default_rng(91)
+    n, d = 5000, 96
+    npdt = np.float16 if dtype == "fp16" else np.float32
+    m = {"SquaredEuclidean": O.METRIC_L2, "InnerProduct": O.METRIC_IP, "Cosine": O.METRIC_COSINE}[metric]
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    qraw = rng.standard_normal(d).astype(np.float32)
+    if metric == "Cosine":
+        base, q = oracle.cosine_transform(raw), oracle.cosine_transform(qraw)[0]
+    else:
+        base, q = raw.astype(npdt), qraw.astype(npdt)
+    dim = base.shape[1]
+    se = zv.HipFlatSearcher(dim, metric, dtype=dtype)
+    assert se.load(base) == 0
+    pos = rng.choice(n, 777, replace=False).astype(np.uint32)
+    pos[5] = n + 3                                           # out of range -> +inf
+    got = se.batch_distance(q, pos)
+    assert np.isinf(got[5])
+    fn = oracle.dist16 if dtype == "fp16" else oracle.dist
+    want = np.array([fn(m, base[p], q) if p < n else np.inf for p in pos], np.float32)
+    ok = np.isfinite(want)
+    qn, bn = float((q[:d].astype(np.float64) ** 2).sum()), (base[pos[ok], :d].astype(np.float64) ** 2).sum(1)
+    tol = 2e-6 * np.abs(want[ok]) + 1e-6 if m == O.METRIC_L2 else 4e-6 * np.sqrt(qn * bn)
+    assert np.all(np.abs(got[ok] - want[ok]) <= tol)
+    # integer data: bit-exact
+    ib = rng.integers(-9, 10, (300, 24)).astype(np.float32)
+    iq = rng.integers(-9, 10, 24).astype(np.float32)
+    s2 = zv.HipFlatSearcher(24, "SquaredEuclidean")
+    assert s2.load(ib) == 0
+    p2 = rng.permutation(300).astype(np.uint32)
+    assert np.array_equal(s2.batch_distance(iq, p2), np.array([oracle.dist(O.METRIC_L2, ib[p], iq) for p in p2], np.float32))

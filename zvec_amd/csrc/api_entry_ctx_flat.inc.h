@@ -304,3 +304,42 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
   ZCHK(hipGetLastError());
   return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, s);
 }
+
+// IndexMetric::batch_distance (index_metric.h:85-87; ailego BaseDistance::ComputeBatch, math_batch/distance_batch.h:29-49):
+// ONE query against `n` scattered stored rows, scores only, in the listed order — for L2 / IP the reference's batch form
+// is a loop of the 1x1 kernel; here one wave per listed row scores it directly (the gather kernel of
+// search_bf_by_p_keys_impl without the selection).  positions out of range score +inf.
+int zvec_hip_flat_batch_distance(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *query, const uint32_t *positions,
+                                 uint32_t n, float *out_scores) {
+  if (!h || !query || (n && (!positions || !out_scores))) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return 0;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  std::shared_lock<FairSharedMutex> r(h->rw);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = c->cur;
+  const Store &st = h->st;
+  if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));
+  std::vector<uint32_t> clean(positions, positions + n);
+  for (auto &p : clean) if (p >= st.n) p = IDX_NONE;
+  const uint32_t offs[2] = {0, n};
+  ZRET(c->io_q.ensure(st.row_bytes()));
+  ZCHK(hipMemcpyAsync(c->io_q.p, query, st.row_bytes(), hipMemcpyHostToDevice, s));
+  ZRET(prep_queries(c, st, c->io_q.p, 1, FLT_MAX, s));
+  ZRET(c->plan.ensure(((size_t)n + 8) * sizeof(uint32_t)));
+  uint32_t *d_pos = c->plan.as<uint32_t>(), *d_off = d_pos + n;
+  ZCHK(hipMemcpyAsync(d_pos, clean.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  ZCHK(hipMemcpyAsync(d_off, offs, sizeof(offs), hipMemcpyHostToDevice, s));
+  ZRET(c->part_s.ensure((size_t)n * 4));
+  ZRET(c->part_i.ensure((size_t)n * 4));
+  if (st.f16)
+    hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, s, st.base, c->qpad.as<float>(), st.dpad,
+                       st.metric, d_pos, d_off, 1u, n, c->part_s.as<float>(), c->part_i.as<uint32_t>());
+  else
+    hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, s, st.base, c->qpad.as<float>(), st.dpad,
+                       st.metric, d_pos, d_off, 1u, n, c->part_s.as<float>(), c->part_i.as<uint32_t>());
+  ZCHK(hipGetLastError());
+  ZCHK(hipMemcpyAsync(out_scores, c->part_s.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  ZCHK(hipStreamSynchronize(s));
+  return 0;
+}

@@ -390,6 +390,15 @@ class _FlatBase:
             ctx._set_results(keys_o, scores, counts, self._vectors_of_keys)
         return rc
 
+    def batch_distance(self, query, positions, ctx=None):
+        """IndexMetric::batch_distance: one query against the listed storage positions, scores in that order"""
+        q = np.ascontiguousarray(query, self.np_dtype).reshape(-1)
+        pos = np.ascontiguousarray(positions, np.uint32)
+        out = np.zeros(pos.size, np.float32)
+        _lib.check(_lib.lib().zvec_hip_flat_batch_distance(self._h, ctx._h if ctx else None, _np_ptr(q), _np_ptr(pos), pos.size,
+                                                           _np_ptr(out)), "zvec_hip_flat_batch_distance")
+        return out
+
     def search_dev(self, d_queries, count, topk, d_out_keys, d_out_scores, d_out_counts, ctx,
                    threshold=FLT_MAX, d_exclude=None, stream=None):
         """device-pointer form (async): all arguments are raw device pointers (ints)."""
