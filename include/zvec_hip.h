@@ -296,6 +296,21 @@ int zvec_hip_ivf_load_segments(zvec_hip_ivf_t h, const void *inverted_header, ui
                                const void *inverted_meta, uint64_t meta_bytes, const void *inverted_body,
                                uint64_t body_bytes, const void *keys, uint64_t keys_bytes, const void *centroids);
 
+/* The container framing of a dumped index FILE (IndexFormat, src/include/zvec/core/framework/index_format.h:26-95;
+ * IndexUnpacker::unpack, index_unpacker.h:103-330): [MetaHeader][segments' data][segment metas + ids][MetaFooter],
+ * possibly chained.  Lists the segments of a whole file image — id, byte offset in the image, size — so that a caller
+ * holding only the file can hand "flat.features" / "flat.keys" / "ivf.*" / "hc.keys" to the loaders above (the plugin
+ * gets them from zvec's IndexStorage instead).  Header / footer / meta CRCs (crc32c) are always checked, the content CRC
+ * when checksum != 0.  Host-only code.  out may be NULL with cap 0 to count; OutOfRange (-17) when cap is too small
+ * (count is still set), Mismatch (-24) for a bad size field or checksum, InvalidArgument for inconsistent offsets. */
+typedef struct {
+  char id[64];
+  uint64_t offset, size, padding;
+  uint32_t crc, reserved_;
+} zvec_hip_segment_t;
+int zvec_hip_container_segments(const void *image, uint64_t bytes, int checksum, zvec_hip_segment_t *out, uint32_t cap,
+                                uint32_t *count);
+
 /* Query reformers on the device, for callers that keep raw fp32 query batches in HBM:
  *   cosine != 0: CosineReformer::transform (src/core/quantizer/cosine_reformer.cc:66-112) — q/||q|| followed by ||q||
  *                (out rows: dim+1 floats, or dim+2 halves with the norm's bytes in the last two slots);

@@ -44,3 +44,42 @@ def dump_ivf_segments(lists, dim, dtype=np.float32, column_major=False, block_ve
                          block_size, blocks, len(index_meta)) + index_meta
     return {"ivf.inverted_header": bytes(header), "ivf.inverted_meta": b"".join(metas), "ivf.inverted_body": bytes(body),
             "hc.keys": np.concatenate(keys).astype("<u8").tobytes() if keys else b""}
+
+
+def pack_container(segments, version=b"zvec-test-writer"):
+    """Test-side WRITER of the container framing of a dumped index file, restated from IndexPacker::setup / pack / finish /
+    pack_version (src/include/zvec/core/framework/index_packer.h:98-231) and IndexFormat (index_format.h:26-200):
+    [MetaHeader 64 B][segments' data, each padded to 32 B]["IndexVersion" segment][padding to 32][SegmentMeta[count] +
+    NUL-terminated ids, padded to 32][MetaFooter 128 B].  segments: list of (id, bytes).  Parity of the byte layout is
+    unpinned (the reference ships no dumped file); the CRC itself is pinned by the reference's known answers."""
+    from oracle.roaring import crc32c
+    content = bytearray()
+    stab = []
+    for sid, data in segments:
+        data = bytes(data)
+        pad = (len(data) + 31) // 32 * 32 - len(data)
+        stab.append((sid, len(data), pad, crc32c(data, 0)))
+        content += data + b"\0" * pad
+    vpad = (len(version) + 31) // 32 * 32 - len(version)
+    stab.append(("IndexVersion", len(version), vpad, crc32c(version, 0)))
+    content += version + b"\0" * vpad
+    content_crc = crc32c(bytes(content), 0)
+    cpad = (len(content) + 31) // 32 * 32 - len(content)
+    metas, ids, off = bytearray(), bytearray(), 0
+    ids_base = 32 * len(stab)
+    for sid, size, pad, crc in stab:
+        metas += struct.pack("<IIQQQ", ids_base + len(ids), crc, off, size, pad)
+        ids += sid.encode() + b"\0"
+        off += size + pad
+    meta_block = bytes(metas + ids)
+    meta_block += b"\0" * ((len(meta_block) + 31) // 32 * 32 - len(meta_block))
+
+    def with_crc(buf):                       # crc field first, zero while the crc is taken
+        return struct.pack("<I", crc32c(buf, 0)) + buf[4:]
+    header = with_crc(struct.pack("<IHHIIHHIQQ24x", 0, 0, 2, 0, 0x5A564543, 64, 128, (1 << 32) - 128, 64, 1700000000))
+    total = 64 + len(content) + cpad + len(meta_block) + 128
+    footer = with_crc(struct.pack("<IIIIIIQQQQ56xQQ", 0, crc32c(meta_block, 0), content_crc, len(stab), len(meta_block), 0,
+                                  len(content), cpad, 0, 1700000001, 0, total))
+    image = header + bytes(content) + b"\0" * cpad + meta_block + footer
+    assert len(header) == 64 and len(footer) == 128 and len(image) == total
+    return image

@@ -95,3 +95,47 @@ def test_boundary_a_parameter_mapping_arithmetic():
     # the reference defaults (scan_ratio 0.1, threshold 1000, ivf_searcher_context.h:211-213)
     assert ivf_probe_params(1024, 50_000, 0.1, 1000) == (102, 5000)
     assert ivf_probe_params(4, 100, 0.1, 1000) == (1, 1000)
+
+
+def _segments(image, checksum=1):
+    from zvec_amd import _lib
+    L = _lib.lib()
+    n = C.c_uint32(0)
+    rc = L.zvec_hip_container_segments(image, len(image), checksum, None, 0, C.byref(n))
+    if rc != 0:
+        return rc, []
+    arr = (_lib.Segment * n.value)()
+    rc = L.zvec_hip_container_segments(image, len(image), checksum, arr, n.value, C.byref(n))
+    return rc, [(s.id.decode(), int(s.offset), int(s.size), int(s.padding), int(s.crc)) for s in arr]
+
+
+def test_container_framing_of_a_dumped_index_file():
+    """IndexUnpacker::unpack restated (index_unpacker.h:103-330, index_format.h:26-95) — host-only: segment table of a
+    file image written by the restated IndexPacker (tests/ivf_format.py::pack_container); header / footer / meta / content
+    checksums verified; corrupt and truncated images refused with the reference's error classes."""
+    import numpy as np
+    from oracle.roaring import crc32c
+    from tests.ivf_format import pack_container
+    rng = np.random.default_rng(2)
+    segs = [("flat.keys", np.arange(37, dtype=np.uint64).tobytes()), ("flat.features", rng.bytes(37 * 20)),
+            ("IndexMeta", rng.bytes(4128)), ("empty.one", b"")]
+    image = pack_container(segs)
+    rc, got = _segments(image)
+    assert rc == 0
+    assert [g[0] for g in got] == [s[0] for s in segs] + ["IndexVersion"]
+    for (sid, data), (gid, off, size, pad, crc) in zip(segs, got):
+        assert image[off:off + size] == data and (size + pad) % 32 == 0 and crc == crc32c(data, 0)
+    # too small an output array: count still reported
+    from zvec_amd import _lib
+    n = C.c_uint32(0)
+    arr = (_lib.Segment * 2)()
+    assert _lib.lib().zvec_hip_container_segments(image, len(image), 1, arr, 2, C.byref(n)) == -17 and n.value == 5
+    # corruption: header byte, footer byte, meta byte -> Mismatch; content byte only with checksum on
+    for pos in (8, 40, len(image) - 60, len(image) - 128 - 8):   # header x2, footer (reserved words), segment-id block
+        bad = bytearray(image)
+        bad[pos] ^= 0x40
+        assert _segments(bytes(bad))[0] == -24, pos
+    bad = bytearray(image)
+    bad[64 + 5] ^= 1
+    assert _segments(bytes(bad), checksum=1)[0] == -24 and _segments(bytes(bad), checksum=0)[0] == 0
+    assert _segments(image[:-1])[0] in (-24, -31) and _segments(image[:40])[0] == -31

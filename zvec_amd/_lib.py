@@ -20,6 +20,12 @@ class DocFilterDesc(C.Structure):
                 ("forward_bits", C.c_void_p), ("forward_len", C.c_uint64)]
 
 
+class Segment(C.Structure):
+    """zvec_hip_segment_t: one segment of a dumped index file"""
+    _fields_ = [("id", C.c_char * 64), ("offset", C.c_uint64), ("size", C.c_uint64), ("padding", C.c_uint64),
+                ("crc", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
 ROARING_NONE, ROARING_32, ROARING_64MAP, ROARING_FILE = 0, 1, 2, 3
 
 # every symbol include/zvec_hip.h declares: name -> (restype, argtypes)
@@ -96,6 +102,7 @@ SYMBOLS = {
     "zvec_hip_flat_build_filter": (C.c_int, [_h, _h, C.POINTER(DocFilterDesc), _u64p, C.c_int, C.c_void_p]),
     "zvec_hip_ivf_build_filter": (C.c_int, [_h, _h, C.POINTER(DocFilterDesc), _u64p, C.c_int, C.c_void_p]),
     "zvec_hip_reform_queries_dev": (C.c_int, [_h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "zvec_hip_container_segments": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Segment), C.c_uint32, C.POINTER(C.c_uint32)]),
     "zvec_hip_crc32c": (C.c_uint32, [C.c_void_p, C.c_uint64, C.c_uint32]),
     "zvec_hip_ctx_profile": (C.c_int, [_h, C.c_int]),
     "zvec_hip_ctx_profile_read": (C.c_int, [_h, C.POINTER(C.c_uint64), C.POINTER(C.c_double),

@@ -37,5 +37,6 @@ extern "C" {
 #include "api_entry_merge_prof.inc.h"
 #include "api_entry_filter.inc.h"
 #include "api_entry_shards.inc.h"
+#include "api_entry_container.inc.h"
 
 }  // extern "C"
