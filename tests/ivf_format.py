@@ -83,3 +83,38 @@ def pack_container(segments, version=b"zvec-test-writer"):
     image = header + bytes(content) + b"\0" * cpad + meta_block + footer
     assert len(header) == 64 and len(footer) == 128 and len(image) == total
     return image
+
+
+def index_meta_blob(dim, dtype=np.float32, column_major=False, metric="SquaredEuclidean"):
+    """the "IndexMeta" segment: IndexMetaFormatHeader + JSON attachment (index_meta.cc:23-80), test-side writer"""
+    import json
+    unit = np.dtype(dtype).itemsize
+    att = json.dumps({"metric": {"name": metric, "revision": 0, "params": {}}}).encode()
+    return struct.pack("<9I", 4128, 0, MO_COLUMN if column_major else MO_ROW, DT_FP16 if unit == 2 else DT_FP32, dim, unit, 0,
+                       0, len(att)) + b"\0" * 4092 + att
+
+
+def flat_features_blob(base, column_major):
+    """FlatBuilder::write_row_index / write_column_index (flat_builder.cc:188-276)"""
+    blob = bytearray()
+    for b0 in range(0, base.shape[0], 32):
+        blk = base[b0:b0 + 32]
+        blob += (np.ascontiguousarray(blk.T) if (column_major and blk.shape[0] == 32) else blk).tobytes()
+    return bytes(blob)
+
+
+def flat_index_file(base, keys, column_major=False, metric="SquaredEuclidean"):
+    return pack_container([("IndexMeta", index_meta_blob(base.shape[1], base.dtype, column_major, metric)),
+                           ("flat.keys", np.asarray(keys, "<u8").tobytes()),
+                           ("flat.features", flat_features_blob(base, column_major))])
+
+
+def ivf_index_file(centroids, lists, column_major=False, centroid_column_major=False, metric="SquaredEuclidean", centroid_perm=None):
+    """a dumped IVF index file: the inverted segments + the centroid index as a NESTED flat index file in "ivf.centroid";
+    centroid_perm: storage order of the centroid rows inside that nested index (flat.keys = their centroid ids)"""
+    dim, dtype = centroids.shape[1], centroids.dtype
+    perm = np.arange(centroids.shape[0]) if centroid_perm is None else np.asarray(centroid_perm)
+    nested = flat_index_file(np.ascontiguousarray(centroids[perm]), perm.astype(np.uint64), centroid_column_major, metric)
+    segs = dump_ivf_segments(lists, dim, dtype, column_major)
+    return pack_container([("IndexMeta", index_meta_blob(dim, dtype, column_major, metric)), ("ivf.centroid", nested)] +
+                          [(k, segs[k]) for k in ("ivf.inverted_header", "ivf.inverted_meta", "ivf.inverted_body", "hc.keys")])

@@ -355,3 +355,43 @@ def test_boundary_a_parameter_mapping_probes_exactly_nprobe(zv):
     clear = (ds[:, nprobe] - ds[:, nprobe - 1]) > 1e-4 * ds[:, nprobe]
     assert clear.sum() > nq // 2 and (scanned[clear] == want[clear]).all()
     assert (ctx.scores[:, 0] == 0).all()                       # self-queries: found in their own list
+
+
+@pytest.mark.parametrize("dtype,column_major", [(np.float32, False), (np.float32, True), (np.float16, True)])
+def test_open_dumped_index_files(zv, oracle, dtype, column_major):
+    """next-2 end to end: a dumped index FILE image -> container framing (zvec_hip_container_segments) -> segment
+    payloads -> the segment loaders -> HBM; for IVF the centroid rows come out of the nested flat index file inside
+    "ivf.centroid" (column-major, permuted).  Files written by the restated packer / dumpers (tests/ivf_format.py:
+    layout parity unpinned); the opened indexes must answer exactly like ones loaded from plain arrays."""
+    from tests.ivf_format import flat_index_file, ivf_index_file
+    rng = np.random.default_rng(17)
+    n, dim, nlist, nq, k = 3000 + 7, 40, 37, 25, 6
+    base = rng.integers(-8, 9, (n, dim)).astype(dtype)
+    keys = rng.permutation(5 * n)[:n].astype(np.uint64)
+    q = rng.integers(-8, 9, (nq, dim)).astype(dtype)
+    dt = "fp16" if dtype == np.float16 else "fp32"
+    # flat
+    fse = zv.open_flat_file(flat_index_file(base, keys, column_major, "InnerProduct"))
+    assert fse.count() == n
+    ref = zv.HipFlatSearcher(dim, "InnerProduct", dtype=dt)
+    assert ref.load(base, keys) == 0
+    c1, c2 = fse.create_context(), ref.create_context()
+    c1.set_topk(k), c2.set_topk(k)
+    assert fse.search_impl(q, nq, c1) == 0 and ref.search_impl(q, nq, c2) == 0
+    assert np.array_equal(c1.keys, c2.keys) and np.array_equal(c1.scores, c2.scores)
+    # ivf
+    cent, offs, order = kmeans_lists(rng, base.astype(np.float32), nlist)
+    cent = np.round(cent).astype(dtype)
+    lists = [(base[order[int(offs[l]):int(offs[l + 1])]], keys[order[int(offs[l]):int(offs[l + 1])]]) for l in range(nlist)]
+    image = ivf_index_file(cent, lists, column_major, centroid_column_major=True, centroid_perm=rng.permutation(nlist))
+    ise = zv.open_ivf_file(image)
+    assert ise.info() == (n, nlist)
+    c2, o2, _ = ise.export()
+    assert np.array_equal(c2.view(np.uint8), cent.view(np.uint8)) and np.array_equal(o2, offs)
+    ise.scan_ratio, ise.brute_force_threshold = 6 / nlist, 10
+    rse = zv.HipIVFSearcher(dim, "SquaredEuclidean", dtype=dt, scan_ratio=6 / nlist, brute_force_threshold=10)
+    assert rse.load(cent, offs, base[order], keys[order]) == 0
+    c1, c2 = ise.create_context(), rse.create_context()
+    c1.set_topk(k), c2.set_topk(k)
+    assert ise.search_impl(q, nq, c1) == 0 and rse.search_impl(q, nq, c2) == 0
+    assert np.array_equal(c1.keys, c2.keys) and np.array_equal(c1.scores, c2.scores)

@@ -692,6 +692,80 @@ class HipIVFSearcher:
 HipIVFStreamer = HipIVFSearcher
 
 
+def container_segments(image, checksum=False):
+    """segment table of a dumped index FILE image (zvec_hip_container_segments): {id: (offset, size)} in file order"""
+    image = bytes(image)
+    n = C.c_uint32(0)
+    L = _lib.lib()
+    _lib.check(L.zvec_hip_container_segments(image, len(image), int(checksum), None, 0, C.byref(n)), "zvec_hip_container_segments")
+    arr = (_lib.Segment * max(int(n.value), 1))()
+    _lib.check(L.zvec_hip_container_segments(image, len(image), int(checksum), arr, n.value, C.byref(n)), "zvec_hip_container_segments")
+    return {arr[i].id.decode(): (int(arr[i].offset), int(arr[i].size)) for i in range(n.value)}
+
+
+def parse_index_meta(blob):
+    """the "IndexMeta" segment: IndexMetaFormatHeader (src/core/framework/index_meta.cc:23-34) + its JSON attachment
+    (metric name under "metric"."name", index_meta.cc:39-80)"""
+    import json
+    import struct
+    hs, meta_type, major, dt, dim, unit, space, aoff, asz = struct.unpack_from("<9I", blob, 0)
+    metric = None
+    if asz:
+        try:
+            metric = json.loads(bytes(blob[hs + aoff:hs + aoff + asz]).decode()).get("metric", {}).get("name")
+        except (ValueError, UnicodeDecodeError):
+            metric = None
+    return {"major_order": major, "data_type": dt, "dimension": dim, "unit_size": unit, "metric": metric}
+
+
+def open_flat_file(image, device=0, metric=None):
+    """FlatSearcher::load from a dumped flat index FILE (container -> "IndexMeta" / "flat.keys" / "flat.features")"""
+    image = bytes(image)
+    seg = container_segments(image)
+    meta = parse_index_meta(image[seg["IndexMeta"][0]:sum(seg["IndexMeta"])])
+    dtype = "fp16" if meta["data_type"] == 1 else "fp32"
+    se = HipFlatSearcher(meta["dimension"], metric or meta["metric"] or "SquaredEuclidean", device=device, dtype=dtype)
+    ko, ks = seg["flat.keys"]
+    fo, fs_ = seg["flat.features"]
+    keys = np.frombuffer(image, np.uint64, ks // 8, ko)
+    _lib.check(se.load_features(image[fo:fo + fs_], ks // 8, column_major=(meta["major_order"] == 2), keys=keys), "load_features")
+    return se
+
+
+def open_ivf_file(image, device=0, metric=None):
+    """IVFSearcher::load from a dumped IVF index FILE: the ivf.* / hc.keys segments, and the centroid rows out of the
+    NESTED flat index file that the "ivf.centroid" segment holds (ivf_searcher.cc:43-103)"""
+    image = bytes(image)
+    seg = container_segments(image)
+    meta = parse_index_meta(image[seg["IndexMeta"][0]:sum(seg["IndexMeta"])])
+    dtype = "fp16" if meta["data_type"] == 1 else "fp32"
+    npdt = np.float16 if dtype == "fp16" else np.float32
+    co, cs = seg["ivf.centroid"]
+    nested = image[co:co + cs]
+    cseg = container_segments(nested)
+    cmeta = parse_index_meta(nested[cseg["IndexMeta"][0]:sum(cseg["IndexMeta"])])
+    ck = np.frombuffer(nested, np.uint64, cseg["flat.keys"][1] // 8, cseg["flat.keys"][0])
+    nlist, dim = ck.size, meta["dimension"]
+    feat = np.frombuffer(nested, npdt, nlist * dim, cseg["flat.features"][0]).copy()
+    rows = np.empty((nlist, dim), npdt)
+    if cmeta["major_order"] == 2:                       # column-major centroid index: full 32-row blocks are transposed
+        full = nlist // 32 * 32
+        rows[:full] = feat[:full * dim].reshape(full // 32, dim, 32).transpose(0, 2, 1).reshape(full, dim)
+        rows[full:] = feat[full * dim:].reshape(nlist - full, dim)
+    else:
+        rows[:] = feat.reshape(nlist, dim)
+    cent = np.empty_like(rows)
+    cent[ck.astype(np.int64)] = rows                    # row i of the centroid index holds centroid ck[i]
+    se = HipIVFSearcher(dim, metric or meta["metric"] or "SquaredEuclidean", device=device, dtype=dtype)
+
+    def payload(name):
+        o, sz = seg[name]
+        return image[o:o + sz]
+    _lib.check(se.load_segments(payload("ivf.inverted_header"), payload("ivf.inverted_meta"), payload("ivf.inverted_body"),
+                                payload("hc.keys"), cent), "load_segments")
+    return se
+
+
 class HipShardedIndex:
     """one index over several GPUs inside ONE process (zvec_hip_shards_*): the in-process counterpart of the
     one-rank-per-GPU sharding in zvec_amd/dist.py, for embedded callers like zvec itself.  kind: "flat" or "ivf";
