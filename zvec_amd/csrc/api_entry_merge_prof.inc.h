@@ -116,3 +116,24 @@ int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *sc
   if (reset) ctx->nprof = 0;
   return 0;
 }
+
+#ifdef ZVK_CLOCK_STAMP
+// diagnostic build only: median in-kernel clock (MHz) of the work-groups of the LAST wide flat launch, 0 if none
+int zvec_hip_debug_flat_clock_mhz(double *mhz, double *wall_ms) {
+  static unsigned long long h[1024][4];
+  ZCHK(hipDeviceSynchronize());
+  ZCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(zvk_clock_stamps), sizeof(h)));
+  std::vector<double> v, w;
+  for (int i = 0; i < 1024; ++i)
+    if (h[i][3] > h[i][1] && h[i][2] > h[i][0]) {
+      v.push_back((double)(h[i][2] - h[i][0]) / (double)(h[i][3] - h[i][1]) * 100.0);
+      w.push_back((double)(h[i][3] - h[i][1]) / 100e3);
+    }
+  if (v.empty()) { *mhz = 0; *wall_ms = 0; return 0; }
+  std::sort(v.begin(), v.end());
+  std::sort(w.begin(), w.end());
+  *mhz = v[v.size() / 2];
+  *wall_ms = w[w.size() / 2];
+  return 0;
+}
+#endif

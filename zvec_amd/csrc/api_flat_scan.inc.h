@@ -97,7 +97,9 @@ struct Knobs {
   bool no_gather = false;     // ZVEC_HIP_NO_GATHER   sparse filters: compact the kept rows instead of gathering them
   int ivf_tpc = 0;            // ZVEC_HIP_IVF_TPC     fixed tiles per IVF chunk (0 = adaptive)
   bool m16_small = true;      // ZVEC_HIP_NO_M16_SMALL  keep flat scans of <= 16 queries on the 32-row MFMA shape
-  bool flat_dyn = true;       // ZVEC_HIP_NO_FLAT_DYN   wide flat kernel: static one-item-per-work-group decomposition
+  bool flat_dyn = false;      // ZVEC_HIP_FLAT_DYN      wide flat kernel: guided self-scheduling instead of one static item per
+                              //                        work-group slot (measured: no gain, 116-124 vs 123-124 TFLOP/s — the
+                              //                        launch is not waiting for a slow CU, see DESIGN.md "flat kernel")
   int flat_rounds = 2;        // ZVEC_HIP_FLAT_ROUNDS   ... long chunks: this many items per resident work-group
   int flat_tail_div = 4;      // ZVEC_HIP_FLAT_TAIL_DIV ... short chunks = long / this
   Knobs() {
@@ -109,7 +111,7 @@ struct Knobs {
     no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;
     if (const char *e = getenv("ZVEC_HIP_IVF_TPC")) ivf_tpc = std::max(1, atoi(e));
     m16_small = getenv("ZVEC_HIP_NO_M16_SMALL") == nullptr;
-    flat_dyn = getenv("ZVEC_HIP_NO_FLAT_DYN") == nullptr;
+    flat_dyn = getenv("ZVEC_HIP_FLAT_DYN") != nullptr;
     if (const char *e = getenv("ZVEC_HIP_FLAT_ROUNDS")) flat_rounds = std::max(1, atoi(e));
     if (const char *e = getenv("ZVEC_HIP_FLAT_TAIL_DIV")) flat_tail_div = std::max(1, atoi(e));
 #endif

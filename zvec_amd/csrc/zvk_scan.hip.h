@@ -457,6 +457,13 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : (NG == 2 && !M16 ? 3 : 1))
 // same base-row reuse, which is what the matrix cores need to stay busy across barriers and epilogues.
 // Flat mode only (mode 0); the IVF list scan keeps the 16-row shape above.
 // ---------------------------------------------------------------------------------------------
+#ifdef ZVK_CLOCK_STAMP
+// Diagnostic build only (tools/build_variant.sh clk -DZVK_CLOCK_STAMP): every work-group of the wide flat kernel stamps
+// the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) when it starts and when it ends; the
+// in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md "DVFS give-back" item 6).  The stamps go
+// to a buffer of their own that nothing else reads.
+__device__ unsigned long long zvk_clock_stamps[1024][4];
+#endif
 constexpr int W8_ROWS = 128;
 __host__ __device__ inline size_t scan8_lds_bytes(uint32_t k) {
   return (2 * (size_t)W8_ROWS * TILE_K + 2 * (size_t)SLAB + 7 * (size_t)W8_ROWS + 4 + 2 * (size_t)W8_ROWS * k) * 4;
@@ -505,6 +512,12 @@ __global__ void __launch_bounds__(512, 4) scan8_kernel(const ScanArgs a) {
   // (keeps the L2 sharing of the chunk's query tiles), then steals from the other classes.
   uint32_t *item_s = slot_s + ROWS;          // [4] hand-off word (inside the dynamic LDS block: the kernel asks for all 160 KiB)
   const bool dyn = a.queue != nullptr;
+#ifdef ZVK_CLOCK_STAMP
+  if (tid == 0 && blockIdx.x < 1024 && a.dump == nullptr) {
+    zvk_clock_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime();
+    zvk_clock_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   for (uint32_t vs = blockIdx.x;; vs += gridDim.x) {           // uniform exit
     uint32_t v = vs;
     if (dyn) {
@@ -736,6 +749,12 @@ __global__ void __launch_bounds__(512, 4) scan8_kernel(const ScanArgs a) {
     }
     __syncthreads();
   }
+#ifdef ZVK_CLOCK_STAMP
+  if (tid == 0 && blockIdx.x < 1024 && a.dump == nullptr) {
+    zvk_clock_stamps[blockIdx.x][2] = __builtin_amdgcn_s_memtime();
+    zvk_clock_stamps[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 }  // namespace zvk
