@@ -196,6 +196,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the scan core has no CPU fallback")
+    # rehearsal of the N > 1 path on a ONE-GPU box: ZVEC_BENCH_BACKEND=gloo puts every rank on cuda:0 and runs the
+    # collectives through the host (the RCCL transport itself is then the only thing not exercised)
+    backend = os.environ.get("ZVEC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # one explicit HIP stream for everything (torch ops, the scan library, RCCL): torch's legacy default
@@ -203,13 +208,30 @@ def main():
     work_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(work_stream)
     rccl = None
+
+    def coll(fn, t, *a, **kw):
+        """a collective on a device tensor: directly over RCCL, or staged through the host for the gloo rehearsal"""
+        if backend == "nccl":
+            return fn(t, *a, **kw)
+        h = t.cpu()
+        fn(h, *a, **kw)
+        t.copy_(h)
+
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         # proof that RCCL sees every rank: one all-gather of (rank, device) over the process group
         mine = torch.tensor([rank, local_rank], dtype=torch.int64, device=dev)
         got = torch.zeros((world, 2), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(got.view(-1), mine)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(got.view(-1), mine)
+        else:
+            hg = got.cpu()
+            dist.all_gather_into_tensor(hg.view(-1), mine.cpu())
+            got.copy_(hg)
         torch.cuda.synchronize()
         rows = got.cpu().tolist()
         rccl = {"ranks": len(set(int(r[0]) for r in rows)), "devices": [int(r[1]) for r in rows], "backend": dist.get_backend()}
@@ -267,7 +289,7 @@ def main():
         fctx = flat.create_context()
         fctx.set_stream(stream_ptr)
         result = run_flat(torch, dist, zvec_amd, ShardedFlat(flat, fctx, rank, world), flat, fctx, queries[:batch].contiguous(), n, hi - lo,
-                          dim, topk, args, dev, stream_ptr, world, rank, base, flat_metric)
+                          dim, topk, args, dev, stream_ptr, world, rank, base, flat_metric, coll)
         recall = 1.0
         nprobe_base = recall_base = None
     else:
@@ -314,7 +336,7 @@ def main():
         del sample
         if world > 1:      # one set of centroids for everybody: rank 0's, bit for bit
             cent = torch.from_numpy(ivf.get_centroids().view(np.uint8)).to(dev)
-            dist.broadcast(cent, 0)
+            coll(dist.broadcast, cent, 0)
             if rank != 0:
                 zvec_amd._lib.check(ivf.set_centroids(cent.cpu().numpy().view(np.float16 if dtype == "fp16" else np.float32)), "set_centroids")
         log("k-means (%d iters, %d lists, %d sample rows) in %.1fs" % (args.kmeans_iters, nlist, S, time.time() - t1))
@@ -325,7 +347,7 @@ def main():
             if ci % world == rank:
                 zvec_amd._lib.check(ivf.label_dev(x.data_ptr(), x.shape[0], labels[o:o + x.shape[0]].data_ptr(), stream=stream_ptr), "label")
         if world > 1:
-            dist.all_reduce(labels)        # every row was labelled by exactly one rank, the others hold 0
+            coll(dist.all_reduce, labels)  # every row was labelled by exactly one rank, the others hold 0
         torch.cuda.synchronize()
         labels_h = labels.cpu().numpy().astype(np.uint32)
         del labels
@@ -418,7 +440,7 @@ def main():
             el = time.perf_counter() - t_start
             if world > 1:
                 t = torch.tensor([el], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                coll(dist.all_reduce, t, op=dist.ReduceOp.MAX)
                 el = float(t.item())
             pr = ctx.profile_read(reset=True)
             ctx.profile(False)
@@ -589,7 +611,7 @@ def cpu_baseline_flat(torch, base, q, topk, metric_name, args, gpu=None):
                           nq, host.shape[0], threads, "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")}
 
 
-def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, topk, args, dev, stream_ptr, world, rank, base, metric_name):
+def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, topk, args, dev, stream_ptr, world, rank, base, metric_name, coll):
     batch = q.shape[0]
     excl = None
     doc_filter = None
@@ -636,7 +658,7 @@ def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, top
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        coll(dist.all_reduce, t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = fctx.profile_read(reset=True)
     ms = prof["scan_ms"] / max(prof["launches"], 1)

@@ -37,11 +37,14 @@ while time.time() - t0 < 3.0:
     torch.cuda.synchronize()
     steps += 20
 L = zvec_amd._lib.lib()
-fn = L.zvec_hip_debug_flat_clock_mhz
+fn = L.zvec_hip_debug_flat_clock
 fn.restype = C.c_int
-mhz, wall = C.c_double(0), C.c_double(0)
-fn(C.byref(mhz), C.byref(wall))
+out = (C.c_double * 16)()
+fn(out)
+mhz, life, last_start, first_end, med_end, last_end, nwg = [float(x) for x in out[:7]]
+pcts = [round(float(x), 4) for x in out[7:15]]
 flops = 2.0 * nq * n * dim
-print(json.dumps({"in_kernel_clock_mhz": mhz.value, "workgroup_wall_ms_median": wall.value, "launches": steps,
-                  "fp32_mfma_peak_at_that_clock_tflops": 1024 * 64 * mhz.value * 1e6 / 1e12,
-                  "tflops_over_workgroup_wall": flops / (wall.value * 1e-3) / 1e12 if wall.value else None}))
+print(json.dumps({"in_kernel_clock_mhz": mhz, "workgroups": int(nwg), "workgroup_lifetime_ms_median": life,
+                  "latest_start_ms": last_start, "earliest_end_ms": first_end, "median_end_ms": med_end, "latest_end_ms": last_end,
+                  "end_ms_p10_25_40_60_75_90_95_99": pcts, "launches": steps, "fp32_mfma_peak_at_that_clock_tflops": 1024 * 64 * mhz * 1e6 / 1e12,
+                  "tflops_over_latest_end": flops / (last_end * 1e-3) / 1e12 if last_end else None}))

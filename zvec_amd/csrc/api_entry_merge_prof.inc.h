@@ -118,22 +118,33 @@ int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *sc
 }
 
 #ifdef ZVK_CLOCK_STAMP
-// diagnostic build only: median in-kernel clock (MHz) of the work-groups of the LAST wide flat launch, 0 if none
-int zvec_hip_debug_flat_clock_mhz(double *mhz, double *wall_ms) {
+// diagnostic build only: in-kernel clock (MHz, median over work-groups) of the LAST wide flat launch and the spread of
+// the work-groups' start / end times in ms relative to the earliest start: out[0] clock, [1] median lifetime,
+// [2] latest start, [3] earliest end, [4] median end, [5] latest end, [6] number of work-groups,
+// [7..15] end-time percentiles 10, 25, 40, 60, 75, 90, 95, 99 and the lifetime p10
+int zvec_hip_debug_flat_clock(double *out) {
   static unsigned long long h[1024][4];
   ZCHK(hipDeviceSynchronize());
   ZCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(zvk_clock_stamps), sizeof(h)));
-  std::vector<double> v, w;
+  std::vector<double> clk, life, st, en;
+  unsigned long long t0 = ~0ull;
+  for (int i = 0; i < 1024; ++i)
+    if (h[i][3] > h[i][1] && h[i][2] > h[i][0]) t0 = std::min(t0, h[i][1]);
   for (int i = 0; i < 1024; ++i)
     if (h[i][3] > h[i][1] && h[i][2] > h[i][0]) {
-      v.push_back((double)(h[i][2] - h[i][0]) / (double)(h[i][3] - h[i][1]) * 100.0);
-      w.push_back((double)(h[i][3] - h[i][1]) / 100e3);
+      clk.push_back((double)(h[i][2] - h[i][0]) / (double)(h[i][3] - h[i][1]) * 100.0);
+      life.push_back((double)(h[i][3] - h[i][1]) / 100e3);
+      st.push_back((double)(h[i][1] - t0) / 100e3);
+      en.push_back((double)(h[i][3] - t0) / 100e3);
     }
-  if (v.empty()) { *mhz = 0; *wall_ms = 0; return 0; }
-  std::sort(v.begin(), v.end());
-  std::sort(w.begin(), w.end());
-  *mhz = v[v.size() / 2];
-  *wall_ms = w[w.size() / 2];
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  if (clk.empty()) return 0;
+  for (auto *v : {&clk, &life, &st, &en}) std::sort(v->begin(), v->end());
+  out[0] = clk[clk.size() / 2]; out[1] = life[life.size() / 2]; out[2] = st.back(); out[3] = en.front();
+  out[4] = en[en.size() / 2]; out[5] = en.back(); out[6] = (double)clk.size();
+  const double pc[8] = {0.10, 0.25, 0.40, 0.60, 0.75, 0.90, 0.95, 0.99};
+  for (int i = 0; i < 8; ++i) out[7 + i] = en[(size_t)(pc[i] * (en.size() - 1))];
+  out[15] = life[(size_t)(0.10 * (life.size() - 1))];
   return 0;
 }
 #endif
