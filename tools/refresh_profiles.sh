@@ -13,6 +13,8 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.log
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.log
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/flat -- python3 $R/bench.py --workload flat1m --steps 10 --warmup 2 --no-cpu-baseline > $O/${tag}_flat1m_bench_under_rocprof.json 2> $O/flat.log
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/shard8 -- python3 $R/bench.py --shard-of 8 --steps 10 --warmup 2 --no-host-path > $O/${tag}_ivf10m_shard8_bench_under_rocprof.json 2> $O/shard8.log
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s100 -- python3 $R/bench.py --workload ivf100m_fp16 --shard-of 8 --steps 10 --warmup 2 --no-host-path > $O/${tag}_ivf100m_fp16_shard8_bench_under_rocprof.json 2> $O/s100.log
 python3 - <<PY
 import csv, glob, json, shutil
 O, tag = "$O", "$tag"
@@ -20,7 +22,9 @@ def one(pat):
     return sorted(glob.glob(O + "/" + pat, recursive=True))[0]
 shutil.copy(one("stats/**/*kernel_stats.csv"), O + "/%s_ivf10m_kernel_stats.csv" % tag)
 shutil.copy(one("flat/**/*kernel_stats.csv"), O + "/%s_flat1m_kernel_stats.csv" % tag)
-for name, d in (("ivf10m", "stats"), ("flat1m", "flat")):
+shutil.copy(one("shard8/**/*kernel_stats.csv"), O + "/%s_ivf10m_shard8_kernel_stats.csv" % tag)
+shutil.copy(one("s100/**/*kernel_stats.csv"), O + "/%s_ivf100m_fp16_shard8_kernel_stats.csv" % tag)
+for name, d in (("ivf10m", "stats"), ("flat1m", "flat"), ("ivf10m_shard8", "shard8")):
     rows = list(csv.DictReader(open(one(d + "/**/*kernel_trace.csv"))))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     keep = ["Kernel_Name", "Start_Timestamp", "End_Timestamp", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size"]
@@ -50,5 +54,5 @@ json.dump({"kernel": "zvk::scan_kernel<1, true, false, false> - IVF list scan (1
 json.dump({"ivf10m": traffic}, open(O + "/pmc_traffic.json", "w"))
 print("traffic/algorithmic", traffic / alg)
 PY
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/flat
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/flat $O/shard8 $O/s100
 ls -la $O
