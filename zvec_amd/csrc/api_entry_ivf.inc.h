@@ -648,15 +648,6 @@ static int ivf_search_dev_locked(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const voi
     SearchOut out{d_out_keys + (size_t)q0 * topk, d_out_scores + (size_t)q0 * topk, nullptr, d_out_counts + q0};
     ZRET(ivf_search_core(h, c, reinterpret_cast<const char *>(d_queries) + (size_t)q0 * h->lists.row_bytes(), m, topk, threshold,
                          nprobe, max_scan_count, brute_force, d_exclude, out, s));
-    if (c->profile && c->nprof > 0 && c->nprof <= PROFILE_MAX && c->stats.p) {
-      int i = c->nprof - 1;
-      if (c->launch_is_ivf[i]) {
-        unsigned long long *st = c->stats.as<unsigned long long>() + 2 * (size_t)i;
-        ZCHK(hipMemsetAsync(st, 0, 16, s));
-        hipLaunchKernelGGL(ivf_work_stats_kernel, dim3(16), dim3(256), 0, s, c->last_list_count, h->d_size, h->nlist, st);
-        ZCHK(hipGetLastError());
-      }
-    }
   }
   return 0;
 }

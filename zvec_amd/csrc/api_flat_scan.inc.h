@@ -97,6 +97,7 @@ struct Knobs {
   bool no_gather = false;     // ZVEC_HIP_NO_GATHER   sparse filters: compact the kept rows instead of gathering them
   int ivf_tpc = 0;            // ZVEC_HIP_IVF_TPC     fixed tiles per IVF chunk (0 = adaptive)
   bool m16_small = true;      // ZVEC_HIP_NO_M16_SMALL  keep flat scans of <= 16 queries on the 32-row MFMA shape
+  bool no_wide_dump = false;  // ZVEC_HIP_NO_WIDE_DUMP  dense-score path (IVF coarse step): never take the 8-wave tile
   bool flat_dyn = false;      // ZVEC_HIP_FLAT_DYN      wide flat kernel: guided self-scheduling instead of one static item per
                               //                        work-group slot (measured: no gain, 116-124 vs 123-124 TFLOP/s — the
                               //                        launch is not waiting for a slow CU, see DESIGN.md "flat kernel")
@@ -112,6 +113,7 @@ struct Knobs {
     if (const char *e = getenv("ZVEC_HIP_IVF_TPC")) ivf_tpc = std::max(1, atoi(e));
     m16_small = getenv("ZVEC_HIP_NO_M16_SMALL") == nullptr;
     flat_dyn = getenv("ZVEC_HIP_FLAT_DYN") != nullptr;
+    no_wide_dump = getenv("ZVEC_HIP_NO_WIDE_DUMP") != nullptr;
     if (const char *e = getenv("ZVEC_HIP_FLAT_ROUNDS")) flat_rounds = std::max(1, atoi(e));
     if (const char *e = getenv("ZVEC_HIP_FLAT_TAIL_DIV")) flat_tail_div = std::max(1, atoi(e));
 #endif
@@ -370,10 +372,15 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
       for (uint32_t q0 = 0; q0 < count; q0 += sub) {
         const uint32_t cnt = std::min(sub, count - q0);
         int ngd = pick_ng(cnt, 1);
+        // wide batches: the 8-wave 128x128 tile in dump mode (LDS-DMA staging, 32 accumulators per wave) — one item per
+        // (tile, 128-query tile); taken when that gives at least one work-group per two CUs
+        const uint32_t nqt8 = (cnt + W8_ROWS - 1) / W8_ROWS;
+        const bool wide_d = !knobs().no_wide_dump && cnt > 2 * QGROUP && ngd == 4 && d_exclude == nullptr &&
+                            ntiles_d * nqt8 * 2 >= (uint64_t)cus_d && scan8_lds_bytes(1) <= LDS_LIMIT - 1024;
         // one item per (tile, query tile): halve the query tile while the items would not fill two work-groups per CU
         // (1024 x 4096 coarse scores: 256 items at 128 rows -> 512 at 64 rows, 92 -> 79 us)
-        while (ngd > 2 && ntiles_d * ((cnt + ngd * QGROUP - 1) / (ngd * QGROUP)) < 2ull * cus_d) ngd /= 2;
-        const uint32_t rows_d = ngd * QGROUP;
+        while (!wide_d && ngd > 2 && ntiles_d * ((cnt + ngd * QGROUP - 1) / (ngd * QGROUP)) < 2ull * cus_d) ngd /= 2;
+        const uint32_t rows_d = wide_d ? W8_ROWS : ngd * QGROUP;
         const uint32_t nqt = (cnt + rows_d - 1) / rows_d;
         ScanArgs a{};
         a.base = st.base; a.bnorm = st.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
@@ -383,7 +390,8 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
         a.gtau = ctx->gtau.as<uint32_t>() + q0;
         a.dump = ctx->part_s.as<float>(); a.dump_stride = (uint32_t)(ntiles_d * TILE_N);
         a.part_s = nullptr; a.part_i = nullptr;
-        ZRET(launch_scan_ng(ngd, a, st.f16, (uint32_t)ntiles_d * nqt, cus_d, stream));
+        if (wide_d) ZRET(launch_scan8(a, st.f16, (uint32_t)((ntiles_d + 7) / 8) * 8 * nqt, cus_d, stream));
+        else ZRET(launch_scan_ng(ngd, a, st.f16, (uint32_t)ntiles_d * nqt, cus_d, stream));
         MergeArgs m{};
         m.part_s = a.dump; m.part_i = nullptr; m.part_keys = nullptr; m.slot_begin = nullptr; m.slots_per_q = 1;
         m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = a.dump_stride; m.threshold = threshold;

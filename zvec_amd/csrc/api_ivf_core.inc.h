@@ -131,6 +131,8 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   p.total_items = pb + o_total; p.csr_q = pb + o_csrq; p.csr_slot = pb + o_csrslot;
   ctx->q_nprobe = p.q_nprobe; ctx->q_scanned = p.q_scanned; ctx->last_count = count;
   ctx->last_list_count = p.list_count;
+  if (ctx->profile && ctx->nprof < PROFILE_MAX && ctx->stats.p)      // the slot prof_begin will take for this launch
+    p.work_stats = ctx->stats.as<unsigned long long>() + 2 * (size_t)ctx->nprof;
   hipLaunchKernelGGL(plan_wave_kernel<false>, dim3((count + 3) / 4), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
   hipLaunchKernelGGL(plan_wave_kernel<true>, dim3((count + 3) / 4), dim3(256), 0, stream, p);
@@ -167,7 +169,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   a.list_dense0 = h->d_dense0; a.list_qoff = p.list_qoff; a.csr_q = p.csr_q; a.csr_slot = p.csr_slot; a.nlist = nlist;
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
   // algorithmic bytes of the list scan = rows of the DISTINCT probed lists (counted on device from
-  // the plan, see ivf_work_stats_kernel) + the query rows + the result lists
+  // the plan: plan_scan_kernel's work_stats) + the query rows + the result lists
   int pi = prof_begin(ctx, stream, (double)count * h->lists.dscan * h->lists.elem + (double)count * topk * 12.0, 0, 1);
   if (pi >= 0) ctx->prof_dscan[pi] = h->lists.dscan | (h->lists.f16 ? 0x80000000u : 0u);
   ZRET(launch_scan_ng(ng, a, h->lists.f16, 0x7fffffffu, cus, stream));
@@ -188,18 +190,6 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   ZCHK(hipGetLastError());
   ZRET(refine_l2(ctx, h->lists, count, topk, threshold, out.keys, out.scores, ridx, out.counts, stream));
   return 0;
-}
-
-// work statistics of an IVF launch (for the roofline line): distinct probed rows & pair rows
-__global__ void ivf_work_stats_kernel(const uint32_t *list_count, const uint32_t *list_size, uint32_t nlist,
-                                      unsigned long long *out2) {
-  unsigned long long rows = 0, pairs = 0;
-  for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
-    uint32_t c = list_count[l];
-    if (c) { rows += list_size[l]; pairs += (unsigned long long)c * list_size[l]; }
-  }
-  atomicAdd(&out2[0], rows);
-  atomicAdd(&out2[1], pairs);
 }
 
 constexpr size_t PIN_LIMIT = 256u << 10;  // staging through pinned memory up to 256 KiB per direction (above that the extra

@@ -30,6 +30,9 @@ struct PlanArgs {
   uint32_t *item_off;             // [nlist+1]
   uint32_t *total_items;          // [1]
   uint32_t *csr_q, *csr_slot;
+  // measurement hook (nullable): [0] rows of the DISTINCT probed lists, [1] sum over lists of count x rows — the
+  // algorithmic bytes / flops of the list scan this plan feeds; written (not added) by plan_scan_kernel
+  unsigned long long *work_stats;
 };
 
 __device__ __forceinline__ uint32_t list_chunks(uint32_t size, uint32_t tiles_per_chunk) {
@@ -172,6 +175,24 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
       },
       [&](uint32_t i, uint32_t v) { p.item_off[i] = v; }, p.nlist, &p.item_off[p.nlist]);
   if (tid == 0) *p.total_items = p.item_off[p.nlist];
+  if (p.work_stats) {                       // (profiling only) folded in here: no extra launches inside a timed step
+    __shared__ unsigned long long red[2][16];
+    unsigned long long rows = 0, pairs = 0;
+    for (uint32_t l = tid; l < p.nlist; l += 1024) {
+      const uint32_t c = p.list_count[l];
+      if (c) { rows += p.list_size[l]; pairs += (unsigned long long)c * p.list_size[l]; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { rows += __shfl_xor(rows, off); pairs += __shfl_xor(pairs, off); }
+    if (lane == 0) { red[0][wave] = rows; red[1][wave] = pairs; }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long r = 0, q = 0;
+      for (int w = 0; w < 16; ++w) { r += red[0][w]; q += red[1][w]; }
+      p.work_stats[0] = r;
+      p.work_stats[1] = q;
+    }
+  }
 }
 
 }  // namespace zvk
