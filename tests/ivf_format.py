@@ -90,8 +90,8 @@ def index_meta_blob(dim, dtype=np.float32, column_major=False, metric="SquaredEu
     import json
     unit = np.dtype(dtype).itemsize
     att = json.dumps({"metric": {"name": metric, "revision": 0, "params": {}}}).encode()
-    return struct.pack("<9I", 4128, 0, MO_COLUMN if column_major else MO_ROW, DT_FP16 if unit == 2 else DT_FP32, dim, unit, 0,
-                       0, len(att)) + b"\0" * 4092 + att
+    return struct.pack("<9I", 4128, 1, MO_COLUMN if column_major else MO_ROW, DT_FP16 if unit == 2 else DT_FP32, dim, unit, 0,
+                       4128, len(att)) + b"\0" * 4092 + att      # meta_type 1 = dense; attachment_offset from the blob start
 
 
 def flat_features_blob(base, column_major):

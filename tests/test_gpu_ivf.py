@@ -395,3 +395,48 @@ def test_open_dumped_index_files(zv, oracle, dtype, column_major):
     c1.set_topk(k), c2.set_topk(k)
     assert ise.search_impl(q, nq, c1) == 0 and rse.search_impl(q, nq, c2) == 0
     assert np.array_equal(c1.keys, c2.keys) and np.array_equal(c1.scores, c2.scores)
+
+
+def test_open_reference_dumped_golden_files(zv):
+    """next-2 pinned: index FILES written by the reference's OWN FlatBuilder / IVFDumper / MemoryDumper (golden fixtures,
+    tests/golden/ref_index_files.npz) -> container parser -> segment loaders -> HBM; every opened index must hold exactly
+    the rows / keys / lists the reference was given and answer like an index loaded from those arrays."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_index_files.npz"))
+    rng = np.random.default_rng(3)
+    for name in [str(x) for x in z["cases"]]:
+        meta = z[name + "_meta"]
+        f16 = bool(meta[0])
+        dt = np.float16 if f16 else np.float32
+        base = z[name + "_base"].view(dt) if f16 else z[name + "_base"]
+        keys = z[name + "_keys"]
+        n, dim = int(meta[1]), int(meta[2])
+        q = rng.integers(-8, 9, (9, dim)).astype(dt)
+        image = z[name + "_image"].tobytes()
+        if name.startswith("flat"):
+            se = zv.open_flat_file(image)
+            assert se.count() == n
+            for pos in (0, n // 2, n - 1):
+                assert np.array_equal(se.get_vector_by_id(pos).view(np.uint8), base[pos].view(np.uint8))
+            ref = zv.HipFlatSearcher(dim, "InnerProduct", dtype="fp16" if f16 else "fp32")
+            assert ref.load(base, keys) == 0
+            c1, c2 = se.create_context(), ref.create_context()
+            c1.set_topk(5), c2.set_topk(5)
+            assert se.search_impl(q, 9, c1) == 0 and ref.search_impl(q, 9, c2) == 0
+            assert np.array_equal(c1.keys, c2.keys) and np.array_equal(c1.scores, c2.scores), name
+        else:
+            cent = z[name + "_cent"].view(dt) if f16 else z[name + "_cent"]
+            offs = z[name + "_offs"]
+            se = zv.open_ivf_file(image)
+            assert se.info() == (n, int(meta[5]))
+            c2, o2, _ = se.export()
+            assert np.array_equal(c2.view(np.uint8), cent.view(np.uint8)) and np.array_equal(o2, offs), name
+            pos = rng.integers(0, n, 12)
+            assert np.array_equal(se.get_vectors_by_ids(pos).view(np.uint8), base[pos].view(np.uint8))
+            se.scan_ratio, se.brute_force_threshold = 1.0, 0           # probe every list
+            ref = zv.HipIVFSearcher(dim, "InnerProduct", dtype="fp16" if f16 else "fp32", scan_ratio=1.0, brute_force_threshold=0)
+            assert ref.load(cent, offs, base, keys) == 0
+            c1, c2 = se.create_context(), ref.create_context()
+            c1.set_topk(5), c2.set_topk(5)
+            assert se.search_impl(q, 9, c1) == 0 and ref.search_impl(q, 9, c2) == 0
+            assert np.array_equal(c1.keys, c2.keys) and np.array_equal(c1.scores, c2.scores), name

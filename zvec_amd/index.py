@@ -710,9 +710,9 @@ def parse_index_meta(blob):
     import struct
     hs, meta_type, major, dt, dim, unit, space, aoff, asz = struct.unpack_from("<9I", blob, 0)
     metric = None
-    if asz:
+    if asz:                               # attachment_offset counts from the start of the blob (index_meta.cc:62-80)
         try:
-            metric = json.loads(bytes(blob[hs + aoff:hs + aoff + asz]).decode()).get("metric", {}).get("name")
+            metric = json.loads(bytes(blob[aoff:aoff + asz]).decode()).get("metric", {}).get("name")
         except (ValueError, UnicodeDecodeError):
             metric = None
     return {"major_order": major, "data_type": dt, "dimension": dim, "unit_size": unit, "metric": metric}
