@@ -38,8 +38,8 @@ def dump_ivf_segments(lists, dim, dtype=np.float32, column_major=False, block_ve
         metas.append(struct.pack("<QIII16x4x", off, nblk, vecs.shape[0], id_off))   # sizeof(InvertedListMeta) == 40 (8-byte aligned)
         total += vecs.shape[0]
         blocks += nblk
-    index_meta = struct.pack("<9I", 4128, 0, MO_COLUMN if column_major else MO_ROW, DT_FP16 if unit == 2 else DT_FP32,
-                             dim, unit, 0, 0, 0) + b"\0" * 4092
+    index_meta = struct.pack("<9I", 4128, 1, MO_COLUMN if column_major else MO_ROW, DT_FP16 if unit == 2 else DT_FP32,
+                             dim, unit, 0, 0, 0) + b"\0" * 4092          # meta_type 1 = MT_DENSE
     header = struct.pack("<IIQIIIII28x", 64 + len(index_meta), total, len(body), len(lists), block_vector_count,
                          block_size, blocks, len(index_meta)) + index_meta
     return {"ivf.inverted_header": bytes(header), "ivf.inverted_meta": b"".join(metas), "ivf.inverted_body": bytes(body),
