@@ -290,8 +290,8 @@ int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_
  *                    index "ivf.centroid", which the caller's storage layer opens)
  * The plugin obtains these blobs from zvec's own IndexStorage (segment->read), exactly as IVFSearcher::load does; the
  * body is uploaded as it is and re-laid out on the GPU.  Mismatch (-24) when data type / dimension differ from the
- * handle's, InvalidArgument for inconsistent sizes or offsets.  Parity note: the byte layouts are restated from the
- * reference's writer code — the reference ships no dumped index to check them against. */
+ * handle's, InvalidArgument for inconsistent sizes or offsets.  Parity: checked against index files dumped by
+ * the reference's own IVFDumper / FlatBuilder / MemoryDumper compiled in place (tests/golden/ref_index_files.npz). */
 int zvec_hip_ivf_load_segments(zvec_hip_ivf_t h, const void *inverted_header, uint64_t header_bytes,
                                const void *inverted_meta, uint64_t meta_bytes, const void *inverted_body,
                                uint64_t body_bytes, const void *keys, uint64_t keys_bytes, const void *centroids);

@@ -29,6 +29,10 @@ def build(force=False):
     ref_so = os.path.join(_HERE, "_ref", "libzvec_ref.so")
     if os.path.isdir("/root/reference/src/ailego/math") and (force or not os.path.exists(ref_so)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    # the reference's index WRITERS (golden index files, tests/golden/make_ref_index_files.py); never needed at test time
+    fmt_so = os.path.join(_HERE, "_ref", "libzvec_ref_format.so")
+    if os.path.isdir("/root/reference/src/core/algorithm/ivf") and (force or not os.path.exists(fmt_so)):
+        subprocess.check_call(["make", "-C", _HERE, "ref_format"], stdout=subprocess.DEVNULL)
 
 
 def _ptr(a, ty):

@@ -1,5 +1,5 @@
-"""Test-side WRITER of the reference's dumped IVF segments, restated from its writer code (the reference holds no dumped
-index to use as a fixture — parity of the byte layout is unpinned, see include/zvec_hip.h):
+"""Test-side WRITER of the reference's dumped IVF segments, restated from its writer code; pinned byte for byte against
+files the reference's own writers dumped (tests/golden/ref_index_files.npz, tests/test_golden_files_cpu.py):
   IVFDumper::dump_inverted_vector / dump_block / dump_inverted_vector_finished   src/core/algorithm/ivf/ivf_dumper.cc:19-32,118-200,388-406
   IVFDumper::Block::do_emplace / transpose                                       src/core/algorithm/ivf/ivf_dumper.h:131-160
   InvertedIndexHeader / InvertedListMeta                                         src/core/algorithm/ivf/ivf_index_format.h:26-47
@@ -50,8 +50,8 @@ def pack_container(segments, version=b"zvec-test-writer"):
     """Test-side WRITER of the container framing of a dumped index file, restated from IndexPacker::setup / pack / finish /
     pack_version (src/include/zvec/core/framework/index_packer.h:98-231) and IndexFormat (index_format.h:26-200):
     [MetaHeader 64 B][segments' data, each padded to 32 B]["IndexVersion" segment][padding to 32][SegmentMeta[count] +
-    NUL-terminated ids, padded to 32][MetaFooter 128 B].  segments: list of (id, bytes).  Parity of the byte layout is
-    unpinned (the reference ships no dumped file); the CRC itself is pinned by the reference's known answers."""
+    NUL-terminated ids, padded to 32][MetaFooter 128 B].  segments: list of (id, bytes).  Checked against files the
+    reference's own MemoryDumper wrote (tests/test_golden_files_cpu.py): same segment table and content, byte for byte."""
     from oracle.roaring import crc32c
     content = bytearray()
     stab = []
