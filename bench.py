@@ -78,7 +78,9 @@ def parse_args():
     ap.add_argument("--intrinsic-dim", type=int, default=12)
     ap.add_argument("--target-recall", type=float, default=0.99)
     ap.add_argument("--nprobe-step", type=int, default=2, help="widening step of the recall sweep")
-    ap.add_argument("--streams", type=int, default=1, help="IVF workloads: alternate consecutive batches over this many streams (1 or 2)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="IVF workloads: consecutive (independent) batches alternate over this many contexts / HIP streams that "
+                         "share a gate (zvec_hip_gate_t): list scans run back to back, everything else overlaps them (1 or 2)")
     ap.add_argument("--keep", type=float, default=0.1, help="filter workloads: fraction of rows the bitmap keeps")
     ap.add_argument("--flat-threshold", type=float, default=None,
                     help="diagnostic: RNN radius for the flat workloads (a huge negative value admits nothing => distance-only time)")
@@ -403,14 +405,19 @@ def main():
                                    gpu=(gk.cpu().numpy(), gs.cpu().numpy(), gc.cpu().numpy()))
 
         # ---------------- timed region ----------------
-        # --streams 2: consecutive (independent) batches alternate between two contexts on two HIP streams, so the
-        # coarse pass / plan of batch i+1 runs under the tail of batch i's list scan (serving-style concurrency);
-        # every step is still one complete pass over one batch and all K steps complete inside the timed region
+        # --streams 2 (default): consecutive (independent) batches alternate between two contexts on two HIP streams
+        # that share a gate: the list scans — the HBM-bound kernel — run strictly one after the other, in step order,
+        # while the coarse pass / plan of batch i+1 and the merge / refine / exchange of batch i-1 run under batch i's
+        # scan (serving-style pipelining).  Every step is still one complete pass over one batch, all K steps complete
+        # inside the timed region, and the scan kernel's HIP-event duration is that of an un-shared device
         lanes = [(sh, stream_ptr, None)]
-        if args.streams > 1 and world == 1:
+        if args.streams > 1:
+            gate = zvec_amd.Gate(local_rank)
+            ctx.set_gate(gate)
             s2 = torch.cuda.Stream(device=dev)
             ctx2 = ivf.create_context()
             ctx2.set_stream(s2.cuda_stream)
+            ctx2.set_gate(gate)
             lanes.append((ShardedIVF(ivf, ctx2, rank, world), s2.cuda_stream, s2))
 
         def run_step(i, np_):
@@ -492,6 +499,7 @@ def main():
             "cpu_baseline": cpu,
             "host_pointer_qps": host_qps,
         }
+        extra_cfg["streams"] = len(lanes)
         extra_cfg.update({"recall_at_nprobe%d" % nprobe_base: recall_base, "qps_nprobe%d" % nprobe_base: qps_base if qps_base else
                           (result["value"] if nprobe == nprobe_base else None), "recall_queries": ngt})
         if shard_mode:

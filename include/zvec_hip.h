@@ -55,6 +55,7 @@ typedef struct zvec_hip_flat_s *zvec_hip_flat_t;
 typedef struct zvec_hip_ivf_s *zvec_hip_ivf_t;
 typedef struct zvec_hip_ctx_s *zvec_hip_ctx_t;
 typedef struct zvec_hip_shards_s *zvec_hip_shards_t;
+typedef struct zvec_hip_gate_s *zvec_hip_gate_t;
 
 /* library / device ------------------------------------------------------------------------- */
 int zvec_hip_abi_version(void);
@@ -69,6 +70,17 @@ int zvec_hip_ctx_destroy(zvec_hip_ctx_t ctx);
 int zvec_hip_ctx_synchronize(zvec_hip_ctx_t ctx);
 /* bind the context to a caller-owned hipStream_t (e.g. torch's current stream); NULL restores its own */
 int zvec_hip_ctx_set_stream(zvec_hip_ctx_t ctx, void *stream);
+
+/* Pipelining consecutive batches.  The reference overlaps queries by giving every caller thread its own context
+ * (index.cc:24-45); on the GPU one search is a short sequence of small kernels around ONE bandwidth- or MFMA-bound scan.
+ * Contexts that share a gate run that dominant scan kernel one after the other, in call order, while everything else of
+ * their searches (query preparation, coarse pass, plan, merges, L2 refinement, the caller's candidate exchange) overlaps
+ * the other context's scan: with two contexts on two streams the device runs scans back to back.  A gate is one HIP
+ * event, re-recorded behind every gated scan and waited for in front of the next; contexts and gate on one device.
+ * Destroy the gate after detaching (set_gate(ctx, NULL)) or destroying its contexts. */
+int zvec_hip_gate_create(int device, zvec_hip_gate_t *out);
+int zvec_hip_gate_destroy(zvec_hip_gate_t gate);
+int zvec_hip_ctx_set_gate(zvec_hip_ctx_t ctx, zvec_hip_gate_t gate);
 
 /* ---- flat (brute force) -------------------------------------------------------------------
  * stands behind FlatStreamer<32> / FlatSearcher<32>

@@ -301,3 +301,81 @@ def test_in_process_shards_ivf_equals_one_index(oracle, ndev):
     assert sb.build(base, nlist, kmeans_iters=4, sample_per_list=64, seed=11) == 0
     gk, gs, gc = sb.search(q, k, nprobe=nprobe, max_scan=n - 1)
     tie_tolerant_compare(gk, gs, gc, ctx.keys, ctx.scores, ctx.counts, what="sharded build vs one-call build")
+
+
+def test_gated_contexts_pipeline_batches_with_identical_results():
+    """zvec_hip_gate_t: two contexts on two streams share a gate, consecutive batches alternate between them (what
+    bench.py times): the dominant scan kernels run in call order, the rest overlaps.  Every batch must get exactly the
+    answer of an ungated, single-context search — IVF and flat, from one host thread and from two."""
+    import threading
+    import torch
+    import zvec_amd as zv
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    n, dim, nlist, nq, k, nprobe = 200_000, 64, 256, 128, 10, 12
+    proj = torch.randn((8, dim), generator=g, device=dev)
+    base = (torch.randn((n, 8), generator=g, device=dev) @ proj).contiguous()
+    batches = [(torch.randn((nq, 8), generator=g, device=dev) @ proj).contiguous() for _ in range(6)]
+    s0 = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(s0)
+    ivf = zv.HipIVFSearcher(dim, "SquaredEuclidean")
+    assert ivf.build_dev(base.data_ptr(), n, nlist, kmeans_iters=3, sample_per_list=64, stream=s0.cuda_stream) == 0
+    flat = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert flat.add_batch_dev(base.data_ptr(), n, stream=s0.cuda_stream) == 0
+    torch.cuda.synchronize()
+
+    def out():
+        return (torch.empty((nq, k), dtype=torch.int64, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
+                torch.empty((nq,), dtype=torch.int32, device=dev))
+
+    def run(idx, ctx, q, o, sp):
+        if idx is ivf:
+            rc = idx.search_dev(q.data_ptr(), nq, k, nprobe, n, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), ctx, stream=sp)
+        else:
+            rc = idx.search_dev(q.data_ptr(), nq, k, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), ctx, stream=sp)
+        assert rc == 0
+    for idx in (ivf, flat):
+        ref_ctx = idx.create_context()
+        ref_ctx.set_stream(s0.cuda_stream)
+        want = []
+        for q in batches:
+            o = out()
+            run(idx, ref_ctx, q, o, s0.cuda_stream)
+            torch.cuda.synchronize()
+            want.append([t.clone() for t in o])
+        gate = zv.Gate(0)
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        ctxs = [idx.create_context(), idx.create_context()]
+        for c, s in zip(ctxs, streams):
+            c.set_stream(s.cuda_stream)
+            c.set_gate(gate)
+        torch.cuda.synchronize()
+        # one host thread, alternating lanes, several rounds without synchronising in between
+        outs = [out() for _ in batches]
+        for rnd in range(3):
+            for i, q in enumerate(batches):
+                run(idx, ctxs[i % 2], q, outs[i], streams[i % 2].cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(len(batches)):
+            assert all(torch.equal(a, b) for a, b in zip(outs[i], want[i])), (idx is ivf, i)
+        # two host threads, one lane each
+        outs2 = [out() for _ in batches]
+        errs = []
+
+        def worker(lane):
+            try:
+                for rnd in range(3):
+                    for i in range(lane, len(batches), 2):
+                        run(idx, ctxs[lane], batches[i], outs2[i], streams[lane].cuda_stream)
+            except Exception as e:   # noqa: BLE001
+                errs.append(repr(e))
+        th = [threading.Thread(target=worker, args=(l,)) for l in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        torch.cuda.synchronize()
+        assert not errs, errs
+        for i in range(len(batches)):
+            assert all(torch.equal(a, b) for a, b in zip(outs2[i], want[i])), ("threads", idx is ivf, i)
+        for c in ctxs:
+            c.set_gate(None)

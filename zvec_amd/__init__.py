@@ -8,6 +8,6 @@ Package layout (only what the hot path needs):
   dist.py   one-process-per-GPU sharding + RCCL all-gather merge of the per-shard candidates
 """
 from .index import (  # noqa: F401
-    DocFilter, HipFlatSearcher, HipShardedIndex, HipFlatStreamer, HipIVFSearcher, HipIVFStreamer, IndexContext, IndexDocument, IndexError_,
+    DocFilter, Gate, HipFlatSearcher, HipShardedIndex, HipFlatStreamer, HipIVFSearcher, HipIVFStreamer, IndexContext, IndexDocument, IndexError_,
     METRIC_L2, METRIC_IP, METRIC_COSINE, metric_from_name, shard_map, container_segments, open_flat_file, open_ivf_file,
 )

@@ -37,6 +37,9 @@ SYMBOLS = {
     "zvec_hip_ctx_destroy": (C.c_int, [_h]),
     "zvec_hip_ctx_synchronize": (C.c_int, [_h]),
     "zvec_hip_ctx_set_stream": (C.c_int, [_h, C.c_void_p]),
+    "zvec_hip_gate_create": (C.c_int, [C.c_int, C.POINTER(_h)]),
+    "zvec_hip_gate_destroy": (C.c_int, [_h]),
+    "zvec_hip_ctx_set_gate": (C.c_int, [_h, _h]),
     "zvec_hip_flat_create": (C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_h)]),
     "zvec_hip_flat_destroy": (C.c_int, [_h]),
     "zvec_hip_flat_reserve": (C.c_int, [_h, C.c_uint64]),

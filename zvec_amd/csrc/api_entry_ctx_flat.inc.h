@@ -45,6 +45,30 @@ int zvec_hip_ctx_set_stream(zvec_hip_ctx_t ctx, void *stream) {
   return 0;
 }
 
+int zvec_hip_gate_create(int device, zvec_hip_gate_t *out) {
+  if (!out) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  ZCHK(hipSetDevice(device));
+  zvec_hip_gate_s *g = new (std::nothrow) zvec_hip_gate_s();
+  if (!g) return ZVEC_HIP_ERR_NO_MEMORY;
+  g->device = device;
+  if (hipEventCreateWithFlags(&g->ev, hipEventDisableTiming) != hipSuccess) { delete g; return ZVEC_HIP_ERR_RUNTIME; }
+  *out = g;
+  return 0;
+}
+int zvec_hip_gate_destroy(zvec_hip_gate_t g) {
+  if (!g) return 0;
+  (void)hipSetDevice(g->device);
+  if (g->ev) (void)hipEventDestroy(g->ev);
+  delete g;
+  return 0;
+}
+int zvec_hip_ctx_set_gate(zvec_hip_ctx_t ctx, zvec_hip_gate_t gate) {
+  if (!ctx || (gate && gate->device != ctx->device)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->gate = gate;
+  return 0;
+}
+
 // ---- flat -----------------------------------------------------------------------------------
 int zvec_hip_flat_create(uint32_t dim, int dtype, int metric, int device, zvec_hip_flat_t *out) {
   if (!out || dim == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;

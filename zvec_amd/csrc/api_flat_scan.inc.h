@@ -197,6 +197,20 @@ void prof_end(zvec_hip_ctx_s *ctx, hipStream_t stream, int i) {
   ctx->nprof = i + 1;
 }
 
+// gate_enter / gate_leave bracket a gated scan launch on `stream` (no-ops without a gate); the gate's mutex is held in
+// between so that wait, launch and record of one context are not interleaved with another thread's
+void gate_enter(zvec_hip_ctx_s *ctx, hipStream_t stream) {
+  if (!ctx->gate) return;
+  ctx->gate->mu.lock();
+  if (ctx->gate->armed) (void)hipStreamWaitEvent(stream, ctx->gate->ev, 0);
+}
+void gate_leave(zvec_hip_ctx_s *ctx, hipStream_t stream) {
+  if (!ctx->gate) return;
+  (void)hipEventRecord(ctx->gate->ev, stream);
+  ctx->gate->armed = true;
+  ctx->gate->mu.unlock();
+}
+
 // Outputs of a search on the device
 struct SearchOut {
   uint64_t *keys;
@@ -482,13 +496,17 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
   int pi = -1;
   if (profile_it) {
+    gate_enter(ctx, stream);            // (user-facing scans only: the seeding pre-pass and coarse passes are not gated)
     double bytes = (double)st.n * st.dscan * st.elem + (double)count * st.dscan * st.elem + (double)count * topk * 12.0;
     double flops = 2.0 * (double)count * (double)st.n * st.dscan;
     pi = prof_begin(ctx, stream, bytes, flops, 0);
   }
-  if (wide) ZRET(launch_scan8(a, st.f16, ((nchunks + 7) / 8) * 8 * nqtiles, cus, stream));   // ids padded to whole XCD groups
-  else ZRET(launch_scan_ng(m16_small ? 0 : ng, a, st.f16, nchunks * nqtiles, cus, stream));
+  int lrc;
+  if (wide) lrc = launch_scan8(a, st.f16, ((nchunks + 7) / 8) * 8 * nqtiles, cus, stream);   // ids padded to whole XCD groups
+  else lrc = launch_scan_ng(m16_small ? 0 : ng, a, st.f16, nchunks * nqtiles, cus, stream);
   prof_end(ctx, stream, pi);
+  if (profile_it) gate_leave(ctx, stream);
+  ZRET(lrc);
 
   MergeArgs m{};
   m.part_s = a.part_s; m.part_i = a.part_i; m.part_keys = nullptr; m.slot_begin = nullptr;

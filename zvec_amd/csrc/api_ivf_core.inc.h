@@ -170,10 +170,13 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
   // algorithmic bytes of the list scan = rows of the DISTINCT probed lists (counted on device from
   // the plan: plan_scan_kernel's work_stats) + the query rows + the result lists
+  gate_enter(ctx, stream);
   int pi = prof_begin(ctx, stream, (double)count * h->lists.dscan * h->lists.elem + (double)count * topk * 12.0, 0, 1);
   if (pi >= 0) ctx->prof_dscan[pi] = h->lists.dscan | (h->lists.f16 ? 0x80000000u : 0u);
-  ZRET(launch_scan_ng(ng, a, h->lists.f16, 0x7fffffffu, cus, stream));
+  const int lrc = launch_scan_ng(ng, a, h->lists.f16, 0x7fffffffu, cus, stream);
   prof_end(ctx, stream, pi);
+  gate_leave(ctx, stream);
+  ZRET(lrc);
 
   // 4. merge the per-(query, probe, chunk) partial lists in probe order
   MergeArgs m{};

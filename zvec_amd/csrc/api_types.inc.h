@@ -139,8 +139,19 @@ struct Store {
 
 }  // namespace
 
+// Contexts that share a gate take turns on their dominant scan kernel (in call order) while everything else of their
+// searches — query preparation, coarse pass, plan, merges, refinement, the caller's exchange — overlaps the other
+// context's scan: one event, re-recorded behind every gated scan, waited for in front of the next one.
+struct zvec_hip_gate_s {
+  int device = 0;
+  hipEvent_t ev = nullptr;
+  bool armed = false;
+  std::mutex mu;
+};
+
 struct zvec_hip_ctx_s {
   int device = 0;
+  zvec_hip_gate_s *gate = nullptr;
   hipStream_t own = nullptr;
   hipStream_t cur = nullptr;
   std::mutex mu;

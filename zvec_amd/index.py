@@ -225,6 +225,12 @@ class IndexContext:
     def set_stream(self, stream_ptr):
         _lib.check(_lib.lib().zvec_hip_ctx_set_stream(self._h, C.c_void_p(stream_ptr)), "ctx_set_stream")
 
+    def set_gate(self, gate):
+        """share a Gate with other contexts: their dominant scan kernels then run one after the other while the rest of
+        their searches overlaps (zvec_hip_ctx_set_gate); None detaches"""
+        _lib.check(_lib.lib().zvec_hip_ctx_set_gate(self._h, gate._h if gate is not None else None), "zvec_hip_ctx_set_gate")
+        self._gate = gate        # keeps the gate alive as long as the context uses it
+
     def profile(self, enable=True):
         _lib.check(_lib.lib().zvec_hip_ctx_profile(self._h, int(enable)), "zvec_hip_ctx_profile")
 
@@ -764,6 +770,22 @@ def open_ivf_file(image, device=0, metric=None):
     _lib.check(se.load_segments(payload("ivf.inverted_header"), payload("ivf.inverted_meta"), payload("ivf.inverted_body"),
                                 payload("hc.keys"), cent), "load_segments")
     return se
+
+
+class Gate:
+    """zvec_hip_gate_t: contexts sharing it take turns on their dominant scan kernel (pipelining consecutive batches)"""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().zvec_hip_gate_create(int(device), C.byref(self._h)), "zvec_hip_gate_create")
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().zvec_hip_gate_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 class HipShardedIndex:
