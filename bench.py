@@ -428,6 +428,8 @@ def main():
                 with torch.cuda.stream(ts):
                     sh_i.search(q, topk, np_, max_scan, sp)
 
+        host_issue = [0.0]
+
         def timed(np_, steps, warmup):
             for i in range(warmup * len(lanes)):
                 run_step(i, np_)
@@ -440,6 +442,7 @@ def main():
             t_start = time.perf_counter()
             for i in range(steps):
                 run_step(i, np_)
+            host_issue[0] = (time.perf_counter() - t_start) / steps * 1e3      # ms of host time to ISSUE one step
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -453,6 +456,7 @@ def main():
             ctx.profile(False)
             return el, pr
         elapsed, prof = timed(nprobe, args.steps, args.warmup)
+        extra_cfg["host_issue_ms_per_step"] = host_issue[0]
         qps_base = None
         if nprobe != nprobe_base:      # the BASELINE nprobe as well (outside the reported region)
             el32, _ = timed(nprobe_base, max(3, min(args.steps, 10)), 1)

@@ -10,6 +10,46 @@ struct KernelInfo {
 KernelInfo g_info[16];
 std::mutex g_info_mu;
 
+// Tuning knobs.  The shipped library has NONE: every value below is a compile-time constant.  Only a build with
+// -DZVEC_HIP_TUNING (tools/build_variant.sh; kernel A/B timing on one GPU box, tools/ab_flat.sh) reads them from the
+// environment, so a stray variable cannot change the product path.
+struct Knobs {
+  int max_ng = 4;             // ZVEC_HIP_MAX_NG      cap of the 4-wave kernel's query-row groups (1, 2, 4)
+  bool no_wide = false;       // ZVEC_HIP_NO_WIDE     never take the 8-wave flat tile
+  bool force_wide = false;    // ZVEC_HIP_FORCE_WIDE  take it on cache-resident bases too
+  bool no_seed = false;       // ZVEC_HIP_NO_SEED     no prefix scan to seed the admission bounds
+  bool no_gather = false;     // ZVEC_HIP_NO_GATHER   sparse filters: compact the kept rows instead of gathering them
+  int ivf_tpc = 0;            // ZVEC_HIP_IVF_TPC     fixed tiles per IVF chunk (0 = adaptive)
+  bool m16_small = true;      // ZVEC_HIP_NO_M16_SMALL  keep flat scans of <= 16 queries on the 32-row MFMA shape
+  int ivf_occ_cap = 0;        // ZVEC_HIP_IVF_OCC_CAP   IVF list scan: at most this many persistent work-groups per CU (0 = all)
+  bool no_wide_dump = false;  // ZVEC_HIP_NO_WIDE_DUMP  dense-score path (IVF coarse step): never take the 8-wave tile
+  bool flat_dyn = false;      // ZVEC_HIP_FLAT_DYN      wide flat kernel: guided self-scheduling instead of one static item per
+                              //                        work-group slot (measured: no gain, 116-124 vs 123-124 TFLOP/s — the
+                              //                        launch is not waiting for a slow CU, see DESIGN.md "flat kernel")
+  int flat_rounds = 2;        // ZVEC_HIP_FLAT_ROUNDS   ... long chunks: this many items per resident work-group
+  int flat_tail_div = 4;      // ZVEC_HIP_FLAT_TAIL_DIV ... short chunks = long / this
+  Knobs() {
+#ifdef ZVEC_HIP_TUNING
+    if (const char *e = getenv("ZVEC_HIP_MAX_NG")) max_ng = std::max(1, std::min(4, atoi(e)));
+    no_wide = getenv("ZVEC_HIP_NO_WIDE") != nullptr;
+    force_wide = getenv("ZVEC_HIP_FORCE_WIDE") != nullptr;
+    no_seed = getenv("ZVEC_HIP_NO_SEED") != nullptr;
+    no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;
+    if (const char *e = getenv("ZVEC_HIP_IVF_TPC")) ivf_tpc = std::max(1, atoi(e));
+    m16_small = getenv("ZVEC_HIP_NO_M16_SMALL") == nullptr;
+    flat_dyn = getenv("ZVEC_HIP_FLAT_DYN") != nullptr;
+    no_wide_dump = getenv("ZVEC_HIP_NO_WIDE_DUMP") != nullptr;
+    if (const char *e = getenv("ZVEC_HIP_IVF_OCC_CAP")) ivf_occ_cap = std::max(0, atoi(e));
+    if (const char *e = getenv("ZVEC_HIP_FLAT_ROUNDS")) flat_rounds = std::max(1, atoi(e));
+    if (const char *e = getenv("ZVEC_HIP_FLAT_TAIL_DIV")) flat_tail_div = std::max(1, atoi(e));
+#endif
+  }
+};
+const Knobs &knobs() {
+  static const Knobs k;
+  return k;
+}
+
 template <int NG, bool M16, bool EXCL, bool F16>
 int launch_scan_t(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
   static bool attr_set[16] = {false};
@@ -24,6 +64,7 @@ int launch_scan_t(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t st
   int occ = 0;
   ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<NG, M16, EXCL, F16>, 256, lds));
   if (occ < 1) occ = 1;
+  if (a.mode == 1 && knobs().ivf_occ_cap > 0) occ = std::min(occ, knobs().ivf_occ_cap);
   uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)max_items, (uint64_t)cus * (uint64_t)occ);
   if (grid == 0) return 0;
   hipLaunchKernelGGL((scan_kernel<NG, M16, EXCL, F16>), dim3(grid), dim3(256), lds, stream, a);
@@ -84,44 +125,6 @@ int launch_scan_ng(int ng, const ScanArgs &a, bool f16, uint32_t max_items, int 
     case 4: return launch_scan<4, false>(a, f16, max_items, cus, stream);
   }
   return ZVEC_HIP_ERR_INVALID_ARGUMENT;
-}
-
-// Tuning knobs.  The shipped library has NONE: every value below is a compile-time constant.  Only a build with
-// -DZVEC_HIP_TUNING (tools/build_variant.sh; kernel A/B timing on one GPU box, tools/ab_flat.sh) reads them from the
-// environment, so a stray variable cannot change the product path.
-struct Knobs {
-  int max_ng = 4;             // ZVEC_HIP_MAX_NG      cap of the 4-wave kernel's query-row groups (1, 2, 4)
-  bool no_wide = false;       // ZVEC_HIP_NO_WIDE     never take the 8-wave flat tile
-  bool force_wide = false;    // ZVEC_HIP_FORCE_WIDE  take it on cache-resident bases too
-  bool no_seed = false;       // ZVEC_HIP_NO_SEED     no prefix scan to seed the admission bounds
-  bool no_gather = false;     // ZVEC_HIP_NO_GATHER   sparse filters: compact the kept rows instead of gathering them
-  int ivf_tpc = 0;            // ZVEC_HIP_IVF_TPC     fixed tiles per IVF chunk (0 = adaptive)
-  bool m16_small = true;      // ZVEC_HIP_NO_M16_SMALL  keep flat scans of <= 16 queries on the 32-row MFMA shape
-  bool no_wide_dump = false;  // ZVEC_HIP_NO_WIDE_DUMP  dense-score path (IVF coarse step): never take the 8-wave tile
-  bool flat_dyn = false;      // ZVEC_HIP_FLAT_DYN      wide flat kernel: guided self-scheduling instead of one static item per
-                              //                        work-group slot (measured: no gain, 116-124 vs 123-124 TFLOP/s — the
-                              //                        launch is not waiting for a slow CU, see DESIGN.md "flat kernel")
-  int flat_rounds = 2;        // ZVEC_HIP_FLAT_ROUNDS   ... long chunks: this many items per resident work-group
-  int flat_tail_div = 4;      // ZVEC_HIP_FLAT_TAIL_DIV ... short chunks = long / this
-  Knobs() {
-#ifdef ZVEC_HIP_TUNING
-    if (const char *e = getenv("ZVEC_HIP_MAX_NG")) max_ng = std::max(1, std::min(4, atoi(e)));
-    no_wide = getenv("ZVEC_HIP_NO_WIDE") != nullptr;
-    force_wide = getenv("ZVEC_HIP_FORCE_WIDE") != nullptr;
-    no_seed = getenv("ZVEC_HIP_NO_SEED") != nullptr;
-    no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;
-    if (const char *e = getenv("ZVEC_HIP_IVF_TPC")) ivf_tpc = std::max(1, atoi(e));
-    m16_small = getenv("ZVEC_HIP_NO_M16_SMALL") == nullptr;
-    flat_dyn = getenv("ZVEC_HIP_FLAT_DYN") != nullptr;
-    no_wide_dump = getenv("ZVEC_HIP_NO_WIDE_DUMP") != nullptr;
-    if (const char *e = getenv("ZVEC_HIP_FLAT_ROUNDS")) flat_rounds = std::max(1, atoi(e));
-    if (const char *e = getenv("ZVEC_HIP_FLAT_TAIL_DIV")) flat_tail_div = std::max(1, atoi(e));
-#endif
-  }
-};
-const Knobs &knobs() {
-  static const Knobs k;
-  return k;
 }
 
 int pick_ng(uint32_t rows_wanted, uint32_t k) {
