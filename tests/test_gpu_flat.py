@@ -520,3 +520,39 @@ def test_batch_distance_one_to_many(zv, oracle, metric, dtype):
     assert s2.load(ib) == 0
     p2 = rng.permutation(300).astype(np.uint32)
     assert np.array_equal(s2.batch_distance(iq, p2), np.array([oracle.dist(O.METRIC_L2, ib[p], iq) for p in p2], np.float32))
+
+
+def test_boundary_a_score_conventions(zv, oracle):
+    """tests/core/interface/index_interface_test.cc:1002-1100 (IndexInterface.Score): two documents (3,4,5) / (1,20,3),
+    query (1,2,3), tolerance 1e-2 — InnerProduct reports +dot, Cosine 1 - cos, L2 the squared distance.  Boundary B
+    (this library) returns the metric kernels' scores; the steps above it are applied here as the product applies them:
+    CosineConverter / CosineReformer on rows and query (oracle.cosine_transform), metric->normalize on the scores
+    (zvec_amd.index.normalize_score)."""
+    from zvec_amd.index import normalize_score
+    docs = {2345: np.array([3.0, 4.0, 5.0], np.float32), 5432: np.array([1.0, 20.0, 3.0], np.float32)}
+    q = np.array([[1.0, 2.0, 3.0]], np.float32)
+    keys = np.array(list(docs), np.uint64)
+    rows = np.stack([docs[int(k_)] for k_ in keys])
+    ip = lambda a, b: float((a * b).sum())                                                     # noqa: E731
+    want = {"InnerProduct": lambda v: ip(v, q[0]),
+            "Cosine": lambda v: 1 - ip(v, q[0]) / (np.sqrt(ip(v, v)) * np.sqrt(ip(q[0], q[0]))),
+            "SquaredEuclidean": lambda v: float(((v - q[0]) ** 2).sum())}
+    for metric, fn in want.items():
+        if metric == "Cosine":
+            se = zv.HipFlatStreamer(4, metric)
+            assert se.add_batch(oracle.cosine_transform(rows), keys) == 0
+            qq = oracle.cosine_transform(q)
+        else:
+            se = zv.HipFlatStreamer(3, metric)
+            assert se.add_batch(rows, keys) == 0
+            qq = q
+        ctx = se.create_context()
+        ctx.set_topk(10)
+        assert se.search_impl(qq, 1, ctx) == 0
+        r = ctx.result(0)
+        assert len(r) == 2
+        for d in r:
+            assert abs(normalize_score(metric, d.score()) - fn(docs[d.key()])) < 1e-2, (metric, d.key(), d.score())
+        # best first: IP -> the larger dot product; cosine / L2 -> the smaller distance
+        best = max(docs, key=lambda k_: fn(docs[k_])) if metric == "InnerProduct" else min(docs, key=lambda k_: fn(docs[k_]))
+        assert r[0].key() == best

@@ -851,6 +851,15 @@ class HipShardedIndex:
         return keys, scores, counts
 
 
+def normalize_score(metric, score):
+    """what core_interface::Index::_dense_search applies ABOVE boundary B (index.cc:624-630): metric->normalize() —
+    InnerProductMetric::normalize negates the kernel's minus-inner-product back to +ip (inner_product_metric.cc:377-384);
+    SquaredEuclidean and Cosine ("1 - ip" already) have no normalize step."""
+    if isinstance(metric, str):
+        metric = metric_from_name(metric)
+    return -score if metric == METRIC_IP else score
+
+
 def ivf_probe_params(nlist, n, scan_ratio, brute_force_threshold):
     """IVFSearcherContext::update (ivf_searcher_context.h:61-79) in the reference's float arithmetic:
     nprobe = max(round(nlist * scan_ratio), 1) (std::round: half away from zero),
