@@ -195,14 +195,25 @@ static int ivf_end_lists(zvec_hip_ivf_s *h) {
     if (knobs().ivf_tpc) h->tiles_per_chunk = (uint32_t)knobs().ivf_tpc;
     // The queue deals lists largest first, so the lists at the END of the order are the tail of every search: one
     // work-group streams only ~7 GB/s (5.7 TB/s over ~768 resident groups), i.e. a 4-tile item lasts ~200 us, and a
-    // tail of such items leaves most of the chip idle.  The last quarter of the tiles is therefore cut into chunks
-    // a quarter as long (guided self-scheduling: coarse items first, fine items last).
-    h->h_tail.assign(nlist, 0);
+    // tail of such items leaves most of the chip idle.  Guided self-scheduling in three levels of the deal order:
+    // the first half of the tiles (level 0) in chunks twice as long (fewer top-k warm-ups and list write-outs per byte
+    // while everybody is busy anyway), the next quarter (level 1) at the base length, the last quarter (level 2) in
+    // chunks a quarter as long.  Measured (head share 0 / 25 / 50 / 75 %): 1/8 shard 0.691 / 0.700 / 0.706 / 0.67 of
+    // peak, whole 10M index 0.758 / 0.767 / 0.775 / 0.770 on one box.
+    h->h_tail.assign(nlist, 1);
+    const uint64_t head_num = knobs().ivf_head_pct;         // per cent of the tiles dealt in double-length chunks
     uint64_t acc = 0;
     for (uint32_t i = nlist; i-- > 0;) {
       const uint32_t l = order[i];
       if (acc * 4 >= tiles) break;
-      h->h_tail[l] = 1;
+      h->h_tail[l] = 2;
+      acc += (h->h_size[l] + TILE_N - 1) / TILE_N;
+    }
+    acc = 0;
+    for (uint32_t i = 0; i < nlist; ++i) {
+      const uint32_t l = order[i];
+      if (acc * 100 >= tiles * head_num || h->h_tail[l] == 2) break;
+      h->h_tail[l] = 0;
       acc += (h->h_size[l] + TILE_N - 1) / TILE_N;
     }
   }

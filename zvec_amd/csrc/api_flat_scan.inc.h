@@ -21,6 +21,7 @@ struct Knobs {
   bool no_gather = false;     // ZVEC_HIP_NO_GATHER   sparse filters: compact the kept rows instead of gathering them
   int ivf_tpc = 0;            // ZVEC_HIP_IVF_TPC     fixed tiles per IVF chunk (0 = adaptive)
   bool m16_small = true;      // ZVEC_HIP_NO_M16_SMALL  keep flat scans of <= 16 queries on the 32-row MFMA shape
+  int ivf_head_pct = 50;      // ZVEC_HIP_IVF_HEAD_PCT  share of the tiles (deal-order head) dealt in double-length chunks
   int ivf_occ_cap = 0;        // ZVEC_HIP_IVF_OCC_CAP   IVF list scan: at most this many persistent work-groups per CU (0 = all)
   bool no_wide_dump = false;  // ZVEC_HIP_NO_WIDE_DUMP  dense-score path (IVF coarse step): never take the 8-wave tile
   bool flat_dyn = false;      // ZVEC_HIP_FLAT_DYN      wide flat kernel: guided self-scheduling instead of one static item per
@@ -40,6 +41,7 @@ struct Knobs {
     flat_dyn = getenv("ZVEC_HIP_FLAT_DYN") != nullptr;
     no_wide_dump = getenv("ZVEC_HIP_NO_WIDE_DUMP") != nullptr;
     if (const char *e = getenv("ZVEC_HIP_IVF_OCC_CAP")) ivf_occ_cap = std::max(0, atoi(e));
+    if (const char *e = getenv("ZVEC_HIP_IVF_HEAD_PCT")) ivf_head_pct = std::max(0, std::min(75, atoi(e)));
     if (const char *e = getenv("ZVEC_HIP_FLAT_ROUNDS")) flat_rounds = std::max(1, atoi(e));
     if (const char *e = getenv("ZVEC_HIP_FLAT_TAIL_DIV")) flat_tail_div = std::max(1, atoi(e));
 #endif

@@ -146,7 +146,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     std::vector<uint32_t> chunks(nlist);
     for (uint32_t l = 0; l < nlist; ++l)
     {
-      const uint32_t t = h->h_tail[l] ? std::max<uint32_t>(1, tpc >> 2) : tpc;
+      const uint32_t t = level_tpc(h->h_tail[l], tpc);
       chunks[l] = sz[l] ? (((sz[l] + TILE_N - 1) / TILE_N + t - 1) / t) : 0;
     }
     uint32_t np = brute_force ? nlist : nprobe;

@@ -133,6 +133,12 @@ __global__ void unpack_rows_kernel(const float *base, const float *extra, const 
   }
 }
 
+// chunk length of a list by its level in the deal order (guided self-scheduling: the queue deals the lists largest first,
+// so level 0 = the head of every search gets long chunks, level 2 = its tail short ones)
+__host__ __device__ inline uint32_t level_tpc(uint32_t level, uint32_t tpc) {
+  return level == 0 ? min(2u * tpc, 32u) : (level == 1 ? tpc : max(1u, tpc >> 2));
+}
+
 // one launch instead of two memsets + fill_gtau before the IVF plan: zero `nzero` plan words (list_count, list_fill),
 // zero the 4 work-queue words, reset the shared bounds of `nq` queries to the threshold
 // ... and set this search's chunk length of every list: `tpc` tiles, a quarter of that for the lists flagged as the tail
@@ -142,7 +148,7 @@ __global__ void ivf_reset_kernel(uint32_t *zero0, uint32_t nzero, uint32_t *queu
   if (i < nzero) zero0[i] = 0;
   if (i < 4) queue[i] = 0;
   if (i < nq) gtau[i] = fkey(threshold);
-  if (i < nlist) list_tpc[i] = list_tail[i] ? max(1u, tpc >> 2) : tpc;
+  if (i < nlist) list_tpc[i] = level_tpc(list_tail[i], tpc);
 }
 
 // gtau[q] = min(gtau[q], k-th score of a sample scan + slack) — only for full sample lists.
