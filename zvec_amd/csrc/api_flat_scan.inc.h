@@ -24,11 +24,6 @@ struct Knobs {
   int ivf_head_pct = 50;      // ZVEC_HIP_IVF_HEAD_PCT  share of the tiles (deal-order head) dealt in double-length chunks
   int ivf_occ_cap = 0;        // ZVEC_HIP_IVF_OCC_CAP   IVF list scan: at most this many persistent work-groups per CU (0 = all)
   bool no_wide_dump = false;  // ZVEC_HIP_NO_WIDE_DUMP  dense-score path (IVF coarse step): never take the 8-wave tile
-  bool flat_dyn = false;      // ZVEC_HIP_FLAT_DYN      wide flat kernel: guided self-scheduling instead of one static item per
-                              //                        work-group slot (measured: no gain, 116-124 vs 123-124 TFLOP/s — the
-                              //                        launch is not waiting for a slow CU, see DESIGN.md "flat kernel")
-  int flat_rounds = 2;        // ZVEC_HIP_FLAT_ROUNDS   ... long chunks: this many items per resident work-group
-  int flat_tail_div = 4;      // ZVEC_HIP_FLAT_TAIL_DIV ... short chunks = long / this
   Knobs() {
 #ifdef ZVEC_HIP_TUNING
     if (const char *e = getenv("ZVEC_HIP_MAX_NG")) max_ng = std::max(1, std::min(4, atoi(e)));
@@ -38,12 +33,9 @@ struct Knobs {
     no_gather = getenv("ZVEC_HIP_NO_GATHER") != nullptr;
     if (const char *e = getenv("ZVEC_HIP_IVF_TPC")) ivf_tpc = std::max(1, atoi(e));
     m16_small = getenv("ZVEC_HIP_NO_M16_SMALL") == nullptr;
-    flat_dyn = getenv("ZVEC_HIP_FLAT_DYN") != nullptr;
     no_wide_dump = getenv("ZVEC_HIP_NO_WIDE_DUMP") != nullptr;
     if (const char *e = getenv("ZVEC_HIP_IVF_OCC_CAP")) ivf_occ_cap = std::max(0, atoi(e));
     if (const char *e = getenv("ZVEC_HIP_IVF_HEAD_PCT")) ivf_head_pct = std::max(0, std::min(75, atoi(e)));
-    if (const char *e = getenv("ZVEC_HIP_FLAT_ROUNDS")) flat_rounds = std::max(1, atoi(e));
-    if (const char *e = getenv("ZVEC_HIP_FLAT_TAIL_DIV")) flat_tail_div = std::max(1, atoi(e));
 #endif
   }
 };
@@ -137,29 +129,15 @@ int pick_ng(uint32_t rows_wanted, uint32_t k) {
   return ng;  // 0 => k too large for the LDS-resident lists
 }
 
-// Decomposition of a wide flat scan into (chunk x query tile) items.  Small scans: one item per resident work-group
-// slot (equal items, one round).  Large scans: guided self-scheduling — the first 3/4 of the tiles in long chunks
-// (`flat_rounds` items per slot), the rest in chunks a quarter as long, dealt dynamically in that order, so that the
-// launch does not wait for its slowest CU with everything else idle.
+// Decomposition of a wide flat scan into (chunk x query tile) items: one item per resident work-group slot (equal
+// items, ONE round).  Finer items dealt dynamically through per-XCD counters were measured in round 2: they even out the
+// work-groups' end times but not the launch (116-124 vs 123-124 TFLOP/s), so the static round stays.
 struct FlatSplit {
-  uint32_t tpc = 1, nchunks = 1, tail_chunk0 = 0, tail_tile0 = 0, tail_tpc = 0;
-  bool dyn = false;
+  uint32_t tpc = 1, nchunks = 1;
 };
 FlatSplit flat_split(uint64_t ntiles, uint32_t nqtiles, uint64_t resident) {
   FlatSplit f;
   const uint64_t slots_q = std::max<uint64_t>(1, (resident + nqtiles - 1) / nqtiles);    // chunks in flight per query tile
-  if (knobs().flat_dyn && ntiles >= 8 * slots_q) {
-    const uint64_t head_tiles = ntiles - ntiles / 4;
-    uint64_t T = std::max<uint64_t>(4, (head_tiles + slots_q * knobs().flat_rounds - 1) / (slots_q * knobs().flat_rounds));
-    uint64_t t = std::max<uint64_t>(2, T / knobs().flat_tail_div);
-    const uint64_t nbig = head_tiles / T;                  // whole long chunks; the tail starts right after them
-    const uint64_t tail0 = nbig * T;
-    const uint64_t nsmall = (ntiles - tail0 + t - 1) / t;
-    f.tpc = (uint32_t)T; f.tail_chunk0 = (uint32_t)nbig; f.tail_tile0 = (uint32_t)tail0; f.tail_tpc = (uint32_t)t;
-    f.nchunks = (uint32_t)(nbig + nsmall);
-    f.dyn = true;
-    return f;
-  }
   uint64_t tpc = std::max<uint64_t>(1, (ntiles + slots_q - 1) / slots_q);
   // >= 4 tiles per top-k warm-up — unless the base is too small to fill the chip that way
   tpc = std::max<uint64_t>(tpc, std::min<uint64_t>(ntiles, ntiles >= 4 * resident ? 4 : 1));
@@ -277,12 +255,6 @@ int flat_scan_gather(zvec_hip_ctx_s *ctx, const Store &st, const uint32_t *d_pos
   ZRET(ctx->part_s.ensure(slots * topk * sizeof(float)));
   ZRET(ctx->part_i.ensure(slots * topk * sizeof(uint32_t)));
   a.n = kept; a.ndense = kept; a.tiles_per_chunk = (uint32_t)tpc; a.nchunks = nchunks; a.nqtiles = nqtiles;
-  a.tail_chunk0 = fs.tail_chunk0; a.tail_tile0 = fs.tail_tile0; a.tail_tpc = fs.tail_tpc;
-  if (fs.dyn) {
-    ZRET(ctx->fqueue.ensure(64));
-    ZCHK(hipMemsetAsync(ctx->fqueue.p, 0, 32, stream));
-    a.queue = ctx->fqueue.as<uint32_t>();
-  }
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
   int pi = -1;
   if (profile_it) {
@@ -492,12 +464,6 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = topk; a.threshold = threshold;
   a.gtau = ctx->gtau.as<uint32_t>();
   a.mode = 0; a.nq = count; a.n = st.n; a.ndense = st.n; a.tiles_per_chunk = (uint32_t)tpc; a.nchunks = nchunks; a.nqtiles = nqtiles;
-  a.tail_chunk0 = fs.tail_chunk0; a.tail_tile0 = fs.tail_tile0; a.tail_tpc = fs.tail_tpc;
-  if (fs.dyn) {
-    ZRET(ctx->fqueue.ensure(64));
-    ZCHK(hipMemsetAsync(ctx->fqueue.p, 0, 32, stream));
-    a.queue = ctx->fqueue.as<uint32_t>();
-  }
   a.part_s = ctx->part_s.as<float>(); a.part_i = ctx->part_i.as<uint32_t>();
   int pi = -1;
   if (profile_it) {
@@ -636,7 +602,7 @@ void ctx_free(zvec_hip_ctx_s *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own) (void)hipStreamSynchronize(c->own);
-  c->gtau.release(); c->ridx.release(); c->fqueue.release(); c->seed_keys.release(); c->seed_scores.release(); c->seed_counts.release(); c->seed_idx.release(); c->cmp_base.release(); c->cmp_norm.release(); c->cmp_extra.release(); c->cmp_keys.release(); c->cmp_pos.release(); c->cmp_cnt.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
+  c->gtau.release(); c->ridx.release(); c->seed_keys.release(); c->seed_scores.release(); c->seed_counts.release(); c->seed_idx.release(); c->cmp_base.release(); c->cmp_norm.release(); c->cmp_extra.release(); c->cmp_keys.release(); c->cmp_pos.release(); c->cmp_cnt.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
   c->coarse_keys.release(); c->coarse_scores.release(); c->coarse_idx.release(); c->coarse_cnt.release();
   c->plan.release(); c->io_q.release(); c->io_ex.release(); c->io_keys.release(); c->io_scores.release();
   c->io_counts.release(); c->stats.release(); c->pin_in.release(); c->pin_out.release();

@@ -157,7 +157,6 @@ struct zvec_hip_ctx_s {
   std::mutex mu;
   // workspace
   DevBuf gtau, ridx;
-  DevBuf fqueue;      // wide flat kernel: 8 item counters (one per XCD residue), zeroed before every launch
   DevBuf seed_keys, seed_scores, seed_counts, seed_idx;   // sample scan that seeds the shared admission bounds
   DevBuf cmp_base, cmp_norm, cmp_extra, cmp_keys, cmp_pos, cmp_cnt;   // compacted keep-set (sparse filters)
   DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;

@@ -52,13 +52,6 @@ struct ScanArgs {
   const uint32_t *gather_pos;
   uint32_t nchunks;
   uint32_t nqtiles;
-  // wide flat kernel, guided self-scheduling: chunks [0, tail_chunk0) are tiles_per_chunk tiles long, chunks from
-  // tail_chunk0 on start at tile tail_tile0 and are tail_tpc tiles long (tail_tpc == 0: no tail, every chunk is
-  // tiles_per_chunk long).  With `queue` set (8 zeroed counters, one per XCD residue of blockIdx) the items are dealt
-  // dynamically in that order — long chunks first, short ones last — instead of by a static grid stride.
-  uint32_t tail_chunk0;
-  uint32_t tail_tile0;
-  uint32_t tail_tpc;
   // ivf decomposition (built on device by the plan kernels)
   const uint32_t *total_items;  // [1]
   uint32_t *queue;              // [1] work-queue head (zeroed per search): items are dealt dynamically

@@ -505,49 +505,12 @@ __global__ void __launch_bounds__(512, 4) scan8_kernel(const ScanArgs a) {
   // stream the SAME chunk of the base are given ids of one residue class: the chunk is then fetched from HBM once
   // and the other query tiles read it from that XCD's L2.  (A speed choice only; any placement is correct.)
   const uint32_t vtotal = ((a.nchunks + 7) / 8) * 8 * a.nqtiles;
-  // Dynamic dealing (a.queue != nullptr): the work-groups of one launch do not run at one speed (two share a CU and its
-  // matrix cores, XCDs differ), and with ONE static item per work-group the launch lasts as long as its slowest CU —
-  // PMC: the waves were resident for only 89.5 % of the kernel's duration.  Items are therefore cut finer, long chunks
-  // first and short ones last, and each work-group draws the next item of its own XCD residue class from a counter
-  // (keeps the L2 sharing of the chunk's query tiles), then steals from the other classes.
-  uint32_t *item_s = slot_s + ROWS;          // [4] hand-off word (inside the dynamic LDS block: the kernel asks for all 160 KiB)
-  const bool dyn = a.queue != nullptr;
-#ifdef ZVK_CLOCK_STAMP
-  if (tid == 0 && blockIdx.x < 1024 && a.dump == nullptr) {
-    zvk_clock_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime();
-    zvk_clock_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
-  for (uint32_t vs = blockIdx.x;; vs += gridDim.x) {           // uniform exit
-    uint32_t v = vs;
-    if (dyn) {
-      if (tid == 0) {
-        uint32_t got = ~0u;
-        for (uint32_t d = 0; d < 8 && got == ~0u; ++d) {
-          const uint32_t x2 = (blockIdx.x + d) & 7;
-          const uint32_t idx = atomicAdd(&a.queue[x2], 1u);
-          if ((uint64_t)idx * 8 + x2 < vtotal) got = idx * 8 + x2;
-        }
-        item_s[0] = got;
-      }
-      __syncthreads();
-      v = item_s[0];
-      __syncthreads();
-      if (v == ~0u) break;
-    } else if (v >= vtotal) {
-      break;
-    }
+  for (uint32_t v = blockIdx.x; v < vtotal; v += gridDim.x) {   // uniform exit
     const uint32_t qtile = (v >> 3) % a.nqtiles;
     const uint32_t chunk = ((v >> 3) / a.nqtiles) * 8 + (v & 7);
     if (chunk >= a.nchunks) continue;
-    uint32_t tile_begin, tile_end;
-    if (a.tail_tpc == 0 || chunk < a.tail_chunk0) {
-      tile_begin = chunk * a.tiles_per_chunk;
-      tile_end = min(tile_begin + a.tiles_per_chunk, a.tail_tpc ? a.tail_tile0 : ntiles_total);
-    } else {
-      tile_begin = a.tail_tile0 + (chunk - a.tail_chunk0) * a.tail_tpc;
-      tile_end = min(tile_begin + a.tail_tpc, ntiles_total);
-    }
+    const uint32_t tile_begin = chunk * a.tiles_per_chunk;
+    const uint32_t tile_end = min(tile_begin + a.tiles_per_chunk, ntiles_total);
     const uint32_t r0 = qtile * ROWS;
     const uint32_t nrows = min((uint32_t)ROWS, a.nq - r0);
 
