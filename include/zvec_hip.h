@@ -269,6 +269,19 @@ int zvec_hip_shards_ivf_build(zvec_hip_shards_t h, const void *vecs, uint64_t n,
 /* IVF: IVFSearcher::load of host arrays (see zvec_hip_ivf_load); every shard keeps its lists */
 int zvec_hip_shards_ivf_load(zvec_hip_shards_t h, const void *centroids, uint32_t nlist, const uint64_t *list_offsets,
                              const void *vecs, const uint64_t *keys);
+/* the segment-payload loaders over the shards (same arguments as zvec_hip_ivf_load_segments /
+ * zvec_hip_flat_load_features): what the plugin's load() / open() call when it is configured with several devices */
+int zvec_hip_shards_ivf_load_segments(zvec_hip_shards_t h, const void *inverted_header, uint64_t header_bytes,
+                                      const void *inverted_meta, uint64_t meta_bytes, const void *inverted_body,
+                                      uint64_t body_bytes, const void *keys, uint64_t keys_bytes, const void *centroids);
+int zvec_hip_shards_flat_load_features(zvec_hip_shards_t h, const void *features, uint64_t bytes, uint64_t count,
+                                       int column_major, uint32_t batch_size, const uint64_t *keys);
+/* FLAT: search_bf_by_p_keys_impl and the fetch_vector gather over the shards; ids / positions are GLOBAL storage
+ * positions (append order), unknown ids are skipped / NO_EXIST like the single-device entries */
+int zvec_hip_shards_flat_search_by_ids(zvec_hip_shards_t h, const void *queries, uint32_t count, const uint64_t *ids,
+                                       const uint32_t *offsets, uint32_t topk, float threshold, const uint64_t *exclude_bitset,
+                                       uint64_t *out_keys, float *out_scores, uint32_t *out_counts);
+int zvec_hip_shards_flat_get_vectors(zvec_hip_shards_t h, const uint64_t *positions, uint64_t n, void *out);
 /* search_impl(query, qmeta, count, ctx) over the shards; host pointers; FLAT ignores nprobe / max_scan_count.
  * exclude_bitset: 1 bit per GLOBAL storage position (FLAT: append order; IVF: list-order positions of the whole
  * index), sliced per shard on the host.  Results: the global top-k, as from one unsharded index. */

@@ -46,6 +46,7 @@ namespace {
 const std::string kParamScanRatio("proxima.ivf.searcher.scan_ratio");                       // ivf_params.h:44-45
 const std::string kParamBruteForceThreshold("proxima.ivf.searcher.brute_force_threshold");  // ivf_params.h:46-47
 const std::string kParamHipDevice("proxima.hip.device");                                    // new: HIP device ordinal
+const std::string kParamHipDeviceCount("proxima.hip.device_count");   // new: > 1 = shard the index over devices [device, device + count)
 
 // segment ids (flat_utility.h:32-34, ivf_index_format.h:152-164)
 const std::string kFlatKeys("flat.keys"), kFlatFeatures("flat.features");
@@ -174,23 +175,31 @@ void size_outputs(HipContext *ctx, uint32_t count) {
 class HipFlatCore {
  public:
   ~HipFlatCore() { destroy(); }
-  int create(const IndexMeta &meta, int device) {
+  //! ndev > 1: one zvec_hip_shards_t (a row-range shard, a worker thread and a stream per device) instead of one handle
+  int create(const IndexMeta &meta, int device, uint32_t ndev = 1) {
     destroy();
     const int metric = metric_of(meta), dtype = dtype_of(meta);
     if (metric < 0 || dtype < 0) return IndexError_Unsupported;
     device_ = device;
     elem_size_ = meta.element_size();
+    if (ndev > 1) {
+      std::vector<int> devs(ndev);
+      for (uint32_t g = 0; g < ndev; ++g) devs[g] = device + (int)g;
+      return zvec_hip_shards_create(meta.dimension(), dtype, metric, ZVEC_HIP_SHARDS_FLAT, devs.data(), ndev, &sh_);
+    }
     return zvec_hip_flat_create(meta.dimension(), dtype, metric, device, &h_);
   }
   void destroy() {
     if (h_) zvec_hip_flat_destroy(h_);
+    if (sh_) zvec_hip_shards_destroy(sh_);
     h_ = nullptr;
+    sh_ = nullptr;
     keys_.clear();
     pos_of_key_.clear();
   }
   int append(const void *rows, size_t n, const uint64_t *keys) {
     std::unique_lock<FairSharedMutex> w(mu_);
-    int rc = zvec_hip_flat_append(h_, rows, n, keys);
+    int rc = sh_ ? zvec_hip_shards_flat_append(sh_, rows, n, keys) : zvec_hip_flat_append(h_, rows, n, keys);
     if (rc != 0) return rc;
     for (size_t i = 0; i < n; ++i) {
       pos_of_key_.emplace(keys[i], (uint32_t)keys_.size());
@@ -203,8 +212,10 @@ class HipFlatCore {
     std::shared_lock<FairSharedMutex> r(mu_);
     size_outputs(ctx, count);
     const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());
-    int rc = zvec_hip_flat_search(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), bits, ctx->keys_.data(),
-                                  ctx->scores_.data(), ctx->counts_.data());
+    int rc = sh_ ? zvec_hip_shards_search(sh_, q, count, ctx->topk(), ctx->threshold(), 0, 0, bits, ctx->keys_.data(),
+                                          ctx->scores_.data(), ctx->counts_.data())
+                 : zvec_hip_flat_search(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), bits, ctx->keys_.data(),
+                                        ctx->scores_.data(), ctx->counts_.data());
     if (rc != 0) return rc;
     ctx->fill(count, ctx->topk(), ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
     return attach_vectors(ctx, count);
@@ -225,8 +236,15 @@ class HipFlatCore {
     if (ids.empty()) ids.push_back(0);
     size_outputs(ctx, count);
     const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());
-    int rc = zvec_hip_flat_search_by_ids(h_, ctx->h_, q, count, ids.data(), offs.data(), ctx->topk(), ctx->threshold(), bits,
-                                         ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+    int rc;
+    if (sh_) {
+      std::vector<uint64_t> wide(ids.begin(), ids.end());
+      rc = zvec_hip_shards_flat_search_by_ids(sh_, q, count, wide.data(), offs.data(), ctx->topk(), ctx->threshold(), bits,
+                                              ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+    } else {
+      rc = zvec_hip_flat_search_by_ids(h_, ctx->h_, q, count, ids.data(), offs.data(), ctx->topk(), ctx->threshold(), bits,
+                                       ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+    }
     if (rc != 0) return rc;
     ctx->fill(count, ctx->topk(), ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
     return attach_vectors(ctx, count);
@@ -234,10 +252,17 @@ class HipFlatCore {
   int vector_of_key(uint64_t key, void *out) const {
     std::shared_lock<FairSharedMutex> r(mu_);
     auto it = pos_of_key_.find(key);
-    return it == pos_of_key_.end() ? (int)IndexError_NoExist : zvec_hip_flat_get_vector(h_, it->second, out);
+    return it == pos_of_key_.end() ? (int)IndexError_NoExist : vector_of_pos(it->second, out);
   }
-  int vector_of_pos(uint32_t pos, void *out) const { return zvec_hip_flat_get_vector(h_, pos, out); }
-  zvec_hip_flat_t handle() const { return h_; }
+  int vector_of_pos(uint32_t pos, void *out) const {
+    const uint64_t p = pos;
+    return sh_ ? zvec_hip_shards_flat_get_vectors(sh_, &p, 1, out) : zvec_hip_flat_get_vector(h_, pos, out);
+  }
+  //! FlatSearcher::load's "flat.features" payload -> HBM (one device, or dealt over the shards)
+  int load_features(const void *features, size_t bytes, size_t n, bool column_major, const uint64_t *keys) {
+    return sh_ ? zvec_hip_shards_flat_load_features(sh_, features, bytes, n, column_major, 32, keys)
+               : zvec_hip_flat_load_features(h_, features, bytes, n, column_major, 32, keys);
+  }
   size_t count() const { return keys_.size(); }
   void adopt_keys(const uint64_t *keys, size_t n) {
     keys_.assign(keys, keys + n);
@@ -253,7 +278,8 @@ class HipFlatCore {
       for (auto &d : ctx->results_[q]) pos.push_back(pos_of_key_.at(d.key()));
     ctx->vectors_.resize(pos.size() * elem_size_);
     if (pos.empty()) return 0;
-    int rc = zvec_hip_flat_get_vectors(h_, pos.data(), pos.size(), &ctx->vectors_[0]);
+    int rc = sh_ ? zvec_hip_shards_flat_get_vectors(sh_, pos.data(), pos.size(), &ctx->vectors_[0])
+                 : zvec_hip_flat_get_vectors(h_, pos.data(), pos.size(), &ctx->vectors_[0]);
     if (rc != 0) return rc;
     size_t j = 0;
     for (uint32_t q = 0; q < count; ++q)
@@ -265,6 +291,7 @@ class HipFlatCore {
   }
 
   zvec_hip_flat_t h_{nullptr};
+  zvec_hip_shards_t sh_{nullptr};         // set instead of h_ when the index is sharded over several devices
   int device_{0};
   uint32_t elem_size_{0};
   mutable FairSharedMutex mu_;            // add (exclusive) vs search (shared): flat_streamer.cc:236-242
@@ -278,6 +305,8 @@ class HipFlatSearcher : public IndexSearcher {
   int init(const ailego::Params &params) override {
     params_ = params;
     params.get(kParamHipDevice, &device_);
+    params.get(kParamHipDeviceCount, &ndev_);
+    if (ndev_ == 0) ndev_ = 1;
     return 0;
   }
   int cleanup() override { return this->unload(); }
@@ -293,10 +322,9 @@ class HipFlatSearcher : public IndexSearcher {
     if (keys.size() % sizeof(uint64_t) != 0) return IndexError_InvalidLength;
     const size_t n = keys.size() / sizeof(uint64_t);
     if (n * meta_.element_size() != features.size()) return IndexError_Mismatch;
-    if ((rc = core_.create(meta_, device_)) != 0) return rc;
-    rc = zvec_hip_flat_load_features(core_.handle(), features.data(), features.size(), n,
-                                     meta_.major_order() == IndexMeta::MO_COLUMN, 32,
-                                     reinterpret_cast<const uint64_t *>(keys.data()));
+    if ((rc = core_.create(meta_, device_, ndev_)) != 0) return rc;
+    rc = core_.load_features(features.data(), features.size(), n, meta_.major_order() == IndexMeta::MO_COLUMN,
+                             reinterpret_cast<const uint64_t *>(keys.data()));
     if (rc != 0) return rc;
     core_.adopt_keys(reinterpret_cast<const uint64_t *>(keys.data()), n);
     magic_ = IndexContext::GenerateMagic();
@@ -332,6 +360,7 @@ class HipFlatSearcher : public IndexSearcher {
   ailego::Params params_;
   Stats stats_;
   int device_{0};
+  uint32_t ndev_{1};
   uint32_t magic_{0};
   HipFlatCore core_;
 };
@@ -344,6 +373,8 @@ class HipFlatStreamer : public IndexStreamer {
   int init(const IndexMeta &meta, const ailego::Params &params) override {
     meta_ = meta;
     params.get(kParamHipDevice, &device_);
+    params.get(kParamHipDeviceCount, &ndev_);
+    if (ndev_ == 0) ndev_ = 1;
     if (metric_of(meta) < 0 || dtype_of(meta) < 0) return IndexError_Unsupported;
     store_ = IndexFactory::CreateStreamer("FlatStreamer");
     if (!store_) return IndexError_NoExist;
@@ -353,7 +384,7 @@ class HipFlatStreamer : public IndexStreamer {
   int open(IndexStorage::Pointer stg) override {
     int rc = store_->open(std::move(stg));
     if (rc != 0) return rc;
-    if ((rc = core_.create(meta_, device_)) != 0) return rc;
+    if ((rc = core_.create(meta_, device_, ndev_)) != 0) return rc;
     // rows already persisted: walk the reference streamer's provider (key, vector) in storage order
     auto provider = store_->create_provider();
     if (provider) {
@@ -427,6 +458,7 @@ class HipFlatStreamer : public IndexStreamer {
  private:
   IndexMeta meta_;
   int device_{0};
+  uint32_t ndev_{1};
   uint32_t magic_{0};
   IndexStreamer::Pointer store_;          // the reference's FlatStreamer: storage engine side
   HipFlatCore core_;
@@ -440,12 +472,15 @@ class HipIVFCore {
   ~HipIVFCore() { destroy(); }
   void destroy() {
     if (h_) zvec_hip_ivf_destroy(h_);
+    if (sh_) zvec_hip_shards_destroy(sh_);
     h_ = nullptr;
+    sh_ = nullptr;
     keys_.clear();
   }
   //! IVFSearcher::load (ivf_searcher.cc:43-103) + IVFEntity::load (ivf_entity.cc:443-570): the centroid index is a
   //! nested flat index inside the "ivf.centroid" segment; the inverted lists come as header / meta / body / keys
-  int load(IndexStorage *stg, IndexMeta *meta, int device) {
+  //! ndev > 1: whole inverted lists dealt over the devices (byte-balanced map), centroids replicated
+  int load(IndexStorage *stg, IndexMeta *meta, int device, uint32_t ndev = 1) {
     destroy();
     int rc = IndexHelper::DeserializeFromStorage(stg, meta);
     if (rc != 0) return rc;
@@ -485,9 +520,17 @@ class HipIVFCore {
     if ((rc = read_segment(stg, kIvfMeta, &lmeta)) != 0) return rc;
     if ((rc = read_segment(stg, kIvfBody, &body)) != 0) return rc;
     if ((rc = read_segment(stg, kIvfKeys, &keys)) != 0) return rc;
-    if ((rc = zvec_hip_ivf_create(meta->dimension(), dtype, metric, device, &h_)) != 0) return rc;
-    rc = zvec_hip_ivf_load_segments(h_, header.data(), header.size(), lmeta.data(), lmeta.size(), body.data(), body.size(),
-                                    keys.data(), keys.size(), centroids.data());
+    if (ndev > 1) {
+      std::vector<int> devs(ndev);
+      for (uint32_t g = 0; g < ndev; ++g) devs[g] = device + (int)g;
+      if ((rc = zvec_hip_shards_create(meta->dimension(), dtype, metric, ZVEC_HIP_SHARDS_IVF, devs.data(), ndev, &sh_)) != 0) return rc;
+      rc = zvec_hip_shards_ivf_load_segments(sh_, header.data(), header.size(), lmeta.data(), lmeta.size(), body.data(),
+                                             body.size(), keys.data(), keys.size(), centroids.data());
+    } else {
+      if ((rc = zvec_hip_ivf_create(meta->dimension(), dtype, metric, device, &h_)) != 0) return rc;
+      rc = zvec_hip_ivf_load_segments(h_, header.data(), header.size(), lmeta.data(), lmeta.size(), body.data(), body.size(),
+                                      keys.data(), keys.size(), centroids.data());
+    }
     if (rc != 0) return rc;
     keys_.assign(reinterpret_cast<const uint64_t *>(keys.data()),
                  reinterpret_cast<const uint64_t *>(keys.data()) + keys.size() / sizeof(uint64_t));
@@ -501,25 +544,28 @@ class HipIVFCore {
     const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());    // keys in list order (ivf_entity.cc:612)
     int rc;
     if (brute_force || keys_.size() <= ctx->bruteforce_threshold_) {         // ivf_searcher.cc:188-190
-      rc = zvec_hip_ivf_search_bf(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), bits, ctx->keys_.data(),
-                                  ctx->scores_.data(), ctx->counts_.data());
+      rc = sh_ ? zvec_hip_shards_search(sh_, q, count, ctx->topk(), ctx->threshold(), nlist_, 0xffffffffu, bits,     // every list
+                                        ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data())
+               : zvec_hip_ivf_search_bf(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), bits, ctx->keys_.data(),
+                                        ctx->scores_.data(), ctx->counts_.data());
     } else {
       // IVFSearcherContext::update (ivf_searcher_context.h:70-78): float arithmetic, std::round / std::ceil
       const uint32_t nprobe = std::max(static_cast<uint32_t>(std::round(nlist_ * ctx->scan_ratio_)), 1u);
       uint32_t max_scan = static_cast<uint32_t>(std::ceil(keys_.size() * ctx->scan_ratio_));
       max_scan = std::max(ctx->bruteforce_threshold_, max_scan);
-      rc = zvec_hip_ivf_search(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits,
-                               ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+      rc = sh_ ? zvec_hip_shards_search(sh_, q, count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits, ctx->keys_.data(),
+                                        ctx->scores_.data(), ctx->counts_.data())
+               : zvec_hip_ivf_search(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits,
+                                     ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
     }
     if (rc != 0) return rc;
     ctx->fill(count, ctx->topk(), ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
     return 0;
   }
   size_t count() const { return keys_.size(); }
-  zvec_hip_ivf_t handle() const { return h_; }
-
  private:
   zvec_hip_ivf_t h_{nullptr};
+  zvec_hip_shards_t sh_{nullptr};         // set instead of h_ when the lists are dealt over several devices
   uint32_t elem_size_{0}, nlist_{0};
   std::vector<uint64_t> keys_;
 };
@@ -530,12 +576,14 @@ class HipIVFSearcher : public IndexSearcher {
   int init(const ailego::Params &params) override {
     params_ = params;
     params.get(kParamHipDevice, &device_);
+    params.get(kParamHipDeviceCount, &ndev_);
+    if (ndev_ == 0) ndev_ = 1;
     return 0;
   }
   int cleanup() override { return this->unload(); }
   int load(IndexStorage::Pointer stg, IndexMetric::Pointer /*metric*/) override {
     if (!stg) return IndexError_InvalidArgument;
-    int rc = core_.load(stg.get(), &meta_, device_);
+    int rc = core_.load(stg.get(), &meta_, device_, ndev_);
     if (rc != 0) return rc;
     magic_ = IndexContext::GenerateMagic();
     stats_.set_loaded_count(core_.count());
@@ -566,6 +614,7 @@ class HipIVFSearcher : public IndexSearcher {
   ailego::Params params_;
   Stats stats_;
   int device_{0};
+  uint32_t ndev_{1};
   uint32_t magic_{0};
   HipIVFCore core_;
 };
@@ -578,12 +627,14 @@ class HipIVFStreamer : public IndexStreamer {
     meta_ = meta;
     params_ = params;
     params.get(kParamHipDevice, &device_);
+    params.get(kParamHipDeviceCount, &ndev_);
+    if (ndev_ == 0) ndev_ = 1;
     return 0;
   }
   int cleanup() override { core_.destroy(); return 0; }
   int open(IndexStorage::Pointer stg) override {
     if (!stg) return IndexError_InvalidArgument;
-    int rc = core_.load(stg.get(), &meta_, device_);
+    int rc = core_.load(stg.get(), &meta_, device_, ndev_);
     if (rc != 0) return rc;
     magic_ = IndexContext::GenerateMagic();
     stats_.set_loaded_count(core_.count());
@@ -614,6 +665,7 @@ class HipIVFStreamer : public IndexStreamer {
   ailego::Params params_;
   Stats stats_;
   int device_{0};
+  uint32_t ndev_{1};
   uint32_t magic_{0};
   HipIVFCore core_;
 };

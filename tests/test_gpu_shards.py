@@ -379,3 +379,76 @@ def test_gated_contexts_pipeline_batches_with_identical_results():
             assert all(torch.equal(a, b) for a, b in zip(outs2[i], want[i])), ("threads", idx is ivf, i)
         for c in ctxs:
             c.set_gate(None)
+
+
+@pytest.mark.parametrize("ndev", [1, 3])
+def test_in_process_shards_load_reference_dumped_files(ndev):
+    """the segment-payload loaders over shards: golden index files dumped by the reference's own writers
+    (tests/golden/ref_index_files.npz) -> container parser -> zvec_hip_shards_{flat_load_features, ivf_load_segments} ->
+    the sharded handle answers exactly like a single-device index opened from the same file."""
+    import os
+    import zvec_amd as zv
+    from zvec_amd.index import container_segments, parse_index_meta
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_index_files.npz"))
+    rng = np.random.default_rng(8)
+    for name in [str(x) for x in z["cases"]]:
+        image = z[name + "_image"].tobytes()
+        seg = container_segments(image)
+        meta = parse_index_meta(image[seg["IndexMeta"][0]:sum(seg["IndexMeta"])])
+        f16 = meta["data_type"] == 1
+        dt, dim = (np.float16 if f16 else np.float32), meta["dimension"]
+        q = rng.integers(-8, 9, (11, dim)).astype(dt)
+
+        def pay(sid):
+            return image[seg[sid][0]:seg[sid][0] + seg[sid][1]]
+        if name.startswith("flat"):
+            one = zv.open_flat_file(image)
+            sh = zv.HipShardedIndex("flat", dim, "InnerProduct", devices=[0] * ndev, dtype="fp16" if f16 else "fp32")
+            keys = np.frombuffer(pay("flat.keys"), np.uint64)
+            assert sh.load_features(pay("flat.features"), keys.size, column_major=(meta["major_order"] == 2), keys=keys) == 0
+            assert sh.counts()[0] == keys.size
+            c = one.create_context()
+            c.set_topk(5)
+            assert one.search_impl(q, 11, c) == 0
+            gk, gs, gc = sh.search(q, 5)
+        else:
+            one = zv.open_ivf_file(image)
+            n, nlist = one.info()
+            cent = one.export()[0]
+            sh = zv.HipShardedIndex("ivf", dim, "InnerProduct", devices=[0] * ndev, dtype="fp16" if f16 else "fp32")
+            assert sh.load_segments(pay("ivf.inverted_header"), pay("ivf.inverted_meta"), pay("ivf.inverted_body"), pay("hc.keys"), cent) == 0
+            assert sh.counts()[0] == n
+            one.scan_ratio, one.brute_force_threshold = 1.0, 0
+            c = one.create_context()
+            c.set_topk(5)
+            assert one.search_impl(q, 11, c) == 0
+            gk, gs, gc = sh.search(q, 5, nprobe=nlist, max_scan=n)
+        tie_tolerant_compare(gk, gs, gc, c.keys, c.scores, c.counts, what="sharded load of " + name)
+
+
+def test_in_process_flat_shards_by_ids_and_fetch(oracle):
+    """search_bf_by_p_keys_impl and the fetch_vector gather over 3 shards fed by two appends; the oracle answer is a
+    flat scan with every position that is not listed (or is excluded) masked out."""
+    import zvec_amd as zv
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    n, dim, nq, k = 3001, 40, 9, 6
+    base = rng.integers(-8, 9, (n, dim)).astype(np.float32)
+    q = rng.integers(-8, 9, (nq, dim)).astype(np.float32)
+    sh = zv.HipShardedIndex("flat", dim, "SquaredEuclidean", devices=[0, 0, 0])
+    sh.append(base[:1700])
+    sh.append(base[1700:])
+    ids = [rng.choice(n + 50, size=int(rng.integers(0, 60)), replace=False) for _ in range(nq)]   # some unknown positions
+    ids[3] = np.zeros(0, np.int64)
+    exm = np.zeros(n, bool)
+    exm[rng.choice(n, 400, replace=False)] = True
+    gk, gs, gc = sh.search_by_ids(q, ids, k, exclude=O.pack_bits(exm))
+    for i in range(nq):
+        mask = np.ones(n, bool)
+        mask[[int(x) for x in ids[i] if x < n]] = False
+        ok, os_, _, oc = oracle.flat_search(base, q[i:i + 1], k, exclude_bits=O.pack_bits(mask | exm))
+        tie_tolerant_compare(gk[i:i + 1], gs[i:i + 1], gc[i:i + 1], ok, os_, oc, what="sharded by_ids q%d" % i)
+    pos = rng.choice(n, 77, replace=False)
+    rc, rows = sh.get_vectors(pos)
+    assert rc == 0 and np.array_equal(rows, base[pos])
+    assert sh.get_vectors([n + 3])[0] != 0

@@ -100,6 +100,12 @@ SYMBOLS = {
     "zvec_hip_shards_flat_append": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p]),
     "zvec_hip_shards_ivf_build": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]),
     "zvec_hip_shards_ivf_load": (C.c_int, [_h, C.c_void_p, C.c_uint32, _u64p, C.c_void_p, _u64p]),
+    "zvec_hip_shards_ivf_load_segments": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                    C.c_void_p, C.c_uint64, C.c_void_p]),
+    "zvec_hip_shards_flat_load_features": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _u64p]),
+    "zvec_hip_shards_flat_search_by_ids": (C.c_int, [_h, C.c_void_p, C.c_uint32, _u64p, _u32p, C.c_uint32, C.c_float, _u64p,
+                                                     _u64p, _f32p, _u32p]),
+    "zvec_hip_shards_flat_get_vectors": (C.c_int, [_h, _u64p, C.c_uint64, C.c_void_p]),
     "zvec_hip_shards_search": (C.c_int, [_h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, _u64p,
                                          _u64p, _f32p, _u32p]),
     "zvec_hip_flat_build_filter": (C.c_int, [_h, _h, C.POINTER(DocFilterDesc), _u64p, C.c_int, C.c_void_p]),

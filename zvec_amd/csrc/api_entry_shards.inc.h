@@ -39,6 +39,8 @@ struct zvec_hip_shards_s {
   std::vector<DevBuf> d_q, d_ex, d_packed;        // per shard: staged queries, exclude words, packed candidate lists
   DevBuf d_gather, d_ok, d_os, d_oc;              // on devices[0]
   std::vector<std::vector<ShardRange>> ranges;    // flat: global position runs of every shard
+  struct DirEntry { uint64_t global0, len, local0; uint32_t g; };
+  std::vector<DirEntry> dir;                      // flat: all runs ordered by global0 (appends arrive in that order)
   uint64_t total = 0;                             // flat: rows appended so far (global storage positions)
   std::vector<std::unique_ptr<ShardWorker>> workers;
   std::mutex mu;                                  // one search / mutation at a time per handle
@@ -92,6 +94,20 @@ void copy_bits(const uint64_t *src, uint64_t s0, uint64_t *dst, uint64_t d0, uin
     dst[dw] |= ((src[sw] >> sb) & mask) << db;
     i += take;
   }
+}
+
+// global storage position -> (shard, local position); false when nobody holds it
+bool shard_locate(const zvec_hip_shards_s *h, uint64_t pos, uint32_t *g, uint64_t *local) {
+  size_t lo = 0, hi = h->dir.size();
+  while (lo < hi) {
+    const size_t mid = (lo + hi) / 2;
+    if (h->dir[mid].global0 + h->dir[mid].len <= pos) lo = mid + 1;
+    else hi = mid;
+  }
+  if (lo == h->dir.size() || pos < h->dir[lo].global0) return false;
+  *g = h->dir[lo].g;
+  *local = h->dir[lo].local0 + (pos - h->dir[lo].global0);
+  return true;
 }
 
 }  // namespace
@@ -205,6 +221,7 @@ int zvec_hip_shards_flat_append(zvec_hip_shards_t h, const void *vecs, uint64_t 
     uint64_t local0 = 0;
     for (const auto &r : h->ranges[g]) local0 += r.len;
     h->ranges[g].push_back(ShardRange{base0 + a, local0, b - a});
+    h->dir.push_back({base0 + a, b - a, local0, g});
   }
   h->total += n;
   return 0;
@@ -279,6 +296,54 @@ int zvec_hip_shards_ivf_load(zvec_hip_shards_t h, const void *centroids, uint32_
   if (!h || h->kind != ZVEC_HIP_SHARDS_IVF) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> lk(h->mu);
   return shards_parallel(h, [&](uint32_t g) -> int { return zvec_hip_ivf_load(h->ivf[g], centroids, nlist, list_offsets, vecs, keys); });
+}
+
+// IVFSearcher::load over G shards from the raw segment payloads of a dumped index (see zvec_hip_ivf_load_segments):
+// every shard parses the same payloads and keeps the lists the byte-balanced map gives it
+int zvec_hip_shards_ivf_load_segments(zvec_hip_shards_t h, const void *inverted_header, uint64_t header_bytes,
+                                      const void *inverted_meta, uint64_t meta_bytes, const void *inverted_body,
+                                      uint64_t body_bytes, const void *keys, uint64_t keys_bytes, const void *centroids) {
+  if (!h || h->kind != ZVEC_HIP_SHARDS_IVF) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(h->mu);
+  return shards_parallel(h, [&](uint32_t g) -> int {
+    return zvec_hip_ivf_load_segments(h->ivf[g], inverted_header, header_bytes, inverted_meta, meta_bytes, inverted_body, body_bytes,
+                                      keys, keys_bytes, centroids);
+  });
+}
+
+// FlatSearcher::load over G shards from the "flat.features" payload (see zvec_hip_flat_load_features): the rows are
+// dealt in G contiguous ranges; a column-major payload (full 32-row blocks transposed) is cut at block boundaries so
+// that every shard receives whole blocks plus, for the last shard, the row-major remainder
+int zvec_hip_shards_flat_load_features(zvec_hip_shards_t h, const void *features, uint64_t bytes, uint64_t count,
+                                       int column_major, uint32_t batch_size, const uint64_t *keys) {
+  if (!h || h->kind != ZVEC_HIP_SHARDS_FLAT || (!features && count) || batch_size == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (bytes < count * h->row_bytes) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(h->mu);
+  const uint64_t base0 = h->total;
+  // range boundaries: multiples of batch_size (so that transposed blocks stay whole), the last range takes the rest
+  std::vector<uint64_t> cut(h->G + 1, count);
+  cut[0] = 0;
+  for (uint32_t g = 1; g < h->G; ++g) cut[g] = std::min<uint64_t>(count, ((uint64_t)g * count / h->G) / batch_size * batch_size);
+  int rc = shards_parallel(h, [&](uint32_t g) -> int {
+    const uint64_t a = cut[g], b = cut[g + 1];
+    if (a >= b) return 0;
+    std::vector<uint64_t> k(b - a);
+    for (uint64_t i = a; i < b; ++i) k[i - a] = keys ? keys[i] : base0 + i;
+    return zvec_hip_flat_load_features(h->flat[g], static_cast<const char *>(features) + (size_t)a * h->row_bytes,
+                                       (b - a) * h->row_bytes, b - a, column_major, batch_size, k.data());
+  });
+  if (rc != 0) return rc;
+  for (uint32_t g = 0; g < h->G; ++g) {
+    const uint64_t a = cut[g], b = cut[g + 1];
+    if (a >= b) continue;
+    uint64_t local0 = 0;
+    for (const auto &r : h->ranges[g]) local0 += r.len;
+    h->ranges[g].push_back(ShardRange{base0 + a, local0, b - a});
+    h->dir.push_back({base0 + a, b - a, local0, g});
+  }
+  h->total += count;
+  return 0;
 }
 
 // the search of CombinedVectorColumnIndexer::Search over device shards (flat: nprobe / max_scan_count ignored).
@@ -366,4 +431,77 @@ int zvec_hip_shards_search(zvec_hip_shards_t h, const void *queries, uint32_t co
   ZCHK(hipMemcpyAsync(out_counts, h->d_oc.p, (size_t)count * 4, hipMemcpyDeviceToHost, c0->own));
   ZCHK(hipStreamSynchronize(c0->own));
   return 0;
+}
+
+// FlatStreamer::search_bf_by_p_keys_impl over the shards: ids are GLOBAL storage positions; every shard scores the ones
+// it holds (zvec_hip_flat_search_by_ids), the lists meet on the first device and are merged there
+int zvec_hip_shards_flat_search_by_ids(zvec_hip_shards_t h, const void *queries, uint32_t count, const uint64_t *ids,
+                                       const uint32_t *offsets, uint32_t topk, float threshold, const uint64_t *exclude_bitset,
+                                       uint64_t *out_keys, float *out_scores, uint32_t *out_counts) {
+  if (!h || h->kind != ZVEC_HIP_SHARDS_FLAT || !queries || !ids || !offsets || !out_keys || !out_scores || !out_counts)
+    return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(h->mu);
+  const uint64_t pb = zvec_hip_packed_bytes(count, topk);
+  const size_t kb = (size_t)count * topk * 8, sb = (size_t)count * topk * 4;
+  // the id lists of every shard, in local positions; excluded and unknown positions are dropped here
+  std::vector<std::vector<uint32_t>> lid(h->G), loff(h->G, std::vector<uint32_t>(count + 1, 0));
+  for (uint32_t q = 0; q < count; ++q) {
+    if (offsets[q + 1] < offsets[q]) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+    for (uint32_t i = offsets[q]; i < offsets[q + 1]; ++i) {
+      const uint64_t pos = ids[i];
+      uint32_t g = 0;
+      uint64_t local = 0;
+      if (!shard_locate(h, pos, &g, &local)) continue;
+      if (exclude_bitset && ((exclude_bitset[pos >> 6] >> (pos & 63)) & 1ull)) continue;
+      lid[g].push_back((uint32_t)local);
+    }
+    for (uint32_t g = 0; g < h->G; ++g) loff[g][q + 1] = (uint32_t)lid[g].size();
+  }
+  std::vector<char> packed((size_t)pb * h->G, 0);
+  ZRET(shards_parallel(h, [&](uint32_t g) -> int {
+    char *p = packed.data() + (size_t)g * pb;
+    if (lid[g].empty()) return 0;                       // counts stay 0
+    return zvec_hip_flat_search_by_ids(h->flat[g], h->ctx[g], queries, count, lid[g].data(), loff[g].data(), topk, threshold, nullptr,
+                                       reinterpret_cast<uint64_t *>(p), reinterpret_cast<float *>(p + kb),
+                                       reinterpret_cast<uint32_t *>(p + kb + sb));
+  }));
+  ZCHK(hipSetDevice(h->devices[0]));
+  zvec_hip_ctx_s *c0 = h->ctx[0];
+  ZRET(h->d_gather.ensure((size_t)pb * h->G));
+  ZRET(h->d_ok.ensure(kb));
+  ZRET(h->d_os.ensure(sb));
+  ZRET(h->d_oc.ensure((size_t)count * 4));
+  ZCHK(hipMemcpyAsync(h->d_gather.p, packed.data(), packed.size(), hipMemcpyHostToDevice, c0->own));
+  ZRET(zvec_hip_merge_topk_packed_dev(c0, h->d_gather.p, pb, h->G, count, topk, h->d_ok.as<uint64_t>(), h->d_os.as<float>(),
+                                      h->d_oc.as<uint32_t>(), c0->own));
+  ZCHK(hipMemcpyAsync(out_keys, h->d_ok.p, kb, hipMemcpyDeviceToHost, c0->own));
+  ZCHK(hipMemcpyAsync(out_scores, h->d_os.p, sb, hipMemcpyDeviceToHost, c0->own));
+  ZCHK(hipMemcpyAsync(out_counts, h->d_oc.p, (size_t)count * 4, hipMemcpyDeviceToHost, c0->own));
+  ZCHK(hipStreamSynchronize(c0->own));
+  return 0;
+}
+
+// IndexContext::set_fetch_vector over the shards: rows by GLOBAL storage position, one gather per shard
+int zvec_hip_shards_flat_get_vectors(zvec_hip_shards_t h, const uint64_t *positions, uint64_t n, void *out) {
+  if (!h || h->kind != ZVEC_HIP_SHARDS_FLAT || (n && (!positions || !out))) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(h->mu);
+  std::vector<std::vector<uint64_t>> local(h->G), where(h->G);
+  for (uint64_t i = 0; i < n; ++i) {
+    uint32_t g = 0;
+    uint64_t l = 0;
+    if (!shard_locate(h, positions[i], &g, &l)) return ZVEC_HIP_ERR_NO_EXIST;
+    local[g].push_back(l);
+    where[g].push_back(i);
+  }
+  const size_t rb = h->row_bytes;
+  return shards_parallel(h, [&](uint32_t g) -> int {
+    if (local[g].empty()) return 0;
+    std::vector<char> tmp(local[g].size() * rb);
+    ZRET(zvec_hip_flat_get_vectors(h->flat[g], local[g].data(), local[g].size(), tmp.data()));
+    for (size_t j = 0; j < local[g].size(); ++j) memcpy(static_cast<char *>(out) + (size_t)where[g][j] * rb, &tmp[j * rb], rb);
+    return 0;
+  });
 }

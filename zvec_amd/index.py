@@ -838,6 +838,39 @@ class HipShardedIndex:
         return _lib.lib().zvec_hip_shards_ivf_load(self._h, _np_ptr(centroids), centroids.shape[0], _np_ptr(lo), _np_ptr(vecs),
                                                    _np_ptr(k))
 
+    def load_segments(self, inverted_header, inverted_meta, inverted_body, keys, centroids):
+        cent = np.ascontiguousarray(centroids, self.np_dtype)
+        hb, mb, bb, kb = bytes(inverted_header), bytes(inverted_meta), bytes(inverted_body), bytes(keys)
+        return _lib.lib().zvec_hip_shards_ivf_load_segments(self._h, hb, len(hb), mb, len(mb), bb, len(bb), kb, len(kb), _np_ptr(cent))
+
+    def load_features(self, features, count, column_major=False, batch_size=32, keys=None):
+        fb = bytes(features)
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+        return _lib.lib().zvec_hip_shards_flat_load_features(self._h, fb, len(fb), int(count), int(bool(column_major)),
+                                                             int(batch_size), _np_ptr(k))
+
+    def search_by_ids(self, queries, ids_per_query, topk, threshold=FLT_MAX, exclude=None):
+        """search_bf_by_p_keys_impl over the shards: ids are global storage positions."""
+        q = np.ascontiguousarray(queries, self.np_dtype)
+        count = q.shape[0]
+        offs = np.zeros(count + 1, np.uint32)
+        offs[1:] = np.cumsum([len(x) for x in ids_per_query])
+        ids = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint64) for x in ids_per_query] + [np.zeros(1, np.uint64)]))
+        ex = None if exclude is None else np.ascontiguousarray(exclude, np.uint64)
+        keys = np.empty((count, topk), np.uint64)
+        scores = np.empty((count, topk), np.float32)
+        counts = np.empty(count, np.uint32)
+        _lib.check(_lib.lib().zvec_hip_shards_flat_search_by_ids(self._h, _np_ptr(q), count, _np_ptr(ids), _np_ptr(offs), int(topk),
+                                                                 float(threshold), _np_ptr(ex), _np_ptr(keys), _np_ptr(scores),
+                                                                 _np_ptr(counts)), "zvec_hip_shards_flat_search_by_ids")
+        return keys, scores, counts
+
+    def get_vectors(self, positions):
+        pos = np.ascontiguousarray(positions, np.uint64)
+        out = np.empty((pos.size, self.dim), self.np_dtype)
+        rc = _lib.lib().zvec_hip_shards_flat_get_vectors(self._h, _np_ptr(pos), pos.size, _np_ptr(out))
+        return rc, out
+
     def search(self, queries, topk, nprobe=1, max_scan=0xffffffff, threshold=FLT_MAX, exclude=None):
         q = np.ascontiguousarray(queries, self.np_dtype)
         count = q.shape[0]
