@@ -125,6 +125,27 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
                                 uint32_t topk, float threshold, const uint64_t *exclude_bitset,
                                 uint64_t *out_keys, float *out_scores, uint32_t *out_counts);
 
+/* Group-by search: search_impl / search_bf_impl of a context with set_group_params(group_num, group_topk) and
+ * set_group_by(fn) (index_context.h:129,215; FlatSearcherContext::group_by_search_impl, flat_searcher_context.h:1005-1043;
+ * FlatStreamer::group_by_search_impl, flat_streamer.cc:391-437; result assembly topk_to_group_result,
+ * flat_streamer_context.h:135-180).  Every group keeps its `group_topk` closest documents; the `group_num` groups whose
+ * best document is closest are returned, best group first.  group_of_position[pos] (host, one entry per stored row, values
+ * < ngroups; larger values = "no group", skipped) is the caller's group_by(key) mapped to dense numbers — the plugin sweeps
+ * the std::function once per key, like the filter.  Outputs: out_groups[count][group_num] group numbers (out_ngroups[q]
+ * valid), out_keys / out_scores [count][group_num][group_topk] ascending, out_counts[count][group_num] documents at or
+ * below `threshold` (a group whose best document is beyond the radius is listed with 0 documents, as the reference does).
+ * Filter bits as in zvec_hip_flat_search. */
+int zvec_hip_flat_search_grouped(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count,
+                                 const uint32_t *group_of_position, uint32_t ngroups, uint32_t group_num, uint32_t group_topk,
+                                 float threshold, const uint64_t *exclude_bitset, uint32_t *out_groups, uint32_t *out_ngroups,
+                                 uint64_t *out_keys, float *out_scores, uint32_t *out_counts);
+/* FlatStreamer::group_by_search_p_keys_impl (flat_streamer.cc:439-483): the grouped form of zvec_hip_flat_search_by_ids */
+int zvec_hip_flat_search_grouped_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count,
+                                        const uint32_t *ids, const uint32_t *offsets, const uint32_t *group_of_position,
+                                        uint32_t ngroups, uint32_t group_num, uint32_t group_topk, float threshold,
+                                        const uint64_t *exclude_bitset, uint32_t *out_groups, uint32_t *out_ngroups,
+                                        uint64_t *out_keys, float *out_scores, uint32_t *out_counts);
+
 /* IndexMetric::batch_distance (src/include/zvec/core/framework/index_metric.h:85-87; ailego BaseDistance::ComputeBatch,
  * src/ailego/math_batch/distance_batch.h:29-49): ONE query against n scattered stored rows (storage positions), scores
  * only, in the listed order — the one-to-many form the graph indexes drive; for L2 / IP the reference's batch form is a

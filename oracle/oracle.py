@@ -245,6 +245,49 @@ class Oracle:
             raise RuntimeError("zo_flat_search rc=%d" % rc)
         return ok, os_, oi, oc
 
+    def flat_group_search(self, base, queries, group_of, group_num, group_topk, metric=METRIC_L2, keys=None, threshold=FLT_MAX,
+                          exclude_bits=None, candidates=None):
+        """group-by search restated (FlatStreamer::group_by_search_impl, flat_streamer.cc:391-437, result assembly
+        topk_to_group_result, flat_streamer_context.h:135-180): every row not filtered out goes into the bounded heap
+        (limit group_topk: the smallest scores, first seen wins a tie) of its group; the groups are ordered by their
+        best score and the first group_num kept; documents beyond `threshold` are cut from the sorted lists.
+        group_of: group number per storage position.  candidates: per query, the storage positions that compete, in
+        scan order (group_by_search_p_keys_impl, :439-483); None = every row in storage order.  Built on flat_search
+        with topk = all rows: the heap's kept set, in ascending (score, scan order).
+        Returns per query a list of (group number, [(key, score, position), ...])."""
+        base = np.asarray(base)
+        queries = np.atleast_2d(queries)
+        n = base.shape[0]
+        out = []
+        for qi in range(queries.shape[0]):
+            if candidates is None:
+                ok, os_, oi, oc = self.flat_search(base, queries[qi:qi + 1], max(n, 1), metric, keys=keys, exclude_bits=exclude_bits)
+                order = [(float(os_[0, j]), int(oi[0, j]), int(ok[0, j])) for j in range(int(oc[0]))]
+            else:
+                cand = [int(p) for p in candidates[qi]]
+                order = []
+                if cand:
+                    sub = np.ascontiguousarray(base[cand])
+                    ok, os_, oi, oc = self.flat_search(sub, queries[qi:qi + 1], len(cand), metric)
+                    for j in range(int(oc[0])):
+                        p = cand[int(oi[0, j])]
+                        order.append((float(os_[0, j]), p, int(keys[p]) if keys is not None else p))
+            heaps, first = {}, []
+            for sc, pos, key in order:                   # ascending (score, scan order): the first group_topk are the heap's
+                g = int(group_of[pos])
+                lst = heaps.get(g)
+                if lst is None:
+                    lst = heaps[g] = []
+                    first.append((sc, g))                # best score of the group
+                if len(lst) < group_topk:
+                    lst.append((key, sc, pos))
+            first.sort(key=lambda t: t[0])
+            res = []
+            for sc, g in first[:group_num]:
+                res.append((g, [d for d in heaps[g] if not (d[1] > threshold)]))
+            out.append(res)
+        return out
+
     def flat_search_column(self, base, queries, topk, metric=METRIC_L2, keys=None, threshold=FLT_MAX, exclude_bits=None):
         """the column-major dense path (FlatSearcherContext::batch_search_column_*, flat_searcher_context.h:682-845):
         32-row transposed blocks x query groups of 32/16/8/4/2/1 through the M x N block kernels.  `base` row-major."""

@@ -117,6 +117,11 @@ class HipContext : public IndexContext {
     return 0;
   }
   void set_bruteforce_threshold(uint32_t v) override { bruteforce_threshold_ = v; }
+  //! group-by search (flat_searcher_context.h:173-183): group_num > 0 switches the next searches to it
+  void set_group_params(uint32_t group_num, uint32_t group_topk) override { group_num_ = group_num; group_topk_ = group_topk; }
+  bool group_by_search() const { return group_num_ > 0; }
+  const IndexGroupDocumentList &group_result() const override { return group_results_[0]; }
+  const IndexGroupDocumentList &group_result(size_t i) const override { return group_results_[i]; }
 
   //! key/score arrays of one batched call -> per-query IndexDocumentList (topk_to_result: lists end at the
   //! RNN threshold, which the device gate already applied)
@@ -135,6 +140,10 @@ class HipContext : public IndexContext {
   float scan_ratio_{0.1f};                  // ivf_searcher_context.h:211-213 defaults
   uint32_t bruteforce_threshold_{1000};
   std::vector<IndexDocumentList> results_{1};
+  uint32_t group_num_{0}, group_topk_{0};
+  std::vector<IndexGroupDocumentList> group_results_{1};
+  std::vector<uint32_t> group_of_, groups_, ngroups_;   // group number of every storage position; picked groups per query
+  std::vector<std::string> group_ids_;                  // group number -> the caller's id
   std::vector<uint64_t> bits_, keys_;
   std::vector<float> scores_;
   std::vector<uint32_t> counts_;
@@ -153,9 +162,25 @@ const uint64_t *sweep_filter(HipContext *ctx, const uint64_t *keys, size_t n) {
   return ctx->bits_.data();
 }
 
+//! IndexGroupBy is an opaque std::function<std::string(uint64_t)> too: swept once over the keys into dense group numbers
+void sweep_groups(HipContext *ctx, const uint64_t *keys, size_t n) {
+  std::unordered_map<std::string, uint32_t> number_of;
+  ctx->group_ids_.clear();
+  ctx->group_of_.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    std::string id = ctx->group_by()(keys[i]);
+    auto it = number_of.find(id);
+    if (it == number_of.end()) {
+      it = number_of.emplace(id, (uint32_t)ctx->group_ids_.size()).first;
+      ctx->group_ids_.push_back(std::move(id));
+    }
+    ctx->group_of_[i] = it->second;
+  }
+}
+
 HipContext *bind(IndexContext::Pointer &c, uint32_t magic) {
   auto *ctx = dynamic_cast<HipContext *>(c.get());
-  if (!ctx || ctx->rc_ != 0 || ctx->topk() == 0) return nullptr;   // "Invalid context or topk not set yet"
+  if (!ctx || ctx->rc_ != 0 || (ctx->topk() == 0 && !ctx->group_by_search())) return nullptr;   // "Invalid context or topk not set yet"
   if (ctx->magic_ != magic) { ctx->magic_ = magic; ctx->reset(); }
   return ctx;
 }
@@ -207,9 +232,61 @@ class HipFlatCore {
     }
     return 0;
   }
+  //! group_by_search_impl / group_by_search_p_keys_impl (flat_streamer.cc:391-483): ids == nullptr scans every row
+  int group_search(const void *q, uint32_t count, HipContext *ctx, const uint32_t *ids, const uint32_t *offs) const {
+    if (!ctx->group_by().is_valid()) return IndexError_InvalidArgument;      // "Invalid group-by function"
+    if (sh_) return IndexError_Unsupported;                                   // (group-by runs on one device)
+    const uint32_t gnum = ctx->group_num_, gk = ctx->group_topk_;
+    if (gk == 0) return IndexError_InvalidArgument;
+    sweep_groups(ctx, keys_.data(), keys_.size());
+    const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());
+    const size_t rows = size_t(count) * gnum;
+    ctx->keys_.resize(rows * gk);
+    ctx->scores_.resize(rows * gk);
+    ctx->counts_.resize(rows);
+    ctx->groups_.resize(rows);
+    ctx->ngroups_.resize(count);
+    const uint32_t ngroups = std::max<uint32_t>(1u, (uint32_t)ctx->group_ids_.size());
+    const uint32_t none = 0;
+    const uint32_t *gof = ctx->group_of_.empty() ? &none : ctx->group_of_.data();
+    int rc = ids ? zvec_hip_flat_search_grouped_by_ids(h_, ctx->h_, q, count, ids, offs, gof, ngroups, gnum, gk, ctx->threshold(), bits,
+                                                       ctx->groups_.data(), ctx->ngroups_.data(), ctx->keys_.data(),
+                                                       ctx->scores_.data(), ctx->counts_.data())
+                 : zvec_hip_flat_search_grouped(h_, ctx->h_, q, count, gof, ngroups, gnum, gk, ctx->threshold(), bits,
+                                                ctx->groups_.data(), ctx->ngroups_.data(), ctx->keys_.data(), ctx->scores_.data(),
+                                                ctx->counts_.data());
+    if (rc != 0) return rc;
+    // topk_to_group_result (flat_streamer_context.h:135-180)
+    std::vector<uint64_t> pos;
+    ctx->group_results_.assign(count, IndexGroupDocumentList());
+    for (uint32_t qi = 0; qi < count; ++qi) {
+      ctx->group_results_[qi].resize(ctx->ngroups_[qi]);
+      for (uint32_t s = 0; s < ctx->ngroups_[qi]; ++s) {
+        const size_t row = size_t(qi) * gnum + s;
+        GroupIndexDocument &g = ctx->group_results_[qi][s];
+        g.set_group_id(ctx->group_ids_[ctx->groups_[row]]);
+        for (uint32_t j = 0; j < ctx->counts_[row]; ++j) {
+          g.mutable_docs()->emplace_back(ctx->keys_[row * gk + j], ctx->scores_[row * gk + j]);
+          if (ctx->fetch_vector()) pos.push_back(pos_of_key_.at(ctx->keys_[row * gk + j]));
+        }
+      }
+    }
+    if (!ctx->fetch_vector() || pos.empty()) return 0;
+    ctx->vectors_.resize(pos.size() * elem_size_);
+    if ((rc = zvec_hip_flat_get_vectors(h_, pos.data(), pos.size(), &ctx->vectors_[0])) != 0) return rc;
+    size_t j = 0;
+    for (auto &lst : ctx->group_results_)
+      for (auto &g : lst)
+        for (auto &d : *g.mutable_docs()) {
+          d = IndexDocument(d.key(), d.score(), (uint32_t)pos[j], ctx->vectors_.data() + j * elem_size_);
+          ++j;
+        }
+    return 0;
+  }
   int search(const void *q, const IndexQueryMeta &qm, uint32_t count, HipContext *ctx) const {
     if (!q || qm.element_size() != elem_size_) return IndexError_InvalidArgument;
     std::shared_lock<FairSharedMutex> r(mu_);
+    if (ctx->group_by_search()) return group_search(q, count, ctx, nullptr, nullptr);   // flat_streamer.cc:323-324
     size_outputs(ctx, count);
     const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());
     int rc = sh_ ? zvec_hip_shards_search(sh_, q, count, ctx->topk(), ctx->threshold(), 0, 0, bits, ctx->keys_.data(),
@@ -234,6 +311,7 @@ class HipFlatCore {
       offs[i + 1] = (uint32_t)ids.size();
     }
     if (ids.empty()) ids.push_back(0);
+    if (ctx->group_by_search()) return group_search(q, count, ctx, ids.data(), offs.data());   // flat_streamer.cc:365-366
     size_outputs(ctx, count);
     const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());
     int rc;

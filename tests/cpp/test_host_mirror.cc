@@ -1,6 +1,7 @@
 // C++ parity test of the host mirror (zvec_amd/csrc/host/hip_index.h) over the C ABI, written like the
 // reference's own tests.  Expectations are those of
 //   tests/core/algorithm/flat/flat_streamer_test.cc:104-178 (TestLinearSearch), :731-801 (TestFilter)
+//   tests/core/algorithm/flat/flat_streamer_test.cc:929-1037 (TestGroup)
 //   tests/core/algorithm/ivf/ivf_searcher_test.cc:200-321 (TestSimple), :2830-2886 (TestRnnSearch shape)
 // Needs a GPU.  Exit code 0 = all checks passed.
 #include <cstdio>
@@ -441,9 +442,73 @@ static int TestBoundaryAMapping() {
   return 0;
 }
 
+// Expectations of flat_streamer_test.cc TestGroup: 5000 rows (row i = i/10 everywhere), query at 250.1; 5 groups of up
+// to 20 documents without any set_topk; group ids are strings made from the key.  The full scan must give non-empty
+// groups — here additionally: the query's own decade first, its best document key 2501, every document in its group;
+// the p_keys leg over {4,3,2,1,5..10} with one key per group must list the keys 10, 9, 8, 7, 6 first.
+static int TestGroup() {
+  constexpr size_t dim = 16;
+  IndexMeta meta(IndexMeta::DT_FP32, dim);
+  meta.set_metric("SquaredEuclidean");
+  HipFlatStreamer streamer;
+  ASSERT(0 == streamer.init(meta, Params()));
+  ASSERT(0 == streamer.open());
+  const size_t rows = 5000;
+  std::vector<float> all(rows * dim);
+  std::vector<uint64_t> keys(rows);
+  for (size_t i = 0; i < rows; ++i) {
+    keys[i] = i;
+    for (size_t j = 0; j < dim; ++j) all[i * dim + j] = i / 10.0f;
+  }
+  ASSERT(0 == streamer.add_batch(all.data(), rows, keys.data()));
+  IndexQueryMeta qmeta(IndexMeta::DT_FP32, dim);
+  std::vector<float> query(dim, (rows / 2) * 1.0f / 10 + 0.1f);
+  const uint32_t group_num = 5, group_topk = 20;
+
+  auto ctx = streamer.create_context();
+  ASSERT(!!ctx);
+  ctx->set_group_params(group_num, group_topk);
+  EXPECT(IndexError_InvalidArgument == streamer.search_impl(query.data(), qmeta, 1, ctx));   // no group-by function yet
+  ctx->set_group_by([](uint64_t key) { return std::string("g_") + std::to_string(key / 10 % 10); });
+  ASSERT(0 == streamer.search_impl(query.data(), qmeta, 1, ctx));
+  auto &by_decade = ctx->group_result();
+  ASSERT(by_decade.size() == group_num);
+  EXPECT(by_decade[0].group_id() == "g_0");
+  EXPECT(by_decade[0].docs().size() == group_topk && by_decade[0].docs()[0].key() == 2501);
+  for (auto &g : by_decade) {
+    EXPECT(g.docs().size() > 0);
+    for (size_t j = 0; j < g.docs().size(); ++j) {
+      EXPECT(std::string("g_") + std::to_string(g.docs()[j].key() / 10 % 10) == g.group_id());
+      if (j) EXPECT(g.docs()[j - 1].score() <= g.docs()[j].score());
+    }
+  }
+  for (size_t i = 1; i < by_decade.size(); ++i) EXPECT(by_decade[i - 1].docs()[0].score() <= by_decade[i].docs()[0].score());
+
+  auto pk = streamer.create_context();
+  pk->set_group_params(group_num, group_topk);
+  pk->set_group_by([](uint64_t key) { return std::string("g_") + std::to_string(key % 10); });
+  std::vector<std::vector<uint64_t>> p_keys(1);
+  p_keys[0] = {4, 3, 2, 1, 5, 6, 7, 8, 9, 10};
+  ASSERT(0 == streamer.search_bf_by_p_keys_impl(query.data(), p_keys, qmeta, 1, pk));
+  auto &by_unit = pk->group_result();
+  ASSERT(by_unit.size() == group_num);
+  for (uint32_t i = 0; i < by_unit.size(); ++i) {
+    ASSERT(by_unit[i].docs().size() > 0);
+    EXPECT(10 - i == by_unit[i].docs()[0].key());
+  }
+  // ungrouped p_keys search through the same entry: the three closest of the listed keys
+  auto plain = streamer.create_context();
+  plain->set_topk(3);
+  ASSERT(0 == streamer.search_bf_by_p_keys_impl(query.data(), p_keys, qmeta, 1, plain));
+  ASSERT(plain->result().size() == 3);
+  EXPECT(plain->result()[0].key() == 10 && plain->result()[1].key() == 9 && plain->result()[2].key() == 8);
+  return 0;
+}
+
 int main() {
   int rc = 0;
   rc |= TestLinearSearch();
+  rc |= TestGroup();
   rc |= TestFilter();
   rc |= TestIVFSimple();
   rc |= TestNullContextFromManyThreads();

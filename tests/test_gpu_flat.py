@@ -556,3 +556,141 @@ def test_boundary_a_score_conventions(zv, oracle):
         # best first: IP -> the larger dot product; cosine / L2 -> the smaller distance
         best = max(docs, key=lambda k_: fn(docs[k_])) if metric == "InnerProduct" else min(docs, key=lambda k_: fn(docs[k_]))
         assert r[0].key() == best
+
+
+def _check_groups(ctx, qi, want, ids, full=None):
+    """ctx.group_result(qi) against the oracle's [(group number, [(key, score, pos)])].  The reference orders groups with
+    an unstable sort on the best score alone and its heaps keep the first seen of tied documents, so: the sequences of
+    best scores are equal; a group whose best score is not shared with another listed group sits at the same place;
+    the groups tied at the LAST place may be any of the groups with that best score (`full`: the oracle's answer with
+    every group listed, to know them); inside a group the scores are equal and the documents strictly better than its
+    last score are the same."""
+    got = ctx.group_result(qi)
+    assert len(got) == len(want), "number of groups of query %d" % qi
+    wbest = [docs[0][1] if docs else None for _, docs in want]
+    by_id = {ids[g]: docs for g, docs in (full if full is not None else want)}
+    for i, g in enumerate(got):
+        docs = by_id.get(g.group_id())
+        assert docs is not None, "query %d: group %r is not a candidate" % (qi, g.group_id())
+        if wbest[i] is not None and docs:
+            assert docs[0][1] == wbest[i], "query %d place %d: best score" % (qi, i)
+        gs = np.array([d.score() for d in g.docs()], np.float32)
+        ws = np.array([d[1] for d in docs], np.float32)
+        assert np.array_equal(gs, ws), "query %d group %r scores" % (qi, g.group_id())
+        if len(docs):
+            last = ws[-1]
+            assert {d.key() for d in g.docs() if d.score() < last} == {d[0] for d in docs if d[1] < last}
+    assert len({g.group_id() for g in got}) == len(got)
+
+
+def test_group_by_reference_known_answers(zv, oracle):
+    """flat_streamer_test.cc TestGroup (:929-1027) through the GPU path: group_num 5, group_topk 20, no set_topk; the
+    p_keys leg must give the keys 10, 9, 8, 7, 6 as the first documents of its five groups."""
+    n, dim = 5000, 16
+    base = np.repeat((np.arange(n, dtype=np.float32) / np.float32(10.0))[:, None], dim, axis=1).astype(np.float32)
+    q = np.full((1, dim), np.float32(n // 2) * np.float32(1.0) / np.float32(10) + np.float32(0.1), np.float32)
+    st = zv.HipFlatStreamer(dim, "SquaredEuclidean")
+    assert st.add_batch(base, np.arange(n, dtype=np.uint64)) == 0
+    ctx = st.create_context()
+    ctx.set_group_params(5, 20)
+    assert st.search_impl(q, 1, ctx) == zv.IndexError_.InvalidArgument     # "Invalid group-by function"
+    ctx.set_group_by(lambda key: "g_%d" % (key // 10 % 10))
+    assert st.search_impl(q, 1, ctx) == 0
+    res = ctx.group_result(0)
+    assert len(res) == 5 and all(len(g.docs()) > 0 for g in res)
+    want = oracle.flat_group_search(base, q, (np.arange(n) // 10) % 10, 5, 20)[0]
+    _check_groups(ctx, 0, want, ["g_%d" % g for g in range(10)])
+    pk = st.create_context()
+    pk.set_group_params(5, 20)
+    pk.set_group_by(lambda key: "g_%d" % (key % 10))
+    assert st.search_bf_by_p_keys_impl(q, [[4, 3, 2, 1, 5, 6, 7, 8, 9, 10]], 1, pk) == 0
+    res = pk.group_result(0)
+    assert len(res) == 5
+    for i, g in enumerate(res):
+        assert len(g.docs()) > 0 and g.docs()[0].key() == 10 - i and g.group_id() == "g_%d" % ((10 - i) % 10)
+
+
+@pytest.mark.parametrize("metric,dtype", [("SquaredEuclidean", "fp32"), ("InnerProduct", "fp32"), ("SquaredEuclidean", "fp16")])
+def test_group_by_matches_oracle(zv, oracle, metric, dtype):
+    """group-by search on integer data (exact distances): groups, their order and their documents equal the restated
+    reference loop — with a filter, a radius, groups smaller than group_topk, fewer groups than group_num for one query
+    set, several queries per call, fetch_vector"""
+    rng = np.random.default_rng(77)
+    n, dim, nq = 6000, 48, 37
+    npdt = np.float16 if dtype == "fp16" else np.float32
+    base = rng.integers(-6, 7, (n, dim)).astype(npdt)
+    q = rng.integers(-6, 7, (nq, dim)).astype(npdt)
+    keys = (rng.permutation(3 * n)[:n] + 5).astype(np.uint64)
+    ngroups = 41
+    gid = lambda key: "grp%d" % (key % ngroups if key % 7 else 1000 + key % 3)     # 41 big groups + 3 small ones
+    st = zv.HipFlatStreamer(dim, metric, dtype=dtype)
+    assert st.add_batch(base, keys) == 0
+    m = O.METRIC_L2 if metric == "SquaredEuclidean" else O.METRIC_IP
+    names, number_of = [], {}
+    of = np.zeros(n, np.int64)
+    for i, k in enumerate(keys):
+        g = gid(int(k))
+        if g not in number_of:
+            number_of[g] = len(names)
+            names.append(g)
+        of[i] = number_of[g]
+    for gnum, gk, filt, thr in [(6, 9, None, None), (50, 3, lambda key: key % 3 == 0, None), (4, 70, None, "radius"), (1, 1, None, None)]:
+        ctx = st.create_context()
+        ctx.set_group_params(gnum, gk)
+        ctx.set_group_by(gid)
+        exb = None
+        if filt is not None:
+            ctx.set_filter(filt)
+            exb = O.pack_bits(np.array([filt(int(k)) for k in keys]))
+        radius = zv.index.FLT_MAX
+        if thr is not None:
+            probe = oracle.flat_search(base, q[:1], 300, m)[1][0]
+            radius = float(probe[150])
+            ctx.set_threshold(radius)
+        assert st.search_impl(q, nq, ctx) == 0
+        want = oracle.flat_group_search(base, q, of, gnum, gk, m, keys=keys, threshold=radius, exclude_bits=exb)
+        full = oracle.flat_group_search(base, q, of, len(names), gk, m, keys=keys, threshold=radius, exclude_bits=exb)
+        for qi in range(nq):
+            _check_groups(ctx, qi, want[qi], names, full[qi])
+    # p_keys + groups + fetch_vector
+    ctx = st.create_context()
+    ctx.set_group_params(3, 4)
+    ctx.set_group_by(gid)
+    ctx.set_fetch_vector(True)
+    p_pos = [rng.choice(n, int(rng.integers(1, 200)), replace=False) for _ in range(nq)]
+    assert st.search_bf_by_p_keys_impl(q, [[int(keys[p]) for p in pp] + [10 ** 12] for pp in p_pos], nq, ctx) == 0
+    want = oracle.flat_group_search(base, q, of, 3, 4, m, keys=keys, candidates=p_pos)
+    full = oracle.flat_group_search(base, q, of, len(names), 4, m, keys=keys, candidates=p_pos)
+    key2pos = {int(k): i for i, k in enumerate(keys)}
+    for qi in range(nq):
+        _check_groups(ctx, qi, want[qi], names, full[qi])
+        for g in ctx.group_result(qi):
+            for d in g.docs():
+                assert np.array_equal(d.vector(), base[key2pos[d.key()]])
+
+
+def test_group_by_gaussian_tolerance_and_large_batch(zv, oracle):
+    """Gaussian data, 300 queries (several query tiles of the dense pass): scores within the flat path's tolerance of
+    the oracle's, group order equal wherever the best scores are separated by more than that tolerance"""
+    rng = np.random.default_rng(5)
+    n, dim, nq = 20000, 96, 300
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    st = zv.HipFlatStreamer(dim, "SquaredEuclidean")
+    assert st.add_batch(base, np.arange(n, dtype=np.uint64)) == 0
+    ctx = st.create_context()
+    ctx.set_group_params(8, 5)
+    ctx.set_group_by(lambda key: key % 300)
+    assert st.search_impl(q, nq, ctx) == 0
+    of = np.arange(n) % 300
+    for qi in list(range(0, nq, 23)):
+        want = oracle.flat_group_search(base, q[qi:qi + 1], of, 8, 5)[0]
+        got = ctx.group_result(qi)
+        assert len(got) == len(want) == 8
+        wb = np.array([docs[0][1] for _, docs in want], np.float32)
+        gb = np.array([g.docs()[0].score() for g in got], np.float32)
+        np.testing.assert_allclose(gb, wb, rtol=4e-6)
+        for g, (wg, docs) in zip(got, want):
+            if g.group_id() == wg:
+                np.testing.assert_allclose([d.score() for d in g.docs()], [d[1] for d in docs], rtol=4e-6)
+                assert [d.key() for d in g.docs()] == [d[0] for d in docs]

@@ -377,3 +377,31 @@ def test_column_major_equals_row_major_on_exact_data(oracle):
             assert all(np.array_equal(x, y) for x, y in zip(a, b))
         none = oracle.flat_search_column(base, q, k, exclude_bits=O.pack_bits(np.ones(n, bool)))
         assert (none[3] == 0).all()
+
+
+def _test_group_corpus():
+    """flat_streamer_test.cc TestGroup (:929-1027): 5000 rows of dim 16, row i = i/10 in every component"""
+    n, dim = 5000, 16
+    base = np.repeat((np.arange(n, dtype=np.float32) / np.float32(10.0))[:, None], dim, axis=1).astype(np.float32)
+    q = np.full((1, dim), np.float32(n // 2) * np.float32(1.0) / np.float32(10) + np.float32(0.1), np.float32)
+    return base, q
+
+
+def test_group_by_known_answers(oracle):
+    """the oracle's group-by restatement against what flat_streamer_test.cc TestGroup asserts: the p_keys leg lists keys
+    {4,3,2,1,5..10} with group = key % 10 and expects exactly group_num = 5 groups whose first documents are the keys
+    10, 9, 8, 7, 6 (:1019-1036); the full-scan leg (group = key / 10 % 10, 5 groups x 20) expects non-empty groups."""
+    base, q = _test_group_corpus()
+    n = base.shape[0]
+    res = oracle.flat_group_search(base, q, np.arange(n) % 10, 5, 20, O.METRIC_L2, candidates=[[4, 3, 2, 1, 5, 6, 7, 8, 9, 10]])[0]
+    assert len(res) == 5
+    for i, (g, docs) in enumerate(res):
+        assert len(docs) > 0 and docs[0][0] == 10 - i and g == (10 - i) % 10
+    res = oracle.flat_group_search(base, q, (np.arange(n) // 10) % 10, 5, 20, O.METRIC_L2)[0]
+    assert len(res) == 5
+    # the query sits at key 2501: its decade (group 0: keys 2500-2509) holds the best document, then the neighbours
+    assert res[0][0] == 0 and res[0][1][0][0] == 2501
+    assert sorted(g for g, _ in res) == [0, 1, 2, 8, 9]
+    for g, docs in res:
+        assert len(docs) == 20 and all((k // 10) % 10 == g for k, _, _ in docs)
+        assert all(docs[j][1] <= docs[j + 1][1] for j in range(19))

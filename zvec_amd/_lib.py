@@ -54,6 +54,10 @@ SYMBOLS = {
                                               _u64p, _u64p, _f32p, _u32p]),
     "zvec_hip_flat_search_dev": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float,
                                            _u64p, _u64p, _f32p, _u32p, C.c_void_p]),
+    "zvec_hip_flat_search_grouped": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
+                                               _u64p, _u32p, _u32p, _u64p, _f32p, _u32p]),
+    "zvec_hip_flat_search_grouped_by_ids": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, C.c_uint32,
+                                                      C.c_uint32, C.c_float, _u64p, _u32p, _u32p, _u64p, _f32p, _u32p]),
     "zvec_hip_flat_batch_distance": (C.c_int, [_h, _h, C.c_void_p, _u32p, C.c_uint32, _f32p]),
     "zvec_hip_ivf_create": (C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_h)]),
     "zvec_hip_ivf_destroy": (C.c_int, [_h]),

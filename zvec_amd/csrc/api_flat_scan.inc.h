@@ -272,6 +272,40 @@ int flat_scan_gather(zvec_hip_ctx_s *ctx, const Store &st, const uint32_t *d_pos
   return 0;
 }
 
+// Dense scores of queries [q0, q0 + cnt) of the prepared batch against every row of the store: the scan kernel in dump
+// mode writes score[query][padded position] once into ctx->part_s (excluded and padding positions hold +inf); the
+// caller selects from the rows (merge_kernel: large k, coarse step; the group-by kernels).  The caller has sized
+// ctx->part_s for cnt rows of ceil(n / 128) * 128 floats.
+int flat_dense_scores(zvec_hip_ctx_s *ctx, const Store &st, uint32_t q0, uint32_t cnt, float threshold, const uint64_t *d_exclude,
+                      hipStream_t stream, float **dump, uint32_t *dump_stride) {
+  const uint64_t ntiles_d = (st.n + TILE_N - 1) / TILE_N;
+  const int cus_d = device_cus(ctx);
+  int ngd = pick_ng(cnt, 1);
+  // wide batches: the 8-wave 128x128 tile in dump mode (LDS-DMA staging, 32 accumulators per wave) — one item per
+  // (tile, 128-query tile); taken when that gives at least one work-group per two CUs
+  const uint32_t nqt8 = (cnt + W8_ROWS - 1) / W8_ROWS;
+  const bool wide_d = !knobs().no_wide_dump && cnt > 2 * QGROUP && ngd == 4 && d_exclude == nullptr &&
+                      ntiles_d * nqt8 * 2 >= (uint64_t)cus_d && scan8_lds_bytes(1) <= LDS_LIMIT - 1024;
+  // one item per (tile, query tile): halve the query tile while the items would not fill two work-groups per CU
+  // (1024 x 4096 coarse scores: 256 items at 128 rows -> 512 at 64 rows, 92 -> 79 us)
+  while (!wide_d && ngd > 2 && ntiles_d * ((cnt + ngd * QGROUP - 1) / (ngd * QGROUP)) < 2ull * cus_d) ngd /= 2;
+  const uint32_t rows_d = wide_d ? W8_ROWS : ngd * QGROUP;
+  const uint32_t nqt = (cnt + rows_d - 1) / rows_d;
+  ScanArgs a{};
+  a.base = st.base; a.bnorm = st.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
+  a.queries = ctx->qpad.as<float>() + (size_t)q0 * st.dpad; a.qnorm = ctx->qnorm.as<float>() + q0;
+  a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = 1; a.threshold = threshold;
+  a.mode = 0; a.nq = cnt; a.n = st.n; a.ndense = st.n; a.tiles_per_chunk = 1; a.nchunks = (uint32_t)ntiles_d; a.nqtiles = nqt;
+  a.gtau = ctx->gtau.as<uint32_t>() + q0;
+  a.dump = ctx->part_s.as<float>(); a.dump_stride = (uint32_t)(ntiles_d * TILE_N);
+  a.part_s = nullptr; a.part_i = nullptr;
+  if (wide_d) ZRET(launch_scan8(a, st.f16, (uint32_t)((ntiles_d + 7) / 8) * 8 * nqt, cus_d, stream));
+  else ZRET(launch_scan_ng(ngd, a, st.f16, (uint32_t)ntiles_d * nqt, cus_d, stream));
+  *dump = a.dump;
+  *dump_stride = a.dump_stride;
+  return 0;
+}
+
 // `user_facing`: a search whose lists go back to the caller (profiled, L2-refined); false for the IVF
 // coarse pass and the k-means labelling, which only need the ranking
 int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold,
@@ -356,36 +390,17 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     const bool want_b = pick_ng(count, topk) < 1;
     if (want_b && !k_fits_merge) return ZVEC_HIP_ERR_UNSUPPORTED;
     if ((want_a || want_b) && k_fits_merge) {
-      const int cus_d = device_cus(ctx);
       // sub-batches so that the score matrix stays <= 1 GiB
       const uint32_t sub = (uint32_t)std::max<double>(1.0, std::min<double>((double)count, std::floor(1073741824.0 / row_bytes_d)));
       ZRET(ctx->part_s.ensure((size_t)(row_bytes_d * sub)));
       for (uint32_t q0 = 0; q0 < count; q0 += sub) {
         const uint32_t cnt = std::min(sub, count - q0);
-        int ngd = pick_ng(cnt, 1);
-        // wide batches: the 8-wave 128x128 tile in dump mode (LDS-DMA staging, 32 accumulators per wave) — one item per
-        // (tile, 128-query tile); taken when that gives at least one work-group per two CUs
-        const uint32_t nqt8 = (cnt + W8_ROWS - 1) / W8_ROWS;
-        const bool wide_d = !knobs().no_wide_dump && cnt > 2 * QGROUP && ngd == 4 && d_exclude == nullptr &&
-                            ntiles_d * nqt8 * 2 >= (uint64_t)cus_d && scan8_lds_bytes(1) <= LDS_LIMIT - 1024;
-        // one item per (tile, query tile): halve the query tile while the items would not fill two work-groups per CU
-        // (1024 x 4096 coarse scores: 256 items at 128 rows -> 512 at 64 rows, 92 -> 79 us)
-        while (!wide_d && ngd > 2 && ntiles_d * ((cnt + ngd * QGROUP - 1) / (ngd * QGROUP)) < 2ull * cus_d) ngd /= 2;
-        const uint32_t rows_d = wide_d ? W8_ROWS : ngd * QGROUP;
-        const uint32_t nqt = (cnt + rows_d - 1) / rows_d;
-        ScanArgs a{};
-        a.base = st.base; a.bnorm = st.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
-        a.queries = ctx->qpad.as<float>() + (size_t)q0 * st.dpad; a.qnorm = ctx->qnorm.as<float>() + q0;
-        a.dpad = st.dpad; a.nks = st.dpad / TILE_K; a.metric = st.metric; a.k = 1; a.threshold = threshold;
-        a.mode = 0; a.nq = cnt; a.n = st.n; a.ndense = st.n; a.tiles_per_chunk = 1; a.nchunks = (uint32_t)ntiles_d; a.nqtiles = nqt;
-        a.gtau = ctx->gtau.as<uint32_t>() + q0;
-        a.dump = ctx->part_s.as<float>(); a.dump_stride = (uint32_t)(ntiles_d * TILE_N);
-        a.part_s = nullptr; a.part_i = nullptr;
-        if (wide_d) ZRET(launch_scan8(a, st.f16, (uint32_t)((ntiles_d + 7) / 8) * 8 * nqt, cus_d, stream));
-        else ZRET(launch_scan_ng(ngd, a, st.f16, (uint32_t)ntiles_d * nqt, cus_d, stream));
+        float *dump = nullptr;
+        uint32_t dump_stride = 0;
+        ZRET(flat_dense_scores(ctx, st, q0, cnt, threshold, d_exclude, stream, &dump, &dump_stride));
         MergeArgs m{};
-        m.part_s = a.dump; m.part_i = nullptr; m.part_keys = nullptr; m.slot_begin = nullptr; m.slots_per_q = 1;
-        m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = a.dump_stride; m.threshold = threshold;
+        m.part_s = dump; m.part_i = nullptr; m.part_keys = nullptr; m.slot_begin = nullptr; m.slots_per_q = 1;
+        m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = dump_stride; m.threshold = threshold;
         m.keymap = st.keys; m.out_keys = out.keys + (size_t)q0 * topk; m.out_scores = out.scores + (size_t)q0 * topk;
         m.out_idx = out.idx ? out.idx + (size_t)q0 * topk : nullptr; m.out_counts = out.counts + q0;
         hipLaunchKernelGGL(merge_kernel, dim3(cnt), dim3(64), (size_t)topk * 12 + 16, stream, m);
@@ -498,10 +513,10 @@ int refine_l2(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t top
   const uint64_t pairs = (uint64_t)count * topk;
   if (st.f16)
     hipLaunchKernelGGL(rescore_l2_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, st.base,
-                       ctx->qpad.as<float>(), st.dpad, idx, counts, count, topk, scores);
+                       ctx->qpad.as<float>(), st.dpad, idx, counts, count, topk, scores, 1u);
   else
     hipLaunchKernelGGL(rescore_l2_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, st.base,
-                       ctx->qpad.as<float>(), st.dpad, idx, counts, count, topk, scores);
+                       ctx->qpad.as<float>(), st.dpad, idx, counts, count, topk, scores, 1u);
   hipLaunchKernelGGL(resort_kernel, dim3(count), dim3(64), (size_t)topk * 16 + 16, stream, keys, scores, idx, counts, topk,
                      threshold);
   ZCHK(hipGetLastError());
@@ -605,7 +620,7 @@ void ctx_free(zvec_hip_ctx_s *c) {
   c->gtau.release(); c->ridx.release(); c->seed_keys.release(); c->seed_scores.release(); c->seed_counts.release(); c->seed_idx.release(); c->cmp_base.release(); c->cmp_norm.release(); c->cmp_extra.release(); c->cmp_keys.release(); c->cmp_pos.release(); c->cmp_cnt.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
   c->coarse_keys.release(); c->coarse_scores.release(); c->coarse_idx.release(); c->coarse_cnt.release();
   c->plan.release(); c->io_q.release(); c->io_ex.release(); c->io_keys.release(); c->io_scores.release();
-  c->io_counts.release(); c->stats.release(); c->pin_in.release(); c->pin_out.release();
+  c->io_counts.release(); c->grp_ws.release(); c->grp_of.release(); c->grp_out.release(); c->stats.release(); c->pin_in.release(); c->pin_out.release();
   for (auto e : c->ev0) (void)hipEventDestroy(e);
   for (auto e : c->ev1) (void)hipEventDestroy(e);
   if (c->own) (void)hipStreamDestroy(c->own);

@@ -108,6 +108,19 @@ class IndexDocument {
 };
 using IndexDocumentList = std::vector<IndexDocument>;
 
+// index_document.h:278-314
+class GroupIndexDocument {
+ public:
+  const std::string &group_id() const { return group_id_; }
+  const std::vector<IndexDocument> &docs() const { return docs_; }
+  std::vector<IndexDocument> *mutable_docs() { return &docs_; }
+  void set_group_id(const std::string &id) { group_id_ = id; }
+ private:
+  std::string group_id_;
+  std::vector<IndexDocument> docs_;
+};
+using IndexGroupDocumentList = std::vector<GroupIndexDocument>;
+
 class IndexFilter {
  public:
   template <typename T> void set(T &&fn) { fn_ = std::forward<T>(fn); }
@@ -155,6 +168,32 @@ class Context {
   template <typename T> void set_filter(T &&fn) { filter_.set(std::forward<T>(fn)); }
   void reset_filter() { filter_.reset(); has_doc_ = false; has_bits_ = false; }
   const IndexFilter &filter() const { return filter_; }
+  // group-by search (index_context.h:129,209-222; flat_streamer_context.h:183-191)
+  void set_group_params(uint32_t group_num, uint32_t group_topk) { group_num_ = group_num; group_topk_ = group_topk; }
+  template <typename T> void set_group_by(T &&fn) { group_by_ = std::forward<T>(fn); }
+  void reset_group_by() { group_by_ = nullptr; }
+  bool group_by_search() const { return group_num_ > 0; }
+  bool group_by_valid() const { return (bool)group_by_; }
+  uint32_t group_num() const { return group_num_; }
+  uint32_t group_topk() const { return group_topk_; }
+  const IndexGroupDocumentList &group_result() const { return group_results_.at(0); }
+  const IndexGroupDocumentList &group_result(size_t i) const { return group_results_.at(i); }
+  std::vector<IndexGroupDocumentList> &mutable_group_results() { return group_results_; }
+  // host sweep of the group-by callback: dense group number of every storage position + the ids they stand for
+  void sweep_groups(const std::vector<uint64_t> &keys_by_position, std::vector<uint32_t> *group_of, std::vector<std::string> *ids) const {
+    std::unordered_map<std::string, uint32_t> number_of;
+    ids->clear();
+    group_of->resize(keys_by_position.size());
+    for (size_t i = 0; i < keys_by_position.size(); ++i) {
+      std::string id = group_by_(keys_by_position[i]);
+      auto it = number_of.find(id);
+      if (it == number_of.end()) {
+        it = number_of.emplace(id, (uint32_t)ids->size()).first;
+        ids->push_back(std::move(id));
+      }
+      (*group_of)[i] = it->second;
+    }
+  }
   // side channel of SURVEY H4: an already materialised predicate (1 bit per storage position)
   void set_exclude_bitset(std::vector<uint64_t> words) { bits_ = std::move(words); has_bits_ = true; has_doc_ = false; }
   // the composite document filter as data (doc_filter.cc:74-87): serialised roaring bitmaps + the forward bool
@@ -202,6 +241,9 @@ class Context {
   bool has_doc_{false};
   bool fetch_vector_{false};
   std::vector<IndexDocumentList> results_{1};
+  uint32_t group_num_{0}, group_topk_{0};
+  std::function<std::string(uint64_t)> group_by_;
+  std::vector<IndexGroupDocumentList> group_results_{1};
 };
 
 // fetch_vector: one gather of the stored rows of every result document (key -> position through `pos_of_key`,
@@ -382,9 +424,10 @@ class HipFlatStreamer {
   int search_impl(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context) const {
     if (!h_ || !query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
     Context *ctx = context.get();
-    if (!ctx || ctx->topk() == 0) return IndexError_InvalidArgument;    // flat_searcher.cc:194-198
+    if (!ctx || (ctx->topk() == 0 && !ctx->group_by_search())) return IndexError_InvalidArgument;    // flat_searcher.cc:194-198
     if (ctx->magic() != magic_) ctx->set_magic(magic_);                 // context made by another index: re-bind
     std::shared_lock<FairSharedMutex> r(keys_mu_);    // keys_ (filter sweep, bitset size, fetch_vector) vs add
+    if (ctx->group_by_search()) return group_search(query, count, ctx, nullptr, nullptr);   // flat_streamer.cc:323-324
     const uint32_t k = ctx->topk();
     std::vector<uint64_t> keys((size_t)count * k);
     std::vector<float> scores((size_t)count * k);
@@ -411,6 +454,41 @@ class HipFlatStreamer {
   int search_bf_impl(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context) const {
     return search_impl(query, qmeta, count, context);
   }
+  //! Linear search by primary keys (index_runner.h:579-585; flat_streamer.cc:346-389): unknown keys are skipped
+  int search_bf_by_p_keys_impl(const void *query, const std::vector<std::vector<uint64_t>> &p_keys, const IndexQueryMeta &qmeta,
+                               uint32_t count, Context::Pointer &context) const {
+    if (!h_ || !query || qmeta.element_size() != meta_.element_size() || p_keys.size() != count) return IndexError_InvalidArgument;
+    Context *ctx = context.get();
+    if (!ctx || (ctx->topk() == 0 && !ctx->group_by_search())) return IndexError_InvalidArgument;
+    if (ctx->magic() != magic_) ctx->set_magic(magic_);
+    std::shared_lock<FairSharedMutex> r(keys_mu_);
+    std::vector<uint32_t> ids, offs(count + 1, 0);
+    {
+      std::lock_guard<std::mutex> g(map_mu_);
+      if (pos_of_key_.size() != keys_.size()) {
+        pos_of_key_.clear();
+        for (uint64_t i = 0; i < keys_.size(); ++i) pos_of_key_.emplace(keys_[i], i);
+      }
+      for (uint32_t q = 0; q < count; ++q) {
+        for (uint64_t key : p_keys[q]) {
+          auto it = pos_of_key_.find(key);
+          if (it != pos_of_key_.end()) ids.push_back((uint32_t)it->second);
+        }
+        offs[q + 1] = (uint32_t)ids.size();
+      }
+    }
+    if (ids.empty()) ids.push_back(0);
+    if (ctx->group_by_search()) return group_search(query, count, ctx, ids.data(), offs.data());   // flat_streamer.cc:365-366
+    const uint32_t k = ctx->topk();
+    std::vector<uint64_t> keys((size_t)count * k);
+    std::vector<float> scores((size_t)count * k);
+    std::vector<uint32_t> counts(count);
+    int rc = zvec_hip_flat_search_by_ids(h_, ctx->handle(), query, count, ids.data(), offs.data(), k, ctx->threshold(),
+                                         ctx->materialise(keys_), keys.data(), scores.data(), counts.data());
+    if (rc != 0) return rc;
+    ctx->take(count, k, keys, scores, counts);
+    return ctx->fetch_vector() ? attach_vectors(ctx, count) : 0;
+  }
   //! Fetch vector by id (index_runner.h:445-453)
   int get_vector_by_id(uint32_t id, std::vector<float> *out) const {
     if (!h_) return IndexError_InvalidArgument;
@@ -419,6 +497,40 @@ class HipFlatStreamer {
   }
   uint64_t count() const { uint64_t n = 0; if (h_) zvec_hip_flat_count(h_, &n); return n; }
  protected:
+  //! group_by_search_impl / group_by_search_p_keys_impl (flat_streamer.cc:391-483) + topk_to_group_result
+  //! (flat_streamer_context.h:135-180); the caller holds keys_mu_ shared.  ids == nullptr: every row competes
+  int group_search(const void *query, uint32_t count, Context *ctx, const uint32_t *ids, const uint32_t *offs) const {
+    if (!ctx->group_by_valid()) return IndexError_InvalidArgument;     // "Invalid group-by function"
+    const uint32_t gnum = ctx->group_num(), gk = ctx->group_topk();
+    if (gk == 0) return IndexError_InvalidArgument;
+    std::vector<uint32_t> group_of;
+    std::vector<std::string> group_ids;
+    ctx->sweep_groups(keys_, &group_of, &group_ids);
+    const size_t rows = (size_t)count * gnum;
+    std::vector<uint64_t> keys(rows * gk);
+    std::vector<float> scores(rows * gk);
+    std::vector<uint32_t> counts(rows), groups(rows), ngroups(count);
+    const uint32_t none = 0;
+    const uint32_t *gof = group_of.empty() ? &none : group_of.data();
+    const uint32_t ng = std::max<uint32_t>(1u, (uint32_t)group_ids.size());
+    const uint64_t *bits = ctx->materialise(keys_);
+    int rc = ids ? zvec_hip_flat_search_grouped_by_ids(h_, ctx->handle(), query, count, ids, offs, gof, ng, gnum, gk, ctx->threshold(),
+                                                       bits, groups.data(), ngroups.data(), keys.data(), scores.data(), counts.data())
+                 : zvec_hip_flat_search_grouped(h_, ctx->handle(), query, count, gof, ng, gnum, gk, ctx->threshold(), bits,
+                                                groups.data(), ngroups.data(), keys.data(), scores.data(), counts.data());
+    if (rc != 0) return rc;
+    auto &res = ctx->mutable_group_results();
+    res.assign(count, IndexGroupDocumentList());
+    for (uint32_t q = 0; q < count; ++q) {
+      res[q].resize(ngroups[q]);
+      for (uint32_t s = 0; s < ngroups[q]; ++s) {
+        const size_t row = (size_t)q * gnum + s;
+        res[q][s].set_group_id(group_ids[groups[row]]);
+        for (uint32_t j = 0; j < counts[row]; ++j) res[q][s].mutable_docs()->emplace_back(keys[row * gk + j], scores[row * gk + j]);
+      }
+    }
+    return 0;
+  }
   IndexMeta meta_;
   int metric_{0};
   int device_{0};

@@ -27,3 +27,4 @@
 #include "zvk_filter.hip.h"
 #include "zvk_plan.hip.h"
 #include "zvk_build.hip.h"
+#include "zvk_group.hip.h"

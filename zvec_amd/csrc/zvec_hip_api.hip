@@ -36,6 +36,7 @@ extern "C" {
 #include "api_entry_ivf.inc.h"
 #include "api_entry_merge_prof.inc.h"
 #include "api_entry_filter.inc.h"
+#include "api_entry_group.inc.h"
 #include "api_entry_shards.inc.h"
 #include "api_entry_container.inc.h"
 

@@ -201,12 +201,14 @@ __global__ void scatter_keys_kernel(uint64_t *keys, const uint64_t *dst_pos, con
 template <bool F16>
 __global__ void __launch_bounds__(256) rescore_l2_kernel(const float *base, const float *queries, uint32_t dpadw,
                                                          const uint32_t *idx, const uint32_t *counts, uint32_t nq,
-                                                         uint32_t k, float *scores) {
+                                                         uint32_t k, float *scores, uint32_t rows_per_query) {
+  // rows_per_query > 1: several result rows belong to one query (the per-group lists of a group-by search)
   const int lane = threadIdx.x & 63;
   const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= (uint64_t)nq * k) return;
-  const uint32_t q = (uint32_t)(w / k), j = (uint32_t)(w - (uint64_t)q * k);
-  if (j >= counts[q]) return;
+  const uint32_t r = (uint32_t)(w / k), j = (uint32_t)(w - (uint64_t)r * k);
+  if (j >= counts[r]) return;
+  const uint32_t q = r / rows_per_query;
   const uint32_t id = idx[w];
   const uint32_t nelem = dpadw * (F16 ? 2u : 1u);
   float acc = 0.f;

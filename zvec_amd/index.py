@@ -74,6 +74,19 @@ class IndexDocument:
         return "IndexDocument(key=%d, score=%r)" % (self._key, self._score)
 
 
+class GroupIndexDocument:
+    """group id + its documents (GroupIndexDocument, index_document.h:270-314)"""
+
+    def __init__(self, group_id, docs):
+        self._group_id, self._docs = group_id, docs
+
+    def group_id(self):
+        return self._group_id
+
+    def docs(self):
+        return self._docs
+
+
 class DocFilter:
     """The reference's composite document filter (DocFilter::is_filtered, doc_filter.cc:74-87) as data:
         excluded(id) = deleted.contains(id) || !invert.contains(uint32(id)) || !forward[id]
@@ -125,6 +138,9 @@ class IndexContext:
         self._filter_fn = None
         self._doc_filter = None   # DocFilter: materialised by zvec_hip_*_build_filter
         self._fetch_vector = False
+        self._group_num, self._group_topk, self._group_by = 0, 0, None
+        self._group_results = []
+        self._group_cache = None  # (fn, n) -> (group number of every position, group ids)
         self._results = []
         self.keys = None
         self.scores = None
@@ -151,6 +167,57 @@ class IndexContext:
 
     def fetch_vector(self):
         return self._fetch_vector
+
+    def set_group_params(self, group_num, group_topk):
+        """IndexContext::set_group_params (index_context.h:129; flat_streamer_context.h:187-191): group_num > 0 turns the
+        next searches into group-by searches"""
+        self._group_num, self._group_topk = int(group_num), int(group_topk)
+
+    def set_group_by(self, fn):
+        """IndexGroupBy: callable(key) -> group id (a string in the reference; any hashable here)"""
+        self._group_by = fn
+        self._group_cache = None
+
+    def reset_group_by(self):
+        self._group_by = None
+        self._group_cache = None
+
+    def group_by_search(self):
+        return self._group_num > 0
+
+    def group_result(self, index=0):
+        """IndexGroupDocumentList of query `index`: groups best first, documents ascending by score"""
+        return self._group_results[index]
+
+    def _groups_for(self, keys_of_positions):
+        """the group_by callback swept once over the stored keys (cached while the key list and the callback are the
+        same): dense group numbers per position + the ids they stand for"""
+        n = len(keys_of_positions)
+        if self._group_cache is not None and self._group_cache[0] is self._group_by and self._group_cache[1] == n:
+            return self._group_cache[2], self._group_cache[3]
+        ids, number_of = [], {}
+        of = np.empty(n, np.uint32)
+        for i, k in enumerate(keys_of_positions):
+            g = self._group_by(int(k))
+            j = number_of.get(g)
+            if j is None:
+                j = number_of[g] = len(ids)
+                ids.append(g)
+            of[i] = j
+        self._group_cache = (self._group_by, n, of, ids)
+        return of, ids
+
+    def _set_group_results(self, ids, groups, ngroups, keys, scores, counts, vectors_of=None):
+        self.group_keys, self.group_scores, self.group_counts, self.group_numbers, self.group_ngroups = keys, scores, counts, groups, ngroups
+        self._group_results = []
+        for q in range(keys.shape[0]):
+            lst = []
+            for s in range(int(ngroups[q])):
+                c = int(counts[q, s])
+                vecs = vectors_of(keys[q, s, :c]) if (self._fetch_vector and vectors_of is not None and c) else None
+                lst.append(GroupIndexDocument(ids[int(groups[q, s])],
+                                              [IndexDocument(keys[q, s, j], scores[q, s, j], None if vecs is None else vecs[j]) for j in range(c)]))
+            self._group_results.append(lst)
 
     def set_threshold(self, val):
         self._threshold = float(val)
@@ -342,11 +409,13 @@ class _FlatBase:
 
     def search_impl(self, query, count, ctx):
         """IndexRunner::search_impl(query, qmeta, count, context); query: [count][dim] fp32."""
-        if ctx is None or ctx.topk() == 0:
+        if ctx is None or (ctx.topk() == 0 and not ctx.group_by_search()):
             return IndexError_.InvalidArgument      # flat_searcher.cc:194-198
         q = np.ascontiguousarray(query, self.np_dtype).reshape(-1)
         if q.size != int(count) * self.dim:
             return IndexError_.InvalidArgument
+        if ctx.group_by_search():
+            return self._group_search(q, count, ctx, None)      # flat_streamer.cc:323-324
         k = ctx.topk()
         keys = np.zeros((count, k), np.uint64)
         scores = np.zeros((count, k), np.float32)
@@ -364,14 +433,38 @@ class _FlatBase:
     # brute force == the flat scan itself (flat_streamer.cc:304-344)
     search_bf_impl = search_impl
 
-    def search_bf_by_p_keys_impl(self, query, p_keys, count, ctx):
-        """FlatStreamer::search_bf_by_p_keys_impl (flat_streamer.cc:346-389): p_keys[q] = primary keys query q
-        is compared with; unknown keys are skipped; the context's filter applies per key."""
-        if ctx is None or ctx.topk() == 0:
-            return IndexError_.InvalidArgument
-        q = np.ascontiguousarray(query, self.np_dtype).reshape(-1)
-        if q.size != int(count) * self.dim or len(p_keys) != count:
-            return IndexError_.InvalidArgument
+    def _group_search(self, q, count, ctx, p_keys):
+        """group_by_search_impl / group_by_search_p_keys_impl (flat_streamer.cc:391-483)"""
+        if ctx._group_by is None:
+            return IndexError_.InvalidArgument                  # "Invalid group-by function"
+        allk = self._all_keys()
+        of, ids = ctx._groups_for(allk)
+        gnum, gk = ctx._group_num, ctx._group_topk
+        groups = np.zeros((count, gnum), np.uint32)
+        ngroups = np.zeros(count, np.uint32)
+        keys = np.zeros((count, gnum, gk), np.uint64)
+        scores = np.zeros((count, gnum, gk), np.float32)
+        counts = np.zeros((count, gnum), np.uint32)
+        L = _lib.lib()
+        if p_keys is None:
+            if ctx._doc_filter is not None:
+                ex = self.build_filter(ctx._doc_filter, ctx)
+            else:
+                ex = ctx._exclude_for(allk) if (ctx._filter_fn or ctx._exclude is not None) else None
+            rc = L.zvec_hip_flat_search_grouped(self._h, ctx._h, _np_ptr(q), count, _np_ptr(of), max(len(ids), 1), gnum, gk,
+                                                ctx.threshold(), _np_ptr(ex), _np_ptr(groups), _np_ptr(ngroups), _np_ptr(keys),
+                                                _np_ptr(scores), _np_ptr(counts))
+        else:
+            ids_l, offs = self._p_keys_positions(p_keys, ctx)
+            rc = L.zvec_hip_flat_search_grouped_by_ids(self._h, ctx._h, _np_ptr(q), count, _np_ptr(ids_l), _np_ptr(offs), _np_ptr(of),
+                                                       max(len(ids), 1), gnum, gk, ctx.threshold(), _np_ptr(ctx._exclude),
+                                                       _np_ptr(groups), _np_ptr(ngroups), _np_ptr(keys), _np_ptr(scores), _np_ptr(counts))
+        if rc == 0:
+            ctx._set_group_results(ids, groups, ngroups, keys, scores, counts, self._vectors_of_keys)
+        return rc
+
+    def _p_keys_positions(self, p_keys, ctx):
+        """primary keys -> storage positions (unknown keys and keys the context's filter rejects are dropped)"""
         allk = self._all_keys()
         if getattr(self, "_key2pos_n", -1) != len(allk):
             self._key2pos = {int(k): i for i, k in enumerate(allk)}
@@ -383,8 +476,19 @@ class _FlatBase:
                 if pos is not None and not (ctx._filter_fn and ctx._filter_fn(int(key))):
                     ids.append(pos)
             offs.append(len(ids))
-        ids = np.asarray(ids if ids else [0], np.uint32)
-        offs = np.asarray(offs, np.uint32)
+        return np.asarray(ids if ids else [0], np.uint32), np.asarray(offs, np.uint32)
+
+    def search_bf_by_p_keys_impl(self, query, p_keys, count, ctx):
+        """FlatStreamer::search_bf_by_p_keys_impl (flat_streamer.cc:346-389): p_keys[q] = primary keys query q
+        is compared with; unknown keys are skipped; the context's filter applies per key."""
+        if ctx is None or (ctx.topk() == 0 and not ctx.group_by_search()):
+            return IndexError_.InvalidArgument
+        q = np.ascontiguousarray(query, self.np_dtype).reshape(-1)
+        if q.size != int(count) * self.dim or len(p_keys) != count:
+            return IndexError_.InvalidArgument
+        if ctx.group_by_search():
+            return self._group_search(q, count, ctx, p_keys)    # flat_streamer.cc:365-366
+        ids, offs = self._p_keys_positions(p_keys, ctx)
         k = ctx.topk()
         keys_o = np.zeros((count, k), np.uint64)
         scores = np.zeros((count, k), np.float32)
