@@ -47,6 +47,10 @@ class Oracle:
             f = getattr(L, name)
             f.restype = C.c_float
             f.argtypes = [_f32p, _f32p, C.c_size_t]
+        L.zo_cosine_batch_f32.restype = C.c_float
+        L.zo_cosine_batch_f32.argtypes = [_f32p, _f32p, C.c_size_t]
+        L.zo_cosine_batch_f16.restype = C.c_float
+        L.zo_cosine_batch_f16.argtypes = [C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_size_t]
         L.zo_norm2_f32.restype = C.c_float
         L.zo_norm2_f32.argtypes = [_f32p, C.c_size_t]
         L.zo_normalize_l2_f32.restype = None
@@ -110,6 +114,10 @@ class Oracle:
             R.zref_to_fp16.argtypes = [_f32p, C.c_size_t, _u16p]
             R.zref_heap_replay.restype = C.c_size_t
             R.zref_heap_replay.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_float, _u32p, _f32p]
+            for name in ("zref_cosine_batch_f32", "zref_cosine_batch_f16"):
+                f = getattr(R, name)
+                f.restype = None
+                f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, _f32p]
 
     # -- kernels -------------------------------------------------------------------------------
     def dist(self, metric, m, q, use_ref=False):
@@ -118,6 +126,30 @@ class Oracle:
         lib, pre = (self.ref, "zref_") if use_ref else (self.lib, "zo_")
         fn = {METRIC_L2: "sqeuclid_f32", METRIC_IP: "minus_ip_f32", METRIC_COSINE: "cosine_f32"}[metric]
         return float(getattr(lib, pre + fn)(_ptr(m, _f32p), _ptr(q, _f32p), m.size))
+
+    def cosine_batch(self, rows, q, use_ref=False):
+        """IndexMetric::batch_distance of the Cosine metric (cosine_metric.cc:202-212): ONE query against the rows, the
+        one-to-many inner product of math_batch/ (NOT the 1x1 kernel's lane order).  rows [n][dim_with_norm] fp32 or fp16
+        (converted rows: normalised vector + norm slot(s)), q likewise.  use_ref: the reference's own function (12 rows at a
+        time + the remainder one by one, as it runs in the product)."""
+        half = np.asarray(rows).dtype == np.float16
+        dt = np.float16 if half else np.float32
+        rows = np.ascontiguousarray(np.atleast_2d(rows), dt)
+        q = np.ascontiguousarray(q, dt)
+        n, dim = rows.shape
+        out = np.zeros(n, np.float32)
+        if use_ref:
+            ptrs = (C.c_void_p * n)(*[rows.ctypes.data + i * rows.strides[0] for i in range(n)])
+            fn = self.ref.zref_cosine_batch_f16 if half else self.ref.zref_cosine_batch_f32
+            fn(C.cast(ptrs, C.c_void_p), C.c_void_p(q.ctypes.data), n, dim, _ptr(out, _f32p))
+            return out
+        for i in range(n):
+            if half:
+                u16 = C.POINTER(C.c_uint16)
+                out[i] = self.lib.zo_cosine_batch_f16(rows[i].ctypes.data_as(u16), q.ctypes.data_as(u16), dim)
+            else:
+                out[i] = self.lib.zo_cosine_batch_f32(_ptr(rows[i], _f32p), _ptr(q, _f32p), dim)
+        return out
 
     def dist16(self, metric, m, q, use_ref=False):
         """fp16 rows (numpy float16): SquaredEuclidean / MinusInnerProduct with fp32 accumulation."""

@@ -13,6 +13,8 @@
 //   ailego::MinusInnerProductMatrix<Float16,1,1>                src/ailego/math/inner_product_matrix_fp16.cc:166
 //   ailego::FloatHelper::ToFP16                                 src/ailego/utility/float_helper.cc
 //   ailego::{SquaredEuclideanDistance,MinusInnerProduct}Matrix<float,M,N>  (block kernels, M in 2..32, N in 1..32)
+//   ailego::BaseDistance<CosineDistanceMatrix, float / Float16, 12, 2>::ComputeBatch   src/ailego/math_batch/distance_batch.h:29-49
+//                                                                (what CosineMetric::batch_distance returns, cosine_metric.cc:202-212)
 #include <cstddef>
 #include <cstdint>
 #include <limits>
@@ -21,6 +23,7 @@
 #include <ailego/math/inner_product_matrix.h>
 #include <ailego/math/norm2_matrix.h>
 #include <ailego/math/normalizer.h>
+#include <ailego/math_batch/distance_batch.h>
 #include <zvec/ailego/container/heap.h>
 #include <zvec/ailego/utility/float_helper.h>
 
@@ -137,6 +140,16 @@ size_t zref_heap_replay(const float *scores, size_t n, size_t limit, float thres
     out_score[i] = heap[i].score;
   }
   return heap.size();
+}
+
+
+// one query against n rows through the Cosine metric's one-to-many function (dim counts the trailing norm slot(s))
+void zref_cosine_batch_f32(const float *const *rows, const float *q, size_t n, size_t dim_with_norm, float *out) {
+  BaseDistance<CosineDistanceMatrix, float, 12, 2>::ComputeBatch(const_cast<const float **>(rows), q, n, dim_with_norm, out);
+}
+void zref_cosine_batch_f16(const uint16_t *const *rows, const uint16_t *q, size_t n, size_t dim_with_norm, float *out) {
+  BaseDistance<CosineDistanceMatrix, Float16, 12, 2>::ComputeBatch(reinterpret_cast<const Float16 **>(const_cast<const uint16_t **>(rows)),
+                                                                    reinterpret_cast<const Float16 *>(q), n, dim_with_norm, out);
 }
 
 }  // extern "C"

@@ -163,6 +163,64 @@ float zo_cosine_f32(const float *m, const float *q, size_t dim_with_norm) {
   return 1 - lane_ip(m, q, d);
 }
 
+/* ---- one-to-many ("batch") distances: IndexMetric::batch_distance (index_metric.h:85-87) ---------------------------
+ * BaseDistance<…>::ComputeBatch (math_batch/distance_batch.h:29-49) is a plain loop of the 1x1 kernel for
+ * SquaredEuclidean and MinusInnerProduct (euclidean_metric.cc:870-876, inner_product_metric.cc:353-362), i.e. zo_dist.
+ * Cosine alone takes another route (cosine_metric.cc:202-212 -> cosine_distance_batch.h:33-47): 1 - ip, with ip from
+ * InnerProductDistanceBatch (inner_product_distance_batch.h:143-163), whose per-vector arithmetic does not depend on the
+ * batch size and differs from the 1x1 kernel's lane order:
+ *   fp32, AVX2 (inner_product_distance_batch_impl.h:46-118): ONE 8-lane accumulator of NEGATED products
+ *     (acc = -(q*b) + acc, fused), folded high + low half to 4 lanes; a 4-step, then a 2-step landing in lanes 2 and 3;
+ *     (l0 + l2) + (l1 + l3); an odd last element is subtracted as a plain product; the sign is flipped at the end.
+ *   fp16, AVX-512F (inner_product_distance_batch_impl_fp16.h:85-167): ONE 16-lane fp32 accumulator, two fused steps
+ *     per 32 elements; one more 16-step only if MORE than 16 elements are left (strict <), fold to 8 lanes (low + high),
+ *     an 8-step only if MORE than 8 are left, ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)), the remaining elements one by one. */
+static float half_to_float(uint16_t h);
+float zo_ip_batch_f32(const float *m, const float *q, size_t d) {
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s[4];
+  size_t k = 0;
+  for (; k + 8 <= d; k += 8)
+    for (int l = 0; l < 8; ++l) acc[l] = fmaf(-q[k + l], m[k + l], acc[l]);
+  for (int l = 0; l < 4; ++l) s[l] = acc[l + 4] + acc[l];
+  if (k + 4 <= d) {
+    for (int l = 0; l < 4; ++l) s[l] = fmaf(-q[k + l], m[k + l], s[l]);
+    k += 4;
+  }
+  if (k + 2 <= d) {
+    s[0] = fmaf(-0.0f, 0.0f, s[0]);
+    s[1] = fmaf(-0.0f, 0.0f, s[1]);
+    s[2] = fmaf(-q[k], m[k], s[2]);
+    s[3] = fmaf(-q[k + 1], m[k + 1], s[3]);
+    k += 2;
+  }
+  float res = (s[0] + s[2]) + (s[1] + s[3]);
+  if (k < d) res = fmaf(-q[k], m[k], res);   /* `res -= q * b` as this image's compiler contracts it (pinned live) */
+  return -res;
+}
+float zo_ip_batch_f16(const uint16_t *m, const uint16_t *q, size_t d) {
+  float acc[16], y[8];
+  for (int l = 0; l < 16; ++l) acc[l] = 0.f;
+  size_t k = 0;
+  for (; k + 32 <= d; k += 32) {
+    for (int l = 0; l < 16; ++l) acc[l] = fmaf(half_to_float(q[k + l]), half_to_float(m[k + l]), acc[l]);
+    for (int l = 0; l < 16; ++l) acc[l] = fmaf(half_to_float(q[k + 16 + l]), half_to_float(m[k + 16 + l]), acc[l]);
+  }
+  if (k + 16 < d) {
+    for (int l = 0; l < 16; ++l) acc[l] = fmaf(half_to_float(q[k + l]), half_to_float(m[k + l]), acc[l]);
+    k += 16;
+  }
+  for (int l = 0; l < 8; ++l) y[l] = acc[l] + acc[l + 8];
+  if (k + 8 < d) {
+    for (int l = 0; l < 8; ++l) y[l] = fmaf(half_to_float(m[k + l]), half_to_float(q[k + l]), y[l]);
+    k += 8;
+  }
+  float res = ((y[0] + y[1]) + (y[2] + y[3])) + ((y[4] + y[5]) + (y[6] + y[7]));
+  for (; k < d; ++k) res = fmaf(half_to_float(q[k]), half_to_float(m[k]), res);   /* contracted `+=`, pinned live */
+  return res;
+}
+float zo_cosine_batch_f32(const float *m, const float *q, size_t dim_with_norm) { return 1 - zo_ip_batch_f32(m, q, dim_with_norm - 1); }
+float zo_cosine_batch_f16(const uint16_t *m, const uint16_t *q, size_t dim_with_norm) { return 1 - zo_ip_batch_f16(m, q, dim_with_norm - 2); }
+
 /* ---- fp16 rows (IndexMeta::DT_FP16, HalfFloatConverter / HalfFloatReformer) ------------------------
  * SquaredEuclideanDistanceMatrix<Float16,1,1> / (Minus)InnerProductMatrix<Float16,1,1> on an AVX-512 CPU
  * WITHOUT AVX512-FP16 (euclidean_distance_matrix_fp16.cc:137-158, inner_product_matrix_fp16.cc:143-186):

@@ -44,6 +44,11 @@ float zo_sqeuclid_f32(const float *m, const float *q, size_t dim);
 float zo_ip_f32(const float *m, const float *q, size_t dim);        /* +ip */
 float zo_minus_ip_f32(const float *m, const float *q, size_t dim);  /* -ip */
 float zo_cosine_f32(const float *m, const float *q, size_t dim_with_norm);
+/* one-to-many cosine (IndexMetric::batch_distance of the Cosine metric): 1 - InnerProductDistanceBatch's ip */
+float zo_ip_batch_f32(const float *m, const float *q, size_t dim);
+float zo_ip_batch_f16(const uint16_t *m, const uint16_t *q, size_t dim);
+float zo_cosine_batch_f32(const float *m, const float *q, size_t dim_with_norm);
+float zo_cosine_batch_f16(const uint16_t *m, const uint16_t *q, size_t dim_with_norm);
 float zo_norm2_f32(const float *m, size_t dim);
 /* Normalizer<float>::L2 : arr /= ||arr|| (if > 0); *norm receives the norm. */
 void zo_normalize_l2_f32(float *arr, size_t dim, float *norm);

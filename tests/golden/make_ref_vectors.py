@@ -124,6 +124,22 @@ for tag, dt, scale in (("sblock", np.float32, 2.0), ("hsblock", np.float16, 2.0)
     out[tag + "_q"] = np.concatenate(SQ)
     out[tag + "_l2"] = np.concatenate(SL2)
     out[tag + "_minus_ip"] = np.concatenate(SIP)
+# one-to-many cosine (CosineMetric::batch_distance -> BaseDistance<CosineDistanceMatrix, T, 12, 2>::ComputeBatch): 29 rows per
+# dimension (two full batches of 12 + a remainder of 5), rows = converted rows (vector + norm slot); drawn last again
+CB_DIMS = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 24, 25, 31, 32, 33, 34, 40, 41, 47, 48, 49, 56, 57, 63, 64, 65, 96, 97,
+           128, 129, 768, 769, 770]
+for tag, dt, extra in (("cosb", np.float32, 1), ("hcosb", np.float16, 2)):
+    R_, Q_, O_ = [], [], []
+    for d in CB_DIMS:
+        rows = (rng.standard_normal((29, d + extra)) * 0.5).astype(dt)
+        q = (rng.standard_normal(d + extra) * 0.5).astype(dt)
+        R_.append(rows.ravel().view(np.uint16) if dt == np.float16 else rows.ravel())
+        Q_.append(q.view(np.uint16) if dt == np.float16 else q)
+        O_.append(o.cosine_batch(rows, q, use_ref=True))
+    out[tag + "_dims"] = np.array([d + extra for d in CB_DIMS], np.int32)
+    out[tag + "_rows"] = np.concatenate(R_)
+    out[tag + "_q"] = np.concatenate(Q_)
+    out[tag + "_out"] = np.concatenate(O_)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_kernel_vectors.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes")

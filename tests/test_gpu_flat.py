@@ -489,7 +489,8 @@ def test_flat_vs_column_major_oracle(zv, oracle, metric, dtype):
 def test_batch_distance_one_to_many(zv, oracle, metric, dtype):
     """SURVEY §8(a) row 5: IndexMetric::batch_distance — one query against scattered rows.  BaseDistance::ComputeBatch
     (distance_batch.h:29-49) is a loop of the 1x1 kernel for L2 / IP, which the oracle restates exactly; the cosine
-    variant sums in another order (inner_product_distance_batch_impl.h), covered by the same stated tolerance."""
+    variant sums in another order (inner_product_distance_batch_impl.h): restated as oracle.cosine_batch (pinned bit for
+    bit to the reference's ComputeBatch, tests/test_oracle_cpu.py) and compared here within the same stated tolerance."""
     rng = np.random.default_rng(91)
     n, d = 5000, 96
     npdt = np.float16 if dtype == "fp16" else np.float32
@@ -508,7 +509,12 @@ def test_batch_distance_one_to_many(zv, oracle, metric, dtype):
     got = se.batch_distance(q, pos)
     assert np.isinf(got[5])
     fn = oracle.dist16 if dtype == "fp16" else oracle.dist
-    want = np.array([fn(m, base[p], q) if p < n else np.inf for p in pos], np.float32)
+    if metric == "Cosine":
+        want = np.full(pos.size, np.inf, np.float32)
+        inr = pos < n
+        want[inr] = oracle.cosine_batch(base[pos[inr]], q)
+    else:
+        want = np.array([fn(m, base[p], q) if p < n else np.inf for p in pos], np.float32)
     ok = np.isfinite(want)
     qn, bn = float((q[:d].astype(np.float64) ** 2).sum()), (base[pos[ok], :d].astype(np.float64) ** 2).sum(1)
     tol = 2e-6 * np.abs(want[ok]) + 1e-6 if m == O.METRIC_L2 else 4e-6 * np.sqrt(qn * bn)

@@ -405,3 +405,24 @@ def test_group_by_known_answers(oracle):
     for g, docs in res:
         assert len(docs) == 20 and all((k // 10) % 10 == g for k, _, _ in docs)
         assert all(docs[j][1] <= docs[j + 1][1] for j in range(19))
+
+
+def test_cosine_batch_distance_bit_exact_vs_reference(oracle, golden_dir):
+    """IndexMetric::batch_distance of the Cosine metric (one-to-many inner product of ailego/math_batch, a different lane
+    order than the 1x1 kernel): the restatement equals the golden vectors the reference's own ComputeBatch produced, fp32
+    and fp16, every tail shape — and the live reference when oracle/_ref is present.  (SquaredEuclidean / InnerProduct
+    batch_distance is a loop of the 1x1 kernels already pinned above.)"""
+    z = np.load(os.path.join(golden_dir, "ref_kernel_vectors.npz"))
+    for tag, dt in (("cosb", np.float32), ("hcosb", np.float16)):
+        ro = qo = oo = 0
+        for dim in z[tag + "_dims"]:
+            rows = z[tag + "_rows"][ro:ro + 29 * dim].view(dt).reshape(29, dim)
+            q = z[tag + "_q"][qo:qo + dim].view(dt)
+            want = z[tag + "_out"][oo:oo + 29]
+            got = oracle.cosine_batch(rows, q)
+            assert np.array_equal(got, want), (tag, int(dim), np.nonzero(got != want)[0][:5])
+            if oracle.ref is not None:
+                assert np.array_equal(oracle.cosine_batch(rows, q, use_ref=True), want), (tag, int(dim))
+            ro += 29 * dim
+            qo += dim
+            oo += 29
