@@ -700,3 +700,33 @@ def test_group_by_gaussian_tolerance_and_large_batch(zv, oracle):
             if g.group_id() == wg:
                 np.testing.assert_allclose([d.score() for d in g.docs()], [d[1] for d in docs], rtol=4e-6)
                 assert [d.key() for d in g.docs()] == [d[0] for d in docs]
+
+
+def test_group_by_consistent_with_plain_topk_at_size(zv):
+    """size-independent property at 400k x 128, 128 queries, 997 groups: with every group listed and group_topk = k the
+    grouped answer contains the plain top-k (same scores), the first group's first document is the plain top-1, every
+    document sits in its group, groups come in ascending order of their best score, and no group is listed twice"""
+    rng = np.random.default_rng(12)
+    n, dim, nq, k, ng = 400000, 128, 128, 10, 997
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    st = zv.HipFlatStreamer(dim, "InnerProduct")
+    assert st.add_batch(base, np.arange(n, dtype=np.uint64)) == 0
+    plain = st.create_context()
+    plain.set_topk(k)
+    assert st.search_impl(q, nq, plain) == 0
+    ctx = st.create_context()
+    ctx.set_group_params(ng, k)
+    ctx.set_group_by(lambda key: key % ng)
+    assert st.search_impl(q, nq, ctx) == 0
+    for qi in range(nq):
+        groups = ctx.group_result(qi)
+        assert len(groups) == ng and len({g.group_id() for g in groups}) == ng
+        best = [g.docs()[0].score() for g in groups]
+        assert all(best[i] <= best[i + 1] for i in range(ng - 1))
+        docs = {d.key(): d.score() for g in groups for d in g.docs()}
+        assert all(d.key() % ng == g.group_id() for g in groups for d in g.docs())
+        top = plain.result(qi)
+        assert groups[0].docs()[0].key() == top[0].key()
+        for d in top:
+            assert d.key() in docs and docs[d.key()] == d.score()

@@ -187,6 +187,7 @@ int zvec_hip_shards_destroy(zvec_hip_shards_t h) {
 
 int zvec_hip_shards_count(zvec_hip_shards_t h, uint64_t *total, uint64_t *per_shard) {
   if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(h->mu);
   uint64_t sum = 0;
   for (uint32_t g = 0; g < h->G; ++g) {
     uint64_t n = 0;
@@ -356,10 +357,10 @@ int zvec_hip_shards_search(zvec_hip_shards_t h, const void *queries, uint32_t co
   if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if ((size_t)topk * 12 + 16 > 64 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
   const bool is_ivf = h->kind == ZVEC_HIP_SHARDS_IVF;
+  std::lock_guard<std::mutex> lk(h->mu);
   if (is_ivf)
     for (auto v : h->ivf)
       if (!v->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
-  std::lock_guard<std::mutex> lk(h->mu);
   const uint64_t pb = zvec_hip_packed_bytes(count, topk);
   const size_t kb = (size_t)count * topk * 8, sb = (size_t)count * topk * 4;
   ZCHK(hipSetDevice(h->devices[0]));
