@@ -42,7 +42,21 @@ int group_select(zvec_hip_ctx_s *c, const Store &st, const float *cs, const uint
   m.out_keys = tmpk; m.out_scores = tmps; m.out_idx = sel; m.out_counts = nsel;
   hipLaunchKernelGGL(merge_kernel, dim3(cnt), dim3(64), (size_t)gnum * 12 + 16, s, m);
   const bool l2 = refine && st.metric == ZVEC_HIP_METRIC_L2;
-  if (ci)
+  // one pass per query when the per-wave lists of all its slots fit the LDS (4 waves, else 1), otherwise a wave per slot
+  const size_t lds1 = ((size_t)gnum * gk * 8 + (size_t)gnum * 8 + 16);
+  const int fill_waves = lds1 * 4 <= 60 * 1024 ? 4 : (lds1 <= 60 * 1024 ? 1 : 0);
+  if (fill_waves && ngroups <= 0x7fffffffu) {
+    ZRET(c->grp_tab.ensure((size_t)cnt * ngroups * 2));
+    uint16_t *tab = c->grp_tab.as<uint16_t>();
+    ZCHK(hipMemsetAsync(tab, 0xff, (size_t)cnt * ngroups * 2, s));
+    hipLaunchKernelGGL(group_slot_kernel, dim3(cnt), dim3(64), 0, s, sel, nsel, gnum, ngroups, tab);
+#define ZVEC_GROUP_FILL_Q(HAS, WV)                                                                                               \
+    hipLaunchKernelGGL((group_fill_query_kernel<HAS, WV>), dim3(cnt), dim3(64 * WV), lds1 * WV, s, cs, ci, stride, len, d_group_of,  \
+                       ngroups, tab, nsel, gnum, gk, threshold, !l2, st.keys, rowk, rows_s, rows_i, rows_c)
+    if (ci) { if (fill_waves == 4) ZVEC_GROUP_FILL_Q(true, 4); else ZVEC_GROUP_FILL_Q(true, 1); }
+    else { if (fill_waves == 4) ZVEC_GROUP_FILL_Q(false, 4); else ZVEC_GROUP_FILL_Q(false, 1); }
+#undef ZVEC_GROUP_FILL_Q
+  } else if (ci)
     hipLaunchKernelGGL(group_fill_kernel<true>, dim3((unsigned)rows), dim3(64), (size_t)gk * 8 + 16, s, cs, ci, stride, len, d_group_of,
                        sel, nsel, gnum, gk, threshold, !l2, st.keys, rowk, rows_s, rows_i, rows_c);
   else

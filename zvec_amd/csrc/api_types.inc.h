@@ -162,7 +162,7 @@ struct zvec_hip_ctx_s {
   DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
   DevBuf plan;        // all u32 plan arrays
   DevBuf io_q, io_ex, io_keys, io_scores, io_counts;   // staging for host-pointer entry points
-  DevBuf grp_ws, grp_of, grp_out;                      // group-by search: per-group bests / lists, group of every position, results
+  DevBuf grp_ws, grp_of, grp_out, grp_tab;                      // group-by search: per-group bests / lists, group of every position, results
   PinnedBuf pin_in, pin_out;                           // (transfers up to PIN_LIMIT bytes go through pinned memory)
   DevBuf stats;       // per-launch {distinct_rows, pair_rows} u64 x PROFILE_MAX
   uint32_t *q_scanned = nullptr, *q_nprobe = nullptr;  // inside plan
