@@ -96,6 +96,14 @@ int zvec_hip_flat_reserve(zvec_hip_flat_t h, uint64_t capacity);
 int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const uint64_t *keys);
 int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n,
                              const uint64_t *d_keys, void *stream);
+/* IndexStreamer::add_with_id_impl(id, vec, qmeta, ctx) in bulk (index_runner.h:483-487) — what core_interface::Index::_dense_add
+ * calls for every document (src/core/interface/index.cc:505-537).  FlatStreamerEntity::add_vector_with_id semantics
+ * (flat_streamer_entity.cc:900-990), row by row: the row of ids[i] lives at storage position ids[i] under key ids[i];
+ * id == count appends, id > count first pads positions [count, id) with holes (kInvalidKey rows no search returns),
+ * id < count overwrites in place.  keys: NULL (key = id, the reference's rule) or the key to store with each row, for
+ * a caller that keeps its own id -> position map.  zvec_hip_flat_holes: hole positions currently in the store. */
+int zvec_hip_flat_put(zvec_hip_flat_t h, const uint32_t *ids, uint64_t n, const void *vecs, const uint64_t *keys);
+int zvec_hip_flat_holes(zvec_hip_flat_t h, uint64_t *count);
 int zvec_hip_flat_count(zvec_hip_flat_t h, uint64_t *count);
 /* IndexRunner::get_vector_by_id (index_runner.h:450-453): copy row `pos` (dim elements) to out. */
 int zvec_hip_flat_get_vector(zvec_hip_flat_t h, uint64_t pos, void *out);

@@ -283,6 +283,25 @@ class HipFlatCore {
         }
     return 0;
   }
+  //! add_with_id_impl (FlatStreamerEntity::add_vector_with_id, flat_streamer_entity.cc:900-990): the document `id` is
+  //! replaced when it exists, appended otherwise.  Results carry keys, never positions, so the mirror keeps its own
+  //! id -> position map instead of the reference's "position == id" rule (no holes to pad, and a re-opened index whose
+  //! rows were compacted by the provider walk stays addressable)
+  int put(uint32_t id, const void *row) {
+    std::unique_lock<FairSharedMutex> w(mu_);
+    const uint64_t key = id;
+    auto it = pos_of_key_.find(key);
+    if (it == pos_of_key_.end()) {
+      int rc = sh_ ? zvec_hip_shards_flat_append(sh_, row, 1, &key) : zvec_hip_flat_append(h_, row, 1, &key);
+      if (rc != 0) return rc;
+      pos_of_key_.emplace(key, (uint32_t)keys_.size());
+      keys_.push_back(key);
+      return 0;
+    }
+    if (sh_) return IndexError_Unsupported;                   // (in-place replacement runs on one device)
+    const uint32_t pos = it->second;
+    return zvec_hip_flat_put(h_, &pos, 1, row, &key);
+  }
   int search(const void *q, const IndexQueryMeta &qm, uint32_t count, HipContext *ctx) const {
     if (!q || qm.element_size() != elem_size_) return IndexError_InvalidArgument;
     std::shared_lock<FairSharedMutex> r(mu_);
@@ -511,8 +530,7 @@ class HipFlatStreamer : public IndexStreamer {
     Context::Pointer none;
     int rc = store_->add_with_id_impl(id, vec, qm, none);
     (void)c;
-    const uint64_t key = id;
-    return rc != 0 ? rc : core_.append(vec, 1, &key);
+    return rc != 0 ? rc : core_.put(id, vec);
   }
   int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
   int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {

@@ -1,7 +1,7 @@
 // C++ parity test of the host mirror (zvec_amd/csrc/host/hip_index.h) over the C ABI, written like the
 // reference's own tests.  Expectations are those of
 //   tests/core/algorithm/flat/flat_streamer_test.cc:104-178 (TestLinearSearch), :731-801 (TestFilter)
-//   tests/core/algorithm/flat/flat_streamer_test.cc:929-1037 (TestGroup)
+//   tests/core/algorithm/flat/flat_streamer_test.cc:929-1037 (TestGroup), :1038-1117 (TestAddAndSearchWithID)
 //   tests/core/algorithm/ivf/ivf_searcher_test.cc:200-321 (TestSimple), :2830-2886 (TestRnnSearch shape)
 // Needs a GPU.  Exit code 0 = all checks passed.
 #include <cstdio>
@@ -505,9 +505,63 @@ static int TestGroup() {
   return 0;
 }
 
+// Expectations of flat_streamer_test.cc TestAddAndSearchWithID: add_with_id_impl with the even ids first (odd positions
+// become holes), then the odd ids (they land on the holes); row i = (i, ..., i); for queries i + 0.1 the linear search
+// returns topk = 200 documents with key i first.  Here additionally: while the holes exist no odd key comes back, and a
+// filter composes with them.
+static int TestAddAndSearchWithID() {
+  constexpr size_t dim = 16;
+  IndexMeta meta(IndexMeta::DT_FP32, dim);
+  meta.set_metric("SquaredEuclidean");
+  HipFlatStreamer streamer;
+  ASSERT(0 == streamer.init(meta, Params()));
+  ASSERT(0 == streamer.open());
+  auto ctx = streamer.create_context();
+  ASSERT(!!ctx);
+  const size_t cnt = 4000;
+  IndexQueryMeta qmeta(IndexMeta::DT_FP32, dim);
+  for (size_t i = 0; i < cnt; i += 2) {
+    std::vector<float> vec(dim, (float)i);
+    ASSERT(0 == streamer.add_with_id_impl((uint32_t)i, vec.data(), qmeta, ctx));
+  }
+  const size_t topk = 200;
+  ctx->set_topk(topk);
+  for (size_t i = 0; i < cnt; i += 500) {
+    std::vector<float> vec(dim, i + 0.1f);
+    ASSERT(0 == streamer.search_impl(vec.data(), qmeta, ctx));
+    auto &res = ctx->result();
+    ASSERT(res.size() == topk);
+    EXPECT(res[0].key() == i);
+    for (auto &d : res) EXPECT(d.key() % 2 == 0);
+  }
+  ctx->set_filter([](uint64_t key) { return key % 4 == 0; });
+  {
+    std::vector<float> vec(dim, 1000.1f);
+    ASSERT(0 == streamer.search_impl(vec.data(), qmeta, ctx));
+    for (auto &d : ctx->result()) EXPECT(d.key() % 4 == 2);
+    EXPECT(ctx->result()[0].key() == 998 || ctx->result()[0].key() == 1002);
+  }
+  ctx->reset_filter();
+  for (size_t i = 1; i < cnt; i += 2) {
+    std::vector<float> vec(dim, (float)i);
+    ASSERT(0 == streamer.add_with_id_impl((uint32_t)i, vec.data(), qmeta, ctx));
+  }
+  EXPECT(streamer.count() == cnt);
+  for (size_t i = 0; i < cnt; i += 100) {
+    std::vector<float> vec(dim, i + 0.1f);
+    ASSERT(0 == streamer.search_bf_impl(vec.data(), qmeta, ctx));
+    auto &res = ctx->result();
+    ASSERT(res.size() == topk);
+    EXPECT(res[0].key() == i);
+    EXPECT(res[1].key() == i + 1);
+  }
+  return 0;
+}
+
 int main() {
   int rc = 0;
   rc |= TestLinearSearch();
+  rc |= TestAddAndSearchWithID();
   rc |= TestGroup();
   rc |= TestFilter();
   rc |= TestIVFSimple();

@@ -730,3 +730,66 @@ def test_group_by_consistent_with_plain_topk_at_size(zv):
         assert groups[0].docs()[0].key() == top[0].key()
         for d in top:
             assert d.key() in docs and docs[d.key()] == d.score()
+
+
+def test_add_with_id_holes_and_overwrites(zv, oracle):
+    """IndexStreamer::add_with_id_impl as core_interface::Index::_dense_add drives it.  flat_streamer_test.cc
+    TestAddAndSearchWithID (:1038-1117): the even ids first — the odd positions are holes no search may return — then the
+    odd ids land on those holes; row i = (i, ..., i), query i + 0.1: the linear search must put key i first.  On top:
+    overwriting a live row replaces what is searched, p_keys and group-by searches skip holes, a filter composes with
+    the hole set, and the result always equals the oracle over the live rows."""
+    dim, cnt = 16, 20000
+    st = zv.HipFlatStreamer(dim, "SquaredEuclidean")
+    ctx = st.create_context()
+    ctx.set_topk(200)
+    rows = np.repeat(np.arange(cnt, dtype=np.float32)[:, None], dim, axis=1)
+    ev = np.arange(0, cnt, 2)
+    assert st.add_with_id_batch(ev[:3000], rows[ev[:3000]]) == 0
+    for i in ev[3000:3040]:                                  # one at a time, as the product calls it
+        assert st.add_with_id_impl(int(i), rows[i]) == 0
+    assert st.add_with_id_batch(ev[3040:], rows[ev[3040:]]) == 0
+    assert st.count() == cnt - 1 and st.holes() == cnt // 2 - 1
+    qs = np.arange(0, cnt, 100, dtype=np.float32)
+    q = np.repeat(qs[:, None], dim, axis=1) + np.float32(0.1)
+    assert st.search_impl(q, q.shape[0], ctx) == 0
+    for j, i in enumerate(range(0, cnt, 100)):
+        res = ctx.result(j)
+        assert len(res) == 200 and res[0].key() == i and all(d.key() % 2 == 0 for d in res)   # no hole (odd position) comes back
+    # (rows up to (20000, ...): the norms dwarf the distances, so the documented L2 selection band is wide here — the
+    # reference's own test asks for the first key and 80 % recall only)
+    band = 4e-6 * ((q.astype(np.float64) ** 2).sum(1) + float((rows[-1].astype(np.float64) ** 2).sum()))
+    ok, os_, _, oc = oracle.flat_search(rows[ev], q, 200, keys=ev.astype(np.uint64))
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, rtol=2e-6, atol=1e-3, what="holes", select_band=band)
+    # a filter on top of the holes; p_keys naming holes; group-by
+    ctx.set_filter(lambda key: key % 4 == 0)
+    assert st.search_impl(q[:5], 5, ctx) == 0
+    assert all(d.key() % 4 == 2 for qi in range(5) for d in ctx.result(qi))
+    ctx.reset_filter()
+    pk = st.create_context()
+    pk.set_topk(4)
+    assert st.search_bf_by_p_keys_impl(q[:1], [[3, 2, 1, 4, 5, 6]], 1, pk) == 0
+    assert [d.key() for d in pk.result(0)] == [2, 4, 6]
+    g = st.create_context()
+    g.set_group_params(3, 2)
+    g.set_group_by(lambda key: key % 3)
+    assert st.search_impl(q[:1], 1, g) == 0
+    assert all(d.key() % 2 == 0 for grp in g.group_result(0) for d in grp.docs()) and len(g.group_result(0)) == 3
+    # the odd ids land on the holes
+    od = np.arange(1, cnt, 2)
+    assert st.add_with_id_batch(od, rows[od]) == 0
+    assert st.count() == cnt and st.holes() == 0
+    assert st.search_bf_impl(q, q.shape[0], ctx) == 0
+    for j, i in enumerate(range(0, cnt, 100)):
+        res = ctx.result(j)
+        assert len(res) == 200 and res[0].key() == i
+    ok, os_, _, oc = oracle.flat_search(rows, q, 200)
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, rtol=2e-6, atol=1e-3, what="filled", select_band=band)
+    # overwrite a live row: the old vector is gone, the new one is found under the same key
+    far = np.full((1, dim), 1.0e6, np.float32)
+    assert st.add_with_id_impl(700, far[0]) == 0
+    ctx.set_topk(3)
+    assert st.search_impl(q[7:8], 1, ctx) == 0               # query 700.1
+    assert [d.key() for d in ctx.result(0)] == [701, 699, 702]
+    assert st.search_impl(far, 1, ctx) == 0
+    assert ctx.result(0)[0].key() == 700 and ctx.result(0)[0].score() == 0.0
+    assert np.array_equal(st.get_vector_by_id(700), far[0])

@@ -44,6 +44,8 @@ SYMBOLS = {
     "zvec_hip_flat_destroy": (C.c_int, [_h]),
     "zvec_hip_flat_reserve": (C.c_int, [_h, C.c_uint64]),
     "zvec_hip_flat_append": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p]),
+    "zvec_hip_flat_put": (C.c_int, [_h, _u32p, C.c_uint64, C.c_void_p, _u64p]),
+    "zvec_hip_flat_holes": (C.c_int, [_h, _u64p]),
     "zvec_hip_flat_append_dev": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p, C.c_void_p]),
     "zvec_hip_flat_count": (C.c_int, [_h, C.POINTER(C.c_uint64)]),
     "zvec_hip_flat_get_vector": (C.c_int, [_h, C.c_uint64, C.c_void_p]),

@@ -90,6 +90,7 @@ int zvec_hip_flat_destroy(zvec_hip_flat_t h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   h->st.release();
+  h->d_holes.release();
   if (h->append_ev) (void)hipEventDestroy(h->append_ev);
   ctx_free(h->defctx);
   delete h;
@@ -104,6 +105,19 @@ int zvec_hip_flat_reserve(zvec_hip_flat_t h, uint64_t capacity) {
   return h->st.reserve(capacity, h->defctx->own);
 }
 
+// the device copy of the hole bits has to span the store whenever holes exist (caller holds h->rw exclusively)
+static int flat_holes_cover(zvec_hip_flat_s *h, hipStream_t s) {
+  if (h->nholes == 0) return 0;
+  const uint64_t words = (h->st.n + 63) / 64 + 1;
+  h->h_holes.resize(words, 0);
+  if (words * 8 <= h->d_holes.cap) return 0;
+  ZRET(h->d_holes.ensure(words * 16));
+  ZCHK(hipMemsetAsync(h->d_holes.p, 0, h->d_holes.cap, s));
+  ZCHK(hipMemcpyAsync(h->d_holes.p, h->h_holes.data(), words * 8, hipMemcpyHostToDevice, s));
+  ZCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
 int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n, const uint64_t *d_keys, void *stream) {
   if (!h || (!d_vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
@@ -112,6 +126,7 @@ int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n, 
   hipStream_t s = pick_stream(h->defctx, stream);
   if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));   // (an earlier append on another stream)
   int rc = store_append_dev(h->st, d_vecs, n, d_keys, s);
+  if (rc == 0) rc = flat_holes_cover(h, s);
   if (rc == 0 && n) {
     // the row count is published now, the pack kernels are only enqueued on `s`: searches on other streams wait for
     // this event before they read the store (flat_search_dev_locked)
@@ -155,6 +170,7 @@ int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_
   hipLaunchKernelGGL(ivf_body_rows_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, a);
   ZCHK(hipGetLastError());
   int rc = store_append_dev(h->st, d_rows, count, keys ? static_cast<const uint64_t *>(d_keys) : nullptr, s);
+  if (rc == 0) rc = flat_holes_cover(h, s);
   ZCHK(hipStreamSynchronize(s));
   return rc;
 }
@@ -178,10 +194,96 @@ int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const 
     ZCHK(hipMemcpyAsync(tmp.p, reinterpret_cast<const char *>(vecs) + (size_t)o * rb, (size_t)m * rb, hipMemcpyHostToDevice, s));
     if (keys) ZCHK(hipMemcpyAsync(tk.p, keys + o, (size_t)m * 8, hipMemcpyHostToDevice, s));
     rc = store_append_dev(h->st, tmp.p, m, keys ? tk.as<uint64_t>() : nullptr, s);
+    if (rc == 0) rc = flat_holes_cover(h, s);
     if (rc != 0) { tmp.release(); tk.release(); return rc; }
     ZCHK(hipStreamSynchronize(s));
   }
   tmp.release(); tk.release();
+  return 0;
+}
+
+// IndexStreamer::add_with_id_impl in bulk: FlatStreamerEntity::add_vector_with_id (flat_streamer_entity.cc:900-990), one row
+// after the other — the row of ids[i] lives at storage position ids[i] with key ids[i] (or keys[i], for callers that
+// keep their own id -> position map):
+//   id == count  appended;   id > count  positions [count, id) are padded with HOLES first (zero rows under kInvalidKey that
+//   no search returns);   id < count  the row at that position is overwritten in place (a hole becomes a row).
+int zvec_hip_flat_put(zvec_hip_flat_t h, const uint32_t *ids, uint64_t n, const void *vecs, const uint64_t *keys) {
+  if (!h || (n && (!ids || !vecs))) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return 0;
+  for (uint64_t i = 0; i < n; ++i)
+    if (ids[i] >= 0xfffffff0u) return ZVEC_HIP_ERR_OUT_OF_RANGE;
+  std::lock_guard<std::mutex> g(h->mu);
+  std::unique_lock<FairSharedMutex> w(h->rw);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = h->defctx->own;
+  Store &st = h->st;
+  const size_t rb = st.row_bytes();
+  const uint64_t rows_per = std::max<uint64_t>(1, ((uint64_t)1 << 28) / (uint64_t)rb);
+  Scoped<char> tmp, zero;
+  Scoped<uint64_t> tk;
+  ZRET(tmp.alloc((size_t)std::min<uint64_t>(n, rows_per) * rb));
+  if (keys) ZRET(tk.alloc(std::min<uint64_t>(n, rows_per)));
+  uint64_t lo = ~0ull, hi = 0;                    // hole words touched
+  auto touch = [&](uint64_t pos) { lo = std::min(lo, pos >> 6); hi = std::max(hi, pos >> 6); };
+  for (uint64_t o = 0; o < n; o += rows_per) {
+    const uint64_t m = std::min(rows_per, n - o);
+    ZCHK(hipMemcpyAsync(tmp, static_cast<const char *>(vecs) + (size_t)o * rb, (size_t)m * rb, hipMemcpyHostToDevice, s));
+    if (keys) ZCHK(hipMemcpyAsync(tk, keys + o, (size_t)m * 8, hipMemcpyHostToDevice, s));
+    for (uint64_t i = 0; i < m;) {
+      const uint64_t id = ids[o + i];
+      if (id > st.n) {                            // pad the gap with holes
+        uint64_t gap = id - st.n;
+        const uint64_t zrows = std::min<uint64_t>(gap, rows_per);
+        if (!zero.p) {
+          ZRET(zero.alloc((size_t)zrows * rb));
+          ZCHK(hipMemsetAsync(zero, 0, (size_t)zrows * rb, s));
+        }
+        while (gap) {
+          const uint64_t z = std::min(gap, zrows);
+          const uint64_t pos0 = st.n;
+          ZRET(store_append_dev(st, zero, z, nullptr, s));
+          ZCHK(hipMemsetAsync(st.keys + pos0, 0xff, (size_t)z * 8, s));     // kInvalidKey (flat_index_format.h:29)
+          h->h_holes.resize((st.n + 63) / 64 + 1, 0);
+          for (uint64_t p = pos0; p < pos0 + z; ++p) { h->h_holes[p >> 6] |= 1ull << (p & 63); touch(p); }
+          h->nholes += z;
+          gap -= z;
+        }
+      }
+      if (id == st.n) {                           // a run of consecutive new ids is one append (key = position)
+        uint64_t j = i + 1;
+        while (j < m && ids[o + j] == ids[o + j - 1] + 1u) ++j;
+        ZRET(store_append_dev(st, static_cast<char *>(tmp) + (size_t)i * rb, j - i, keys ? static_cast<uint64_t *>(tk) + i : nullptr, s));
+        i = j;
+      } else {                                    // overwrite in place
+        ZRET(launch_pack(st, static_cast<char *>(tmp) + (size_t)i * rb, 1, nullptr, id, nullptr, s));
+        hipLaunchKernelGGL(fill_keys_kernel, dim3(1), dim3(64), 0, s, st.keys, id, (uint64_t)1,
+                           keys ? static_cast<const uint64_t *>(tk) + i : (const uint64_t *)nullptr);
+        ZCHK(hipGetLastError());
+        if (h->is_hole(id)) { h->h_holes[id >> 6] &= ~(1ull << (id & 63)); h->nholes -= 1; touch(id); }
+        ++i;
+      }
+    }
+    ZCHK(hipStreamSynchronize(s));
+  }
+  // device copy of the hole bits: everything after a reallocation, else the words that changed
+  const uint64_t words = (st.n + 63) / 64 + 1;
+  h->h_holes.resize(words, 0);
+  if (h->nholes || h->d_holes.p) {
+    if (words * 8 > h->d_holes.cap) {
+      ZRET(h->d_holes.ensure(words * 16));
+      ZCHK(hipMemsetAsync(h->d_holes.p, 0, h->d_holes.cap, s));
+      lo = 0; hi = words - 1;
+    }
+    if (lo <= hi && lo != ~0ull)
+      ZCHK(hipMemcpyAsync(h->d_holes.as<uint64_t>() + lo, h->h_holes.data() + lo, (size_t)(std::min(hi, words - 1) - lo + 1) * 8, hipMemcpyHostToDevice, s));
+    ZCHK(hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+int zvec_hip_flat_holes(zvec_hip_flat_t h, uint64_t *count) {
+  if (!h || !count) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  *count = h->nholes;
   return 0;
 }
 
@@ -222,12 +324,27 @@ int zvec_hip_flat_get_vectors(zvec_hip_flat_t h, const uint64_t *positions, uint
   return store_get_rows(h->defctx, h->st, pos, out);
 }
 
+// the exclude set a scan of this store has to use: the caller's, plus the holes add-with-id left (caller holds h->rw)
+static int flat_effective_exclude(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, const uint64_t *d_exclude, hipStream_t s, const uint64_t **out) {
+  *out = d_exclude;
+  if (h->nholes == 0) return 0;
+  if (!d_exclude) { *out = h->d_holes.as<uint64_t>(); return 0; }
+  const uint64_t words = (h->st.n + 63) / 64;
+  ZRET(c->holes_ex.ensure(words * 8 + 8));
+  hipLaunchKernelGGL(or_bits_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, c->holes_ex.as<uint64_t>(), d_exclude,
+                     h->d_holes.as<uint64_t>(), words);
+  ZCHK(hipGetLastError());
+  *out = c->holes_ex.as<uint64_t>();
+  return 0;
+}
+
 // the flat search proper; the caller holds c->mu and h->rw (shared) and has validated the arguments
 static int flat_search_dev_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, const void *d_queries, uint32_t count, uint32_t topk,
                                   float threshold, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys, float *d_out_scores,
                                   uint32_t *d_out_counts, hipStream_t s) {
   // rows appended through the asynchronous device-pointer form may still be in flight on another stream
   if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));
+  ZRET(flat_effective_exclude(h, c, d_exclude_bitset, s, &d_exclude_bitset));
   // the kernels address the padded query matrix with 32-bit word offsets: very large batches go in slices
   const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(h->st.dpad, 1u));
   for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
@@ -298,7 +415,7 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
   std::vector<uint32_t> clean(std::max<uint32_t>(total, 1));
   for (uint32_t i = 0; i < total; ++i) {
     uint32_t id = ids[i];
-    bool ok = id < st.n;
+    bool ok = id < st.n && !h->is_hole(id);
     if (ok && exclude_bitset) ok = ((exclude_bitset[id >> 6] >> (id & 63)) & 1ull) == 0;
     clean[i] = ok ? id : IDX_NONE;
   }

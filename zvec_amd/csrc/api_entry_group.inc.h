@@ -150,7 +150,9 @@ int zvec_hip_flat_search_grouped(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const vo
     const uint32_t cnt = std::min(sub, count - q0);
     float *dump = nullptr;
     uint32_t stride = 0;
-    ZRET(flat_dense_scores(c, st, q0, cnt, threshold, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr, s, &dump, &stride));
+    const uint64_t *d_ex = exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr;
+    ZRET(flat_effective_exclude(h, c, d_ex, s, &d_ex));
+    ZRET(flat_dense_scores(c, st, q0, cnt, threshold, d_ex, s, &dump, &stride));
     ZRET(group_select(c, st, dump, nullptr, stride, (uint32_t)st.n, q0, cnt, c->grp_of.as<uint32_t>(), ngroups, group_num, group_topk,
                       threshold, true, o, s));
   }
@@ -183,7 +185,7 @@ int zvec_hip_flat_search_grouped_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, c
   std::vector<uint32_t> clean(std::max<uint32_t>(total, 1));
   for (uint32_t i = 0; i < total; ++i) {
     uint32_t id = ids[i];
-    bool ok = id < st.n;
+    bool ok = id < st.n && !h->is_hole(id);
     if (ok && exclude_bitset) ok = ((exclude_bitset[id >> 6] >> (id & 63)) & 1ull) == 0;
     clean[i] = ok ? id : IDX_NONE;
   }

@@ -162,7 +162,8 @@ struct zvec_hip_ctx_s {
   DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
   DevBuf plan;        // all u32 plan arrays
   DevBuf io_q, io_ex, io_keys, io_scores, io_counts;   // staging for host-pointer entry points
-  DevBuf grp_ws, grp_of, grp_out, grp_tab;                      // group-by search: per-group bests / lists, group of every position, results
+  DevBuf grp_ws, grp_of, grp_out, grp_tab;
+  DevBuf holes_ex;                                     // caller's exclude set OR the store's holes                      // group-by search: per-group bests / lists, group of every position, results
   PinnedBuf pin_in, pin_out;                           // (transfers up to PIN_LIMIT bytes go through pinned memory)
   DevBuf stats;       // per-launch {distinct_rows, pair_rows} u64 x PROFILE_MAX
   uint32_t *q_scanned = nullptr, *q_nprobe = nullptr;  // inside plan
@@ -193,6 +194,13 @@ struct zvec_hip_flat_s {
   // waited for by every reader of the store on its own stream
   hipEvent_t append_ev = nullptr;
   bool append_pending = false;
+  // add-with-id gaps (FlatStreamerEntity::add_vector_with_id pads positions [count, id) with kInvalidKey rows that no scan
+  // returns, flat_streamer_entity.cc:935-952): one bit per storage position, host copy + device copy, OR-ed into every
+  // search's exclude set while any hole exists
+  std::vector<uint64_t> h_holes;
+  uint64_t nholes = 0;
+  DevBuf d_holes;
+  bool is_hole(uint64_t pos) const { return (pos >> 6) < h_holes.size() && ((h_holes[pos >> 6] >> (pos & 63)) & 1ull); }
 };
 
 struct zvec_hip_ivf_s {

@@ -217,7 +217,7 @@ class Context {
     if (!filter_.is_valid()) return nullptr;
     bits_.assign((keys_by_position.size() + 63) / 64, 0);
     for (size_t i = 0; i < keys_by_position.size(); ++i)
-      if (filter_(keys_by_position[i])) bits_[i >> 6] |= (1ull << (i & 63));
+      if (keys_by_position[i] != ~0ull && filter_(keys_by_position[i])) bits_[i >> 6] |= (1ull << (i & 63));   // (holes carry kInvalidKey)
     return bits_.data();
   }
   void take(uint32_t count, uint32_t topk, const std::vector<uint64_t> &keys, const std::vector<float> &scores,
@@ -409,6 +409,19 @@ class HipFlatStreamer {
     if (rc == 0) keys_.push_back(key);
     return rc;
   }
+  //! Add a vector with id into index (index_runner.h:483-487) — the call core_interface::Index::_dense_add makes.
+  //! FlatStreamerEntity::add_vector_with_id (flat_streamer_entity.cc:900-990): position == id == key; ids beyond the count
+  //! leave holes (kInvalidKey rows no search returns), an id below the count overwrites in place
+  int add_with_id_impl(uint32_t id, const void *query, const IndexQueryMeta &qmeta, Context::Pointer & /*context*/) {
+    if (!h_ || !query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
+    std::unique_lock<FairSharedMutex> w(keys_mu_);
+    int rc = zvec_hip_flat_put(h_, &id, 1, query, nullptr);
+    if (rc != 0) return rc;
+    if (keys_.size() <= id) keys_.resize((size_t)id + 1, kInvalidKey);
+    keys_[id] = id;
+    return 0;
+  }
+  static constexpr uint64_t kInvalidKey = ~0ull;              // flat_index_format.h:29
   //! bulk form used by FlatBuilder::build / FlatSearcher::load (flat_builder.cc:188-276)
   int add_batch(const void *vecs, uint64_t n, const uint64_t *keys) {
     if (!h_) return IndexError_InvalidArgument;

@@ -181,6 +181,12 @@ __global__ void fill_keys_kernel(uint64_t *keys, uint64_t pos0, uint64_t n, cons
   if (i < n) keys[pos0 + i] = src ? src[i] : pos0 + i;
 }
 
+// exclude set of a search over a store with holes: the caller's bits OR the store's hole bits
+__global__ void or_bits_kernel(uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t words) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < words) out[i] = a[i] | b[i];
+}
+
 // keys of rows packed at scattered positions (streamed IVF build: a chunk's kept rows land in their lists)
 __global__ void scatter_keys_kernel(uint64_t *keys, const uint64_t *dst_pos, const uint64_t *src, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

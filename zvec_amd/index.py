@@ -260,7 +260,7 @@ class IndexContext:
         if self._filter_fn is None:
             return None
         n = len(keys_of_positions)
-        mask = np.fromiter((bool(self._filter_fn(int(k))) for k in keys_of_positions), bool, n)
+        mask = np.fromiter((bool(self._filter_fn(int(k))) if k != 0xffffffffffffffff else False for k in keys_of_positions), bool, n)
         words = np.zeros((n + 63) // 64, np.uint64)
         idx = np.nonzero(mask)[0]
         np.bitwise_or.at(words, idx // 64, np.uint64(1) << (idx % 64).astype(np.uint64))
@@ -523,6 +523,35 @@ class HipFlatStreamer(_FlatBase):
 
     def add_impl(self, key, vec, ctx=None):
         return self.add_batch(np.asarray(vec, self.np_dtype).reshape(1, -1), np.array([key], np.uint64))
+
+    INVALID_KEY = np.uint64(0xffffffffffffffff)          # kInvalidKey (flat_index_format.h:29)
+
+    def add_with_id_impl(self, doc_id, vec, ctx=None):
+        """IndexStreamer::add_with_id_impl (index_runner.h:483-487): what core_interface::Index::_dense_add calls"""
+        return self.add_with_id_batch([doc_id], np.asarray(vec, self.np_dtype).reshape(1, -1))
+
+    def add_with_id_batch(self, ids, vecs):
+        """FlatStreamerEntity::add_vector_with_id row by row (flat_streamer_entity.cc:900-990): row ids[i] lives at
+        storage position ids[i] under key ids[i]; gaps are padded with holes no search returns, an id below the count
+        overwrites in place."""
+        vecs = np.ascontiguousarray(vecs, self.np_dtype)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        if vecs.ndim != 2 or vecs.shape[1] != self.dim or ids.size != vecs.shape[0]:
+            return IndexError_.InvalidArgument
+        rc = _lib.lib().zvec_hip_flat_put(self._h, _np_ptr(ids), ids.size, _np_ptr(vecs), None)
+        if rc == 0:
+            keys = self._all_keys()
+            n = self.count()
+            if keys.size < n:
+                keys = np.concatenate([keys, np.full(n - keys.size, self.INVALID_KEY, np.uint64)])
+            keys[ids.astype(np.int64)] = ids.astype(np.uint64)
+            self._keys_host = [keys]
+        return rc
+
+    def holes(self):
+        c = C.c_uint64(0)
+        _lib.check(_lib.lib().zvec_hip_flat_holes(self._h, C.byref(c)), "zvec_hip_flat_holes")
+        return int(c.value)
 
 
 class _FlatFeatures:
