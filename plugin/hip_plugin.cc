@@ -35,6 +35,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "hip_plugin_common.h"
 #include "zvec_hip.h"
 
 namespace zvec {
@@ -43,29 +44,13 @@ namespace core {
 namespace {
 
 // parameter keys of the operators this plugin stands in for
-const std::string kParamScanRatio("proxima.ivf.searcher.scan_ratio");                       // ivf_params.h:44-45
 const std::string kParamBruteForceThreshold("proxima.ivf.searcher.brute_force_threshold");  // ivf_params.h:46-47
-const std::string kParamHipDevice("proxima.hip.device");                                    // new: HIP device ordinal
 const std::string kParamHipDeviceCount("proxima.hip.device_count");   // new: > 1 = shard the index over devices [device, device + count)
 
 // segment ids (flat_utility.h:32-34, ivf_index_format.h:152-164)
 const std::string kFlatKeys("flat.keys"), kFlatFeatures("flat.features");
 const std::string kIvfCentroid("ivf.centroid"), kIvfBody("ivf.inverted_body"), kIvfHeader("ivf.inverted_header"),
     kIvfMeta("ivf.inverted_meta"), kIvfKeys("hc.keys");
-
-int metric_of(const IndexMeta &meta) {          // names chosen in src/core/interface/index.cc:47-106
-  const std::string &m = meta.metric_name();
-  if (m == "SquaredEuclidean") return ZVEC_HIP_METRIC_L2;
-  if (m == "InnerProduct") return ZVEC_HIP_METRIC_IP;
-  if (m == "Cosine") return ZVEC_HIP_METRIC_COSINE;
-  return -1;
-}
-
-int dtype_of(const IndexMeta &meta) {
-  if (meta.data_type() == IndexMeta::DT_FP32) return ZVEC_HIP_DT_FP32;
-  if (meta.data_type() == IndexMeta::DT_FP16) return ZVEC_HIP_DT_FP16;
-  return -1;
-}
 
 // whole payload of a segment as one contiguous host buffer
 int read_segment(IndexStorage *stg, const std::string &id, std::string *out, int level = -1) {

@@ -848,13 +848,18 @@ def parse_index_meta(blob):
     import json
     import struct
     hs, meta_type, major, dt, dim, unit, space, aoff, asz = struct.unpack_from("<9I", blob, 0)
-    metric = None
+    metric, att = None, {}
     if asz:                               # attachment_offset counts from the start of the blob (index_meta.cc:62-80)
         try:
-            metric = json.loads(bytes(blob[aoff:aoff + asz]).decode()).get("metric", {}).get("name")
+            att = json.loads(bytes(blob[aoff:aoff + asz]).decode())
+            metric = att.get("metric", {}).get("name")
         except (ValueError, UnicodeDecodeError):
-            metric = None
-    return {"major_order": major, "data_type": dt, "dimension": dim, "unit_size": unit, "metric": metric}
+            metric, att = None, {}
+    out = {"major_order": major, "data_type": dt, "dimension": dim, "unit_size": unit, "metric": metric}
+    for role in ("builder", "searcher", "streamer"):      # index_meta.cc:80-107
+        out[role + "_name"] = att.get(role, {}).get("name")
+        out[role + "_params"] = att.get(role, {}).get("params", {})
+    return out
 
 
 def open_flat_file(image, device=0, metric=None):
