@@ -793,3 +793,41 @@ def test_add_with_id_holes_and_overwrites(zv, oracle):
     assert st.search_impl(far, 1, ctx) == 0
     assert ctx.result(0)[0].key() == 700 and ctx.result(0)[0].score() == 0.0
     assert np.array_equal(st.get_vector_by_id(700), far[0])
+
+
+@pytest.mark.parametrize("metric,dtype", [("InnerProduct", "fp16"), ("Cosine", "fp32"), ("SquaredEuclidean", "fp32")])
+def test_add_with_id_random_order_equals_oracle(zv, oracle, metric, dtype):
+    """add_with_id in a random order with repeats (later writes win), chunks of mixed appends / gap fills / overwrites,
+    fp16 and cosine rows included: after every chunk the search equals the oracle over the rows that are live"""
+    rng = np.random.default_rng(404)
+    n, d, nq, k = 3000, 40, 25, 12
+    npdt = np.float16 if dtype == "fp16" else np.float32
+    m = {"SquaredEuclidean": O.METRIC_L2, "InnerProduct": O.METRIC_IP, "Cosine": O.METRIC_COSINE}[metric]
+    raw = rng.integers(-7, 8, (2 * n, d)).astype(np.float32)
+    qraw = rng.integers(-7, 8, (nq, d)).astype(np.float32)
+    if metric == "Cosine":
+        pool, q = oracle.cosine_transform(raw + 0.25), oracle.cosine_transform(qraw + 0.25)
+    else:
+        pool, q = raw.astype(npdt), qraw.astype(npdt)
+    st = zv.HipFlatStreamer(pool.shape[1], metric, dtype=dtype)
+    ctx = st.create_context()
+    ctx.set_topk(k)
+    live = {}                                               # id -> row of `pool` currently stored
+    order = rng.integers(0, n, 2 * n)                       # ids with repeats; write j stores pool[j]
+    for c0 in range(0, 2 * n, 750):
+        ids = order[c0:c0 + 750]
+        assert st.add_with_id_batch(ids, pool[c0:c0 + 750]) == 0
+        for j, i in enumerate(ids):
+            live[int(i)] = c0 + j
+        top = max(live) + 1
+        assert st.count() == top and st.holes() == top - len(live)
+        lid = np.array(sorted(live), np.int64)
+        rows = pool[[live[int(i)] for i in lid]]
+        assert st.search_impl(q, nq, ctx) == 0
+        ok, os_, _, oc = oracle.flat_search(rows, q, k, m, keys=lid.astype(np.uint64))
+        if metric == "Cosine":
+            tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, atol=4e-6, what="put cosine chunk %d" % c0)
+        else:
+            tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="put chunk %d" % c0)
+    i0 = int(lid[7])
+    assert np.array_equal(st.get_vector_by_id(i0), pool[live[i0]])
