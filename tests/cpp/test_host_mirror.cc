@@ -383,6 +383,100 @@ static int TestConcurrentAddWithFilterAndFetch() {
   return 0;
 }
 
+// add_with_id_impl from one thread — appends with gaps, gap fills and in-place overwrites — while three threads search
+// (plain with a filter, p_keys, group-by).  Every row ever written for id i is (i % 500 + j): an overwrite changes
+// nothing a searcher could tell apart, so the invariants hold at every moment: full result lists in ascending order, no
+// hole ever returned (kInvalidKey, or an id never written), filtered keys absent, top score 0 for a query that equals a
+// stored row, group documents inside their group.
+static int TestConcurrentPutAndSearch() {
+  const uint32_t dim = 16, n0 = 3000, n1 = 9000, topk = 8;
+  IndexMeta meta(IndexMeta::DT_FP32, dim);
+  meta.set_metric("SquaredEuclidean");
+  HipFlatStreamer st;
+  ASSERT(0 == st.init(meta, Params()));
+  ASSERT(0 == st.open());
+  IndexQueryMeta qmeta(IndexMeta::DT_FP32, dim);
+  auto row = [&](uint64_t i) { std::vector<float> v(dim); for (uint32_t j = 0; j < dim; ++j) v[j] = (float)(i % 500) + (float)j; return v; };
+  Context::Pointer none;
+  for (uint32_t i = 0; i < n0; ++i) { auto v = row(i); ASSERT(0 == st.add_with_id_impl(i, v.data(), qmeta, none)); }
+  std::atomic<int> bad{0};
+  std::atomic<bool> done{false};
+  std::thread writer([&]() {
+    Context::Pointer c;
+    uint32_t seed = 7;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
+    // multiples of 3 first (gaps of two holes each), overwrites of live rows in between, then the gaps
+    for (uint32_t i = n0; i < n1; i += 3) {
+      auto v = row(i);
+      if (st.add_with_id_impl(i, v.data(), qmeta, c) != 0) ++bad;
+      const uint32_t o = rnd() % n0;
+      auto w = row(o);
+      if (st.add_with_id_impl(o, w.data(), qmeta, c) != 0) ++bad;
+    }
+    for (uint32_t i = n0; i < n1; ++i)
+      if (i % 3 != n0 % 3) { auto v = row(i); if (st.add_with_id_impl(i, v.data(), qmeta, c) != 0) ++bad; }
+    done = true;
+  });
+  auto written = [&](uint64_t key) { return key < n1; };
+  std::vector<std::thread> th;
+  th.emplace_back([&]() {                                       // plain search with a filter
+    auto ctx = st.create_context();
+    ctx->set_topk(topk);
+    ctx->set_filter([](uint64_t key) { return key % 5 == 0; });
+    std::vector<float> q = row(123);
+    int loops = 0;
+    while (!done.load() || loops < 3) {
+      ++loops;
+      if (st.search_impl(q.data(), qmeta, ctx) != 0) { ++bad; continue; }
+      const auto &r = ctx->result();
+      if (r.size() != topk) { ++bad; continue; }
+      if (r[0].score() != 0.0f) ++bad;
+      for (size_t j = 0; j < r.size(); ++j) {
+        if (!written(r[j].key()) || r[j].key() % 5 == 0) ++bad;
+        if (j && r[j - 1].score() > r[j].score()) ++bad;
+      }
+    }
+  });
+  th.emplace_back([&]() {                                       // p_keys naming live rows, future rows and never-written ids
+    auto ctx = st.create_context();
+    ctx->set_topk(4);
+    std::vector<float> q = row(10);
+    std::vector<std::vector<uint64_t>> pk(1);
+    pk[0] = {10, 510, 1010, n1 - 1, n1 - 2, (uint64_t)n1 + 50, 11, 12};
+    int loops = 0;
+    while (!done.load() || loops < 3) {
+      ++loops;
+      if (st.search_bf_by_p_keys_impl(q.data(), pk, qmeta, 1, ctx) != 0) { ++bad; continue; }
+      const auto &r = ctx->result();
+      if (r.size() != 4 || r[0].score() != 0.0f) { ++bad; continue; }
+      for (const auto &d : r) if (!written(d.key())) ++bad;
+    }
+  });
+  th.emplace_back([&]() {                                       // group-by
+    auto ctx = st.create_context();
+    ctx->set_group_params(4, 3);
+    ctx->set_group_by([](uint64_t key) { return std::to_string(key % 7); });
+    std::vector<float> q = row(250);
+    int loops = 0;
+    while (!done.load() || loops < 3) {
+      ++loops;
+      if (st.search_impl(q.data(), qmeta, 1, ctx) != 0) { ++bad; continue; }
+      const auto &g = ctx->group_result();
+      if (g.size() != 4) { ++bad; continue; }
+      for (const auto &grp : g) {
+        if (grp.docs().size() != 3) ++bad;
+        for (const auto &d : grp.docs()) if (!written(d.key()) || std::to_string(d.key() % 7) != grp.group_id()) ++bad;
+      }
+      if (g[0].docs().empty() || g[0].docs()[0].score() != 0.0f) ++bad;
+    }
+  });
+  writer.join();
+  for (auto &x : th) x.join();
+  EXPECT(bad.load() == 0);
+  EXPECT(st.count() == n1);
+  return 0;
+}
+
 // patches/boundary_a.diff: boundary A's nprobe arrives as scan_ratio = nprobe / nlist (ivf_searcher_context.h:61-79);
 // with brute_force_threshold = N - 1 the operator probes exactly nprobe lists.  The operator-level search
 // must equal the C ABI called with those two numbers.
@@ -567,6 +661,7 @@ int main() {
   rc |= TestIVFSimple();
   rc |= TestNullContextFromManyThreads();
   rc |= TestConcurrentAddWithFilterAndFetch();
+  rc |= TestConcurrentPutAndSearch();
   rc |= TestBoundaryAMapping();
   rc |= TestMicroBatcher();
   if (rc == 0 && g_fail == 0) { printf("host mirror: all tests passed\n"); return 0; }
