@@ -21,6 +21,7 @@
 // the GPU; there is no CPU fallback (a missing device makes open / load fail with the ABI's error).
 #include <zvec/core/framework/index_factory.h>
 #include <zvec/core/framework/index_helper.h>
+#include <zvec/core/framework/index_provider.h>
 #include <zvec/core/framework/index_searcher.h>
 #include <zvec/core/framework/index_segment_storage.h>
 #include <zvec/core/framework/index_streamer.h>
@@ -615,9 +616,28 @@ class HipIVFCore {
     if (rc != 0) return rc;
     keys_.assign(reinterpret_cast<const uint64_t *>(keys.data()),
                  reinterpret_cast<const uint64_t *>(keys.data()) + keys.size() / sizeof(uint64_t));
+    pos_of_key_.clear();
+    pos_of_key_.reserve(keys_.size());
+    for (size_t i = 0; i < keys_.size(); ++i) pos_of_key_.emplace(keys_[i], i);
     nlist_ = (uint32_t)nlist;
     return 0;
   }
+  //! IVFEntity::get_vector_by_key: the stored row of a document (list-order position through the key map)
+  int vector_of_key(uint64_t key, void *out) const {
+    auto it = pos_of_key_.find(key);
+    if (it == pos_of_key_.end()) return IndexError_NoExist;
+    if (sh_) return IndexError_Unsupported;                  // (row fetches run on one device)
+    return zvec_hip_ivf_get_vector(h_, it->second, out);
+  }
+  //! rows of list-order positions [pos0, pos0 + n) -> host (the provider's iterator walks the index in chunks)
+  int rows_at(uint64_t pos0, size_t n, void *out) const {
+    if (sh_) return IndexError_Unsupported;
+    std::vector<uint64_t> pos(n);
+    for (size_t i = 0; i < n; ++i) pos[i] = pos0 + i;
+    return zvec_hip_ivf_get_vectors(h_, pos.data(), n, out);
+  }
+  uint64_t key_at(size_t pos) const { return keys_[pos]; }
+  uint32_t elem_size() const { return elem_size_; }
   //! IVFSearcher::search_impl / search_bf_impl (ivf_searcher.cc:106-250)
   int search(const void *q, const IndexQueryMeta &qm, uint32_t count, HipContext *ctx, bool brute_force) const {
     if (!q || qm.element_size() != elem_size_) return IndexError_InvalidArgument;
@@ -641,15 +661,104 @@ class HipIVFCore {
     }
     if (rc != 0) return rc;
     ctx->fill(count, ctx->topk(), ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
-    return 0;
+    return attach_vectors(ctx, count);
   }
   size_t count() const { return keys_.size(); }
  private:
+  //! fetch_vector (ivf_searcher_context.h:186-197: entity_->get_vector_by_key per result): one gather for the batch
+  int attach_vectors(HipContext *ctx, uint32_t count) const {
+    if (!ctx->fetch_vector()) return 0;
+    if (sh_) return IndexError_Unsupported;
+    std::vector<uint64_t> pos;
+    for (uint32_t q = 0; q < count; ++q)
+      for (auto &d : ctx->results_[q]) pos.push_back(pos_of_key_.at(d.key()));
+    ctx->vectors_.resize(pos.size() * elem_size_);
+    if (pos.empty()) return 0;
+    int rc = zvec_hip_ivf_get_vectors(h_, pos.data(), pos.size(), &ctx->vectors_[0]);
+    if (rc != 0) return rc;
+    size_t j = 0;
+    for (uint32_t q = 0; q < count; ++q)
+      for (auto &d : ctx->results_[q]) {
+        d = IndexDocument(d.key(), d.score(), (uint32_t)d.key(), ctx->vectors_.data() + j * elem_size_);
+        ++j;
+      }
+    return 0;
+  }
+
   zvec_hip_ivf_t h_{nullptr};
   zvec_hip_shards_t sh_{nullptr};         // set instead of h_ when the lists are dealt over several devices
+  std::unordered_map<uint64_t, uint64_t> pos_of_key_;   // key -> list-order position
   uint32_t elem_size_{0}, nlist_{0};
   std::vector<uint64_t> keys_;
 };
+
+/*! IVFIndexProvider (ivf_index_provider.h:24-106) over the device-resident lists: documents in list order; the iterator
+ *  pulls the rows to the host 4096 at a time (one gather launch each); like the reference's, data() is valid until next() */
+class HipIVFProvider : public IndexProvider {
+ public:
+  HipIVFProvider(const IndexMeta &meta, const HipIVFCore *core, const std::string &owner) : meta_(meta), core_(core), owner_(owner) {}
+  Iterator::Pointer create_iterator() override { return Iterator::Pointer(new Walk(core_)); }
+  size_t count() const override { return core_->count(); }
+  size_t dimension() const override { return meta_.dimension(); }
+  IndexMeta::DataType data_type() const override { return meta_.data_type(); }
+  size_t element_size() const override { return meta_.element_size(); }
+  const void *get_vector(const uint64_t key) const override {
+    static thread_local std::string row;
+    row.resize(core_->elem_size());
+    return core_->vector_of_key(key, &row[0]) == 0 ? row.data() : nullptr;
+  }
+  int get_vector(const uint64_t key, IndexStorage::MemoryBlock &block) const override {
+    const void *p = this->get_vector(key);
+    if (!p) return IndexError_NoExist;
+    block.reset(const_cast<void *>(p));
+    return 0;
+  }
+  const std::string &owner_class() const override { return owner_; }
+
+ private:
+  class Walk : public Iterator {
+   public:
+    explicit Walk(const HipIVFCore *core) : core_(core) { fetch(); }
+    const void *data() const override { return chunk_.data() + (pos_ - chunk0_) * core_->elem_size(); }
+    bool is_valid() const override { return ok_ && pos_ < core_->count(); }
+    uint64_t key() const override { return core_->key_at(pos_); }
+    void next() override {
+      ++pos_;
+      if (pos_ >= chunk0_ + chunk_n_) fetch();
+    }
+   private:
+    void fetch() {
+      chunk0_ = pos_;
+      chunk_n_ = std::min<size_t>(4096, core_->count() > pos_ ? core_->count() - pos_ : 0);
+      chunk_.resize(chunk_n_ * core_->elem_size());
+      ok_ = chunk_n_ == 0 || core_->rows_at(chunk0_, chunk_n_, &chunk_[0]) == 0;
+    }
+    const HipIVFCore *core_;
+    std::string chunk_;
+    size_t pos_{0}, chunk0_{0}, chunk_n_{0};
+    bool ok_{true};
+  };
+  IndexMeta meta_;
+  const HipIVFCore *core_;
+  std::string owner_;
+};
+
+//! get_vector / get_vector_by_key / get_vector_by_id of the IVF operators (ivf_streamer.h:74-85: the id is looked up as a key)
+#define ZVEC_HIP_IVF_VECTOR_ACCESSORS(OWNER)                                                                                   \
+  Provider::Pointer create_provider() const override { return Provider::Pointer(new HipIVFProvider(meta_, &core_, OWNER)); }  \
+  const void *get_vector(uint64_t key) const override {                                                                        \
+    static thread_local std::string row;                                                                                       \
+    row.resize(core_.elem_size());                                                                                             \
+    return core_.vector_of_key(key, &row[0]) == 0 ? row.data() : nullptr;                                                      \
+  }                                                                                                                            \
+  int get_vector(const uint64_t key, IndexStorage::MemoryBlock &block) const override {                                        \
+    const void *p = this->get_vector(key);                                                                                     \
+    if (!p) return IndexError_NoExist;                                                                                         \
+    block.reset(const_cast<void *>(p));                                                                                        \
+    return 0;                                                                                                                  \
+  }                                                                                                                            \
+  int get_vector_by_key(const uint64_t key, IndexStorage::MemoryBlock &block) const override { return this->get_vector(key, block); } \
+  int get_vector_by_id(const uint32_t id, IndexStorage::MemoryBlock &block) const override { return this->get_vector(id, block); }
 
 /*! "HipIVFSearcher": stands where IVFSearcher is registered (ivf_searcher.cc). */
 class HipIVFSearcher : public IndexSearcher {
@@ -679,6 +788,7 @@ class HipIVFSearcher : public IndexSearcher {
     ctx->update(params_);
     return Context::Pointer(ctx);
   }
+  ZVEC_HIP_IVF_VECTOR_ACCESSORS("HipIVFSearcher")
   int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
   int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
     HipContext *ctx = bind(c, magic_);
@@ -730,6 +840,7 @@ class HipIVFStreamer : public IndexStreamer {
     ctx->update(params_);
     return Context::Pointer(ctx);
   }
+  ZVEC_HIP_IVF_VECTOR_ACCESSORS("HipIVFStreamer")
   int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
   int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
     HipContext *ctx = bind(c, magic_);
