@@ -347,6 +347,14 @@ class HipFlatCore {
                : zvec_hip_flat_load_features(h_, features, bytes, n, column_major, 32, keys);
   }
   size_t count() const { return keys_.size(); }
+  uint64_t key_at(size_t pos) const { return keys_[pos]; }
+  uint32_t elem_size() const { return elem_size_; }
+  //! rows of storage positions [pos0, pos0 + n) -> host (the provider's iterator)
+  int rows_at(uint64_t pos0, size_t n, void *out) const {
+    std::vector<uint64_t> pos(n);
+    for (size_t i = 0; i < n; ++i) pos[i] = pos0 + i;
+    return sh_ ? zvec_hip_shards_flat_get_vectors(sh_, pos.data(), n, out) : zvec_hip_flat_get_vectors(h_, pos.data(), n, out);
+  }
   void adopt_keys(const uint64_t *keys, size_t n) {
     keys_.assign(keys, keys + n);
     for (size_t i = 0; i < n; ++i) pos_of_key_.emplace(keys[i], (uint32_t)i);
@@ -381,6 +389,77 @@ class HipFlatCore {
   std::vector<uint64_t> keys_;            // key of every storage position
   std::unordered_map<uint64_t, uint32_t> pos_of_key_;
 };
+
+/*! IVFIndexProvider (ivf_index_provider.h:24-106) / the flat searcher's provider over the device-resident rows: documents in
+ *  storage (list) order; the iterator pulls the rows to the host 4096 at a time (one gather launch each); like the
+ *  reference's, data() is valid until next().  Core = HipFlatCore or HipIVFCore. */
+template <typename Core>
+class HipRowsProvider : public IndexProvider {
+ public:
+  HipRowsProvider(const IndexMeta &meta, const Core *core, const std::string &owner) : meta_(meta), core_(core), owner_(owner) {}
+  Iterator::Pointer create_iterator() override { return Iterator::Pointer(new Walk(core_)); }
+  size_t count() const override { return core_->count(); }
+  size_t dimension() const override { return meta_.dimension(); }
+  IndexMeta::DataType data_type() const override { return meta_.data_type(); }
+  size_t element_size() const override { return meta_.element_size(); }
+  const void *get_vector(const uint64_t key) const override {
+    static thread_local std::string row;
+    row.resize(core_->elem_size());
+    return core_->vector_of_key(key, &row[0]) == 0 ? row.data() : nullptr;
+  }
+  int get_vector(const uint64_t key, IndexStorage::MemoryBlock &block) const override {
+    const void *p = this->get_vector(key);
+    if (!p) return IndexError_NoExist;
+    block.reset(const_cast<void *>(p));
+    return 0;
+  }
+  const std::string &owner_class() const override { return owner_; }
+
+ private:
+  class Walk : public Iterator {
+   public:
+    explicit Walk(const Core *core) : core_(core) { fetch(); }
+    const void *data() const override { return chunk_.data() + (pos_ - chunk0_) * core_->elem_size(); }
+    bool is_valid() const override { return ok_ && pos_ < core_->count(); }
+    uint64_t key() const override { return core_->key_at(pos_); }
+    void next() override {
+      ++pos_;
+      if (pos_ >= chunk0_ + chunk_n_) fetch();
+    }
+   private:
+    void fetch() {
+      chunk0_ = pos_;
+      chunk_n_ = std::min<size_t>(4096, core_->count() > pos_ ? core_->count() - pos_ : 0);
+      chunk_.resize(chunk_n_ * core_->elem_size());
+      ok_ = chunk_n_ == 0 || core_->rows_at(chunk0_, chunk_n_, &chunk_[0]) == 0;
+    }
+    const Core *core_;
+    std::string chunk_;
+    size_t pos_{0}, chunk0_{0}, chunk_n_{0};
+    bool ok_{true};
+  };
+  IndexMeta meta_;
+  const Core *core_;
+  std::string owner_;
+};
+
+//! create_provider / get_vector / get_vector_by_key / get_vector_by_id of the immutable operators (ivf_streamer.h:74-85: the id
+//! is looked up as a key; flat_searcher.h:111,158)
+#define ZVEC_HIP_VECTOR_ACCESSORS(CORE, OWNER)                                                                                 \
+  Provider::Pointer create_provider() const override { return Provider::Pointer(new HipRowsProvider<CORE>(meta_, &core_, OWNER)); } \
+  const void *get_vector(uint64_t key) const override {                                                                        \
+    static thread_local std::string row;                                                                                       \
+    row.resize(core_.elem_size());                                                                                             \
+    return core_.vector_of_key(key, &row[0]) == 0 ? row.data() : nullptr;                                                      \
+  }                                                                                                                            \
+  int get_vector(const uint64_t key, IndexStorage::MemoryBlock &block) const override {                                        \
+    const void *p = this->get_vector(key);                                                                                     \
+    if (!p) return IndexError_NoExist;                                                                                         \
+    block.reset(const_cast<void *>(p));                                                                                        \
+    return 0;                                                                                                                  \
+  }                                                                                                                            \
+  int get_vector_by_key(const uint64_t key, IndexStorage::MemoryBlock &block) const override { return this->get_vector(key, block); } \
+  int get_vector_by_id(const uint32_t id, IndexStorage::MemoryBlock &block) const override { return this->get_vector(id, block); }
 
 /*! "HipFlatSearcher": stands where FlatSearcher<32> is registered (flat_searcher.cc:247-250). */
 class HipFlatSearcher : public IndexSearcher {
@@ -419,6 +498,7 @@ class HipFlatSearcher : public IndexSearcher {
   const IndexMeta &meta() const override { return meta_; }
   const ailego::Params &params() const override { return params_; }
   Context::Pointer create_context() const override { return Context::Pointer(new HipContext(device_, magic_)); }
+  ZVEC_HIP_VECTOR_ACCESSORS(HipFlatCore, "HipFlatSearcher")
   int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
   int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
     HipContext *ctx = bind(c, magic_);
@@ -692,74 +772,6 @@ class HipIVFCore {
   std::vector<uint64_t> keys_;
 };
 
-/*! IVFIndexProvider (ivf_index_provider.h:24-106) over the device-resident lists: documents in list order; the iterator
- *  pulls the rows to the host 4096 at a time (one gather launch each); like the reference's, data() is valid until next() */
-class HipIVFProvider : public IndexProvider {
- public:
-  HipIVFProvider(const IndexMeta &meta, const HipIVFCore *core, const std::string &owner) : meta_(meta), core_(core), owner_(owner) {}
-  Iterator::Pointer create_iterator() override { return Iterator::Pointer(new Walk(core_)); }
-  size_t count() const override { return core_->count(); }
-  size_t dimension() const override { return meta_.dimension(); }
-  IndexMeta::DataType data_type() const override { return meta_.data_type(); }
-  size_t element_size() const override { return meta_.element_size(); }
-  const void *get_vector(const uint64_t key) const override {
-    static thread_local std::string row;
-    row.resize(core_->elem_size());
-    return core_->vector_of_key(key, &row[0]) == 0 ? row.data() : nullptr;
-  }
-  int get_vector(const uint64_t key, IndexStorage::MemoryBlock &block) const override {
-    const void *p = this->get_vector(key);
-    if (!p) return IndexError_NoExist;
-    block.reset(const_cast<void *>(p));
-    return 0;
-  }
-  const std::string &owner_class() const override { return owner_; }
-
- private:
-  class Walk : public Iterator {
-   public:
-    explicit Walk(const HipIVFCore *core) : core_(core) { fetch(); }
-    const void *data() const override { return chunk_.data() + (pos_ - chunk0_) * core_->elem_size(); }
-    bool is_valid() const override { return ok_ && pos_ < core_->count(); }
-    uint64_t key() const override { return core_->key_at(pos_); }
-    void next() override {
-      ++pos_;
-      if (pos_ >= chunk0_ + chunk_n_) fetch();
-    }
-   private:
-    void fetch() {
-      chunk0_ = pos_;
-      chunk_n_ = std::min<size_t>(4096, core_->count() > pos_ ? core_->count() - pos_ : 0);
-      chunk_.resize(chunk_n_ * core_->elem_size());
-      ok_ = chunk_n_ == 0 || core_->rows_at(chunk0_, chunk_n_, &chunk_[0]) == 0;
-    }
-    const HipIVFCore *core_;
-    std::string chunk_;
-    size_t pos_{0}, chunk0_{0}, chunk_n_{0};
-    bool ok_{true};
-  };
-  IndexMeta meta_;
-  const HipIVFCore *core_;
-  std::string owner_;
-};
-
-//! get_vector / get_vector_by_key / get_vector_by_id of the IVF operators (ivf_streamer.h:74-85: the id is looked up as a key)
-#define ZVEC_HIP_IVF_VECTOR_ACCESSORS(OWNER)                                                                                   \
-  Provider::Pointer create_provider() const override { return Provider::Pointer(new HipIVFProvider(meta_, &core_, OWNER)); }  \
-  const void *get_vector(uint64_t key) const override {                                                                        \
-    static thread_local std::string row;                                                                                       \
-    row.resize(core_.elem_size());                                                                                             \
-    return core_.vector_of_key(key, &row[0]) == 0 ? row.data() : nullptr;                                                      \
-  }                                                                                                                            \
-  int get_vector(const uint64_t key, IndexStorage::MemoryBlock &block) const override {                                        \
-    const void *p = this->get_vector(key);                                                                                     \
-    if (!p) return IndexError_NoExist;                                                                                         \
-    block.reset(const_cast<void *>(p));                                                                                        \
-    return 0;                                                                                                                  \
-  }                                                                                                                            \
-  int get_vector_by_key(const uint64_t key, IndexStorage::MemoryBlock &block) const override { return this->get_vector(key, block); } \
-  int get_vector_by_id(const uint32_t id, IndexStorage::MemoryBlock &block) const override { return this->get_vector(id, block); }
-
 /*! "HipIVFSearcher": stands where IVFSearcher is registered (ivf_searcher.cc). */
 class HipIVFSearcher : public IndexSearcher {
  public:
@@ -788,7 +800,7 @@ class HipIVFSearcher : public IndexSearcher {
     ctx->update(params_);
     return Context::Pointer(ctx);
   }
-  ZVEC_HIP_IVF_VECTOR_ACCESSORS("HipIVFSearcher")
+  ZVEC_HIP_VECTOR_ACCESSORS(HipIVFCore, "HipIVFSearcher")
   int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
   int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
     HipContext *ctx = bind(c, magic_);
@@ -840,7 +852,7 @@ class HipIVFStreamer : public IndexStreamer {
     ctx->update(params_);
     return Context::Pointer(ctx);
   }
-  ZVEC_HIP_IVF_VECTOR_ACCESSORS("HipIVFStreamer")
+  ZVEC_HIP_VECTOR_ACCESSORS(HipIVFCore, "HipIVFStreamer")
   int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
   int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
     HipContext *ctx = bind(c, magic_);
