@@ -430,10 +430,10 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
   ZRET(c->part_s.ensure(pairs * 4));
   ZRET(c->part_i.ensure(pairs * 4));
   if (st.f16)
-    hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
+    hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3(pkeys_score_blocks(count, maxlen)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
                        st.dpad, st.metric, d_pos, d_off, count, maxlen, c->part_s.as<float>(), c->part_i.as<uint32_t>());
   else
-    hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
+    hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3(pkeys_score_blocks(count, maxlen)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
                        st.dpad, st.metric, d_pos, d_off, count, maxlen, c->part_s.as<float>(), c->part_i.as<uint32_t>());
   ZCHK(hipGetLastError());
   MergeArgs m{};
@@ -474,10 +474,10 @@ int zvec_hip_flat_batch_distance(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const vo
   ZRET(c->part_s.ensure((size_t)n * 4));
   ZRET(c->part_i.ensure((size_t)n * 4));
   if (st.f16)
-    hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, s, st.base, c->qpad.as<float>(), st.dpad,
+    hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3(pkeys_score_blocks(1, n)), dim3(256), 0, s, st.base, c->qpad.as<float>(), st.dpad,
                        st.metric, d_pos, d_off, 1u, n, c->part_s.as<float>(), c->part_i.as<uint32_t>());
   else
-    hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, s, st.base, c->qpad.as<float>(), st.dpad,
+    hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3(pkeys_score_blocks(1, n)), dim3(256), 0, s, st.base, c->qpad.as<float>(), st.dpad,
                        st.metric, d_pos, d_off, 1u, n, c->part_s.as<float>(), c->part_i.as<uint32_t>());
   ZCHK(hipGetLastError());
   ZCHK(hipMemcpyAsync(out_scores, c->part_s.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));

@@ -144,7 +144,8 @@ int zvec_hip_flat_search_grouped(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const vo
   ZRET(prep_queries(c, st, c->io_q.p, count, threshold, s));
   const uint64_t ntiles = (st.n + TILE_N - 1) / TILE_N;
   const double row_bytes = (double)ntiles * TILE_N * 4.0;
-  const uint32_t sub = (uint32_t)std::max<double>(1.0, std::min<double>((double)count, std::floor(1073741824.0 / row_bytes)));
+  // query slices: the score matrix stays <= 1 GiB, and a slice is one grid dimension of group_best_kernel (<= 65535)
+  const uint32_t sub = (uint32_t)std::max<double>(1.0, std::min<double>(std::min<double>((double)count, 32768.0), std::floor(1073741824.0 / row_bytes)));
   ZRET(c->part_s.ensure((size_t)(row_bytes * sub)));
   for (uint32_t q0 = 0; q0 < count; q0 += sub) {
     const uint32_t cnt = std::min(sub, count - q0);
@@ -204,15 +205,17 @@ int zvec_hip_flat_search_grouped_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, c
   ZRET(c->part_s.ensure(pairs * 4));
   ZRET(c->part_i.ensure(pairs * 4));
   if (st.f16)
-    hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
+    hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3(pkeys_score_blocks(count, maxlen)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
                        st.dpad, st.metric, d_pos, d_off, count, maxlen, c->part_s.as<float>(), c->part_i.as<uint32_t>());
   else
-    hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
+    hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3(pkeys_score_blocks(count, maxlen)), dim3(256), 0, s, st.base, c->qpad.as<float>(),
                        st.dpad, st.metric, d_pos, d_off, count, maxlen, c->part_s.as<float>(), c->part_i.as<uint32_t>());
   ZCHK(hipGetLastError());
   ZCHK(hipStreamSynchronize(s));                         // `clean` goes away
   // the pair scores are already direct distances: no refinement
-  ZRET(group_select(c, st, c->part_s.as<float>(), c->part_i.as<uint32_t>(), maxlen, maxlen, 0, count, c->grp_of.as<uint32_t>(), ngroups,
-                    group_num, group_topk, threshold, false, o, s));
+  for (uint32_t q0 = 0; q0 < count; q0 += 32768)       // (a slice is one grid dimension of group_best_kernel)
+    ZRET(group_select(c, st, c->part_s.as<float>() + (size_t)q0 * maxlen, c->part_i.as<uint32_t>() + (size_t)q0 * maxlen, maxlen, maxlen,
+                      q0, std::min<uint32_t>(32768, count - q0), c->grp_of.as<uint32_t>(), ngroups, group_num, group_topk, threshold,
+                      false, o, s));
   return group_copy_out(c, o, count, group_num, group_topk, out_groups, out_ngroups, out_keys, out_scores, out_counts, s);
 }

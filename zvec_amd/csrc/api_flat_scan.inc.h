@@ -24,6 +24,7 @@ struct Knobs {
   int ivf_head_pct = 50;      // ZVEC_HIP_IVF_HEAD_PCT  share of the tiles (deal-order head) dealt in double-length chunks
   int ivf_occ_cap = 0;        // ZVEC_HIP_IVF_OCC_CAP   IVF list scan: at most this many persistent work-groups per CU (0 = all)
   bool no_wide_dump = false;  // ZVEC_HIP_NO_WIDE_DUMP  dense-score path (IVF coarse step): never take the 8-wave tile
+  int ivf_direct_q = 8;       // ZVEC_HIP_IVF_DIRECT_Q  IVF searches of at most this many queries take the direct (wave per row) route
   Knobs() {
 #ifdef ZVEC_HIP_TUNING
     if (const char *e = getenv("ZVEC_HIP_MAX_NG")) max_ng = std::max(1, std::min(4, atoi(e)));
@@ -36,6 +37,7 @@ struct Knobs {
     no_wide_dump = getenv("ZVEC_HIP_NO_WIDE_DUMP") != nullptr;
     if (const char *e = getenv("ZVEC_HIP_IVF_OCC_CAP")) ivf_occ_cap = std::max(0, atoi(e));
     if (const char *e = getenv("ZVEC_HIP_IVF_HEAD_PCT")) ivf_head_pct = std::max(0, std::min(75, atoi(e)));
+    if (const char *e = getenv("ZVEC_HIP_IVF_DIRECT_Q")) ivf_direct_q = std::max(0, atoi(e));
 #endif
   }
 };
@@ -619,8 +621,8 @@ void ctx_free(zvec_hip_ctx_s *c) {
   if (c->own) (void)hipStreamSynchronize(c->own);
   c->gtau.release(); c->ridx.release(); c->seed_keys.release(); c->seed_scores.release(); c->seed_counts.release(); c->seed_idx.release(); c->cmp_base.release(); c->cmp_norm.release(); c->cmp_extra.release(); c->cmp_keys.release(); c->cmp_pos.release(); c->cmp_cnt.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
   c->coarse_keys.release(); c->coarse_scores.release(); c->coarse_idx.release(); c->coarse_cnt.release();
-  c->plan.release(); c->io_q.release(); c->io_ex.release(); c->io_keys.release(); c->io_scores.release();
-  c->io_counts.release(); c->grp_ws.release(); c->grp_of.release(); c->grp_out.release(); c->grp_tab.release(); c->holes_ex.release(); c->stats.release(); c->pin_in.release(); c->pin_out.release();
+  c->plan.release(); c->io_q.release(); c->io_ex.release(); c->io_out.release();
+  c->grp_ws.release(); c->grp_of.release(); c->grp_out.release(); c->grp_tab.release(); c->holes_ex.release(); c->direct_pos.release(); c->direct_keys.release(); c->direct_scores.release(); c->direct_idx.release(); c->direct_cnt.release(); c->stats.release(); c->pin_in.release(); c->pin_out.release();
   for (auto e : c->ev0) (void)hipEventDestroy(e);
   for (auto e : c->ev1) (void)hipEventDestroy(e);
   if (c->own) (void)hipStreamDestroy(c->own);

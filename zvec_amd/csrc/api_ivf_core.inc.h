@@ -13,6 +13,19 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   if (nprobe > nlist) nprobe = nlist;
   ZRET(prep_queries(ctx, h->lists, d_queries, count, FLT_MAX, stream));   // coarse pass: no RNN radius
 
+  // A handful of queries (the product's count = 1 calls): both steps go wave-per-row instead of through the MFMA tile
+  // kernels, whose few work items would each be a chain of dependent HBM round trips (1 query, 2M x 768, nprobe 32:
+  // coarse 90 us + list scan 113 us for 6 + 96 MB).  Bound of the rows one query can scan: the nprobe largest lists.
+  if (h->h_rows_of_largest.size() != (size_t)nlist + 1) {
+    std::vector<uint32_t> sz(h->h_size);
+    std::sort(sz.begin(), sz.end(), std::greater<uint32_t>());
+    h->h_rows_of_largest.assign((size_t)nlist + 1, 0);
+    for (uint32_t i = 0; i < nlist; ++i) h->h_rows_of_largest[i + 1] = h->h_rows_of_largest[i] + sz[i];
+  }
+  const uint64_t direct_rows = std::max<uint64_t>(1, h->h_rows_of_largest[nprobe]);
+  const bool direct = !brute_force && count <= (uint32_t)knobs().ivf_direct_q && (uint64_t)count * direct_rows <= (4u << 20) &&
+                      (size_t)topk * 12 + 16 <= 60 * 1024 && (size_t)nprobe * 12 + 16 <= 60 * 1024;
+
   // 1. coarse assign: flat scan over the centroids, k = nprobe (IVFCentroidIndex::search)
   if (!brute_force) {
     ZRET(ctx->coarse_keys.ensure((size_t)count * nprobe * sizeof(uint64_t)));
@@ -21,7 +34,88 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     ZRET(ctx->coarse_cnt.ensure((size_t)count * sizeof(uint32_t)));
     SearchOut co{ctx->coarse_keys.as<uint64_t>(), ctx->coarse_scores.as<float>(), ctx->coarse_idx.as<uint32_t>(),
                  ctx->coarse_cnt.as<uint32_t>()};
-    ZRET(flat_scan_prepared(ctx, h->cent, count, nprobe, FLT_MAX, nullptr, co, stream, false));
+    if (direct) {
+      const uint32_t stride = (nlist + 63) / 64 * 64;
+      const uint64_t pairs = (uint64_t)count * stride;
+      ZRET(ctx->part_s.ensure(pairs * 4));
+      if (h->cent.f16)
+        hipLaunchKernelGGL(rows_score_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->cent.base,
+                           ctx->qpad.as<float>(), h->cent.dpad, h->metric, nlist, count, stride, ctx->part_s.as<float>());
+      else
+        hipLaunchKernelGGL(rows_score_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->cent.base,
+                           ctx->qpad.as<float>(), h->cent.dpad, h->metric, nlist, count, stride, ctx->part_s.as<float>());
+      MergeArgs m{};
+      m.part_s = ctx->part_s.as<float>(); m.slots_per_q = 1; m.slot_stride = 1; m.k = nprobe; m.slot_len = stride; m.threshold = FLT_MAX;
+      m.out_keys = co.keys; m.out_scores = co.scores; m.out_idx = co.idx; m.out_counts = co.counts;
+      hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)nprobe * 12 + 16, stream, m);
+      ZCHK(hipGetLastError());
+    } else {
+      ZRET(flat_scan_prepared(ctx, h->cent, count, nprobe, FLT_MAX, nullptr, co, stream, false));
+    }
+  }
+  if (direct) {
+    // 2'. every query's probed rows as positions (same probe rule), 3'. one wave per (query, row): direct distance,
+    // 4'. selection in two steps: runs of 4096 candidates -> top-k lists, those -> the result (no refinement needed:
+    // the scores already are sum((q - b)^2))
+    constexpr uint32_t RUN = 1024;                                      // one gather round of merge_kernel
+    uint32_t stride = (uint32_t)((direct_rows + 63) / 64 * 64);
+    if (stride > RUN) stride = (stride + RUN - 1) / RUN * RUN;          // whole runs for the two-step selection
+    const uint32_t runs = (stride + RUN - 1) / RUN;
+    const uint64_t pairs = (uint64_t)count * stride;
+    ZRET(ctx->plan.ensure(((size_t)3 * count + 8) * sizeof(uint32_t)));
+    uint32_t *pb = ctx->plan.as<uint32_t>();
+    PlanArgs p{};
+    p.coarse_idx = ctx->coarse_idx.as<uint32_t>(); p.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
+    p.nq = count; p.nprobe = nprobe; p.nlist = nlist; p.max_scan_count = max_scan_count; p.brute_force = 0;
+    p.list_size = h->d_size; p.list_size_global = h->d_size_global;
+    p.q_nprobe = pb; p.q_scanned = pb + count;
+    uint32_t *d_off = pb + 2 * (size_t)count;
+    ZRET(ctx->direct_pos.ensure(pairs * 4));
+    ZRET(ctx->part_s.ensure(pairs * 4));
+    ZRET(ctx->part_i.ensure(pairs * 4));
+    ZCHK(hipMemsetAsync(ctx->direct_pos.p, 0xff, pairs * 4, stream));     // IDX_NONE everywhere; the probed rows overwrite it
+    hipLaunchKernelGGL(ivf_expand_direct_kernel, dim3(nprobe, count), dim3(256), 0, stream, p, h->d_tile0, h->d_dense0,
+                       reinterpret_cast<const uint32_t *>(d_exclude), stride, d_off, ctx->direct_pos.as<uint32_t>());
+    gate_enter(ctx, stream);                                              // (the radius is applied by the selection)
+    if (h->lists.f16)
+      hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3(pkeys_score_blocks(count, stride)), dim3(256), 0, stream, h->lists.base,
+                         ctx->qpad.as<float>(), h->lists.dpad, h->metric, ctx->direct_pos.as<uint32_t>(), d_off, count, stride,
+                         ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3(pkeys_score_blocks(count, stride)), dim3(256), 0, stream, h->lists.base,
+                         ctx->qpad.as<float>(), h->lists.dpad, h->metric, ctx->direct_pos.as<uint32_t>(), d_off, count, stride,
+                         ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
+    gate_leave(ctx, stream);
+    ZCHK(hipGetLastError());
+    // equal scores keep the reference's order — probe rank, then position in the list — which here is the ORDER of the
+    // candidate stream, not the order of the positions
+    MergeArgs m{};
+    m.part_s = ctx->part_s.as<float>(); m.part_i = ctx->part_i.as<uint32_t>(); m.slots_per_q = 1; m.slot_stride = 1;
+    m.k = topk; m.threshold = threshold; m.order_by_ordinal = 1;
+    if (runs > 1) {
+      // step 1: block (query, run) keeps the top-k of its 1024 candidates; step 2: a query's `runs` lists -> its result
+      const uint64_t blocks = (uint64_t)count * runs;
+      ZRET(ctx->direct_keys.ensure(blocks * topk * 8));
+      ZRET(ctx->direct_scores.ensure(blocks * topk * 4));
+      ZRET(ctx->direct_idx.ensure(blocks * topk * 4));
+      ZRET(ctx->direct_cnt.ensure(blocks * 4));
+      m.slot_len = RUN;
+      m.out_keys = ctx->direct_keys.as<uint64_t>(); m.out_scores = ctx->direct_scores.as<float>();
+      m.out_idx = ctx->direct_idx.as<uint32_t>(); m.out_counts = ctx->direct_cnt.as<uint32_t>();
+      hipLaunchKernelGGL(merge_kernel, dim3((unsigned)blocks), dim3(64), (size_t)topk * 12 + 16, stream, m);
+      MergeArgs f{};
+      f.part_s = m.out_scores; f.part_i = m.out_idx; f.slots_per_q = runs; f.slot_stride = 1; f.k = topk; f.slot_len = topk;
+      f.threshold = threshold; f.order_by_ordinal = 1; f.keymap = h->lists.keys;
+      f.out_keys = out.keys; f.out_scores = out.scores; f.out_idx = out.idx; f.out_counts = out.counts;
+      hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, f);
+    } else {
+      m.slot_len = stride;
+      m.keymap = h->lists.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;
+      hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
+    }
+    ZCHK(hipGetLastError());
+    ctx->q_nprobe = p.q_nprobe; ctx->q_scanned = p.q_scanned; ctx->last_count = count; ctx->last_list_count = nullptr;
+    return 0;
   }
 
   // 2. plan: list-major work items
@@ -66,11 +160,11 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     // (re-prepare the queries with the caller's RNN radius: the coarse pass ran without one)
     ZRET(prep_queries(ctx, h->lists, d_queries, count, threshold, stream));
     if (h->lists.f16)
-      hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->lists.base,
+      hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3(pkeys_score_blocks(count, maxlen)), dim3(256), 0, stream, h->lists.base,
                          ctx->qpad.as<float>(), h->lists.dpad, h->metric, d_pos, d_off, count, (uint32_t)maxlen,
                          ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
     else
-      hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->lists.base,
+      hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3(pkeys_score_blocks(count, maxlen)), dim3(256), 0, stream, h->lists.base,
                          ctx->qpad.as<float>(), h->lists.dpad, h->metric, d_pos, d_off, count, (uint32_t)maxlen,
                          ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
     ZCHK(hipGetLastError());
@@ -212,28 +306,31 @@ int host_search_wrap_begin(zvec_hip_ctx_s *ctx, const void *queries, size_t qbyt
     ZRET(ctx->io_ex.ensure(words * 8 + 8));
     ZCHK(hipMemcpyAsync(ctx->io_ex.p, exclude, words * 8, hipMemcpyHostToDevice, stream));
   }
-  ZRET(ctx->io_keys.ensure((size_t)count * topk * sizeof(uint64_t)));
-  ZRET(ctx->io_scores.ensure((size_t)count * topk * sizeof(float)));
-  ZRET(ctx->io_counts.ensure((size_t)count * sizeof(uint32_t)));
+  // keys | scores | counts in ONE device buffer (16-byte aligned parts): a single copy brings a result back
+  const size_t kb = (size_t)count * topk * sizeof(uint64_t), sb = ((size_t)count * topk * sizeof(float) + 15) & ~(size_t)15,
+               cb = (size_t)count * sizeof(uint32_t);
+  ZRET(ctx->io_out.ensure(kb + sb + cb));
+  ctx->io_keys.p = ctx->io_out.p;
+  ctx->io_scores.p = ctx->io_out.as<char>() + kb;
+  ctx->io_counts.p = ctx->io_out.as<char>() + kb + sb;
   return 0;
 }
 
 int host_search_wrap_end(zvec_hip_ctx_s *ctx, uint32_t count, uint32_t topk, uint64_t *out_keys, float *out_scores,
                          uint32_t *out_counts, hipStream_t stream) {
-  const size_t kb = (size_t)count * topk * sizeof(uint64_t), sb = (size_t)count * topk * sizeof(float), cb = (size_t)count * sizeof(uint32_t);
+  const size_t kb = (size_t)count * topk * sizeof(uint64_t), sbytes = (size_t)count * topk * sizeof(float),
+               sb = (sbytes + 15) & ~(size_t)15, cb = (size_t)count * sizeof(uint32_t);
   if (kb + sb + cb <= PIN_LIMIT && ctx->pin_out.ensure(kb + sb + cb) == 0) {
     char *h = static_cast<char *>(ctx->pin_out.p);
-    ZCHK(hipMemcpyAsync(h, ctx->io_keys.p, kb, hipMemcpyDeviceToHost, stream));
-    ZCHK(hipMemcpyAsync(h + kb, ctx->io_scores.p, sb, hipMemcpyDeviceToHost, stream));
-    ZCHK(hipMemcpyAsync(h + kb + sb, ctx->io_counts.p, cb, hipMemcpyDeviceToHost, stream));
+    ZCHK(hipMemcpyAsync(h, ctx->io_out.p, kb + sb + cb, hipMemcpyDeviceToHost, stream));
     ZCHK(hipStreamSynchronize(stream));
     memcpy(out_keys, h, kb);
-    memcpy(out_scores, h + kb, sb);
+    memcpy(out_scores, h + kb, sbytes);
     memcpy(out_counts, h + kb + sb, cb);
     return 0;
   }
   ZCHK(hipMemcpyAsync(out_keys, ctx->io_keys.p, kb, hipMemcpyDeviceToHost, stream));
-  ZCHK(hipMemcpyAsync(out_scores, ctx->io_scores.p, sb, hipMemcpyDeviceToHost, stream));
+  ZCHK(hipMemcpyAsync(out_scores, ctx->io_scores.p, sbytes, hipMemcpyDeviceToHost, stream));
   ZCHK(hipMemcpyAsync(out_counts, ctx->io_counts.p, cb, hipMemcpyDeviceToHost, stream));
   ZCHK(hipStreamSynchronize(stream));
   return 0;

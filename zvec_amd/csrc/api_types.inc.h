@@ -37,6 +37,12 @@ struct DevBuf {
   template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// a typed window into somebody else's device buffer
+struct DevView {
+  void *p = nullptr;
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 // pinned host staging (small transfers of the host-pointer entry points: a copy from / to pageable memory is staged
 // and synchronised by the runtime, a pinned one is a plain asynchronous DMA)
 struct PinnedBuf {
@@ -161,8 +167,10 @@ struct zvec_hip_ctx_s {
   DevBuf cmp_base, cmp_norm, cmp_extra, cmp_keys, cmp_pos, cmp_cnt;   // compacted keep-set (sparse filters)
   DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
   DevBuf plan;        // all u32 plan arrays
-  DevBuf io_q, io_ex, io_keys, io_scores, io_counts;   // staging for host-pointer entry points
+  DevBuf io_q, io_ex, io_out;                          // staging for host-pointer entry points
+  DevView io_keys, io_scores, io_counts;               // the result arrays inside io_out: ONE copy brings them back
   DevBuf grp_ws, grp_of, grp_out, grp_tab;
+  DevBuf direct_pos, direct_keys, direct_scores, direct_idx, direct_cnt;   // small-batch IVF route: positions, stage-1 lists
   DevBuf holes_ex;                                     // caller's exclude set OR the store's holes                      // group-by search: per-group bests / lists, group of every position, results
   PinnedBuf pin_in, pin_out;                           // (transfers up to PIN_LIMIT bytes go through pinned memory)
   DevBuf stats;       // per-launch {distinct_rows, pair_rows} u64 x PROFILE_MAX
@@ -219,6 +227,7 @@ struct zvec_hip_ivf_s {
   Store lists;    // inverted lists, each padded to whole tiles
   uint64_t count_local = 0, count_global = 0;
   std::vector<uint32_t> h_size, h_size_global, h_tile0;
+  std::vector<uint64_t> h_rows_of_largest;   // [i] = rows of the i largest local lists (bound of what i probes can scan)
   std::vector<uint64_t> h_dense0;      // local dense offsets (nlist+1)
   std::vector<uint64_t> h_row_ids;     // local dense position -> original row
   std::vector<char> h_centroids;       // [nlist][dim] in the index element type

@@ -25,6 +25,10 @@ struct MergeArgs {
   uint64_t packed_stride;
   float threshold;
   const uint32_t *bound_keys;    // optional [nq]: order-preserving key of an upper bound of each query's final k-th score
+  // 1: equal scores are ordered by the candidate's ORDINAL in the query's candidate stream (slot * slot_len + entry) instead
+  // of (slot, index): for streams that are already in scan order while their indices are not (the small-batch IVF route:
+  // positions of probed rows in probe order).  Only for part_keys == nullptr.
+  uint32_t order_by_ordinal;
   const uint64_t *keymap;        // position -> key (nullable => key = position)
   uint64_t *out_keys;            // [nq][k]
   float *out_scores;             // [nq][k]
@@ -58,7 +62,8 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
   // lane takes the minimum of its own strided elements; those are 64 distinct candidates, so the k-th
   // smallest of them is >= the k-th smallest of the whole row.  Cuts the insertions to the few elements
   // at or below that bound.
-  if (a.part_i == nullptr && a.part_keys == nullptr && a.part_counts == nullptr && k <= 64 && total >= 64 && nwaves == 1) {
+  if ((a.part_i == nullptr || (nslots == 1 && a.slot_stride == 1 && a.packed_stride == 0)) && a.part_keys == nullptr &&
+      a.part_counts == nullptr && k <= 64 && total >= 64 && nwaves == 1) {
     float mn = __builtin_inff();
     for (uint64_t base = 0; base < total; base += 64 * U) {
       float v[U];
@@ -156,7 +161,7 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
             }
             sv[u] = valid ? sc : __builtin_inff();      // (+inf never passes: tau <= FLT_MAX)
             iv[u] = idx;
-            jv[u] = j;
+            jv[u] = a.order_by_ordinal ? e : j;
           }
         }
 #pragma unroll
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
             if (in && pos < GATHER) {
               uint32_t sj = jv[u], si = iv[u];
               if constexpr (LINEAR) {                // survivors only: which slot, which stored position
-                sj = iv[u] / sl;
+                sj = a.order_by_ordinal ? iv[u] : iv[u] / sl;
                 si = a.part_i[(size_t)sb * sl + iv[u]];
               }
               surv_hi[pos] = ((unsigned long long)fkey(sv[u] + 0.f) << 32) | sj;
@@ -301,7 +306,7 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
       }
       sv[u] = valid ? s : __builtin_inff();
       iv[u] = idx;
-      jv[u] = j;
+      jv[u] = a.order_by_ordinal ? (uint32_t)e : j;
       vv[u] = valid;
     }
 #pragma unroll

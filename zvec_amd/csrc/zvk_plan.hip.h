@@ -136,6 +136,66 @@ __global__ void __launch_bounds__(256) ivf_expand_kernel(const PlanArgs p, const
   if (!FILL && lane == 0) q_rows[q] = rows;
 }
 
+// Small-batch route of the IVF search (a handful of queries: the list-major tile scan would run a few hundred work items
+// whose k-steps are a chain of dependent HBM round trips): block (rank, query) evaluates the probe rule of plan_wave_kernel
+// for its query (one lane per probe rank, prefix sums of the list sizes) and, if its rank is probed, writes the padded
+// positions of that list's rows into the query's fixed-stride slice pos[q * stride ...] (excluded rows as IDX_NONE; the
+// slice is pre-set to IDX_NONE).  Block rank 0 also writes the slice bounds for pkeys_score_kernel (off[q] = q * stride)
+// and the per-query statistics the tile path reports (lists probed, rows scanned).
+__global__ void __launch_bounds__(256) ivf_expand_direct_kernel(const PlanArgs p, const uint32_t *list_tile0, const uint64_t *list_dense0,
+                                                                const uint32_t *exclude, uint32_t stride, uint32_t *off, uint32_t *pos) {
+  __shared__ uint32_t sh[4];                     // my list, my offset, probed?, (unused)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t q = blockIdx.y, mine = blockIdx.x;
+  const uint32_t np = min(p.coarse_cnt[q], p.nprobe);
+  if (tid < 64) {
+    uint32_t before_g = 0, before_l = 0, probes = 0, scanned = 0;    // uniform carries across 64-rank passes
+    uint32_t my_l = 0, my_o = 0, my_p = 0;
+    for (uint32_t r0 = 0; r0 < np; r0 += 64) {
+      const uint32_t rnk = r0 + lane;
+      const bool in = rnk < np;
+      const uint32_t l = in ? probe_list(p, q, rnk) : 0;
+      const uint32_t szg = in ? p.list_size_global[l] : 0;
+      const uint32_t incl_g = wave_incl_scan(szg, lane);
+      const bool probed = in && (before_g + incl_g - szg) < p.max_scan_count;
+      const uint32_t szl = probed ? p.list_size[l] : 0;
+      const uint32_t incl_l = wave_incl_scan(szl, lane);
+      if (mine >= r0 && mine < r0 + 64) {
+        const int ml = (int)(mine - r0);
+        my_l = __shfl(l, ml);
+        my_o = before_l + __shfl(incl_l - szl, ml);
+        my_p = __shfl((uint32_t)probed, ml);
+      }
+      probes += (uint32_t)__popcll(__ballot(probed));
+      scanned += __shfl(wave_incl_scan(probed ? szg : 0, lane), 63);
+      before_g += __shfl(incl_g, 63);
+      before_l += __shfl(incl_l, 63);
+      if (before_g >= p.max_scan_count) break;   // uniform: no later rank is probed
+    }
+    if (lane == 0) {
+      sh[0] = my_l; sh[1] = my_o; sh[2] = (mine < np) ? my_p : 0u;
+      if (mine == 0) {
+        p.q_nprobe[q] = probes;
+        p.q_scanned[q] = scanned;
+        off[q] = q * stride;
+        if (q == p.nq - 1) off[p.nq] = p.nq * stride;
+      }
+    }
+  }
+  __syncthreads();
+  if (!sh[2]) return;
+  const uint32_t l = sh[0], o = sh[1];
+  const uint32_t sz = min(p.list_size[l], stride > o ? stride - o : 0u);   // (stride bounds the rows of any probe set)
+  const uint32_t p0 = list_tile0[l] * TILE_N;
+  const uint64_t d0 = list_dense0[l];
+  uint32_t *dst = pos + (size_t)q * stride + o;
+  for (uint32_t j = tid; j < sz; j += 256) {
+    bool ex = false;
+    if (exclude) { const uint64_t d = d0 + j; ex = (exclude[d >> 5] >> (d & 31)) & 1u; }
+    dst[j] = ex ? IDX_NONE : p0 + j;
+  }
+}
+
 // single work-group exclusive scans: slot_begin over queries, list_qoff / item_off over lists
 __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
   __shared__ uint32_t wtot[16];
