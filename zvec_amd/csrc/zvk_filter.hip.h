@@ -203,41 +203,6 @@ __global__ void __launch_bounds__(256) compact_rows_kernel(const float *src, con
   }
 }
 
-// direct distance of one stored row against one prepared query row, a whole wave per pair: lane-strided over the row's
-// 16-byte chunks (4 floats / 8 halves of consecutive dimensions: one chunk of the blocked layout, see blocked_offset), so a
-// 768-d fp32 row is three independent 16-byte loads per lane; per-lane partial sums, then a butterfly
-template <bool F16>
-__device__ __forceinline__ float wave_row_distance(const float *base, uint32_t pos, const float *qrow, uint32_t dpadw, int metric, int lane) {
-  const uint32_t tile = pos >> 7, r = pos & 127, swz = (r >> 1) & 7;
-  const float *trow = base + (size_t)tile * TILE_N * dpadw + (size_t)(r * 8) * 4;
-  const uint32_t nchunks = dpadw >> 2;
-  float acc = 0.f;
-  for (uint32_t id = lane; id < nchunks; id += 64) {
-    const uint32_t ks = id >> 3, c = id & 7;
-    const f32x4 bv = *reinterpret_cast<const f32x4 *>(trow + (size_t)ks * SLAB + (size_t)((c ^ swz) * 4));
-    const f32x4 qv = *reinterpret_cast<const f32x4 *>(qrow + (size_t)ks * TILE_K + c * 4);
-    if constexpr (F16) {
-      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-      const h8 bh = __builtin_bit_cast(h8, bv), qh = __builtin_bit_cast(h8, qv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float x = (float)qh[e], b = (float)bh[e];
-        if (metric == METRIC_L2) { const float d = x - b; acc = fmaf(d, d, acc); }
-        else acc = fmaf(x, b, acc);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (metric == METRIC_L2) { const float d = qv[e] - bv[e]; acc = fmaf(d, d, acc); }
-        else acc = fmaf(qv[e], bv[e], acc);
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
-  return (metric == METRIC_L2) ? acc : (metric == METRIC_IP ? -acc : 1.f - acc);
-}
-
 // ---------------------------------------------------------------------------------------------
 // brute force by primary keys (FlatStreamer::search_bf_by_p_keys_impl, flat_streamer.cc:346-389): every
 // query comes with its own short list of storage positions; one wave scores one (query, position) pair

@@ -196,6 +196,41 @@ __global__ void scatter_keys_kernel(uint64_t *keys, const uint64_t *dst_pos, con
 // bitset widening is not needed: the API bitset is uint64 words, bit i of word i/64 == bit (i&31) of
 // 32-bit word i/32 on a little-endian host/device, so the kernel reads it as uint32 words directly.
 
+// direct distance of one stored row against one prepared query row, a whole wave per pair: lane-strided over the row's
+// 16-byte chunks (4 floats / 8 halves of consecutive dimensions: one chunk of the blocked layout, see blocked_offset), so a
+// 768-d fp32 row is three independent 16-byte loads per lane; per-lane partial sums, then a butterfly
+template <bool F16>
+__device__ __forceinline__ float wave_row_distance(const float *base, uint32_t pos, const float *qrow, uint32_t dpadw, int metric, int lane) {
+  const uint32_t tile = pos >> 7, r = pos & 127, swz = (r >> 1) & 7;
+  const float *trow = base + (size_t)tile * TILE_N * dpadw + (size_t)(r * 8) * 4;
+  const uint32_t nchunks = dpadw >> 2;
+  float acc = 0.f;
+  for (uint32_t id = lane; id < nchunks; id += 64) {
+    const uint32_t ks = id >> 3, c = id & 7;
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(trow + (size_t)ks * SLAB + (size_t)((c ^ swz) * 4));
+    const f32x4 qv = *reinterpret_cast<const f32x4 *>(qrow + (size_t)ks * TILE_K + c * 4);
+    if constexpr (F16) {
+      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+      const h8 bh = __builtin_bit_cast(h8, bv), qh = __builtin_bit_cast(h8, qv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = (float)qh[e], b = (float)bh[e];
+        if (metric == METRIC_L2) { const float d = x - b; acc = fmaf(d, d, acc); }
+        else acc = fmaf(x, b, acc);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (metric == METRIC_L2) { const float d = qv[e] - bv[e]; acc = fmaf(d, d, acc); }
+        else acc = fmaf(qv[e], bv[e], acc);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  return (metric == METRIC_L2) ? acc : (metric == METRIC_IP ? -acc : 1.f - acc);
+}
+
 // ---------------------------------------------------------------------------------------------
 // L2 refinement of the final lists.  The scan forms squared distances as |q|^2 + |b|^2 - 2 q.b on the
 // matrix cores, whose rounding error scales with the NORMS; the reference sums (q-b)^2 directly
@@ -215,18 +250,9 @@ __global__ void __launch_bounds__(256) rescore_l2_kernel(const float *base, cons
   const uint32_t r = (uint32_t)(w / k), j = (uint32_t)(w - (uint64_t)r * k);
   if (j >= counts[r]) return;
   const uint32_t q = r / rows_per_query;
-  const uint32_t id = idx[w];
-  const uint32_t nelem = dpadw * (F16 ? 2u : 1u);
-  float acc = 0.f;
-  for (uint32_t c = lane; c < nelem; c += 64) {
-    float x;
-    if constexpr (F16) x = (float)reinterpret_cast<const _Float16 *>(queries)[(size_t)q * nelem + c];
-    else x = queries[(size_t)q * dpadw + c];
-    const float d = x - load_elem<F16>(base, id, c, dpadw);
-    acc = fmaf(d, d, acc);
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  // the same summation as the small-batch route's direct scores (wave_row_distance): a document's L2 score does not depend
+  // on the route that found it
+  const float acc = wave_row_distance<F16>(base, idx[w], queries + (size_t)q * dpadw, dpadw, METRIC_L2, lane);
   if (lane == 0) scores[w] = acc;
 }
 
