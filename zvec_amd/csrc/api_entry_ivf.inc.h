@@ -230,6 +230,14 @@ static int ivf_end_lists(zvec_hip_ivf_s *h) {
   ZCHK(hipMemcpy(h->d_tile0, h->h_tile0.data(), nlist * 4, hipMemcpyHostToDevice));
   ZCHK(hipMemcpy(h->d_dense0, h->h_dense0.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
   h->filling = false;
+  // rows of the i largest local lists: the bound of what i probes can scan (small-batch route); computed here, once,
+  // because searches on different contexts read it concurrently
+  {
+    std::vector<uint32_t> sz(h->h_size);
+    std::sort(sz.begin(), sz.end(), std::greater<uint32_t>());
+    h->h_rows_of_largest.assign((size_t)h->nlist + 1, 0);
+    for (uint32_t i = 0; i < h->nlist; ++i) h->h_rows_of_largest[i + 1] = h->h_rows_of_largest[i] + sz[i];
+  }
   h->loaded = true;
   return 0;
 }

@@ -16,13 +16,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   // A handful of queries (the product's count = 1 calls): both steps go wave-per-row instead of through the MFMA tile
   // kernels, whose few work items would each be a chain of dependent HBM round trips (1 query, 2M x 768, nprobe 32:
   // coarse 90 us + list scan 113 us for 6 + 96 MB).  Bound of the rows one query can scan: the nprobe largest lists.
-  if (h->h_rows_of_largest.size() != (size_t)nlist + 1) {
-    std::vector<uint32_t> sz(h->h_size);
-    std::sort(sz.begin(), sz.end(), std::greater<uint32_t>());
-    h->h_rows_of_largest.assign((size_t)nlist + 1, 0);
-    for (uint32_t i = 0; i < nlist; ++i) h->h_rows_of_largest[i + 1] = h->h_rows_of_largest[i] + sz[i];
-  }
-  const uint64_t direct_rows = std::max<uint64_t>(1, h->h_rows_of_largest[nprobe]);
+  const uint64_t direct_rows = h->h_rows_of_largest.size() > nprobe ? std::max<uint64_t>(1, h->h_rows_of_largest[nprobe]) : ~0ull;
   // (measured, 2M x 768 fp32, nprobe 32 of 2048 lists, host-pointer calls: 1 query 223 -> 116 us, 2: 244 -> 153, 4: 290 -> 222,
   // 8: 390 -> 369, 16: 586 -> 655 — the direct route costs the same for every query, the tile route shares the lists)
   const bool direct = !brute_force && count <= (uint32_t)knobs().ivf_direct_q && (uint64_t)count * direct_rows <= (4u << 20) &&
