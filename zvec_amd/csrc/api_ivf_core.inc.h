@@ -70,10 +70,16 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     ZRET(ctx->direct_pos.ensure(pairs * 4));
     ZRET(ctx->part_s.ensure(pairs * 4));
     ZRET(ctx->part_i.ensure(pairs * 4));
+    if (ctx->profile && ctx->nprof < PROFILE_MAX && ctx->stats.p) {       // the slot prof_begin will take for this launch
+      p.work_stats = ctx->stats.as<unsigned long long>() + 2 * (size_t)ctx->nprof;
+      ZCHK(hipMemsetAsync(p.work_stats, 0, 16, stream));
+    }
     ZCHK(hipMemsetAsync(ctx->direct_pos.p, 0xff, pairs * 4, stream));     // IDX_NONE everywhere; the probed rows overwrite it
     hipLaunchKernelGGL(ivf_expand_direct_kernel, dim3(nprobe, count), dim3(256), 0, stream, p, h->d_tile0, h->d_dense0,
                        reinterpret_cast<const uint32_t *>(d_exclude), stride, d_off, ctx->direct_pos.as<uint32_t>());
     gate_enter(ctx, stream);                                              // (the radius is applied by the selection)
+    const int pi = prof_begin(ctx, stream, (double)count * h->lists.dscan * h->lists.elem + (double)count * topk * 12.0, 0, 1);
+    if (pi >= 0) ctx->prof_dscan[pi] = h->lists.dscan | (h->lists.f16 ? 0x80000000u : 0u);
     if (h->lists.f16)
       hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3(pkeys_score_blocks(count, stride)), dim3(256), 0, stream, h->lists.base,
                          ctx->qpad.as<float>(), h->lists.dpad, h->metric, ctx->direct_pos.as<uint32_t>(), d_off, count, stride,
@@ -82,6 +88,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
       hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3(pkeys_score_blocks(count, stride)), dim3(256), 0, stream, h->lists.base,
                          ctx->qpad.as<float>(), h->lists.dpad, h->metric, ctx->direct_pos.as<uint32_t>(), d_off, count, stride,
                          ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
+    prof_end(ctx, stream, pi);
     gate_leave(ctx, stream);
     ZCHK(hipGetLastError());
     // equal scores keep the reference's order — probe rank, then position in the list — which here is the ORDER of the

@@ -179,6 +179,10 @@ __global__ void __launch_bounds__(256) ivf_expand_direct_kernel(const PlanArgs p
         p.q_scanned[q] = scanned;
         off[q] = q * stride;
         if (q == p.nq - 1) off[p.nq] = p.nq * stride;
+        if (p.work_stats) {                      // measurement hook: rows this launch scores (no list is shared here)
+          atomicAdd(&p.work_stats[0], (unsigned long long)before_l);
+          atomicAdd(&p.work_stats[1], (unsigned long long)before_l);
+        }
       }
     }
   }
