@@ -307,6 +307,7 @@ def main():
         lo, hi = flat_row_range(n, rank, world)
         if ngt:
             flat = zvec_amd.HipFlatSearcher(dim, flat_metric, device=local_rank, dtype=dtype)
+            zvec_amd._lib.check(flat.reserve(hi - lo), "flat reserve")      # no growth copies: at 100M x 768 fp16 the rows are 154 GB
         t1 = time.time()
         for o, x in corpus_chunks(torch, n, dim, dev, SEED, proj, tdtype):
             m = x.shape[0]
