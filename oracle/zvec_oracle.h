@@ -10,7 +10,7 @@
  * against the reference's own sources compiled by oracle/Makefile into oracle/_ref/
  * (src/ailego/math/{euclidean_distance,inner_product}_matrix_fp32.cc, norm2_matrix_fp32.cc,
  * normalizer.cc, src/include/zvec/ailego/container/heap.h) and against the known-answer values
- * of the reference's unit tests (tests/golden/*.json).  The scan loops (flat, IVF) are pinned by
+ * of the reference's unit tests (the .json files under tests/golden/).  The scan loops (flat, IVF) are pinned by
  * the reference's structured-data tests (flat_streamer_test.cc:104-178,731-801,
  * ivf_searcher_test.cc:200-321).  The full reference FlatSearcher/IVFSearcher classes are
  * unbuildable here without stand-ins (IndexStorage::MemoryBlock needs ailego::BufferHandle, whose

@@ -320,7 +320,6 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   }
   if (st.n == 0) {
     // no rows: empty results
-    MergeArgs m{};
     ZCHK(hipMemsetAsync(out.counts, 0, sizeof(uint32_t) * count, stream));
     ZCHK(hipMemsetAsync(out.keys, 0xff, sizeof(uint64_t) * (size_t)count * topk, stream));
     return 0;
