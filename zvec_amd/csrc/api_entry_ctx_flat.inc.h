@@ -91,6 +91,9 @@ int zvec_hip_flat_destroy(zvec_hip_flat_t h) {
   (void)hipDeviceSynchronize();
   h->st.release();
   h->d_holes.release();
+  h->ring.release();
+  for (uint32_t i = 0; i < zvec_hip_flat_s::RING / zvec_hip_flat_s::RING_GROUP; ++i)
+    if (h->ring_used[i]) (void)hipEventDestroy(h->ring_ev[i]);
   if (h->append_ev) (void)hipEventDestroy(h->append_ev);
   ctx_free(h->defctx);
   delete h;
@@ -118,21 +121,73 @@ static int flat_holes_cover(zvec_hip_flat_s *h, hipStream_t s) {
   return 0;
 }
 
+// a pinned slot for a tiny add: rows at *rows, keys at *keys (device-visible host memory).  Slots are handed out in
+// order; the event of a group of RING_GROUP slots is recorded behind the kernel that reads the group's last slot and
+// waited for before the group's first slot is written again — by then it is RING - RING_GROUP adds old.
+static int flat_ring_slot(zvec_hip_flat_s *h, char **rows, uint64_t **keys, uint32_t *slot) {
+  const size_t rb = h->st.row_bytes();
+  if (!h->ring.p) {
+    h->ring_slot_bytes = (zvec_hip_flat_s::FAST_ROWS * (rb + 8) + 63) & ~(size_t)63;
+    ZRET(h->ring.ensure(h->ring_slot_bytes * zvec_hip_flat_s::RING));
+  }
+  const uint32_t sl = h->ring_next++ % zvec_hip_flat_s::RING;
+  const uint32_t grp = sl / zvec_hip_flat_s::RING_GROUP;
+  if (sl % zvec_hip_flat_s::RING_GROUP == 0 && h->ring_used[grp]) ZCHK(hipEventSynchronize(h->ring_ev[grp]));
+  *rows = static_cast<char *>(h->ring.p) + (size_t)sl * h->ring_slot_bytes;
+  *keys = reinterpret_cast<uint64_t *>(*rows + zvec_hip_flat_s::FAST_ROWS * rb);
+  *slot = sl;
+  return 0;
+}
+// an asynchronous mutation has been enqueued on `s`: note it for the readers (flat_wait_appends); slot = the ring slot
+// its kernels read, or ~0u
+static int flat_publish_async(zvec_hip_flat_s *h, uint32_t slot, hipStream_t s) {
+  if (slot != ~0u && slot % zvec_hip_flat_s::RING_GROUP == zvec_hip_flat_s::RING_GROUP - 1) {
+    const uint32_t grp = slot / zvec_hip_flat_s::RING_GROUP;
+    if (!h->ring_used[grp]) ZCHK(hipEventCreateWithFlags(&h->ring_ev[grp], hipEventDisableTiming));
+    h->ring_used[grp] = true;
+    ZCHK(hipEventRecord(h->ring_ev[grp], s));
+  }
+  h->append_stream = s;
+  h->append_pending = true;
+  h->append_dirty = true;
+  return 0;
+}
+// a mutation is about to be enqueued on `s`: it must follow the ones enqueued on another stream (caller holds rw exclusively)
+static int flat_order_after_appends(zvec_hip_flat_s *h, hipStream_t s) {
+  if (!h->append_pending || h->append_stream == s) return 0;
+  if (!h->append_ev) ZCHK(hipEventCreateWithFlags(&h->append_ev, hipEventDisableTiming));
+  if (h->append_dirty) { ZCHK(hipEventRecord(h->append_ev, h->append_stream)); h->append_dirty = false; }
+  ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));
+  return 0;
+}
+// a reader is about to enqueue work on `s` (caller holds rw shared): see zvec_hip_flat_s::append_ev
+static int flat_wait_appends(zvec_hip_flat_s *h, hipStream_t s) {
+  if (!h->append_pending || h->append_stream == s) return 0;
+  {
+    std::lock_guard<std::mutex> g(h->ev_mu);
+    if (!h->append_ev) ZCHK(hipEventCreateWithFlags(&h->append_ev, hipEventDisableTiming));
+    if (h->append_dirty) { ZCHK(hipEventRecord(h->append_ev, h->append_stream)); h->append_dirty = false; }
+  }
+  ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));
+  return 0;
+}
+
 int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n, const uint64_t *d_keys, void *stream) {
   if (!h || (!d_vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
   std::unique_lock<FairSharedMutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(h->defctx, stream);
-  if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));   // (an earlier append on another stream)
+  ZRET(flat_order_after_appends(h, s));                                    // (an earlier append on another stream)
   int rc = store_append_dev(h->st, d_vecs, n, d_keys, s);
   if (rc == 0) rc = flat_holes_cover(h, s);
-  if (rc == 0 && n) {
-    // the row count is published now, the pack kernels are only enqueued on `s`: searches on other streams wait for
-    // this event before they read the store (flat_search_dev_locked)
+  // the row count is published now, the pack kernel is only enqueued on `s`: readers on other streams wait for it
+  if (rc == 0 && n) rc = flat_publish_async(h, ~0u, s);
+  if (rc == 0 && n && s != h->defctx->own) {
+    // the caller's stream may not outlive this call: its event is recorded now, not when a reader first needs it
     if (!h->append_ev) ZCHK(hipEventCreateWithFlags(&h->append_ev, hipEventDisableTiming));
     ZCHK(hipEventRecord(h->append_ev, s));
-    h->append_pending = true;
+    h->append_dirty = false;
   }
   return rc;
 }
@@ -182,8 +237,21 @@ int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const 
   std::unique_lock<FairSharedMutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
-  // stage through the device in slices of <= 1 GiB
   const size_t rb = h->st.row_bytes();
+  if (n <= zvec_hip_flat_s::FAST_ROWS) {              // a document at a time: pinned ring, nothing to wait for
+    char *prow = nullptr;
+    uint64_t *pkey = nullptr;
+    uint32_t slot = 0;
+    ZRET(flat_ring_slot(h, &prow, &pkey, &slot));
+    memcpy(prow, vecs, (size_t)n * rb);
+    if (keys) memcpy(pkey, keys, (size_t)n * 8);
+    ZRET(flat_order_after_appends(h, s));
+    int rc = store_append_dev(h->st, prow, n, keys ? pkey : nullptr, s);
+    if (rc == 0) rc = flat_holes_cover(h, s);
+    if (rc == 0) rc = flat_publish_async(h, slot, s);
+    return rc;
+  }
+  // stage through the device in slices of <= 1 GiB
   const uint64_t rows_per = std::max<uint64_t>(1, ((uint64_t)1 << 30) / (uint64_t)rb);
   DevBuf tmp, tk;
   for (uint64_t o = 0; o < n; o += rows_per) {
@@ -219,16 +287,33 @@ int zvec_hip_flat_put(zvec_hip_flat_t h, const uint32_t *ids, uint64_t n, const 
   Store &st = h->st;
   const size_t rb = st.row_bytes();
   const uint64_t rows_per = std::max<uint64_t>(1, ((uint64_t)1 << 28) / (uint64_t)rb);
-  Scoped<char> tmp, zero;
-  Scoped<uint64_t> tk;
-  ZRET(tmp.alloc((size_t)std::min<uint64_t>(n, rows_per) * rb));
-  if (keys) ZRET(tk.alloc(std::min<uint64_t>(n, rows_per)));
+  // a document at a time (the product's ingest): the rows are read in place from a pinned ring slot, nothing is allocated
+  // and nothing waited for; larger calls are staged through a device buffer
+  const bool fast = n <= zvec_hip_flat_s::FAST_ROWS;
+  Scoped<char> tmp_buf, zero;
+  Scoped<uint64_t> tk_buf;
+  char *tmp = nullptr;
+  uint64_t *tk = nullptr;
+  uint32_t slot = 0;
+  if (fast) {
+    ZRET(flat_ring_slot(h, &tmp, &tk, &slot));
+    memcpy(tmp, vecs, (size_t)n * rb);
+    if (keys) memcpy(tk, keys, (size_t)n * 8);
+    ZRET(flat_order_after_appends(h, s));
+  } else {
+    ZRET(tmp_buf.alloc((size_t)std::min<uint64_t>(n, rows_per) * rb));
+    if (keys) ZRET(tk_buf.alloc(std::min<uint64_t>(n, rows_per)));
+    tmp = tmp_buf;
+    tk = tk_buf;
+  }
   uint64_t lo = ~0ull, hi = 0;                    // hole words touched
   auto touch = [&](uint64_t pos) { lo = std::min(lo, pos >> 6); hi = std::max(hi, pos >> 6); };
   for (uint64_t o = 0; o < n; o += rows_per) {
     const uint64_t m = std::min(rows_per, n - o);
-    ZCHK(hipMemcpyAsync(tmp, static_cast<const char *>(vecs) + (size_t)o * rb, (size_t)m * rb, hipMemcpyHostToDevice, s));
-    if (keys) ZCHK(hipMemcpyAsync(tk, keys + o, (size_t)m * 8, hipMemcpyHostToDevice, s));
+    if (!fast) {
+      ZCHK(hipMemcpyAsync(tmp, static_cast<const char *>(vecs) + (size_t)o * rb, (size_t)m * rb, hipMemcpyHostToDevice, s));
+      if (keys) ZCHK(hipMemcpyAsync(tk, keys + o, (size_t)m * 8, hipMemcpyHostToDevice, s));
+    }
     for (uint64_t i = 0; i < m;) {
       const uint64_t id = ids[o + i];
       if (id > st.n) {                            // pad the gap with holes
@@ -252,19 +337,17 @@ int zvec_hip_flat_put(zvec_hip_flat_t h, const uint32_t *ids, uint64_t n, const 
       if (id == st.n) {                           // a run of consecutive new ids is one append (key = position)
         uint64_t j = i + 1;
         while (j < m && ids[o + j] == ids[o + j - 1] + 1u) ++j;
-        ZRET(store_append_dev(st, static_cast<char *>(tmp) + (size_t)i * rb, j - i, keys ? static_cast<uint64_t *>(tk) + i : nullptr, s));
+        ZRET(store_append_dev(st, tmp + (size_t)i * rb, j - i, keys ? tk + i : nullptr, s));
         i = j;
       } else {                                    // overwrite in place
-        ZRET(launch_pack(st, static_cast<char *>(tmp) + (size_t)i * rb, 1, nullptr, id, nullptr, s));
-        hipLaunchKernelGGL(fill_keys_kernel, dim3(1), dim3(64), 0, s, st.keys, id, (uint64_t)1,
-                           keys ? static_cast<const uint64_t *>(tk) + i : (const uint64_t *)nullptr);
-        ZCHK(hipGetLastError());
+        ZRET(launch_pack(st, tmp + (size_t)i * rb, 1, nullptr, id, nullptr, s, st.keys, keys ? tk + i : nullptr));
         if (h->is_hole(id)) { h->h_holes[id >> 6] &= ~(1ull << (id & 63)); h->nholes -= 1; touch(id); }
         ++i;
       }
     }
-    ZCHK(hipStreamSynchronize(s));
+    if (!fast) ZCHK(hipStreamSynchronize(s));
   }
+  if (fast) ZRET(flat_publish_async(h, slot, s));
   // device copy of the hole bits: everything after a reallocation, else the words that changed
   const uint64_t words = (st.n + 63) / 64 + 1;
   h->h_holes.resize(words, 0);
@@ -274,9 +357,11 @@ int zvec_hip_flat_put(zvec_hip_flat_t h, const uint32_t *ids, uint64_t n, const 
       ZCHK(hipMemsetAsync(h->d_holes.p, 0, h->d_holes.cap, s));
       lo = 0; hi = words - 1;
     }
-    if (lo <= hi && lo != ~0ull)
+    if (lo <= hi && lo != ~0ull) {
       ZCHK(hipMemcpyAsync(h->d_holes.as<uint64_t>() + lo, h->h_holes.data() + lo, (size_t)(std::min(hi, words - 1) - lo + 1) * 8, hipMemcpyHostToDevice, s));
-    ZCHK(hipStreamSynchronize(s));
+      ZCHK(hipStreamSynchronize(s));             // (h_holes is pageable and may be resized by the next call)
+      if (fast) ZRET(flat_publish_async(h, slot, s));
+    }
   }
   return 0;
 }
@@ -301,7 +386,7 @@ int zvec_hip_flat_get_vector(zvec_hip_flat_t h, uint64_t pos, void *out) {
   std::shared_lock<FairSharedMutex> r(h->rw);
   if (pos >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
   ZCHK(hipSetDevice(h->device));
-  if (h->append_pending) ZCHK(hipStreamWaitEvent(c->own, h->append_ev, 0));
+  ZRET(flat_wait_appends(h, c->own));
   ZRET(c->io_q.ensure(h->st.row_bytes()));
   ZRET(launch_unpack(h->st, pos, c->io_q.p, c->own));
   ZCHK(hipMemcpyAsync(out, c->io_q.p, h->st.row_bytes(), hipMemcpyDeviceToHost, c->own));
@@ -320,7 +405,7 @@ int zvec_hip_flat_get_vectors(zvec_hip_flat_t h, const uint64_t *positions, uint
   for (uint64_t p : pos)
     if (p >= h->st.n) return ZVEC_HIP_ERR_NO_EXIST;
   ZCHK(hipSetDevice(h->device));
-  if (h->append_pending) ZCHK(hipStreamWaitEvent(h->defctx->own, h->append_ev, 0));
+  ZRET(flat_wait_appends(h, h->defctx->own));
   return store_get_rows(h->defctx, h->st, pos, out);
 }
 
@@ -343,7 +428,7 @@ static int flat_search_dev_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, const v
                                   float threshold, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys, float *d_out_scores,
                                   uint32_t *d_out_counts, hipStream_t s) {
   // rows appended through the asynchronous device-pointer form may still be in flight on another stream
-  if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));
+  ZRET(flat_wait_appends(h, s));
   ZRET(flat_effective_exclude(h, c, d_exclude_bitset, s, &d_exclude_bitset));
   // the kernels address the padded query matrix with 32-bit word offsets: very large batches go in slices
   const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(h->st.dpad, 1u));
@@ -404,7 +489,7 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = c->cur;
   const Store &st = h->st;
-  if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));
+  ZRET(flat_wait_appends(h, s));
   // host-side sanitising: positions out of range or excluded by the filter bitset become holes
   const uint32_t total = offsets[count];
   uint32_t maxlen = 1;
@@ -460,7 +545,7 @@ int zvec_hip_flat_batch_distance(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const vo
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = c->cur;
   const Store &st = h->st;
-  if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));
+  ZRET(flat_wait_appends(h, s));
   std::vector<uint32_t> clean(positions, positions + n);
   for (auto &p : clean) if (p >= st.n) p = IDX_NONE;
   const uint32_t offs[2] = {0, n};

@@ -227,7 +227,7 @@ extern "C" int zvec_hip_flat_build_filter(zvec_hip_flat_t h, zvec_hip_ctx_t ctx,
   std::shared_lock<FairSharedMutex> r(h->rw);
   if (h->append_pending) {
     ZCHK(hipSetDevice(h->device));
-    ZCHK(hipStreamWaitEvent(stream ? reinterpret_cast<hipStream_t>(stream) : c->cur, h->append_ev, 0));
+    ZRET(flat_wait_appends(h, stream ? reinterpret_cast<hipStream_t>(stream) : c->cur));
   }
   return build_filter(c, h->device, h->st.keys, h->st.n, nullptr, nullptr, 0, filter, out_words,
                       out_on_device, stream);

@@ -130,7 +130,7 @@ int zvec_hip_flat_search_grouped(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const vo
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = c->cur;
   const Store &st = h->st;
-  if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));
+  ZRET(flat_wait_appends(h, s));
   GroupOut o{};
   ZRET(group_outputs(c, count, group_num, group_topk, &o));
   if (st.n == 0) {                                       // empty index: no groups
@@ -176,7 +176,7 @@ int zvec_hip_flat_search_grouped_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, c
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = c->cur;
   const Store &st = h->st;
-  if (h->append_pending) ZCHK(hipStreamWaitEvent(s, h->append_ev, 0));
+  ZRET(flat_wait_appends(h, s));
   const uint32_t total = offsets[count];
   uint32_t maxlen = 1;
   for (uint32_t q = 0; q < count; ++q) {

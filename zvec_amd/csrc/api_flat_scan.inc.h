@@ -542,13 +542,13 @@ int prep_queries(zvec_hip_ctx_s *ctx, const Store &st, const void *d_queries, ui
 }
 
 int launch_pack(const Store &st, const void *d_rows, uint64_t n, const uint64_t *d_src, uint64_t pos0,
-                const uint64_t *d_dst, hipStream_t stream) {
+                const uint64_t *d_dst, hipStream_t stream, uint64_t *keys_out = nullptr, const uint64_t *key_src = nullptr) {
   if (st.f16)
     hipLaunchKernelGGL(pack_rows_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_rows, n, st.dim_in,
-                       st.dscan, st.dpad, d_src, pos0, d_dst, st.base, st.bnorm, st.extra);
+                       st.dscan, st.dpad, d_src, pos0, d_dst, st.base, st.bnorm, st.extra, keys_out, key_src);
   else
     hipLaunchKernelGGL(pack_rows_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_rows, n, st.dim_in,
-                       st.dscan, st.dpad, d_src, pos0, d_dst, st.base, st.bnorm, st.extra);
+                       st.dscan, st.dpad, d_src, pos0, d_dst, st.base, st.bnorm, st.extra, keys_out, key_src);
   ZCHK(hipGetLastError());
   return 0;
 }
@@ -585,10 +585,7 @@ int store_append_dev(Store &st, const void *d_vecs, uint64_t n, const uint64_t *
   if (n == 0) return 0;
   if (st.n + n >= 0xfffffff0ull) return ZVEC_HIP_ERR_OUT_OF_RANGE;   // positions are 32-bit (IDX_NONE reserved)
   ZRET(st.reserve(st.n + n, stream));
-  ZRET(launch_pack(st, d_vecs, n, nullptr, st.n, nullptr, stream));
-  ZCHK(hipGetLastError());
-  hipLaunchKernelGGL(fill_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st.keys, st.n, n, d_keys);
-  ZCHK(hipGetLastError());
+  ZRET(launch_pack(st, d_vecs, n, nullptr, st.n, nullptr, stream, st.keys, d_keys));    // rows, norms and keys in one launch
   st.n += n;
   return 0;
 }

@@ -200,14 +200,29 @@ struct zvec_hip_flat_s {
   FairSharedMutex rw;
   // zvec_hip_flat_append_dev returns with its pack kernels only enqueued: recorded after them on the append stream,
   // waited for by every reader of the store on its own stream
+  // asynchronous mutations (append_dev, single-document adds): `append_stream` carries kernels that are only enqueued.
+  // A reader on ANOTHER stream makes its stream wait for them: it records append_ev behind them if nobody has since
+  // the last mutation (append_dirty, under ev_mu — readers run concurrently) and waits for the event; a reader on the
+  // same stream is ordered by the stream.  Writers hold `rw` exclusively, so these fields do not move under a reader.
   hipEvent_t append_ev = nullptr;
   bool append_pending = false;
+  bool append_dirty = false;
+  hipStream_t append_stream = nullptr;
+  std::mutex ev_mu;
   // add-with-id gaps (FlatStreamerEntity::add_vector_with_id pads positions [count, id) with kInvalidKey rows that no scan
   // returns, flat_streamer_entity.cc:935-952): one bit per storage position, host copy + device copy, OR-ed into every
   // search's exclude set while any hole exists
   std::vector<uint64_t> h_holes;
   uint64_t nholes = 0;
   DevBuf d_holes;
+  // single-document adds (the product ingests one add_with_id_impl per document): a ring of pinned slots that the pack
+  // kernel reads in place — no staging copy, no allocation, no synchronisation per document
+  static constexpr uint32_t FAST_ROWS = 8, RING = 64, RING_GROUP = 16;     // one event per group of slots
+  PinnedBuf ring;
+  size_t ring_slot_bytes = 0;
+  hipEvent_t ring_ev[RING / RING_GROUP] = {};
+  bool ring_used[RING / RING_GROUP] = {};
+  uint32_t ring_next = 0;
   bool is_hole(uint64_t pos) const { return (pos >> 6) < h_holes.size() && ((h_holes[pos >> 6] >> (pos & 63)) & 1ull); }
 };
 

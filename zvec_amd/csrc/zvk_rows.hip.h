@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const void *src, uint64_
                                                         uint32_t dscan, uint32_t dpadw,
                                                         const uint64_t *src_row,   // nullable gather
                                                         uint64_t pos0, const uint64_t *dst_pos,
-                                                        float *base, float *bnorm, float *extra /*cosine norm*/) {
+                                                        float *base, float *bnorm, float *extra /*cosine norm*/,
+                                                        uint64_t *keys_out /*nullable*/, const uint64_t *key_src /*nullable: key = position*/) {
   const int lane = threadIdx.x & 63;
   uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -57,6 +58,7 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const void *src, uint64_
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
   if (lane == 0) {
     if (bnorm) bnorm[pos] = acc;
+    if (keys_out) keys_out[pos] = key_src ? key_src[i] : pos;     // (appends: one launch instead of pack + fill_keys)
     if (extra) {
       // the stored norm column: one float, or (fp16 rows) the two half slots that hold its bits
       if constexpr (F16) {
@@ -176,10 +178,6 @@ __global__ void seed_gtau_kernel(uint32_t *gtau, const float *scores, const uint
   if (b == b) atomicMin(&gtau[i], fkey(b));
 }
 
-__global__ void fill_keys_kernel(uint64_t *keys, uint64_t pos0, uint64_t n, const uint64_t *src) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) keys[pos0 + i] = src ? src[i] : pos0 + i;
-}
 
 // exclude set of a search over a store with holes: the caller's bits OR the store's hole bits
 __global__ void or_bits_kernel(uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t words) {
