@@ -170,3 +170,54 @@ def test_ivf_fuzz_big(zv, oracle, seed):
     assert len(sel) > 0
     tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel],
                          what="ivf big fuzz seed=%d n=%d d=%d nlist=%d nq=%d k=%d ratio=%g %s" % (seed, n, dim, nlist, nq, k, ratio, dt.__name__))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_ivf_fuzz_small_batches(zv, oracle, seed):
+    """the small-batch (wave per row) route: 1..8 queries, up to 300 lists (more than 64 probe ranks: several passes of
+    the probe rule), candidate streams of several 1024-runs (two-step selection), k up to 300, radius, filter, IP too"""
+    rng = np.random.default_rng(7000 + seed)
+    dim = int(rng.choice([8, 33, 64, 130, 768]))
+    n = int(rng.choice([2000, 9000, 30000]))
+    nlist = int(rng.choice([3, 40, 129, 300]))
+    nq = int(rng.integers(1, 9))
+    k = int(rng.choice([1, 10, 64, 65, 128, 300]))
+    half = bool(rng.random() < 0.3)
+    dt = np.float16 if half else np.float32
+    name, metric = [("SquaredEuclidean", O.METRIC_L2), ("InnerProduct", O.METRIC_IP)][int(rng.integers(0, 2))]
+    base, q = _data(rng, n, dim, dt), _data(rng, nq, dim, dt)
+    lab = rng.integers(0, nlist, n) if rng.random() < 0.6 else np.minimum(rng.geometric(0.05, n) - 1, nlist - 1)
+    order = np.argsort(lab, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(lab, minlength=nlist))]).astype(np.uint64)
+    cent = np.stack([np.round(base[lab == l].astype(np.float32).mean(0)) if (lab == l).any() else base[0].astype(np.float32)
+                     for l in range(nlist)]).astype(dt)
+    vecs, keys = base[order], (order.astype(np.uint64) * 5 + 2)
+    ratio = float(rng.choice([0.02, 0.3, 0.7, 1.0]))
+    bft = int(rng.choice([0, 50]))
+    se = zv.HipIVFSearcher(dim, name, scan_ratio=ratio, brute_force_threshold=bft, dtype="fp16" if half else "fp32")
+    assert se.load(cent, offs, vecs, keys) == 0
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    words = None
+    if rng.random() < 0.4:
+        words = O.pack_bits(rng.random(n) < 0.4)
+        ctx.set_exclude_bitset(words)
+    thr = O.FLT_MAX
+    if rng.random() < 0.3:
+        thr = float(np.median(oracle.ivf_search(cent, offs, vecs, q[:1], min(k, 20), nprobe, max_scan, metric=metric)[1][0][:5]))
+        ctx.set_threshold(thr)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc, osc = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, metric=metric, keys=keys, threshold=thr, exclude_bits=words)
+    if nprobe >= nlist:
+        sel = np.arange(nq)
+    else:   # the probe set is only well defined where the coarse ranking has no tie across the cut
+        if metric == O.METRIC_L2:
+            cd = np.sort(exact_l2(cent.astype(np.float32), q.astype(np.float32)), 1)
+        else:
+            cd = np.sort(-(q.astype(np.float64) @ cent.astype(np.float64).T), 1)
+        sel = np.nonzero((np.diff(cd[:, :min(nprobe + 1, nlist)], axis=1) != 0).all(1))[0]
+    tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel],
+                         what="ivf small fuzz seed=%d n=%d d=%d nlist=%d nq=%d k=%d nprobe=%d %s %s" % (seed, n, dim, nlist, nq, k, nprobe, name, dt.__name__))
+    scanned, probes = se.last_stats(ctx, nq)
+    assert np.array_equal(scanned[sel], osc[sel])
