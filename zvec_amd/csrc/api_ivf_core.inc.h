@@ -232,7 +232,9 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   if (ctx->profile && ctx->nprof < PROFILE_MAX && ctx->stats.p)      // the slot prof_begin will take for this launch
     p.work_stats = ctx->stats.as<unsigned long long>() + 2 * (size_t)ctx->nprof;
   hipLaunchKernelGGL(plan_wave_kernel<false>, dim3((count + 3) / 4), dim3(256), 0, stream, p);
-  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+  // (a gated context runs beside another lane's resident list scan: a 1024-thread work-group is not dispatched until
+  // that scan drains — 714 us for this 20 us kernel in the round-2 trace — four waves are)
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(ctx->gate ? 256 : 1024), 0, stream, p);
   hipLaunchKernelGGL(plan_wave_kernel<true>, dim3((count + 3) / 4), dim3(256), 0, stream, p);
   ZCHK(hipGetLastError());
 

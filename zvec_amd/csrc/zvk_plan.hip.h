@@ -206,11 +206,12 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
   __shared__ uint32_t carry;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  // 1024 elements per round: wave-level shuffle scan, 16 wave totals through LDS (two barriers per round)
+  const uint32_t NT = blockDim.x, NW = NT >> 6;      // 1024 threads, or 256 when another lane's scan may be resident
+  // NT elements per round: wave-level shuffle scan, the wave totals through LDS (two barriers per round)
   auto block_scan = [&](auto getv, auto putv, uint32_t n, uint32_t *total_out) {
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
+    for (uint32_t base = 0; base < n; base += NT) {
       const uint32_t i = base + tid;
       const uint32_t v = (i < n) ? getv(i) : 0;
       const uint32_t incl = wave_incl_scan(v, lane);
@@ -220,7 +221,7 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
       for (int w = 0; w < wave; ++w) before += wtot[w];
       if (i < n) putv(i, before + incl - v);
       __syncthreads();
-      if (tid == 1023) carry = before + incl;
+      if ((uint32_t)tid == NT - 1) carry = before + incl;
     }
     __syncthreads();
     if (tid == 0) *total_out = carry;
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
   if (p.work_stats) {                       // (profiling only) folded in here: no extra launches inside a timed step
     __shared__ unsigned long long red[2][16];
     unsigned long long rows = 0, pairs = 0;
-    for (uint32_t l = tid; l < p.nlist; l += 1024) {
+    for (uint32_t l = tid; l < p.nlist; l += NT) {
       const uint32_t c = p.list_count[l];
       if (c) { rows += p.list_size[l]; pairs += (unsigned long long)c * p.list_size[l]; }
     }
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanArgs p) {
     __syncthreads();
     if (tid == 0) {
       unsigned long long r = 0, q = 0;
-      for (int w = 0; w < 16; ++w) { r += red[0][w]; q += red[1][w]; }
+      for (uint32_t w = 0; w < NW; ++w) { r += red[0][w]; q += red[1][w]; }
       p.work_stats[0] = r;
       p.work_stats[1] = q;
     }
