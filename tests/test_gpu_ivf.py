@@ -440,3 +440,32 @@ def test_open_reference_dumped_golden_files(zv):
             c1.set_topk(5), c2.set_topk(5)
             assert se.search_impl(q, 9, c1) == 0 and ref.search_impl(q, 9, c2) == 0
             assert np.array_equal(c1.keys, c2.keys) and np.array_equal(c1.scores, c2.scores), name
+
+
+def test_search_with_empty_centroid_reference_expectations(zv):
+    """ivf_searcher_test.cc:1569-1673 (TestSearchWithEmptyCentroid): 10 documents holding only 5 distinct vectors, built
+    into 9 lists (so some lists are empty and some centroids coincide), scan_ratio 1.0, brute_force_threshold 1; the query
+    (999, ...) must find key 4 or 9 first (brute force, topk 1) and {4, 9}, {4, 9}, {3, 8} (knn, topk 3).  Here the index
+    is built by the GPU builder — k-means on 10 points with duplicates — as the product's builder slot would."""
+    dim, n = 256, 10
+    base = np.repeat((np.arange(n) % 5).astype(np.float32)[:, None], dim, axis=1)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=1.0, brute_force_threshold=1)
+    assert se.build(base, 9, keys=np.arange(n, dtype=np.uint64)) == 0
+    cnt, nlist = se.info()
+    assert cnt == n and nlist == 9
+    q = np.full((1, dim), 999.0, np.float32)
+    ctx = se.create_context()
+    ctx.set_topk(1)
+    assert se.search_bf_impl(q, 1, ctx) == 0
+    assert len(ctx.result(0)) == 1 and ctx.result(0)[0].key() in (4, 9)
+    ctx.set_topk(3)
+    assert se.search_impl(q, 1, ctx) == 0
+    r = ctx.result(0)
+    assert len(r) == 3
+    assert r[0].key() in (4, 9) and r[1].key() in (4, 9) and r[0].key() != r[1].key() and r[2].key() in (3, 8)
+    # the same through a batch large enough for the list-major route
+    qq = np.repeat(q, 20, axis=0)
+    assert se.search_impl(qq, 20, ctx) == 0
+    for i in range(20):
+        r = ctx.result(i)
+        assert {r[0].key(), r[1].key()} == {4, 9} and r[2].key() in (3, 8)
