@@ -469,3 +469,31 @@ def test_search_with_empty_centroid_reference_expectations(zv):
     for i in range(20):
         r = ctx.result(i)
         assert {r[0].key(), r[1].key()} == {4, 9} and r[2].key() in (3, 8)
+
+
+def test_context_update_overrides_probe_parameters(zv, oracle):
+    """IndexContext::update(params) (ivf_searcher_context.h:61-79): scan_ratio / brute_force_threshold set on ONE context
+    change what that context probes — nprobe = max(round(nlist * ratio), 1), max_scan_count = max(bft, ceil(N * ratio)) —
+    other contexts keep the searcher's defaults; a ratio <= 0 is refused."""
+    rng = np.random.default_rng(31)
+    n, dim, nlist, nq, k = 6000, 32, 50, 12, 5
+    base = rng.integers(0, 40, (n, dim)).astype(np.float32)
+    q = rng.integers(0, 40, (nq, dim)).astype(np.float32)
+    cent, offs, order = kmeans_lists(rng, base, nlist)
+    cent = np.round(cent)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=0.1, brute_force_threshold=10)
+    assert se.load(cent, offs, base[order], order.astype(np.uint64)) == 0
+    a, b = se.create_context(), se.create_context()
+    a.set_topk(k)
+    b.set_topk(k)
+    assert b.update({"proxima.ivf.searcher.scan_ratio": 0.0}) == zv.IndexError_.InvalidArgument
+    assert b.update({"proxima.ivf.searcher.scan_ratio": 0.5, "proxima.ivf.searcher.brute_force_threshold": n - 1}) == 0
+    assert se.search_impl(q, nq, a) == 0 and se.search_impl(q, nq, b) == 0
+    _, pa = se.last_stats(a, nq)
+    _, pb = se.last_stats(b, nq)
+    assert (pb == 25).all()                                  # round(50 * 0.5) lists, max_scan_count = N - 1 never cuts
+    assert (pa <= 5).all() and (pa >= 1).all()               # round(50 * 0.1) = 5 lists at most (max_scan_count = ceil(N * 0.1))
+    for ctx in (a, b):
+        nprobe, max_scan = se.probe_params(ctx)
+        ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, base[order], q, k, nprobe, max_scan, keys=order.astype(np.uint64))
+        tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="ctx.update")

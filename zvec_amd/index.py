@@ -138,6 +138,7 @@ class IndexContext:
         self._filter_fn = None
         self._doc_filter = None   # DocFilter: materialised by zvec_hip_*_build_filter
         self._fetch_vector = False
+        self._scan_ratio, self._bf_threshold = None, None   # update(params) overrides of the IVF searcher's defaults
         self._group_num, self._group_topk, self._group_by = 0, 0, None
         self._group_results = []
         self._group_cache = None  # (fn, n) -> (group number of every position, group ids)
@@ -218,6 +219,18 @@ class IndexContext:
                 lst.append(GroupIndexDocument(ids[int(groups[q, s])],
                                               [IndexDocument(keys[q, s, j], scores[q, s, j], None if vecs is None else vecs[j]) for j in range(c)]))
             self._group_results.append(lst)
+
+    def update(self, params):
+        """IndexContext::update(params) (index_context.h:163-166): per-context overrides of the IVF search parameters,
+        as IVFSearcherContext::update reads them (ivf_searcher_context.h:61-79) — "proxima.ivf.searcher.scan_ratio" and
+        "proxima.ivf.searcher.brute_force_threshold"; a scan_ratio <= 0 is InvalidArgument; flat contexts ignore it."""
+        ratio = params.get("proxima.ivf.searcher.scan_ratio", self._scan_ratio)
+        if ratio is not None and float(ratio) <= 0.0:
+            return IndexError_.InvalidArgument
+        self._scan_ratio = None if ratio is None else float(ratio)
+        bft = params.get("proxima.ivf.searcher.brute_force_threshold", self._bf_threshold)
+        self._bf_threshold = None if bft is None else int(bft)
+        return 0
 
     def set_threshold(self, val):
         self._threshold = float(val)
@@ -735,8 +748,11 @@ class HipIVFSearcher:
         return self.get_vectors_by_ids(order[np.searchsorted(lk[order], keys)])
 
     # IVFSearcherContext::update (ivf_searcher_context.h:61-79)
-    def probe_params(self):
-        return ivf_probe_params(self.info()[1], self.total_count, self.scan_ratio, self.brute_force_threshold)
+    def probe_params(self, ctx=None):
+        """nprobe / max_scan_count from the searcher's defaults, or from what the context's update(params) set"""
+        ratio = self.scan_ratio if ctx is None or ctx._scan_ratio is None else ctx._scan_ratio
+        bft = self.brute_force_threshold if ctx is None or ctx._bf_threshold is None else ctx._bf_threshold
+        return ivf_probe_params(self.info()[1], self.total_count, ratio, bft)
 
     def set_nprobe(self, nprobe, exact=True):
         """boundary A's `nprobe` as patches/boundary_a.diff hands it to the searcher context: scan_ratio = nprobe / nlist;
@@ -776,13 +792,14 @@ class HipIVFSearcher:
     def search_impl(self, query, count, ctx):
         if ctx is None or ctx.topk() == 0:
             return IndexError_.InvalidArgument      # ivf_searcher.cc:197-200
-        if self.total_count <= self.brute_force_threshold:
+        bft = self.brute_force_threshold if ctx._bf_threshold is None else ctx._bf_threshold
+        if self.total_count <= bft:
             return self.search_bf_impl(query, count, ctx)   # ivf_searcher.cc:188-190
         q = np.ascontiguousarray(query, self.np_dtype).reshape(-1)
         if q.size != int(count) * self.dim:
             return IndexError_.InvalidArgument
         k = ctx.topk()
-        nprobe, max_scan = self.probe_params()
+        nprobe, max_scan = self.probe_params(ctx)
         keys = np.zeros((count, k), np.uint64)
         scores = np.zeros((count, k), np.float32)
         counts = np.zeros(count, np.uint32)
