@@ -139,3 +139,19 @@ def test_container_framing_of_a_dumped_index_file():
     bad[64 + 5] ^= 1
     assert _segments(bytes(bad), checksum=1)[0] == -24 and _segments(bytes(bad), checksum=0)[0] == 0
     assert _segments(image[:-1])[0] in (-24, -31) and _segments(image[:40])[0] == -31
+
+
+def test_header_is_plain_c_and_a_c_program_links():
+    """the boundary is a C ABI: include/zvec_hip.h compiles as C99 (-pedantic), and examples/flat_search.c — a C program
+    written against it — compiles and links with the shared library (it needs a GPU to RUN: tests/test_gpu_flat.py does)"""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "zvec_hip.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "flat_search")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), "-o", exe,
+                               os.path.join(root, "examples", "flat_search.c"), "-L" + os.path.join(root, "zvec_amd"), "-lzvec_hip",
+                               "-Wl,-rpath," + os.path.join(root, "zvec_amd")])
+        assert os.path.exists(exe)

@@ -833,3 +833,19 @@ def test_add_with_id_random_order_equals_oracle(zv, oracle, metric, dtype):
             tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="put chunk %d" % c0)
     i0 = int(lid[7])
     assert np.array_equal(st.get_vector_by_id(i0), pool[live[i0]])
+
+
+def test_c_example_program_runs(zv):
+    """examples/flat_search.c: the boundary from plain C — add-with-id per document, a small batch search; exit code 0 means
+    every query found the document it had to"""
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "flat_search")
+        subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), "-o", exe, os.path.join(root, "examples", "flat_search.c"),
+                               "-L" + os.path.join(root, "zvec_amd"), "-lzvec_hip", "-Wl,-rpath," + os.path.join(root, "zvec_amd")])
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+        assert "query 0: (100," in out.stdout
