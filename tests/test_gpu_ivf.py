@@ -216,6 +216,15 @@ def test_ivf_ip_and_cosine(zv, oracle, metric_name, metric):
     scale = 1.0 if metric == O.METRIC_COSINE else float(np.abs(os_).max())
     tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel], rtol=4e-6, scale=scale,
                          what="ivf " + metric_name)
+    # the same queries a few at a time: the small-batch (wave per row) route, same answers
+    small = se.create_context()
+    small.set_topk(k)
+    for a0 in range(0, 24, 6):
+        assert se.search_impl(q[a0:a0 + 6], 6, small) == 0
+        ss = sel[(sel >= a0) & (sel < a0 + 6)]
+        if len(ss):
+            tie_tolerant_compare(small.keys[ss - a0], small.scores[ss - a0], small.counts[ss - a0], ok[ss], os_[ss], oc[ss], rtol=4e-6,
+                                 scale=scale, what="ivf small batches " + metric_name)
     for p in (0, n - 1):
         assert np.array_equal(se.get_vector_by_id(p), vecs[p])
 
