@@ -269,6 +269,17 @@ class Runner:
             return rc, None
         return 0, [ctx.result(i) for i in range(len(q))]
 
+    def search_lists_single(self, ctx, q, mode=0, p_keys=None):
+        """one call per query (count = 1): how the product calls boundary B (index.cc:617) — and the only correct way to batch the
+        reference's FlatStreamer, whose count > 1 loop reuses one heap across queries (flat_streamer.cc:330-342)."""
+        out = []
+        for i in range(len(q)):
+            rc = self.search(ctx, q[i:i + 1], mode, None if p_keys is None else p_keys[i:i + 1])
+            if rc != 0:
+                return rc, None
+            out.append(ctx.result(0))
+        return 0, out
+
     def search_mt(self, q, topk, threads, mode=0, ctx_params=None):
         """Queries dealt over `threads` threads, one query per call (tools/core/bench.cc:145-245); returns arrays + wall seconds."""
         q = np.ascontiguousarray(q, self.dtype)

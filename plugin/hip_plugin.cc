@@ -53,12 +53,22 @@ const std::string kFlatKeys("flat.keys"), kFlatFeatures("flat.features");
 const std::string kIvfCentroid("ivf.centroid"), kIvfBody("ivf.inverted_body"), kIvfHeader("ivf.inverted_header"),
     kIvfMeta("ivf.inverted_meta"), kIvfKeys("hc.keys");
 
-// whole payload of a segment as one contiguous host buffer
+// whole payload of a segment as one contiguous host buffer.  Zero-copy Segment::read first, as the reference's own loaders
+// do (flat_searcher.cc:139-145, ivf_entity.cc:443-570) — the storages that map or hold the file serve it without a copy, and
+// IndexMemory::Block::fetch ignores its offset (index_memory.h:86-97), so "MemoryReadStorage" is only correct through read();
+// storages that cannot lend a pointer (file reads) fall back to fetch
 int read_segment(IndexStorage *stg, const std::string &id, std::string *out, int level = -1) {
   auto seg = stg->get(id, level);
   if (!seg) return IndexError_NoExist;
-  out->resize(seg->data_size());
-  if (seg->fetch(0, &(*out)[0], out->size()) != out->size()) return IndexError_ReadData;
+  const size_t size = seg->data_size();
+  out->resize(size);
+  if (size == 0) return 0;
+  const void *p = nullptr;
+  if (seg->read(0, &p, size) == size && p) {
+    memcpy(&(*out)[0], p, size);
+    return 0;
+  }
+  if (seg->fetch(0, &(*out)[0], size) != size) return IndexError_ReadData;
   return 0;
 }
 
@@ -134,6 +144,7 @@ class HipContext : public IndexContext {
   std::vector<float> scores_;
   std::vector<uint32_t> counts_;
   std::string vectors_;                     // fetch_vector payload the documents point into (valid until the next search)
+  IndexContext::Pointer inner_;             // HipFlatStreamer: a context of the wrapped reference streamer (its add paths cast-check one)
 };
 
 namespace {
@@ -586,16 +597,16 @@ class HipFlatStreamer : public IndexStreamer {
   //! add_impl / add_with_id_impl (index_runner.h:476-487): persist through the reference streamer, then mirror
   int add_impl(uint64_t key, const void *vec, const IndexQueryMeta &qm, Context::Pointer &c) override {
     if (!vec || qm.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
-    Context::Pointer none;
-    int rc = store_->add_impl(key, vec, qm, none);
-    (void)c;
+    Context::Pointer *inner = inner_context(c);
+    if (!inner) return IndexError_Cast;                      // flat_streamer.cc:226-231 "Failed to cast FlatStreamerContext"
+    int rc = store_->add_impl(key, vec, qm, *inner);
     return rc != 0 ? rc : core_.append(vec, 1, &key);
   }
   int add_with_id_impl(uint32_t id, const void *vec, const IndexQueryMeta &qm, Context::Pointer &c) override {
     if (!vec || qm.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
-    Context::Pointer none;
-    int rc = store_->add_with_id_impl(id, vec, qm, none);
-    (void)c;
+    Context::Pointer *inner = inner_context(c);
+    if (!inner) return IndexError_Cast;
+    int rc = store_->add_with_id_impl(id, vec, qm, *inner);
     return rc != 0 ? rc : core_.put(id, vec);
   }
   int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
@@ -622,6 +633,15 @@ class HipFlatStreamer : public IndexStreamer {
   int device_{0};
   uint32_t ndev_{1};
   uint32_t magic_{0};
+  //! the wrapped streamer's add paths insist on a context of their own type (dynamic_cast, flat_streamer.cc:226-231,276-281):
+  //! the caller's HipContext carries one, made on first use
+  Context::Pointer *inner_context(Context::Pointer &c) const {
+    auto *ctx = dynamic_cast<HipContext *>(c.get());
+    if (!ctx) return nullptr;
+    if (!ctx->inner_) ctx->inner_ = store_->create_context();
+    return ctx->inner_ ? &ctx->inner_ : nullptr;
+  }
+
   IndexStreamer::Pointer store_;          // the reference's FlatStreamer: storage engine side
   HipFlatCore core_;
 };

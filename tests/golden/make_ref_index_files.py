@@ -64,7 +64,8 @@ dump_flat("flat3", np.float16, 31, 7, False, True)
 dump_ivf("ivf0", np.float32, [10, 0, 35, 15, 64, 1, 33], 24, False, False)
 dump_ivf("ivf1", np.float32, [40, 32, 7, 0, 96], 16, True, True)
 dump_ivf("ivf2", np.float16, [33, 64, 5, 70], 10, True, False)
-out["cases"] = np.array(["flat0", "flat1", "flat2", "flat3", "ivf0", "ivf1", "ivf2"])
+dump_ivf("ivf3", np.float32, [20, 0, 33, 0, 0], 8, False, False)      # TRAILING empty lists: their meta stays zeroed (ivf_dumper.cc:284-291)
+out["cases"] = np.array(["flat0", "flat1", "flat2", "flat3", "ivf0", "ivf1", "ivf2", "ivf3"])
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_index_files.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes")

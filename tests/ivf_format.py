@@ -35,9 +35,15 @@ def dump_ivf_segments(lists, dim, dtype=np.float32, column_major=False, block_ve
             body += raw
             nblk += 1
         keys.append(np.asarray(ks, np.uint64))
-        metas.append(struct.pack("<QIII16x4x", off, nblk, vecs.shape[0], id_off))   # sizeof(InvertedListMeta) == 40 (8-byte aligned)
+        metas.append([off, nblk, vecs.shape[0], id_off])
         total += vecs.shape[0]
         blocks += nblk
+    # empty lists AFTER the last dumped vector keep the zeroed meta they were created with: check_dump_inverted_list fills
+    # offset / id_offset of skipped lists only up to the next list that receives a vector (ivf_dumper.cc:284-291)
+    last = max([i for i, m in enumerate(metas) if m[2]], default=-1)
+    for m in metas[last + 1:]:
+        m[0] = m[3] = 0
+    metas = [struct.pack("<QIII16x4x", *m) for m in metas]          # sizeof(InvertedListMeta) == 40 (8-byte aligned)
     index_meta = struct.pack("<9I", 4128, 1, MO_COLUMN if column_major else MO_ROW, DT_FP16 if unit == 2 else DT_FP32,
                              dim, unit, 0, 0, 0) + b"\0" * 4092          # meta_type 1 = MT_DENSE
     header = struct.pack("<IIQIIIII28x", 64 + len(index_meta), total, len(body), len(lists), block_vector_count,

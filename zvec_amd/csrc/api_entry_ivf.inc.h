@@ -298,37 +298,46 @@ struct RefIndexMetaHeader {
 };
 }  // namespace
 
+// a dumped index that does not parse is reported like the reference's loaders do (LOG_ERROR, ivf_entity.cc:443-570): which check, on stderr
+static int load_fail(int check, int code) {
+  fprintf(stderr, "zvec_hip_ivf_load_segments: segment check %d failed (error %d)\n", check, code);
+  return code;
+}
+
 int zvec_hip_ivf_load_segments(zvec_hip_ivf_t h, const void *inverted_header, uint64_t header_bytes,
                                const void *inverted_meta, uint64_t meta_bytes, const void *inverted_body,
                                uint64_t body_bytes, const void *keys, uint64_t keys_bytes, const void *centroids) {
-  if (!h || !inverted_header || !inverted_meta || !centroids) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
-  if (header_bytes < sizeof(RefInvertedIndexHeader) + sizeof(RefIndexMetaHeader)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h || !inverted_header || !inverted_meta || !centroids) return load_fail(1, ZVEC_HIP_ERR_INVALID_ARGUMENT);
+  if (header_bytes < sizeof(RefInvertedIndexHeader) + sizeof(RefIndexMetaHeader)) return load_fail(2, ZVEC_HIP_ERR_INVALID_ARGUMENT);
   RefInvertedIndexHeader hd;
   memcpy(&hd, inverted_header, sizeof(hd));
   RefIndexMetaHeader im;
   memcpy(&im, static_cast<const char *>(inverted_header) + sizeof(hd), sizeof(im));
   // IndexMeta::DataType: DT_FP16 = 1, DT_FP32 = 2 (index_meta.h:31-41); MajorOrder: MO_ROW = 1, MO_COLUMN = 2 (:45-49)
   const int dtype = im.data_type == 1 ? ZVEC_HIP_DT_FP16 : (im.data_type == 2 ? ZVEC_HIP_DT_FP32 : -1);
-  if (dtype < 0) return ZVEC_HIP_ERR_UNSUPPORTED;
-  if (dtype != h->dtype || im.dimension != h->dim) return ZVEC_HIP_ERR_MISMATCH;
+  if (dtype < 0) return load_fail(3, ZVEC_HIP_ERR_UNSUPPORTED);
+  if (dtype != h->dtype || im.dimension != h->dim) return load_fail(4, ZVEC_HIP_ERR_MISMATCH);
   const uint32_t nlist = hd.inverted_list_count, bvc = hd.block_vector_count;
   const uint64_t total = hd.total_vector_count;
   const uint32_t unit = dtype == ZVEC_HIP_DT_FP16 ? 2u : 4u;
   const uint64_t elem = (uint64_t)h->dim * unit;
-  if (nlist == 0 || bvc == 0 || meta_bytes < (uint64_t)nlist * sizeof(RefInvertedListMeta)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
-  if (total && (!inverted_body || !keys || keys_bytes < total * 8)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (nlist == 0 || bvc == 0 || meta_bytes < (uint64_t)nlist * sizeof(RefInvertedListMeta)) return load_fail(5, ZVEC_HIP_ERR_INVALID_ARGUMENT);
+  if (total && (!inverted_body || !keys || keys_bytes < total * 8)) return load_fail(6, ZVEC_HIP_ERR_INVALID_ARGUMENT);
   const uint64_t block_size = (bvc * elem + 31) / 32 * 32;                   // IVFUtility::AlignedSize
-  if (hd.block_size != 0 && hd.block_size != block_size) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (hd.block_size != 0 && hd.block_size != block_size) return load_fail(7, ZVEC_HIP_ERR_INVALID_ARGUMENT);
   const bool column_major = im.major_order == 2;
   std::vector<uint64_t> list_off(nlist), row0(nlist + 1), list_offsets(nlist + 1);
   uint64_t seen = 0;
   for (uint32_t l = 0; l < nlist; ++l) {
     RefInvertedListMeta m;
     memcpy(&m, static_cast<const char *>(inverted_meta) + (size_t)l * sizeof(m), sizeof(m));
-    if (m.id_offset != seen) return ZVEC_HIP_ERR_INVALID_ARGUMENT;          // lists are dumped in id order, back to back
+    // lists are dumped in id order, back to back; an empty list AFTER the last dumped vector keeps the zeroed meta it was
+    // created with (IVFDumper::check_dump_inverted_list only fills the skipped lists up to the next non-empty one,
+    // ivf_dumper.cc:284-291), and the reference's reader never looks at the id_offset of an empty list
+    if (m.vector_count && m.id_offset != seen) return load_fail(8, ZVEC_HIP_ERR_INVALID_ARGUMENT);
     const uint64_t full = m.vector_count / bvc, rem = m.vector_count % bvc;
     const uint64_t bytes = full * block_size + (rem ? (rem * elem + 31) / 32 * 32 : 0);
-    if (m.vector_count && (m.offset > body_bytes || bytes > body_bytes - m.offset)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+    if (m.vector_count && (m.offset > body_bytes || bytes > body_bytes - m.offset)) return load_fail(9, ZVEC_HIP_ERR_INVALID_ARGUMENT);
     list_off[l] = m.offset;
     row0[l] = seen;
     list_offsets[l] = seen;
@@ -336,7 +345,7 @@ int zvec_hip_ivf_load_segments(zvec_hip_ivf_t h, const void *inverted_header, ui
   }
   row0[nlist] = seen;
   list_offsets[nlist] = seen;
-  if (seen != total) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (seen != total) return load_fail(10, ZVEC_HIP_ERR_INVALID_ARGUMENT);
 
   std::lock_guard<std::mutex> g(h->mu);
   ZCHK(hipSetDevice(h->device));
