@@ -29,18 +29,9 @@ def build(force=False):
     ref_so = os.path.join(_HERE, "_ref", "libzvec_ref.so")
     if os.path.isdir("/root/reference/src/ailego/math") and (force or not os.path.exists(ref_so)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
-    # the reference's index WRITERS (golden index files, tests/golden/make_ref_index_files.py); never needed at test time
-    fmt_so = os.path.join(_HERE, "_ref", "libzvec_ref_format.so")
-    if os.path.isdir("/root/reference/src/core/algorithm/ivf") and (force or not os.path.exists(fmt_so)):
-        subprocess.check_call(["make", "-C", _HERE, "ref_format"], stdout=subprocess.DEVNULL)
-    # the plugin's HipIVFBuilder linked into the reference's framework (tests/test_gpu_plugin_builder.py runs it on the GPU box);
-    # rebuilt when the plugin source or the product library is newer
-    plug_so = os.path.join(_HERE, "_ref", "libzvec_ref_plugin.so")
-    hip_so = os.path.join(os.path.dirname(_HERE), "zvec_amd", "libzvec_hip.so")
-    plug_src = [os.path.join(os.path.dirname(_HERE), "plugin", "hip_ivf_builder.cc"), os.path.join(_HERE, "ref_plugin_shim.cc")]
-    if os.path.isdir("/root/reference/src/core/algorithm/ivf") and os.path.exists(hip_so):
-        if force or not os.path.exists(plug_so) or any(os.path.getmtime(f) > os.path.getmtime(plug_so) for f in plug_src):
-            subprocess.check_call(["make", "-C", _HERE, "ref_plugin"], stdout=subprocess.DEVNULL)
+    # the reference's whole core library + the plugin as a loadable library (oracle/Makefile `ref_core`; make decides what is stale)
+    if os.path.isdir("/root/reference/src/core/algorithm/ivf"):
+        subprocess.check_call(["make", "-j8", "-C", _HERE, "ref_core"], stdout=subprocess.DEVNULL)
 
 
 def _ptr(a, ty):

@@ -1,5 +1,5 @@
 // ref_format_shim.cc — TEST INFRASTRUCTURE ONLY.  extern "C" doors onto the reference's own index WRITERS, compiled IN
-// PLACE from /root/reference by oracle/Makefile (target `ref_format`, output oracle/_ref/libzvec_ref_format.so; nothing
+// PLACE from /root/reference by oracle/Makefile (target `ref_core`, part of oracle/_ref/libzvec_ref_core.so; nothing
 // of the reference is copied, no stand-in headers, the reference's build system is not used):
 //   FlatBuilder<32>::init / build / dump          src/core/algorithm/flat/flat_builder.cc:22-276
 //   IVFDumper                                      src/core/algorithm/ivf/ivf_dumper.{h,cc}
@@ -10,9 +10,8 @@
 // (SURVEY §8(f) next-2).  The IVF image is assembled with the call sequence of IVFBuilder::dump_index / dump
 // (ivf_builder.cc:405-440,652-729): inverted vectors list by list, finish, (no quantizer params), the centroid index as
 // the image a FlatBuilder dumps into a MemoryDumper (IVFCentroidIndex::build, ivf_centroid_index.cc:468-490), then the
-// IndexMeta.  k-means / labelling are NOT run here: the caller passes centroids and lists (the metrics a real
-// IVFBuilder::train would need pull in kernels that do not compile without Arrow headers — hamming_distance_matrix.cc).
-// The metric registered in this library is "InnerProduct" only, for the same reason.
+// IndexMeta.  k-means / labelling are NOT run here: the caller passes centroids and lists, so the files hold exactly the
+// structure the test states (empty, ragged and trailing-empty lists).  Whole IVFBuilder runs: ref_core_shim.cc zref_build.
 #include <zvec/core/framework/index_factory.h>
 #include <zvec/core/framework/index_helper.h>
 #include <zvec/core/framework/index_holder.h>

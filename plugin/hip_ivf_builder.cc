@@ -2,7 +2,7 @@
 // (src/include/zvec/core/framework/index_builder.h, index_runner.h:653-740), to live beside hip_plugin.cc in
 // libzvec_hip_plugin.so.  Unlike the streamers / searchers, this class needs nothing of zvec that is unbuildable in this
 // container, so besides the syntax check of __graft_entry__.build() it is LINKED against the reference's own framework
-// sources compiled in place (oracle/Makefile target `ref_plugin`, test infrastructure) and RUN on the GPU box by
+// sources compiled in place (oracle/Makefile target `ref_core`: oracle/_ref/libzvec_hip_plugin.so, test infrastructure) and RUN on the GPU box by
 // tests/test_gpu_plugin_builder.py: factory registration, holder walk, GPU build, the reference's IVFDumper / FlatBuilder /
 // IndexMeta writers — the file it dumps is then opened by the loaders.
 #include <zvec/core/framework/index_builder.h>

@@ -1,8 +1,8 @@
 """Generates tests/golden/ref_index_files.npz: index FILE images dumped by the REFERENCE's own writers.
 
-Needs oracle/_ref/libzvec_ref_format.so = the reference's FlatBuilder<32>, IVFDumper, MemoryDumper + IndexPacker and
-IndexMeta serialisation compiled in place by `make -C oracle ref_format` behind oracle/ref_format_shim.cc (no stand-ins,
-nothing copied).  Each case stores its inputs and the byte image the reference wrote; the images pin the product's
+Needs oracle/_ref/libzvec_ref_core.so = the reference's core library (FlatBuilder<32>, IVFDumper, MemoryDumper + IndexPacker,
+IndexMeta serialisation, ...) compiled in place by `make -C oracle ref_core`; the doors used here are oracle/ref_format_shim.cc
+(no stand-ins, nothing copied).  Each case stores its inputs and the byte image the reference wrote; the images pin the product's
 container parser (zvec_hip_container_segments) and segment loaders (zvec_hip_flat_load_features,
 zvec_hip_ivf_load_segments) — SURVEY §8(f) next-2 — and the restated test-side writers in tests/ivf_format.py.
 Run:  python tests/golden/make_ref_index_files.py
@@ -15,7 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libzvec_ref_format.so"))
+L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libzvec_ref_core.so"))
 rng = np.random.default_rng(20260321)
 buf = np.zeros(8 << 20, np.uint8)
 out = {}

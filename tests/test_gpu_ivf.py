@@ -301,7 +301,8 @@ def test_ivf_load_from_reference_segments(zv, oracle, dtype, column_major, dim):
     wrong = zv.HipIVFSearcher(dim + 1, "SquaredEuclidean", dtype=dt)
     assert wrong.load_segments(seg["ivf.inverted_header"], seg["ivf.inverted_meta"], seg["ivf.inverted_body"], seg["hc.keys"],
                                np.zeros((nlist, dim + 1), dtype)) == zv.IndexError_.Mismatch
-    assert a.load_segments(seg["ivf.inverted_header"], seg["ivf.inverted_meta"][40:] + seg["ivf.inverted_meta"][:40],
+    m = seg["ivf.inverted_meta"]                       # the metas of two non-empty lists swapped: id offsets no longer back to back
+    assert a.load_segments(seg["ivf.inverted_header"], m[:80] + m[120:160] + m[80:120] + m[160:],
                            seg["ivf.inverted_body"], seg["hc.keys"], cent) == zv.IndexError_.InvalidArgument
 
 

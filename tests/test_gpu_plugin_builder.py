@@ -1,14 +1,12 @@
 """The plugin's "HipIVFBuilder" (plugin/hip_ivf_builder.cc) RUN inside the reference's own framework.
 
-oracle/_ref/libzvec_ref_plugin.so (built in the build container by oracle/Makefile `ref_plugin`; test infrastructure) holds the
-plugin translation unit linked with the reference's framework sources compiled in place — IndexFactory, IndexMeta,
-MultiPassIndexHolder, IVFDumper, FlatBuilder, MemoryDumper + IndexPacker — and the product library for the GPU work.  The
-driver (oracle/ref_plugin_shim.cc) creates the builder by its REGISTERED name, trains / builds from a holder and dumps into a
-MemoryDumper.  Here the dumped FILE is opened by the product's loaders and searched: it must answer like an index built
-directly through the C ABI with the same parameters, and like the oracle over the exported structure.  Only the
-"InnerProduct" metric is linked into that library (see oracle/Makefile).  Skipped when the library was not built (no
-reference checkout at build time)."""
-import ctypes as C
+oracle/_ref/libzvec_ref_core.so (the reference's whole core library compiled in place, oracle/Makefile `ref_core`; test
+infrastructure) + oracle/_ref/libzvec_hip_plugin.so (plugin/*.cc linked to it and to the product library, loaded through the
+reference's IndexPluginBroker).  The driver (oracle/ref_core_shim.cc zref_build) creates the builder by its REGISTERED name through
+IndexFactory::CreateBuilder, trains / builds from a holder over the caller's rows and dumps into the reference's MemoryDumper.  Here
+the dumped FILE is opened by the product's loaders and searched: it must answer like an index built directly through the C ABI with
+the same parameters, and like the oracle over the exported structure; the reference's own IVFSearcher must open it too.  Skipped
+when the libraries were not built (no reference checkout at build time)."""
 import os
 
 import numpy as np
@@ -17,30 +15,25 @@ import pytest
 from tests.util import tie_tolerant_compare
 
 pytestmark = pytest.mark.gpu
-_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libzvec_ref_plugin.so")
 
 
-@pytest.mark.skipif(not os.path.exists(_SO), reason="oracle/_ref/libzvec_ref_plugin.so not built (needs the reference checkout at build time)")
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 def test_plugin_builder_dumps_an_index_the_loaders_open(oracle, dtype):
     import zvec_amd as zv
     from oracle import oracle as O
-    lib = C.CDLL(_SO)
-    fn = lib.zref_plugin_ivf_build_and_dump
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_int, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
-                   C.POINTER(C.c_uint64)]
+    from oracle import refcore as R
+    if not (os.path.exists(R.CORE) and os.path.exists(R.PLUGIN)):
+        pytest.skip("oracle/_ref/libzvec_ref_core.so / libzvec_hip_plugin.so not built (needs the reference checkout at build time)")
+    R.load_plugin()
     rng = np.random.default_rng(2026)
     n, dim, nlist, nq, k = 6000, 40, 24, 50, 10
     npdt = np.float16 if dtype == "fp16" else np.float32
     base = rng.integers(-8, 9, (n, dim)).astype(npdt)
     keys = (rng.permutation(4 * n)[:n] + 11).astype(np.uint64)
     q = rng.integers(-8, 9, (nq, dim)).astype(npdt)
-    out = np.zeros(n * dim * 8 + (1 << 20), np.uint8)
-    size = C.c_uint64(0)
-    rc = fn(int(dtype == "fp16"), dim, b"InnerProduct", base.ctypes.data, keys.ctypes.data, n, nlist, 8, out.ctypes.data, out.size, C.byref(size))
-    assert rc == 0, rc
-    image = out[:size.value].tobytes()
+    R.build("HipIVFBuilder", base, "InnerProduct", "plugin_built", keys=keys,
+            params={"proxima.ivf.builder.centroid_count": str(nlist), "proxima.hip.builder.kmeans_iters": 8})
+    image = R.mem_get("plugin_built").tobytes()
     # the file is a reference index file: container -> segments -> IndexMeta naming the builder and the searcher defaults
     from zvec_amd.index import container_segments, parse_index_meta
     seg = container_segments(image)
@@ -71,6 +64,23 @@ def test_plugin_builder_dumps_an_index_the_loaders_open(oracle, dtype):
     vecs, lkeys = direct_rows_in_list_order(direct, base, keys)
     ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, metric=O.METRIC_IP, keys=lkeys)
     tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="plugin-built vs oracle")
+    # the reference's OWN IVFSearcher opens the plugin-built file (every list probed) and answers like the GPU over it
+    ref = R.Runner.searcher("IVFSearcher", "plugin_built", dim, npdt,
+                            params={"proxima.ivf.searcher.scan_ratio": 1.0, "proxima.ivf.searcher.brute_force_threshold": 0})
+    rctx = ref.create_context()
+    rctx.set_topk(k)
+    rc, lists = ref.search_lists(rctx, q)
+    assert rc == 0
+    se.scan_ratio = 1.0
+    assert se.search_impl(q, nq, ctx) == 0
+    rk = np.zeros((nq, k), np.uint64)
+    rs = np.full((nq, k), np.inf, np.float32)
+    rn = np.zeros(nq, np.uint32)
+    for i, l in enumerate(lists):
+        rn[i] = len(l[0])
+        rk[i, :rn[i]], rs[i, :rn[i]] = l[0], l[1]
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, rk, rs, rn, what="plugin-built file: GPU vs the reference's IVFSearcher")
+    ref.close()
     # searcher defaults as IVFBuilder::dump writes them (ivf_builder.cc:418-426)
     want_ratio = max(-0.004 * np.log(n) + 0.0751, 0.0001)
     assert abs(float(meta["searcher_params"]["proxima.ivf.searcher.scan_ratio"]) - want_ratio) < 1e-6
