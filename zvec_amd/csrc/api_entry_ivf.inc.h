@@ -377,23 +377,24 @@ int zvec_hip_ivf_load_segments(zvec_hip_ivf_t h, const void *inverted_header, ui
 }
 
 // nearest centroid of every row (IVFBuilder::label, ivf_builder.h:253-274: top-1 of the centroid index): device rows ->
-// device labels, in batches through the flat scan over the centroid store
+// device labels, in batches through assign_kernel (zvk_assign.hip.h): 128 rows x every centroid per work item, arg-min kept
+// in registers — no partial lists, no merge pass
 static int ivf_label_rows(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const Store &cs, const char *d_rows, uint64_t n,
                           uint32_t *d_labels, hipStream_t s) {
   const size_t rb = cs.row_bytes();
   const uint64_t BATCH = 1u << 18;
-  const uint64_t maxq = std::min<uint64_t>(n, BATCH);
-  Scoped<uint64_t> d_lab_keys; Scoped<float> d_lab_scores; Scoped<uint32_t> d_lab_cnt;
-  ZRET(d_lab_keys.alloc(maxq));
-  ZRET(d_lab_scores.alloc(maxq));
-  ZRET(d_lab_cnt.alloc(maxq));
+  if (cs.n == 0 || cs.n > 0xffffffffull) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  const int cus = device_cus(c);
   for (uint64_t o = 0; o < n; o += BATCH) {
     const uint32_t m = (uint32_t)std::min<uint64_t>(BATCH, n - o);
     ZRET(prep_queries(c, cs, d_rows + (size_t)o * rb, m, FLT_MAX, s));
-    SearchOut out{d_lab_keys.p, d_lab_scores.p, d_labels + o, d_lab_cnt.p};
-    ZRET(flat_scan_prepared(c, cs, m, 1, FLT_MAX, nullptr, out, s, false));
+    AssignArgs a{};
+    a.base = cs.base; a.bnorm = cs.bnorm; a.queries = c->qpad.as<float>(); a.qnorm = c->qnorm.as<float>();
+    a.dpad = cs.dpad; a.nks = cs.dpad / TILE_K; a.metric = cs.metric; a.nq = m; a.n = (uint32_t)cs.n;
+    a.out_label = d_labels + o; a.out_score = nullptr;
+    ZRET(cs.f16 ? launch_assign<true>(a, cus, s) : launch_assign<false>(a, cus, s));
   }
-  ZCHK(hipStreamSynchronize(s));      // the scratch lists are freed on return
+  ZCHK(hipStreamSynchronize(s));      // callers read the labels with plain copies (the context's stream is non-blocking)
   (void)h;
   return 0;
 }

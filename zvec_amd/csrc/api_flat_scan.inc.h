@@ -112,6 +112,24 @@ int launch_scan8(const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipSt
                    : launch_scan8_t<false, false, false>(a, max_items, cus, stream, occ_out);
 }
 
+// nearest-centroid assignment (zvk_assign.hip.h): one work item = 128 rows x every centroid, two work-groups per CU
+template <bool F16>
+int launch_assign(const AssignArgs &a, int cus, hipStream_t s) {
+  static bool attr_set[16] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set[dev & 15]) {
+    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&assign_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ASSIGN_LDS));
+    attr_set[dev & 15] = true;
+  }
+  const uint32_t items = (a.nq + ASSIGN_ROWS - 1) / ASSIGN_ROWS;
+  const uint32_t grid = std::min<uint32_t>(items, (uint32_t)cus * 2u);
+  if (grid == 0) return 0;
+  hipLaunchKernelGGL(assign_kernel<F16>, dim3(grid), dim3(256), ASSIGN_LDS, s, a);
+  ZCHK(hipGetLastError());
+  return 0;
+}
+
 // ng == 0 selects the 16-row-halves (16x16 MFMA) shape
 int launch_scan_ng(int ng, const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStream_t stream) {
   switch (ng) {
