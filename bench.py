@@ -20,9 +20,10 @@ every rank) three times — (A) ground-truth flat shard + k-means sample, (B) ne
 round-robin to the ranks, labels summed over RCCL), (C) list fill (every rank keeps the rows of the lists it owns).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the list scan, timed with HIP events
-on its launch stream inside the library) and `cpu_baseline` (the oracle's restated reference loops on
-the host cores, same index / queries; N=1 only).  oracle/ is used ONLY for that baseline and the
-parity cross-check — never on the timed GPU path.
+on its launch stream inside the library) and `cpu_baseline` (kind "reference": the reference's OWN IVFSearcher /
+FlatSearcher — oracle/_ref/libzvec_ref_core.so, its core library compiled in place — on the host cores, same index /
+queries; N=1 only; kind "port" = the oracle's restated loops when that library did not travel).  oracle/ is used ONLY
+for that baseline and the parity cross-check — never on the timed GPU path.
 """
 import argparse
 import json
@@ -89,6 +90,7 @@ def parse_args():
                          "recall is not computed) — the per-rank compute of an N-GPU run; with --workload ivf100m_fp16 "
                          "--shard-of 8 this is one rank's real share of BASELINE configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-port", action="store_true", help="time the oracle's restated loops (kind \"port\") even when the reference's own classes are available")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
     ap.add_argument("--cpu-queries", type=int, default=0, help="0 = one whole batch")
     ap.add_argument("--launch-check", action="store_true",
@@ -600,28 +602,43 @@ def parity_vs_cpu(gpu, ok, os_, oc, nq):
 
 
 def cpu_baseline_flat(torch, base, q, topk, metric_name, args, gpu=None):
-    """Reference CPU flat scan restated (oracle: FlatSearcherContext row-major loops + the reference's AVX-512 1x1
-    kernels when oracle/_ref travelled) on a bounded sample of the timed batch, same base rows."""
+    """The reference's CPU flat scan on a bounded sample of the timed batch over the same base rows.  kind "reference": the
+    reference's own FlatBuilder dumps the rows, its FlatSearcher searches them (one query per call and thread, as the product calls
+    boundary B); kind "port" when that library did not travel: oracle loops + the reference's AVX-512 1x1 kernels."""
     from oracle import oracle as O
+    from oracle import refcore as R
     o = O.get()
     host = base.cpu().numpy()
     threads = host_threads()
+    cores = host_cores()
     nq = min(q.shape[0], args.cpu_queries or 2 * threads)
     qh = q[:nq].cpu().numpy()
-    used_ref = o.use_reference_kernels(True)
-    metric = O.METRIC_IP if metric_name == "InnerProduct" else O.METRIC_L2
     best = None
-    for _ in range(2):
-        t1 = time.perf_counter()
-        ok, os_, _, oc = o.flat_search(host, qh, topk, metric, threads=threads)
-        dt = time.perf_counter() - t1
-        best = dt if best is None else min(best, dt)
-    o.use_reference_kernels(False)
+    if R.available() and not args.cpu_port:
+        R.build("FlatBuilder", host, metric_name, "bench_flat")
+        ref = R.Runner.searcher("FlatSearcher", "bench_flat", host.shape[1], host.dtype)
+        for _ in range(2):
+            ok, os_, oc, dt = ref.search_mt(qh, topk, threads)
+            best = dt if best is None else min(best, dt)
+        ref.close()
+        R.mem_remove("bench_flat")
+        kind, what = "reference", "the reference's own FlatBuilder + FlatSearcher::search_impl (libzvec_ref_core.so, -O2 -march=skylake-avx512)"
+    else:
+        used_ref = o.use_reference_kernels(True)
+        metric = O.METRIC_IP if metric_name == "InnerProduct" else O.METRIC_L2
+        for _ in range(2):
+            t1 = time.perf_counter()
+            ok, os_, _, oc = o.flat_search(host, qh, topk, metric, threads=threads)
+            dt = time.perf_counter() - t1
+            best = dt if best is None else min(best, dt)
+        o.use_reference_kernels(False)
+        kind, what = "port", "scan loop = oracle restatement, 1x1 distance kernel = %s" % (
+            "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")
     parity = parity_vs_cpu(gpu, ok, os_, oc, nq) if gpu is not None else None
-    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": "port", "parity": parity,
-            "sample": "%d queries of the timed batch over the same %d rows, %d threads across queries, best of 2; scan loop = "
-                      "oracle restatement, 1x1 distance kernel = %s" % (
-                          nq, host.shape[0], threads, "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")}
+    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": kind, "parity": parity,
+            "host_physical_cores": cores.get("physical"), "host_logical_cpus": cores.get("logical"), "host_usable_cpus": cores.get("usable"),
+            "sample": "%d queries of the timed batch over the same %d rows, one query per call, %d threads across queries, best of 2; %s" % (
+                nq, host.shape[0], threads, what)}
 
 
 def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, topk, args, dev, stream_ptr, world, rank, base, metric_name, coll):
@@ -706,13 +723,35 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("ZVEC_BENCH_CPU_THREADS", "16"))))
 
 
+def host_cores():
+    """what the node has (BASELINE.md §2 asks for the physical core count next to the threads used): lscpu's sockets x cores per
+    socket, its logical CPUs, and the CPUs this process may run on"""
+    info = {"logical": os.cpu_count() or 0, "usable": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0}
+    try:
+        import subprocess
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        f = {}
+        for line in txt.splitlines():
+            if ":" in line:
+                a, b = line.split(":", 1)
+                f[a.strip()] = b.strip()
+        info["physical"] = int(f.get("Socket(s)", "1")) * int(f.get("Core(s) per socket", "0"))
+        info["model"] = f.get("Model name", "")
+    except Exception:                                    # noqa: BLE001 - lscpu missing: the counts above still stand
+        info["physical"] = 0
+    return info
+
+
 def cpu_baseline_ivf(torch, ivf, q, topk, nprobe, max_scan, args, dtype, gpu=None):
-    """The reference's CPU path restated (oracle/zvec_oracle.c: IVFSearcher::search_impl loops, the
-    reference's own AVX-512 distance kernels from oracle/_ref when that library travelled), on the
-    host cores of this box, searching THE SAME index (exported centroids / list order, rows read back from
-    the HBM store) with the same queries.  Parallel across queries, one query per thread at a time
-    (tools/core/bench.cc:145-245)."""
+    """The reference's CPU path on the host cores of this box, searching THE SAME index (exported centroids / list order, rows
+    read back from the HBM store) with the same queries, parallel across queries, one query per call and thread at a time
+    (tools/core/bench.cc:145-245; the product calls boundary B with count = 1, index.cc:617).
+    kind "reference": the reference's OWN IVFSearcher (oracle/_ref/libzvec_ref_core.so = its core library compiled in place),
+    opened over the exported arrays — its IVFDumper writes every small segment, the 30 GB body is lent, not copied
+    (oracle/ref_core_shim.cc zref_ivf_searcher_over_rows).  kind "port" (only when that library did not travel or the element
+    size is not a multiple of 32 bytes): the oracle's restated loops with the reference's AVX-512 1x1 kernels."""
     from oracle import oracle as O
+    from oracle import refcore as R
     o = O.get()
     t0 = time.time()
     cent, offs, rows = ivf.export()
@@ -726,29 +765,53 @@ def cpu_baseline_ivf(torch, ivf, q, topk, nprobe, max_scan, args, dtype, gpu=Non
     nq = args.cpu_queries or qh.shape[0]
     qh = qh[:nq]
     threads = host_threads()
-    used_ref = o.use_reference_kernels(True)
-    log("cpu baseline: index copied to host in %.1fs; %d queries on %d threads (reference AVX-512 kernels: %s)" % (
-        time.time() - t0, nq, threads, used_ref))
+    cores = host_cores()
+    log("cpu baseline: index copied to host in %.1fs; %d queries on %d threads (host: %s physical cores, %s logical, %s usable)" % (
+        time.time() - t0, nq, threads, cores.get("physical"), cores.get("logical"), cores.get("usable")))
+    ref = None
+    if R.available() and (vecs.shape[1] * vecs.dtype.itemsize) % 32 == 0 and not args.cpu_port:
+        t1 = time.time()
+        nlist = cent.shape[0]
+        ratio = float(np.float32(nprobe) / np.float32(max(nlist, 1)))          # ivf_searcher_context.h:70-78, see set_nprobe
+        # brute_force_threshold doubles as the max_scan_count floor (ivf_searcher_context.h:70-78) and, when >= N, sends the whole
+        # search to brute force (ivf_searcher.cc:183-185): N - 1 keeps the probe walk and never cuts it short
+        params = {"proxima.ivf.searcher.scan_ratio": ratio, "proxima.ivf.searcher.brute_force_threshold": int(max(min(max_scan, n - 1), 1))}
+        ref = R.Runner.ivf_over_rows("IVFSearcher", cent, offs, vecs, rows.astype(np.uint64), "SquaredEuclidean", params=params)
+        log("cpu baseline: the reference's IVFSearcher opened over the exported index in %.1fs" % (time.time() - t1))
     best = None
     reps = 0
     t_all = time.time()
-    while reps < 3 and (time.time() - t_all) < 25.0:
+    if ref is not None:
+        while reps < 3 and (time.time() - t_all) < 25.0:
+            ok, os_, oc, dt = ref.search_mt(qh, topk, threads)
+            best = dt if best is None else min(best, dt)
+            reps += 1
+        n1 = min(32, nq)
+        _, _, _, d1 = ref.search_mt(qh[:n1], topk, 1)
+        one = n1 / d1
+        ref.close()
+        kind, what = "reference", "the reference's own IVFSearcher::search_impl (libzvec_ref_core.so, -O2 -march=skylake-avx512)"
+    else:
+        used_ref = o.use_reference_kernels(True)
+        while reps < 3 and (time.time() - t_all) < 25.0:
+            t1 = time.perf_counter()
+            ok, os_, _, oc, _ = o.ivf_search(cent, offs, vecs, qh, topk, nprobe, max_scan, keys=rows, threads=threads)
+            dt = time.perf_counter() - t1
+            best = dt if best is None else min(best, dt)
+            reps += 1
+        # single-thread figure as well (report T = 1 and T = all cores), on a 32-query sample
+        n1 = min(32, nq)
         t1 = time.perf_counter()
-        ok, os_, _, oc, _ = o.ivf_search(cent, offs, vecs, qh, topk, nprobe, max_scan, keys=rows, threads=threads)
-        dt = time.perf_counter() - t1
-        best = dt if best is None else min(best, dt)
-        reps += 1
-    # single-thread figure as well (report T = 1 and T = all cores), on a 32-query sample
-    n1 = min(32, nq)
-    t1 = time.perf_counter()
-    o.ivf_search(cent, offs, vecs, qh[:n1], topk, nprobe, max_scan, keys=rows, threads=1)
-    one = n1 / (time.perf_counter() - t1)
-    o.use_reference_kernels(False)
+        o.ivf_search(cent, offs, vecs, qh[:n1], topk, nprobe, max_scan, keys=rows, threads=1)
+        one = n1 / (time.perf_counter() - t1)
+        o.use_reference_kernels(False)
+        kind, what = "port", "scan loops = oracle restatement, 1x1 distance kernel = %s" % (
+            "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")
     parity = parity_vs_cpu(gpu, ok, os_, oc, nq) if gpu is not None else None
-    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": "port", "value_1_thread": one, "parity": parity,
-            "sample": "%d queries of the timed batch, same IVF index (exported), %d threads across queries, best of %d; "
-                      "scan loops = oracle restatement, 1x1 distance kernel = %s" % (
-                          nq, threads, reps, "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")}
+    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": kind, "value_1_thread": one, "parity": parity,
+            "host_physical_cores": cores.get("physical"), "host_logical_cpus": cores.get("logical"), "host_usable_cpus": cores.get("usable"),
+            "sample": "%d queries of the timed batch, same IVF index (exported), one query per call, %d threads across queries "
+                      "(the box's share of its host; capped by ZVEC_BENCH_CPU_THREADS), best of %d; %s" % (nq, threads, reps, what)}
 
 
 if __name__ == "__main__":

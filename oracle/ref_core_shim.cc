@@ -9,6 +9,8 @@
 // Index files live in the reference's IndexMemory ("MemoryDumper" writes, "MemoryReadStorage" reads) or on disk
 // ("FileDumper", "MMapFileReadStorage", "MMapFileStorage").
 #include <zvec/core/framework/index_builder.h>
+#include <zvec/core/framework/index_dumper.h>
+#include <zvec/core/framework/index_helper.h>
 #include <zvec/core/framework/index_cluster.h>
 #include <zvec/core/framework/index_factory.h>
 #include <zvec/core/framework/index_holder.h>
@@ -17,7 +19,10 @@
 #include <zvec/core/framework/index_searcher.h>
 #include <zvec/core/framework/index_streamer.h>
 
+#include "core/algorithm/ivf/ivf_dumper.h"
+
 #include <atomic>
+#include <map>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -82,6 +87,118 @@ struct Ctx {
   IndexContext::Pointer c;
   std::vector<uint8_t> exclude;        // by key: 1 = excluded (IndexFilter: true = exclude, index_filter.h:48-50)
   std::vector<uint32_t> group_of_key;  // by key
+};
+
+
+// ---- an index whose big segments stay where the caller has them -------------------------------------------------------------
+// SkeletonDumper: an IndexDumper (index_dumper.h:25-53) that keeps every segment in memory EXCEPT the first `skip` bytes
+// written, which it only counts: the reference's own IVFDumper then produces header / list meta / keys / offsets / mapping /
+// centroid index / IndexMeta byte for byte while the 30 GB body it writes first is dropped.
+class SkeletonDumper : public IndexDumper {
+ public:
+  explicit SkeletonDumper(size_t skip) : skip_(skip) {}
+  int init(const ailego::Params &) override { return 0; }
+  int cleanup() override { return 0; }
+  int create(const std::string &) override { return 0; }
+  int close() override { return 0; }
+  uint32_t magic() const override { return 0; }
+  size_t write(const void *data, size_t len) override {
+    size_t drop = std::min(len, skip_ - skipped_);
+    skipped_ += drop;
+    if (len > drop) pending_.append(static_cast<const char *>(data) + drop, len - drop);
+    written_ += len;
+    return len;
+  }
+  int append(const std::string &id, size_t data_size, size_t padding_size, uint32_t crc) override {
+    const size_t region = data_size + padding_size;
+    if (first_) {                       // the skipped bytes are exactly the first segment
+      first_ = false;
+      if (skip_ != 0) {
+        if (skipped_ != skip_ || region != skip_ || !pending_.empty()) return IndexError_Logic;
+        skipped_id_ = id;
+        return 0;
+      }
+    }
+    if (pending_.size() != region) return IndexError_Logic;
+    segments_[id] = std::make_pair(pending_.substr(0, data_size), crc);
+    pending_.clear();
+    return 0;
+  }
+  std::map<std::string, std::pair<std::string, uint32_t>> segments_;
+  std::string skipped_id_;
+
+ private:
+  size_t skip_, skipped_{0}, written_{0};
+  bool first_{true};
+  std::string pending_;
+};
+
+// BorrowedStorage: an IndexStorage (index_storage.h:228-270) over segments that are either owned strings or memory the caller
+// keeps alive (numpy arrays): read() lends the pointer, as the mmap storages do.
+class BorrowedStorage : public IndexStorage {
+ public:
+  struct Seg : public IndexStorage::Segment, public std::enable_shared_from_this<Seg> {
+    Seg(const void *p, size_t n, uint32_t crc) : p_(static_cast<const char *>(p)), n_(n), crc_(crc) {}
+    size_t data_size() const override { return n_; }
+    uint32_t data_crc() const override { return crc_; }
+    size_t padding_size() const override { return 0; }
+    size_t capacity() const override { return n_; }
+    size_t fetch(size_t off, void *buf, size_t len) const override {
+      if (off > n_) off = n_;
+      len = std::min(len, n_ - off);
+      memcpy(buf, p_ + off, len);
+      return len;
+    }
+    size_t read(size_t off, const void **data, size_t len) override {
+      if (off > n_) off = n_;
+      len = std::min(len, n_ - off);
+      *data = p_ + off;
+      return len;
+    }
+    size_t read(size_t off, MemoryBlock &data, size_t len) override {
+      const void *p = nullptr;
+      size_t r = this->read(off, &p, len);
+      data.reset(const_cast<void *>(p));
+      return r;
+    }
+    bool read(SegmentData *iov, size_t count) override {
+      for (auto *e = iov + count; iov != e; ++iov) {
+        if (iov->offset + iov->length > n_) return false;
+        iov->data = p_ + iov->offset;
+      }
+      return true;
+    }
+    size_t write(size_t, const void *, size_t) override { return 0; }
+    size_t resize(size_t) override { return 0; }
+    void update_data_crc(uint32_t) override {}
+    IndexStorage::Segment::Pointer clone() override { return shared_from_this(); }
+    const char *p_;
+    size_t n_;
+    uint32_t crc_;
+  };
+  void own(const std::string &id, std::string bytes, uint32_t crc) {
+    owned_.push_back(std::make_unique<std::string>(std::move(bytes)));
+    segs_[id] = std::make_shared<Seg>(owned_.back()->data(), owned_.back()->size(), crc);
+  }
+  void borrow(const std::string &id, const void *p, size_t n) { segs_[id] = std::make_shared<Seg>(p, n, 0); }
+  int init(const ailego::Params &) override { return 0; }
+  int cleanup() override { return 0; }
+  int open(const std::string &, bool) override { return 0; }
+  int flush() override { return 0; }
+  int close() override { return 0; }
+  int append(const std::string &, size_t) override { return IndexError_NotImplemented; }
+  void refresh(uint64_t) override {}
+  uint64_t check_point() const override { return 0; }
+  IndexStorage::Segment::Pointer get(const std::string &id, int) override {
+    auto it = segs_.find(id);
+    return it == segs_.end() ? nullptr : it->second;
+  }
+  bool has(const std::string &id) const override { return segs_.count(id) != 0; }
+  uint32_t magic() const override { return 0x5a564543u; }
+
+ private:
+  std::map<std::string, std::shared_ptr<Seg>> segs_;
+  std::vector<std::unique_ptr<std::string>> owned_;
 };
 
 IndexPluginBroker &broker() {
@@ -309,6 +426,75 @@ void zref_ctx_set_group(void *c, const uint32_t *group_of_key, uint64_t n, uint3
   x->group_of_key.assign(group_of_key, group_of_key + n);
   const std::vector<uint32_t> *g = &x->group_of_key;
   x->c->set_group_by([g](uint64_t key) { return std::to_string(key < g->size() ? (*g)[key] : 0xffffffffu); });
+}
+
+
+// ---- a searcher over an IVF index given as ARRAYS (the structure the GPU built, exported): the reference's own IVFDumper walks
+// the rows list by list exactly as IVFBuilder::dump does (ivf_builder.cc:652-729) and writes every small segment; the body — the
+// rows in list order, which for a row-major index whose element size is a multiple of 32 bytes IS the dumped body byte for byte
+// (blocks of 32 vectors, no padding: ivf_dumper.h:131-160) — is lent from the caller's array instead of being copied into a file.
+// The caller keeps rows / keys alive while the runner lives.
+void *zref_ivf_searcher_over_rows(const char *cls, const char *params_json, int dtype, uint32_t dim, const char *metric,
+                                  const void *centroids, uint32_t nlist, const uint64_t *list_offsets, const void *rows,
+                                  const uint64_t *keys, int *rc_out) {
+  auto r = std::make_unique<Runner>();
+  int rc = 0;
+  do {
+    ailego::Params params;
+    if (!parse_params(params_json, &params)) { rc = -1000; break; }
+    IndexMeta meta = make_meta(dtype, dim, metric);
+    meta.set_major_order(IndexMeta::MO_ROW);
+    const size_t es = meta.element_size();
+    const uint64_t n = list_offsets[nlist];
+    if (es % 32 != 0) { rc = IndexError_Unsupported; break; }       // (a partial block would carry padding the array lacks)
+    auto sd = std::make_shared<SkeletonDumper>((size_t)n * es);
+    IndexDumper::Pointer dumper = sd;
+    {
+      IVFDumper ivf(meta, dumper, nlist);
+      const char *p = static_cast<const char *>(rows);
+      for (uint32_t l = 0; l < nlist && rc == 0; ++l)
+        for (uint64_t i = list_offsets[l]; i < list_offsets[l + 1]; ++i)
+          if ((rc = ivf.dump_inverted_vector(l, keys ? keys[i] : i, p + (size_t)i * es)) != 0) break;
+      if (rc != 0) break;
+      if ((rc = ivf.dump_inverted_vector_finished()) != 0) break;
+      if ((rc = ivf.dump_quantizer_params({})) != 0) break;
+      // the centroid index: the file a FlatBuilder dumps (IVFCentroidIndex::build, ivf_centroid_index.cc:468-490)
+      auto fb = IndexFactory::CreateBuilder("FlatBuilder");
+      auto md = IndexFactory::CreateDumper("MemoryDumper");
+      if (!fb || !md) { rc = -1001; break; }
+      IndexMeta cmeta = make_meta(dtype, dim, metric);
+      cmeta.set_major_order(IndexMeta::MO_ROW);
+      if ((rc = fb->init(cmeta, ailego::Params())) != 0) break;
+      IndexHolder::Pointer ch = std::make_shared<BorrowedHolder>(cmeta.data_type(), dim, es, centroids, nullptr, nlist);
+      if ((rc = fb->train(ch)) != 0 && rc != IndexError_NotImplemented) break;
+      if ((rc = fb->build(ch)) != 0) break;
+      static std::atomic<uint32_t> serial{0};
+      const std::string cpath = "zref_cent_" + std::to_string(serial.fetch_add(1));
+      if ((rc = md->init(ailego::Params())) != 0 || (rc = md->create(cpath)) != 0) break;
+      if ((rc = fb->dump(md)) != 0 || (rc = md->close()) != 0) break;
+      auto crope = IndexMemory::Instance()->open(cpath);
+      if (!crope || crope->count() != 1) { rc = -1004; break; }
+      const void *cdata = nullptr;
+      (*crope)[0].read(0, &cdata, 0);
+      rc = ivf.dump_centroid_index(cdata, (*crope)[0].size());
+      IndexMemory::Instance()->remove(cpath);
+      if (rc != 0) break;
+    }
+    meta.set_searcher("IVFSearcher", 0, ailego::Params());
+    meta.set_builder("IVFBuilder", 0, ailego::Params());
+    if ((rc = IndexHelper::SerializeToDumper(meta, dumper.get())) != 0) break;
+    if (sd->skipped_id_ != "ivf.inverted_body" && n != 0) { rc = IndexError_Logic; break; }
+    auto st = std::make_shared<BorrowedStorage>();
+    for (auto &kv : sd->segments_) st->own(kv.first, std::move(kv.second.first), kv.second.second);
+    st->borrow("ivf.inverted_body", rows, (size_t)n * es);
+    r->storage = st;
+    r->searcher = IndexFactory::CreateSearcher(cls);
+    if (!r->searcher) { rc = -1001; break; }
+    if ((rc = r->searcher->init(params)) != 0) break;
+    rc = r->searcher->load(r->storage, IndexMetric::Pointer());
+  } while (false);
+  if (rc_out) *rc_out = rc;
+  return rc == 0 ? r.release() : nullptr;
 }
 
 // ---- searches: mode 0 search_impl, 1 search_bf_impl, 2 search_bf_by_p_keys_impl (index_runner.h:490-585) ----------------

@@ -58,6 +58,7 @@ def lib():
             "zref_ctx_result": (i32, [vp, u32, vp, vp, vp, vp, u32, P(u32)]),
             "zref_ctx_group_count": (u32, [vp, u32]),
             "zref_ctx_group": (i32, [vp, u32, u32, P(u32), vp, vp, u32]),
+            "zref_ivf_searcher_over_rows": (vp, [cp, cp, i32, u32, cp, vp, u32, vp, vp, vp, P(i32)]),
             "zref_search_mt": (i32, [vp, i32, vp, i32, u32, u32, u32, cp, u32, vp, vp, vp, P(C.c_double)]),
         }
         for name, (res, args) in sig.items():
@@ -211,6 +212,23 @@ class Runner:
         if not h:
             raise RuntimeError("%s open: rc %d" % (name, rc.value))
         return cls(h, dim, np.dtype(dtype))
+
+    @classmethod
+    def ivf_over_rows(cls, name, centroids, list_offsets, rows, keys, metric, params=None):
+        """An IVF searcher over an index given as arrays (centroids, list offsets, rows and keys in list order): the reference's own
+        IVFDumper writes every small segment, the body is LENT from `rows` (no 30 GB file).  fp32 / fp16 rows, element size % 32 == 0."""
+        centroids = np.ascontiguousarray(centroids, rows.dtype)
+        lo = np.ascontiguousarray(list_offsets, np.uint64)
+        keys = np.ascontiguousarray(keys, np.uint64)
+        assert rows.flags.c_contiguous
+        rc = C.c_int()
+        h = lib().zref_ivf_searcher_over_rows(name.encode(), _js(params), _dt(rows), rows.shape[1], metric.encode(), _p(centroids),
+                                              centroids.shape[0], _p(lo), _p(rows), _p(keys), C.byref(rc))
+        if not h:
+            raise RuntimeError("%s over rows: rc %d" % (name, rc.value))
+        r = cls(h, rows.shape[1], rows.dtype)
+        r._keep = (centroids, lo, rows, keys)           # the storage lends these
+        return r
 
     def close(self):
         if self.h:

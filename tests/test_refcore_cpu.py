@@ -233,3 +233,51 @@ def test_flat_streamer_single_calls_and_add_with_id(oracle):
         st.close()
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_searcher_over_lent_rows_equals_searcher_over_the_dumped_file(oracle):
+    """refcore.Runner.ivf_over_rows (bench.py's cpu_baseline leg): the reference's IVFDumper writes every small segment, the body is
+    lent from the caller's rows.  Must answer exactly like the same structure dumped to a complete file (ref_format_shim) — and the
+    lent body IS the dumped body byte for byte."""
+    import ctypes as C
+    from zvec_amd.index import container_segments
+    rng = np.random.default_rng(51)
+    n, dim, nlist, k = 5000, 32, 24, 9
+    for dt in (np.float32, np.float16):
+        base = rng.standard_normal((n, dim)).astype(dt)
+        cent = base[rng.choice(n, nlist, replace=False)].copy()
+        sizes = rng.multinomial(n, np.ones(nlist) / nlist)
+        sizes[3] = 0
+        sizes[-1] += n - sizes.sum()
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        keys = rng.permutation(3 * n)[:n].astype(np.uint64)
+        params = {"proxima.ivf.searcher.scan_ratio": 0.2, "proxima.ivf.searcher.brute_force_threshold": 100}
+        lent = R.Runner.ivf_over_rows("IVFSearcher", cent, offs, base, keys, "SquaredEuclidean", params=params)
+        buf = np.zeros(base.nbytes + (4 << 20), np.uint8)
+        sz = C.c_uint64(0)
+        L = R.lib()
+        L.zref_dump_ivf_index.restype = C.c_int
+        rc = L.zref_dump_ivf_index(int(dt == np.float16), dim, 0, 0, b"SquaredEuclidean", cent.ctypes.data_as(C.c_void_p), nlist,
+                                   offs.ctypes.data_as(C.c_void_p), base.ctypes.data_as(C.c_void_p), keys.ctypes.data_as(C.c_void_p),
+                                   buf.ctypes.data_as(C.c_void_p), C.c_uint64(buf.size), C.byref(sz))
+        assert rc == 0
+        image = buf[:sz.value].tobytes()
+        bo, bs = container_segments(image)["ivf.inverted_body"]
+        assert image[bo:bo + bs] == base.tobytes()                      # the premise of lending the rows
+        R.mem_put("lent_cmp", image)
+        filed = R.Runner.searcher("IVFSearcher", "lent_cmp", dim, dt, params=params)
+        q = rng.standard_normal((20, dim)).astype(dt)
+        c1, c2 = lent.create_context(), filed.create_context()
+        c1.set_topk(k), c2.set_topk(k)
+        for mode in (0, 1):
+            r1, l1 = lent.search_lists(c1, q, mode)
+            r2, l2 = filed.search_lists(c2, q, mode)
+            assert r1 == 0 and r2 == 0
+            for a, b in zip(l1, l2):
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        kk, ss, cc, _ = lent.search_mt(q, k, 3)
+        for i, b in enumerate(l2 if False else filed.search_lists(c2, q, 0)[1]):
+            assert np.array_equal(kk[i, :cc[i]], b[0]) and np.array_equal(ss[i, :cc[i]], b[1])
+        c1.close(), c2.close()
+        lent.close(), filed.close()
+        R.mem_remove("lent_cmp")
