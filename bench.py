@@ -417,11 +417,12 @@ def main():
         if args.streams > 1:
             gate = zvec_amd.Gate(local_rank)
             ctx.set_gate(gate)
-            s2 = torch.cuda.Stream(device=dev)
-            ctx2 = ivf.create_context()
-            ctx2.set_stream(s2.cuda_stream)
-            ctx2.set_gate(gate)
-            lanes.append((ShardedIVF(ivf, ctx2, rank, world), s2.cuda_stream, s2))
+            for _ in range(args.streams - 1):
+                s2 = torch.cuda.Stream(device=dev)
+                ctx2 = ivf.create_context()
+                ctx2.set_stream(s2.cuda_stream)
+                ctx2.set_gate(gate)
+                lanes.append((ShardedIVF(ivf, ctx2, rank, world), s2.cuda_stream, s2))
 
         def run_step(i, np_):
             sh_i, sp, ts = lanes[i % len(lanes)]

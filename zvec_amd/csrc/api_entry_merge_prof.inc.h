@@ -81,6 +81,10 @@ int zvec_hip_ctx_profile(zvec_hip_ctx_t ctx, int enable) {
   if (ctx->profile) {
     ZCHK(hipSetDevice(ctx->device));
     ZRET(ctx->stats.ensure(sizeof(uint64_t) * 2 * PROFILE_MAX));
+    // every launch slot starts at zero (the small-batch route ADDS its per-query row counts); zeroed here and at every reset,
+    // not per launch: a fill kernel in front of every search is 5 us of a single query's 70 us chain
+    ZCHK(hipMemsetAsync(ctx->stats.p, 0, sizeof(uint64_t) * 2 * PROFILE_MAX, ctx->cur));
+    ZCHK(hipStreamSynchronize(ctx->cur));
   }
   return 0;
 }
@@ -113,7 +117,13 @@ int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *sc
   if (scan_ms) *scan_ms = ms;
   if (algorithmic_bytes) *algorithmic_bytes = bytes;
   if (algorithmic_flops) *algorithmic_flops = flops;
-  if (reset) ctx->nprof = 0;
+  if (reset) {
+    ctx->nprof = 0;
+    if (ctx->stats.p) {
+      ZCHK(hipMemsetAsync(ctx->stats.p, 0, sizeof(uint64_t) * 2 * PROFILE_MAX, ctx->cur));
+      ZCHK(hipStreamSynchronize(ctx->cur));
+    }
+  }
   return 0;
 }
 

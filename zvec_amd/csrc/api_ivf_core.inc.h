@@ -11,7 +11,6 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   const uint32_t nlist = h->nlist;
   if (nprobe < 1) nprobe = 1;
   if (nprobe > nlist) nprobe = nlist;
-  ZRET(prep_queries(ctx, h->lists, d_queries, count, FLT_MAX, stream));   // coarse pass: no RNN radius
 
   // A handful of queries (the product's count = 1 calls): both steps go wave-per-row instead of through the MFMA tile
   // kernels, whose few work items would each be a chain of dependent HBM round trips (1 query, 2M x 768, nprobe 32:
@@ -22,6 +21,18 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   const bool direct = !brute_force && count <= (uint32_t)knobs().ivf_direct_q && (uint64_t)count * direct_rows <= (4u << 20) &&
                       (double)count * (double)direct_rows * (double)h->lists.row_bytes() <= 2.5e9 &&
                       (size_t)topk * 12 + 16 <= 60 * 1024 && (size_t)nprobe * 12 + 16 <= 60 * 1024;
+
+  // The direct route scores rows straight from the prepared query rows and needs no norms: when the caller's rows already ARE
+  // prepared rows (no padding: dim_in == the scanned dims == whole 128-byte k-steps; 16-byte aligned) the preparation launch is
+  // skipped — one kernel and one launch gap less in a chain of eight short dependent kernels (single query, 10M x 768:
+  // 5 us + gap of the ~70 us one lane needs between two of its scoring kernels).
+  const bool raw_rows = direct && h->lists.dim_in == h->lists.dscan && (size_t)h->lists.dpad * 4 == h->lists.row_bytes() &&
+                        (reinterpret_cast<uintptr_t>(d_queries) & 15u) == 0;
+  const float *qrows = raw_rows ? reinterpret_cast<const float *>(d_queries) : nullptr;
+  if (!raw_rows) {
+    ZRET(prep_queries(ctx, h->lists, d_queries, count, FLT_MAX, stream));   // coarse pass: no RNN radius
+    qrows = ctx->qpad.as<float>();
+  }
 
   // 1. coarse assign: flat scan over the centroids, k = nprobe (IVFCentroidIndex::search)
   if (!brute_force) {
@@ -37,14 +48,14 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
       ZRET(ctx->part_s.ensure(pairs * 4));
       if (h->cent.f16)
         hipLaunchKernelGGL(rows_score_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->cent.base,
-                           ctx->qpad.as<float>(), h->cent.dpad, h->metric, nlist, count, stride, ctx->part_s.as<float>());
+                           qrows, h->cent.dpad, h->metric, nlist, count, stride, ctx->part_s.as<float>());
       else
         hipLaunchKernelGGL(rows_score_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->cent.base,
-                           ctx->qpad.as<float>(), h->cent.dpad, h->metric, nlist, count, stride, ctx->part_s.as<float>());
+                           qrows, h->cent.dpad, h->metric, nlist, count, stride, ctx->part_s.as<float>());
       MergeArgs m{};
       m.part_s = ctx->part_s.as<float>(); m.slots_per_q = 1; m.slot_stride = 1; m.k = nprobe; m.slot_len = stride; m.threshold = FLT_MAX;
       m.out_keys = co.keys; m.out_scores = co.scores; m.out_idx = co.idx; m.out_counts = co.counts;
-      hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)nprobe * 12 + 16, stream, m);
+      hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(256), (size_t)nprobe * 12 + 16, stream, m);     // four waves share the row
       ZCHK(hipGetLastError());
     } else {
       ZRET(flat_scan_prepared(ctx, h->cent, count, nprobe, FLT_MAX, nullptr, co, stream, false));
@@ -71,10 +82,8 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     ZRET(ctx->part_s.ensure(pairs * 4));
     ZRET(ctx->part_i.ensure(pairs * 4));
     if (ctx->profile && ctx->nprof < PROFILE_MAX && ctx->stats.p) {       // the slot prof_begin will take for this launch
-      p.work_stats = ctx->stats.as<unsigned long long>() + 2 * (size_t)ctx->nprof;
-      ZCHK(hipMemsetAsync(p.work_stats, 0, 16, stream));
+      p.work_stats = ctx->stats.as<unsigned long long>() + 2 * (size_t)ctx->nprof;     // (zero since the last profile reset)
     }
-    ZCHK(hipMemsetAsync(ctx->direct_pos.p, 0xff, pairs * 4, stream));     // IDX_NONE everywhere; the probed rows overwrite it
     hipLaunchKernelGGL(ivf_expand_direct_kernel, dim3(nprobe, count), dim3(256), 0, stream, p, h->d_tile0, h->d_dense0,
                        reinterpret_cast<const uint32_t *>(d_exclude), stride, d_off, ctx->direct_pos.as<uint32_t>());
     gate_enter(ctx, stream);                                              // (the radius is applied by the selection)
@@ -82,11 +91,11 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     if (pi >= 0) ctx->prof_dscan[pi] = h->lists.dscan | (h->lists.f16 ? 0x80000000u : 0u);
     if (h->lists.f16)
       hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3(pkeys_score_blocks(count, stride)), dim3(256), 0, stream, h->lists.base,
-                         ctx->qpad.as<float>(), h->lists.dpad, h->metric, ctx->direct_pos.as<uint32_t>(), d_off, count, stride,
+                         qrows, h->lists.dpad, h->metric, ctx->direct_pos.as<uint32_t>(), d_off, count, stride,
                          ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
     else
       hipLaunchKernelGGL(pkeys_score_kernel<false>, dim3(pkeys_score_blocks(count, stride)), dim3(256), 0, stream, h->lists.base,
-                         ctx->qpad.as<float>(), h->lists.dpad, h->metric, ctx->direct_pos.as<uint32_t>(), d_off, count, stride,
+                         qrows, h->lists.dpad, h->metric, ctx->direct_pos.as<uint32_t>(), d_off, count, stride,
                          ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
     prof_end(ctx, stream, pi);
     gate_leave(ctx, stream);
@@ -111,7 +120,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
       f.part_s = m.out_scores; f.part_i = m.out_idx; f.slots_per_q = runs; f.slot_stride = 1; f.k = topk; f.slot_len = topk;
       f.threshold = threshold; f.order_by_ordinal = 1; f.keymap = h->lists.keys;
       f.out_keys = out.keys; f.out_scores = out.scores; f.out_idx = out.idx; f.out_counts = out.counts;
-      hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, f);
+      hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(256), (size_t)topk * 12 + 16, stream, f);
     } else {
       m.slot_len = stride;
       m.keymap = h->lists.keys; m.out_keys = out.keys; m.out_scores = out.scores; m.out_idx = out.idx; m.out_counts = out.counts;

@@ -63,9 +63,9 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
   // smallest of them is >= the k-th smallest of the whole row.  Cuts the insertions to the few elements
   // at or below that bound.
   if ((a.part_i == nullptr || (nslots == 1 && a.slot_stride == 1 && a.packed_stride == 0)) && a.part_keys == nullptr &&
-      a.part_counts == nullptr && k <= 64 && total >= 64 && nwaves == 1) {
+      a.part_counts == nullptr && k <= 64 && total >= 64) {
     float mn = __builtin_inff();
-    for (uint64_t base = 0; base < total; base += 64 * U) {
+    for (uint64_t base = (uint64_t)wave * 64 * U; base < total; base += (uint64_t)nwaves * 64 * U) {
       float v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -74,6 +74,12 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) mn = fminf(mn, v[u]);
+    }
+    if (nwaves > 1) {      // several waves (small batches): lane l's minimum over every wave's share — still 64 disjoint subsets
+      __shared__ float wave_min[4][64];
+      wave_min[wave & 3][lane] = mn;
+      __syncthreads();
+      for (uint32_t w = 0; w < nwaves && w < 4; ++w) mn = fminf(mn, wave_min[w][lane]);
     }
     uint32_t rank = 0;
     for (int m = 0; m < 64; ++m) {

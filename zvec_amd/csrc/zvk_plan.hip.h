@@ -140,11 +140,11 @@ __global__ void __launch_bounds__(256) ivf_expand_kernel(const PlanArgs p, const
 // whose k-steps are a chain of dependent HBM round trips): block (rank, query) evaluates the probe rule of plan_wave_kernel
 // for its query (one lane per probe rank, prefix sums of the list sizes) and, if its rank is probed, writes the padded
 // positions of that list's rows into the query's fixed-stride slice pos[q * stride ...] (excluded rows as IDX_NONE; the
-// slice is pre-set to IDX_NONE).  Block rank 0 also writes the slice bounds for pkeys_score_kernel (off[q] = q * stride)
+// unused tail of the slice is set to IDX_NONE by the same blocks).  Block rank 0 also writes the slice bounds for pkeys_score_kernel (off[q] = q * stride)
 // and the per-query statistics the tile path reports (lists probed, rows scanned).
 __global__ void __launch_bounds__(256) ivf_expand_direct_kernel(const PlanArgs p, const uint32_t *list_tile0, const uint64_t *list_dense0,
                                                                 const uint32_t *exclude, uint32_t stride, uint32_t *off, uint32_t *pos) {
-  __shared__ uint32_t sh[4];                     // my list, my offset, probed?, (unused)
+  __shared__ uint32_t sh[4];                     // my list, my offset, probed?, rows of the whole probe set
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t q = blockIdx.y, mine = blockIdx.x;
   const uint32_t np = min(p.coarse_cnt[q], p.nprobe);
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) ivf_expand_direct_kernel(const PlanArgs p
       if (before_g >= p.max_scan_count) break;   // uniform: no later rank is probed
     }
     if (lane == 0) {
-      sh[0] = my_l; sh[1] = my_o; sh[2] = (mine < np) ? my_p : 0u;
+      sh[0] = my_l; sh[1] = my_o; sh[2] = (mine < np) ? my_p : 0u; sh[3] = before_l;
       if (mine == 0) {
         p.q_nprobe[q] = probes;
         p.q_scanned[q] = scanned;
@@ -187,6 +187,14 @@ __global__ void __launch_bounds__(256) ivf_expand_direct_kernel(const PlanArgs p
     }
   }
   __syncthreads();
+  {
+    // the unused tail of the query's slice holds IDX_NONE (no separate fill launch): every block of the query writes its share
+    const uint32_t total = min(sh[3], stride), tail = stride - total;
+    const uint32_t share = (tail + gridDim.x - 1) / gridDim.x;
+    const uint32_t b = total + min(mine * share, tail), e = total + min((mine + 1) * share, tail);
+    uint32_t *dst = pos + (size_t)q * stride;
+    for (uint32_t j = b + tid; j < e; j += 256) dst[j] = IDX_NONE;
+  }
   if (!sh[2]) return;
   const uint32_t l = sh[0], o = sh[1];
   const uint32_t sz = min(p.list_size[l], stride > o ? stride - o : 0u);   // (stride bounds the rows of any probe set)
