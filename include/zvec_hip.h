@@ -333,6 +333,14 @@ int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *sc
 int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_t bytes, uint64_t count, int column_major,
                                 uint32_t batch_size, const uint64_t *keys);
 
+/* HipFlatStreamer::open over a storage the reference's FlatStreamer has written (FlatStreamerEntity, flat_streamer_entity.cc:43-47,
+ * flat_streamer_entity.h:287-311, BlockHeader / DeletionMap flat_index_format.h:91-126): `blocks` = a run of `nblocks` blocks of
+ * `block_size` bytes as they lie in a "flat.features<i>" segment — [block_vector_count x element][block_vector_count x u64 key]
+ * ... [DeletionMap][BlockHeader] — and keep[b] = the live rows of block b (bit r: r < vector_count, not deleted, key valid).
+ * One strided copy + one launch per run instead of a provider walk row by row.  Appends, in block / row order. */
+int zvec_hip_flat_load_blocks(zvec_hip_flat_t h, const void *blocks, uint64_t nblocks, uint32_t block_size,
+                              uint32_t block_vector_count, const uint32_t *keep);
+
 /* IVFSearcher::load from the raw payloads of the segments a dumped reference index holds (SURVEY next-2):
  *   inverted_header  "ivf.inverted_header": InvertedIndexHeader (ivf_index_format.h:26-37) + the serialised IndexMeta
  *                    (IndexMetaFormatHeader, src/core/framework/index_meta.cc:23-34: major order, data type, dimension)

@@ -36,6 +36,9 @@
 #include <unordered_map>
 #include <vector>
 
+#include "algorithm/flat/flat_index_format.h"    // StreamerLinearMeta, BlockHeader, DeletionMap: the mutable streamer's persisted blocks
+#include "algorithm/flat/flat_utility.h"         // its segment ids
+
 #include "hip_plugin_common.h"
 #include "zvec_hip.h"
 
@@ -357,6 +360,36 @@ class HipFlatCore {
     return sh_ ? zvec_hip_shards_flat_load_features(sh_, features, bytes, n, column_major, 32, keys)
                : zvec_hip_flat_load_features(h_, features, bytes, n, column_major, 32, keys);
   }
+  //! a run of FlatStreamerEntity blocks (one "flat.features<i>" segment) -> HBM: one strided copy + one pack launch
+  int load_blocks(const void *blocks, size_t nblocks, uint32_t block_size, uint32_t bvc, const std::vector<uint32_t> &keep) {
+    std::unique_lock<FairSharedMutex> w(mu_);
+    if (sh_) {            // sharded mirror: rows dealt by the shards' own append (no strided path there)
+      const char *p = static_cast<const char *>(blocks);
+      for (size_t b = 0; b < nblocks; ++b)
+        for (uint32_t m = keep[b]; m; m &= m - 1) {
+          const uint32_t r = (uint32_t)__builtin_ctz(m);
+          uint64_t key;
+          memcpy(&key, p + b * block_size + (size_t)bvc * elem_size_ + (size_t)r * 8, 8);
+          int rc = zvec_hip_shards_flat_append(sh_, p + b * block_size + (size_t)r * elem_size_, 1, &key);
+          if (rc != 0) return rc;
+          pos_of_key_.emplace(key, (uint32_t)keys_.size());
+          keys_.push_back(key);
+        }
+      return 0;
+    }
+    int rc = zvec_hip_flat_load_blocks(h_, blocks, nblocks, block_size, bvc, keep.data());
+    if (rc != 0) return rc;
+    const char *p = static_cast<const char *>(blocks);
+    for (size_t b = 0; b < nblocks; ++b)
+      for (uint32_t m = keep[b]; m; m &= m - 1) {
+        const uint32_t r = (uint32_t)__builtin_ctz(m);
+        uint64_t key;
+        memcpy(&key, p + b * block_size + (size_t)bvc * elem_size_ + (size_t)r * 8, 8);
+        pos_of_key_.emplace(key, (uint32_t)keys_.size());
+        keys_.push_back(key);
+      }
+    return 0;
+  }
   size_t count() const { return keys_.size(); }
   uint64_t key_at(size_t pos) const { return keys_[pos]; }
   uint32_t elem_size() const { return elem_size_; }
@@ -556,11 +589,15 @@ class HipFlatStreamer : public IndexStreamer {
   }
   int cleanup() override { core_.destroy(); return store_ ? store_->cleanup() : 0; }
   int open(IndexStorage::Pointer stg) override {
+    stg_keep_ = stg;
     int rc = store_->open(std::move(stg));
     if (rc != 0) return rc;
     if ((rc = core_.create(meta_, device_, ndev_)) != 0) return rc;
-    // rows already persisted: walk the reference streamer's provider (key, vector) in storage order
-    auto provider = store_->create_provider();
+    // rows already persisted: the block runs of the storage's feature segments go to HBM whole (bulk_open); a storage whose
+    // layout this reader does not recognise falls back to the reference streamer's provider walk (key, vector), row by row
+    int bulk = this->bulk_open(stg_keep_.get());
+    if (bulk < 0) return bulk;
+    auto provider = bulk == 0 ? store_->create_provider() : Provider::Pointer();
     if (provider) {
       const size_t es = meta_.element_size(), chunk = 16384;
       std::string rows;
@@ -580,7 +617,7 @@ class HipFlatStreamer : public IndexStreamer {
     return 0;
   }
   int flush(uint64_t check_point) override { return store_->flush(check_point); }
-  int close() override { core_.destroy(); return store_->close(); }
+  int close() override { core_.destroy(); stg_keep_.reset(); return store_->close(); }
   const IndexMeta &meta() const override { return meta_; }
   const Stats &stats() const override { return store_->stats(); }
   int dump(const IndexDumper::Pointer &dumper) override { return store_->dump(dumper); }
@@ -633,6 +670,51 @@ class HipFlatStreamer : public IndexStreamer {
   int device_{0};
   uint32_t ndev_{1};
   uint32_t magic_{0};
+  //! The persisted rows of a FlatStreamer storage, read the way FlatStreamerEntity lays them out (flat_streamer_entity.cc:43-47,
+  //! flat_streamer_entity.h:287-311; meta StreamerLinearMeta, flat_index_format.h:128-146): segments "flat.features1" ..
+  //! "flat.features<segment_count>", each a run of blocks [bvc x element][bvc x key] ... [DeletionMap][BlockHeader].  Live rows =
+  //! below the block's vector_count, not deleted, key valid — the rows FlatStreamerEntity::search scans (flat_streamer_entity.cc:
+  //! 212-316), in the order its iterator walks them (:428-460).  Returns 1 when loaded, 0 to fall back to the provider walk.
+  int bulk_open(IndexStorage *stg) {
+    if (!stg) return 0;
+    auto mseg = stg->get(FLAT_LINEAR_META_SEG_ID);
+    if (!mseg || mseg->data_size() < sizeof(StreamerLinearMeta)) return 0;
+    const void *mp = nullptr;
+    if (mseg->read(0, &mp, sizeof(StreamerLinearMeta)) != sizeof(StreamerLinearMeta) || !mp) return 0;
+    StreamerLinearMeta lm;
+    memcpy(static_cast<void *>(&lm), mp, sizeof(lm));
+    const uint32_t bvc = lm.header.block_vector_count, bs = lm.header.block_size;
+    const size_t es = meta_.element_size();
+    if (bvc == 0 || bvc > 32 || bs < bvc * (es + 8) + sizeof(DeletionMap) + sizeof(BlockHeader)) return 0;
+    for (uint32_t si = 1; si <= lm.segment_count; ++si) {
+      auto seg = stg->get(FLAT_SEGMENT_FEATURES_SEG_ID + std::to_string(si));
+      if (!seg) return core_.count() == 0 ? 0 : (int)IndexError_InvalidFormat;
+      const size_t nblk = seg->data_size() / bs;
+      if (nblk == 0) continue;
+      const void *p = nullptr;
+      if (seg->read(0, &p, nblk * bs) != nblk * bs || !p) return core_.count() == 0 ? 0 : (int)IndexError_ReadData;
+      std::vector<uint32_t> keep(nblk, 0);
+      const char *base = static_cast<const char *>(p);
+      for (size_t b = 0; b < nblk; ++b) {
+        BlockHeader hd;
+        DeletionMap dm;
+        memcpy(static_cast<void *>(&hd), base + (b + 1) * bs - sizeof(BlockHeader), sizeof(hd));
+        memcpy(static_cast<void *>(&dm), base + (b + 1) * bs - sizeof(BlockHeader) - sizeof(DeletionMap), sizeof(dm));
+        const uint64_t *keys = reinterpret_cast<const uint64_t *>(base + b * bs + bvc * es);
+        uint32_t m = 0;
+        for (uint32_t r = 0; r < hd.vector_count && r < bvc; ++r) {
+          uint64_t key;
+          memcpy(&key, keys + r, 8);
+          if (!dm.test(r) && key != kInvalidKey) m |= 1u << r;
+        }
+        keep[b] = m;
+      }
+      int rc = core_.load_blocks(p, nblk, bs, bvc, keep);
+      if (rc != 0) return rc;
+    }
+    return 1;
+  }
+
   //! the wrapped streamer's add paths insist on a context of their own type (dynamic_cast, flat_streamer.cc:226-231,276-281):
   //! the caller's HipContext carries one, made on first use
   Context::Pointer *inner_context(Context::Pointer &c) const {
@@ -643,6 +725,7 @@ class HipFlatStreamer : public IndexStreamer {
   }
 
   IndexStreamer::Pointer store_;          // the reference's FlatStreamer: storage engine side
+  IndexStorage::Pointer stg_keep_;        // the storage it was opened on (bulk_open reads the block runs from it)
   HipFlatCore core_;
 };
 

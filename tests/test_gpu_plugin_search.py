@@ -283,8 +283,12 @@ def test_flat_streamer_wraps_the_reference_streamer(R):
         ref = R.Runner.streamer("FlatStreamer", os.path.join(tmp, "ref"), dim, "SquaredEuclidean")
         hip = R.Runner.streamer("HipFlatStreamer", os.path.join(tmp, "hip"), dim, "SquaredEuclidean")
         assert ref.add(keys[:2000], base[:2000]) == 0 and hip.add(keys[:2000], base[:2000]) == 0
-        # add_with_id: the product's add path (index.cc:505-537): ids beyond the count, then an overwrite
+        # add_with_id: the product's add path (index.cc:505-537): ids at the count, then ids BEYOND it — the gap is padded with
+        # invalid rows that no scan may return (flat_streamer_entity.cc:900-990)
         assert ref.add(keys[2000:], base[2000:], with_id=True) == 0 and hip.add(keys[2000:], base[2000:], with_id=True) == 0
+        far = rng.standard_normal((40, dim)).astype(np.float32)
+        far_ids = np.arange(n + 75, n + 115, dtype=np.uint64)
+        assert ref.add(far_ids, far, with_id=True) == 0 and hip.add(far_ids, far, with_id=True) == 0
         q = rng.standard_normal((7, dim)).astype(np.float32)
         k = 8
         rc_, hc = ref.create_context(), hip.create_context()
@@ -315,12 +319,15 @@ def test_flat_streamer_wraps_the_reference_streamer(R):
         # re-open: the rows come back from the persisted block chain
         hip = R.Runner.streamer("HipFlatStreamer", os.path.join(tmp, "hip"), dim, "SquaredEuclidean", create=False)
         ref = R.Runner.streamer("FlatStreamer", os.path.join(tmp, "ref"), dim, "SquaredEuclidean", create=False)
-        assert hip.count() == n
         rc_, hc = ref.create_context(), hip.create_context()
         rc_.set_topk(k), hc.set_topk(k)
-        both("re-opened streamer knn")
+        both("re-opened streamer knn")                       # (block runs read straight from the storage: HipFlatStreamer::bulk_open)
+        q[:] = far[:len(q)] + 0.01                           # the rows behind the gap are found, the gap's padding is not
+        both("re-opened streamer, rows behind the add_with_id gap")
+        r2, v2 = hip.get_vector(int(far_ids[3]))
+        assert r2 == 0 and np.array_equal(v2, far[3])
         more = rng.standard_normal((100, dim)).astype(np.float32)
-        mk = np.arange(n, n + 100, dtype=np.uint64)
+        mk = np.arange(n + 200, n + 300, dtype=np.uint64)
         assert ref.add(mk, more) == 0 and hip.add(mk, more) == 0
         both("re-opened streamer after more adds")
         rc_.close(), hc.close()

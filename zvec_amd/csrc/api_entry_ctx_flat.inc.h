@@ -230,6 +230,59 @@ int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_
   return rc;
 }
 
+// FlatStreamerEntity's persisted rows (flat_streamer_entity.cc:43-47, flat_streamer_entity.h:287-311): a storage segment is a run
+// of blocks of `block_size` bytes, each [block_vector_count x element][block_vector_count x u64 key] ... [DeletionMap 4 B]
+// [BlockHeader 12 B]; the rows of a block are contiguous and always row-major (header.column_major is never set,
+// flat_streamer_entity.cc:826).  `keep[b]`: bit r set = row r of block b is live (r < header.vector_count, not deleted, key
+// valid) — the caller derives it from the 16 tail bytes of each block.  One strided H2D copy brings the row regions of the
+// whole run over, one pack launch appends the kept rows (in block / row order = the reference iterator's order,
+// flat_streamer_entity.cc:428-460) with the keys read from the run.
+int zvec_hip_flat_load_blocks(zvec_hip_flat_t h, const void *blocks, uint64_t nblocks, uint32_t block_size,
+                              uint32_t block_vector_count, const uint32_t *keep) {
+  if (!h || (nblocks && (!blocks || !keep)) || block_vector_count == 0 || block_vector_count > 32) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (nblocks == 0) return 0;
+  const uint64_t elem = h->st.row_bytes();
+  const uint64_t rows_bytes = (uint64_t)block_vector_count * elem;
+  if (rows_bytes + (uint64_t)block_vector_count * 8 > block_size) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::vector<uint64_t> src, keys;
+  const char *p = static_cast<const char *>(blocks);
+  for (uint64_t b = 0; b < nblocks; ++b) {
+    uint32_t m = keep[b];
+    if (block_vector_count < 32) m &= (1u << block_vector_count) - 1u;
+    const char *kp = p + b * block_size + rows_bytes;
+    for (; m; m &= m - 1) {
+      const uint32_t r = (uint32_t)__builtin_ctz(m);
+      uint64_t key;
+      memcpy(&key, kp + (size_t)r * 8, 8);
+      src.push_back(b * block_vector_count + r);
+      keys.push_back(key);
+    }
+  }
+  const uint64_t kept = src.size();
+  if (kept == 0) return 0;
+  std::lock_guard<std::mutex> g(h->mu);
+  std::unique_lock<FairSharedMutex> w(h->rw);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = h->defctx->own;
+  Scoped<char> d_rows;
+  Scoped<uint64_t> d_src, d_keys;
+  ZRET(d_rows.alloc(nblocks * rows_bytes));
+  ZRET(d_src.alloc(kept));
+  ZRET(d_keys.alloc(kept));
+  ZCHK(hipMemcpy2DAsync(d_rows, rows_bytes, blocks, block_size, rows_bytes, nblocks, hipMemcpyHostToDevice, s));
+  ZCHK(hipMemcpyAsync(d_src, src.data(), kept * 8, hipMemcpyHostToDevice, s));
+  ZCHK(hipMemcpyAsync(d_keys, keys.data(), kept * 8, hipMemcpyHostToDevice, s));
+  if (h->st.n + kept >= 0xfffffff0ull) return ZVEC_HIP_ERR_OUT_OF_RANGE;
+  ZRET(h->st.reserve(h->st.n + kept, s));
+  int rc = launch_pack(h->st, d_rows, kept, d_src, h->st.n, nullptr, s, h->st.keys, d_keys);
+  if (rc == 0) {
+    h->st.n += kept;
+    rc = flat_holes_cover(h, s);
+  }
+  ZCHK(hipStreamSynchronize(s));
+  return rc;
+}
+
 int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const uint64_t *keys) {
   if (!h || (!vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (n == 0) return 0;
