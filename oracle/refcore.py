@@ -74,6 +74,10 @@ def load_plugin(path=PLUGIN):
     global _plugin_loaded
     if _plugin_loaded:
         return
+    # ONE HIP runtime per process: the plugin links zvec_amd/libzvec_hip.so, which must already be loaded the way the package loads
+    # it (after torch, whose wheel bundles its own libamdhip64 — see zvec_amd/_lib.py); a C++ host has no such concern
+    from zvec_amd import _lib as _product
+    _product.lib()
     err = C.create_string_buffer(512)
     rc = lib().zref_load_plugin(path.encode(), err, 512)
     if rc != 0:

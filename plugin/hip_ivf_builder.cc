@@ -29,10 +29,12 @@ namespace core {
 
 namespace {
 const std::string kParamCentroidCount("proxima.ivf.builder.centroid_count");   // ivf_params.h:25-26 ("4096" or "64*64")
-const std::string kParamHipKmeansIters("proxima.hip.builder.kmeans_iters");   // new: Lloyd iterations (default 10)
+const std::string kParamHipKmeansIters("proxima.hip.builder.kmeans_iters");   // new: Lloyd rounds (default 20 = OptKmeansCluster's max_iterations, opt_kmeans_cluster.cc:115)
+const std::string kParamTrainSampleCount("proxima.ivf.builder.train_sample_count");   // ivf_params.h:33-36: 0 / absent = train on every row
+const std::string kParamTrainSampleRatio("proxima.ivf.builder.train_sample_ratio");
 }  // namespace
 
-/*! "HipIVFBuilder": stands where IVFBuilder is registered (ivf_builder.cc).  train + build = k-means over a strided sample,
+/*! "HipIVFBuilder": stands where IVFBuilder is registered (ivf_builder.cc).  train + build = k-means (20 Lloyd rounds over every row by default, like the reference's trainer; a strided sample when train_sample_count / _ratio say so),
  *  nearest-centroid labels and list packing on the device (zvec_hip_ivf_build); dump writes the SAME index file as
  *  IVFBuilder::dump_index / dump (ivf_builder.cc:405-440,652-729) through the reference's own IVFDumper, with the centroid
  *  index as the image its FlatBuilder dumps (IVFCentroidIndex::build, ivf_centroid_index.cc:468-490) — so IVFSearcher /
@@ -46,6 +48,8 @@ class HipIVFBuilder : public IndexBuilder {
     if (metric_of(meta) < 0 || dtype_of(meta) < 0) return IndexError_Unsupported;
     params.get(kParamHipDevice, &device_);
     params.get(kParamHipKmeansIters, &kmeans_iters_);
+    params.get(kParamTrainSampleCount, &sample_count_);
+    params.get(kParamTrainSampleRatio, &sample_ratio_);
     std::string spec;
     params.get(kParamCentroidCount, &spec);
     uint64_t total = spec.empty() ? 0 : 1;
@@ -89,7 +93,13 @@ class HipIVFBuilder : public IndexBuilder {
     nlist = (uint32_t)std::min<uint64_t>(nlist, n);
     int rc = zvec_hip_ivf_create(meta_.dimension(), dtype_of(meta_), metric_of(meta_), device_, &h_);
     if (rc != 0) return rc;
-    if ((rc = zvec_hip_ivf_build(h_, rows_.data(), n, keys_.data(), nlist, kmeans_iters_, 256, 20260320ull)) != 0) return rc;
+    // training sample as StratifiedClusterTrainer takes it (stratified_cluster_trainer.cc:150-185): max(sample_count,
+    // sample_ratio * n) rows when either is set, every row otherwise — the reference's default, and what the cluster-quality
+    // fixture (tests/golden/kmeans_quality.json) pins the GPU trainer against
+    uint64_t sample = std::max<uint64_t>(sample_count_, (uint64_t)((double)sample_ratio_ * (double)n));
+    if (sample == 0 || sample > n) sample = n;
+    const uint32_t per_list = (uint32_t)std::min<uint64_t>((sample + nlist - 1) / nlist, 0xffffffffu);
+    if ((rc = zvec_hip_ivf_build(h_, rows_.data(), n, keys_.data(), nlist, kmeans_iters_, per_list, 20260320ull)) != 0) return rc;
     nlist_built_ = nlist;
     stats_.set_built_count(n);
     return 0;
@@ -177,7 +187,8 @@ class HipIVFBuilder : public IndexBuilder {
   ailego::Params params_;
   Stats stats_;
   int device_{0};
-  uint32_t nlist_{0}, nlist_built_{0}, kmeans_iters_{10};
+  uint32_t nlist_{0}, nlist_built_{0}, kmeans_iters_{20}, sample_count_{0};
+  float sample_ratio_{0.0f};
   zvec_hip_ivf_t h_{nullptr};
   std::string rows_;                      // the holder's rows, kept for the dump (the reference keeps the holder)
   std::vector<uint64_t> keys_;

@@ -152,3 +152,58 @@ def test_streamed_build_errors(zv):
     assert se.begin_lists(np.array([4, 0], np.uint32)) == 0
     assert se.add_dev(d.data_ptr(), 16, np.zeros(16, np.uint32), 0) == zv.IndexError_.InvalidArgument    # list 0 overflows
     assert se.add_dev(d.data_ptr(), 1, np.array([5], np.uint32), 0) == zv.IndexError_.InvalidArgument     # no such list
+
+
+def _kmeans_quality_corpus(fx):
+    c = fx["corpus"]
+    rng = np.random.default_rng(c["seed"])
+    means = rng.standard_normal((1024, c["dim"])).astype(np.float32) * 1.0
+    base = (means[rng.integers(0, 1024, c["n"])] + rng.standard_normal((c["n"], c["dim"])).astype(np.float32)).astype(np.float32)
+    q = (means[rng.integers(0, 1024, c["queries"])] + rng.standard_normal((c["queries"], c["dim"])).astype(np.float32)).astype(np.float32)
+    return base, q
+
+
+def test_kmeans_quality_vs_reference_trainer(zv):
+    """The reference's trainer (IVFBuilder: StratifiedClusterTrainer + OptKmeansCluster, ivf_builder.cc:524-531) seeds from
+    std::random_device, so its centroids are not reproducible bit for bit; its clustering QUALITY is.  Fixture
+    tests/golden/kmeans_quality.json (made by tests/golden/make_kmeans_quality.py with the reference's builder compiled in place):
+    five runs on a seeded 200k x 64 corpus of overlapping Gaussians — within-cluster sum of squares per row, list-size spread,
+    recall@10 at nprobe 4 of 256 through the reference's own IVFSearcher.  The GPU build (zvec_hip_ivf_build: Lloyd on a strided
+    sample + labelling of every row) of the same corpus must sit inside the reference's own seed-to-seed spread: SSE no worse than
+    its worst run (+0.2 %), recall no lower than its lowest (-0.01), list-size spread no worse than its worst (+15 %)."""
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kmeans_quality.json")))
+    c = fx["corpus"]
+    base, q = _kmeans_quality_corpus(fx)
+    n, dim, nlist, k, nprobe = c["n"], c["dim"], c["nlist"], c["k"], c["nprobe"]
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean")
+    # the reference's defaults: at most 20 Lloyd rounds (opt_kmeans_cluster.cc:115) over EVERY row (train_sample_count 0 =
+    # no sampling, stratified_cluster_trainer.cc:150-185)
+    assert se.build(base, nlist, kmeans_iters=20, sample_per_list=(n + nlist - 1) // nlist) == 0
+    cent, offs, rows = se.export()
+    labels = np.empty(n, np.int64)
+    for l in range(nlist):
+        labels[rows[int(offs[l]):int(offs[l + 1])].astype(np.int64)] = l
+    diff = base.astype(np.float64) - cent.astype(np.float64)[labels]
+    sse = float((diff ** 2).sum() / n)
+    sizes = np.bincount(labels, minlength=nlist)
+    spread = float(sizes.max() / sizes.mean())
+    se.set_nprobe(nprobe, exact=True)
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, len(q), ctx) == 0
+    d = (q.astype(np.float64) ** 2).sum(1)[:, None] + (base.astype(np.float64) ** 2).sum(1)[None] - 2 * q.astype(np.float64) @ base.astype(np.float64).T
+    gt = np.argsort(d, 1, kind="stable")[:, :k]
+    rec = float(np.mean([len(set(ctx.keys[i, :ctx.counts[i]].tolist()) & set(gt[i].tolist())) / k for i in range(len(q))]))
+    ref = fx["runs"]
+    worst_sse = max(r["sse_per_row"] for r in ref)
+    low_rec = min(r["recall_at_10"] for r in ref)
+    worst_spread = max(r["size_max_over_mean"] for r in ref)
+    print("GPU k-means: SSE/row %.3f (reference %.3f .. %.3f), spread %.2f (reference <= %.2f), recall@10 %.4f (reference %.4f .. %.4f), empty lists %d"
+          % (sse, min(r["sse_per_row"] for r in ref), worst_sse, spread, worst_spread, rec, low_rec, max(r["recall_at_10"] for r in ref),
+             int((sizes == 0).sum())))
+    assert sse <= worst_sse * 1.002
+    assert rec >= low_rec - 0.01
+    assert spread <= worst_spread * 1.15
+    assert (sizes == 0).sum() == 0

@@ -91,3 +91,31 @@ def direct_rows_in_list_order(direct, base, keys):
     _, _, rows = direct.export()
     rows = rows.astype(np.int64)
     return base[rows], keys[rows]
+
+
+def test_plugin_builder_defaults_reach_the_reference_trainers_quality():
+    """"HipIVFBuilder" with its DEFAULT parameters (20 Lloyd rounds over every row, as the reference's trainer) on the cluster-quality
+    corpus of tests/golden/kmeans_quality.json; the dumped file is searched by the reference's OWN IVFSearcher at nprobe 4 of 256:
+    recall@10 must not fall below the lowest of the reference builder's five runs (-0.01)."""
+    import json
+    from oracle import refcore as R
+    from tests.test_gpu_build import _kmeans_quality_corpus
+    if not (os.path.exists(R.CORE) and os.path.exists(R.PLUGIN)):
+        pytest.skip("oracle/_ref libraries not built (needs the reference checkout at build time)")
+    R.load_plugin()
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kmeans_quality.json")))
+    c = fx["corpus"]
+    base, q = _kmeans_quality_corpus(fx)
+    R.build("HipIVFBuilder", base, "SquaredEuclidean", "plugin_quality", params={"proxima.ivf.builder.centroid_count": str(c["nlist"])})
+    se = R.Runner.searcher("IVFSearcher", "plugin_quality", c["dim"],
+                           params={"proxima.ivf.searcher.scan_ratio": c["nprobe"] / c["nlist"], "proxima.ivf.searcher.brute_force_threshold": c["n"] - 1})
+    kk, _, cc, _ = se.search_mt(q, c["k"], 8)
+    se.close()
+    R.mem_remove("plugin_quality")
+    d = (q.astype(np.float64) ** 2).sum(1)[:, None] + (base.astype(np.float64) ** 2).sum(1)[None] - 2 * q.astype(np.float64) @ base.astype(np.float64).T
+    gt = np.argsort(d, 1, kind="stable")[:, :c["k"]]
+    rec = float(np.mean([len(set(kk[i, :cc[i]].tolist()) & set(gt[i].tolist())) / c["k"] for i in range(len(q))]))
+    low = min(r["recall_at_10"] for r in fx["runs"])
+    print("plugin-built index searched by the reference's IVFSearcher: recall@10 %.4f (reference builder %.4f .. %.4f)"
+          % (rec, low, max(r["recall_at_10"] for r in fx["runs"])))
+    assert rec >= low - 0.01
