@@ -10,12 +10,52 @@
 #include <chrono>
 #include <cstdlib>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "../../zvec_amd/csrc/host/hip_index.h"
 
 using namespace zvec_hip_host;
 static int g_fail = 0;
+
+// Bounded waits.  Round 2's reader/writer starvation showed up as a silent 300 s kill with no output: every thread of the
+// concurrent tests now reports what it is about to do (TICK), and a watchdog ends the program with that picture — the test that
+// is running, each worker's last reported step, how long nothing has moved — when NO thread has reported for STALL_SECONDS.
+static std::atomic<uint64_t> g_progress{0};
+static std::atomic<const char *> g_test{"(start)"};
+constexpr int kSlots = 8;
+static std::atomic<const char *> g_where[kSlots];
+static std::atomic<uint64_t> g_steps[kSlots];
+constexpr int STALL_SECONDS = 60;
+#define TICK(slot, what)            \
+  do {                              \
+    g_where[(slot)] = (what);       \
+    ++g_steps[(slot)];              \
+    ++g_progress;                   \
+  } while (0)
+static void watchdog() {
+  uint64_t last = g_progress.load();
+  int idle = 0;
+  for (;;) {
+    std::this_thread::sleep_for(std::chrono::seconds(1));
+    const uint64_t now = g_progress.load();
+    if (now != last) { last = now; idle = 0; continue; }
+    if (++idle < STALL_SECONDS) continue;
+    printf("STALL: no thread has made progress for %d s in %s\n", STALL_SECONDS, g_test.load());
+    for (int i = 0; i < kSlots; ++i)
+      if (g_where[i].load()) printf("  worker %d: last step \"%s\" (%llu steps)\n", i, g_where[i].load(), (unsigned long long)g_steps[i].load());
+    fflush(stdout);
+    _exit(3);
+  }
+}
+#define RUN(test)                                   \
+  do {                                              \
+    g_test = #test;                                 \
+    for (int i_ = 0; i_ < kSlots; ++i_) { g_where[i_] = nullptr; g_steps[i_] = 0; } \
+    ++g_progress;                                   \
+    rc |= test();                                   \
+    ++g_progress;                                   \
+  } while (0)
 #define EXPECT(cond)                                                              \
   do {                                                                            \
     if (!(cond)) { printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); ++g_fail; } \
@@ -265,6 +305,7 @@ static int TestMicroBatcher() {
         ctx->set_topk(topk);
         for (uint32_t i = 0; i < per_thread; ++i) {
           const size_t qi = (size_t)t * per_thread + i;
+          TICK(t % kSlots, pass ? "micro-batched single query" : "direct single query");
           if (se.search_impl(&queries[qi * dim], qmeta, ctx) != 0) { ++bad; continue; }
           // same documents, same scores; documents with EQUAL scores may come in either order (a batch of > 8 queries
           // takes the list-major route, a single query the direct one: both keep the k best under (score, scan order), the
@@ -332,6 +373,7 @@ static int TestNullContextFromManyThreads() {
     th.emplace_back([&, t]() {
       for (uint32_t r = 0; r < rounds; ++r) {
         Out a = mk(), b = mk();
+        TICK(t % kSlots, "NULL-context flat + ivf search");
         if (zvec_hip_flat_search(flat, nullptr, q[t].data(), nq, topk, FLT_MAX, nullptr, a.k.data(), a.s.data(), a.c.data()) != 0 ||
             zvec_hip_ivf_search(ivf, nullptr, q[t].data(), nq, topk, FLT_MAX, 4, n, nullptr, b.k.data(), b.s.data(), b.c.data()) != 0) { ++bad; continue; }
         if (a.k != want_f[t].k || a.s != want_f[t].s || a.c != want_f[t].c) ++bad;
@@ -366,7 +408,8 @@ static int TestConcurrentAddWithFilterAndFetch() {
   std::atomic<bool> done{false};
   std::thread adder([&]() {
     Context::Pointer c;
-    for (uint64_t i = n0; i < n1; ++i) { auto v = row(i); if (st.add_impl(i, v.data(), qmeta, c) != 0) ++bad; }
+    for (uint64_t i = n0; i < n1; ++i) { auto v = row(i); TICK(0, "adder: add_impl"); if (st.add_impl(i, v.data(), qmeta, c) != 0) ++bad; }
+    TICK(0, "adder: done");
     done = true;
   });
   std::vector<std::thread> th;
@@ -380,7 +423,9 @@ static int TestConcurrentAddWithFilterAndFetch() {
       int loops = 0;
       while (!done.load() || loops < 3) {
         ++loops;
+        TICK(1 + t, "searcher: search_impl (filter + fetch_vector)");
         if (st.search_impl(q.data(), qmeta, ctx) != 0) { ++bad; continue; }
+        TICK(1 + t, "searcher: checking the result");
         const auto &r = ctx->result();
         if (r.size() != topk) { ++bad; continue; }
         for (const auto &d : r) {
@@ -423,13 +468,16 @@ static int TestConcurrentPutAndSearch() {
     // multiples of 3 first (gaps of two holes each), overwrites of live rows in between, then the gaps
     for (uint32_t i = n0; i < n1; i += 3) {
       auto v = row(i);
+      TICK(0, "writer: add_with_id_impl (append behind a gap)");
       if (st.add_with_id_impl(i, v.data(), qmeta, c) != 0) ++bad;
       const uint32_t o = rnd() % n0;
       auto w = row(o);
+      TICK(0, "writer: add_with_id_impl (overwrite)");
       if (st.add_with_id_impl(o, w.data(), qmeta, c) != 0) ++bad;
     }
     for (uint32_t i = n0; i < n1; ++i)
-      if (i % 3 != n0 % 3) { auto v = row(i); if (st.add_with_id_impl(i, v.data(), qmeta, c) != 0) ++bad; }
+      if (i % 3 != n0 % 3) { auto v = row(i); TICK(0, "writer: add_with_id_impl (gap fill)"); if (st.add_with_id_impl(i, v.data(), qmeta, c) != 0) ++bad; }
+    TICK(0, "writer: done");
     done = true;
   });
   auto written = [&](uint64_t key) { return key < n1; };
@@ -442,7 +490,9 @@ static int TestConcurrentPutAndSearch() {
     int loops = 0;
     while (!done.load() || loops < 3) {
       ++loops;
+      TICK(1, "filtered search: search_impl");
       if (st.search_impl(q.data(), qmeta, ctx) != 0) { ++bad; continue; }
+      TICK(1, "filtered search: checking");
       const auto &r = ctx->result();
       if (r.size() != topk) { ++bad; continue; }
       if (r[0].score() != 0.0f) ++bad;
@@ -461,7 +511,9 @@ static int TestConcurrentPutAndSearch() {
     int loops = 0;
     while (!done.load() || loops < 3) {
       ++loops;
+      TICK(2, "p_keys search: search_bf_by_p_keys_impl");
       if (st.search_bf_by_p_keys_impl(q.data(), pk, qmeta, 1, ctx) != 0) { ++bad; continue; }
+      TICK(2, "p_keys search: checking");
       const auto &r = ctx->result();
       if (r.size() != 4 || r[0].score() != 0.0f) { ++bad; continue; }
       for (const auto &d : r) if (!written(d.key())) ++bad;
@@ -475,7 +527,9 @@ static int TestConcurrentPutAndSearch() {
     int loops = 0;
     while (!done.load() || loops < 3) {
       ++loops;
+      TICK(3, "group-by search: search_impl");
       if (st.search_impl(q.data(), qmeta, 1, ctx) != 0) { ++bad; continue; }
+      TICK(3, "group-by search: checking");
       const auto &g = ctx->group_result();
       if (g.size() != 4) { ++bad; continue; }
       for (const auto &grp : g) {
@@ -669,16 +723,17 @@ static int TestAddAndSearchWithID() {
 
 int main() {
   int rc = 0;
-  rc |= TestLinearSearch();
-  rc |= TestAddAndSearchWithID();
-  rc |= TestGroup();
-  rc |= TestFilter();
-  rc |= TestIVFSimple();
-  rc |= TestNullContextFromManyThreads();
-  rc |= TestConcurrentAddWithFilterAndFetch();
-  rc |= TestConcurrentPutAndSearch();
-  rc |= TestBoundaryAMapping();
-  rc |= TestMicroBatcher();
+  std::thread(watchdog).detach();
+  RUN(TestLinearSearch);
+  RUN(TestAddAndSearchWithID);
+  RUN(TestGroup);
+  RUN(TestFilter);
+  RUN(TestIVFSimple);
+  RUN(TestNullContextFromManyThreads);
+  RUN(TestConcurrentAddWithFilterAndFetch);
+  RUN(TestConcurrentPutAndSearch);
+  RUN(TestBoundaryAMapping);
+  RUN(TestMicroBatcher);
   if (rc == 0 && g_fail == 0) { printf("host mirror: all tests passed\n"); return 0; }
   printf("host mirror: %d failures (rc=%d)\n", g_fail, rc);
   return 1;

@@ -160,7 +160,7 @@ def test_config2_ivf_10m_768_batch1024_properties(zv, oracle, ten_million):
                          what="10M oracle spot")
 
 
-def test_config4_filtered_scan_10m_bitmap_batch512(zv, ten_million):
+def test_config4_filtered_scan_10m_bitmap_batch512(zv, oracle, ten_million):
     t = ten_million
     stream, dev, n, dim, base = t["stream"], t["dev"], t["n"], t["dim"], t["base"]
     nq, k = 512, 10
@@ -183,6 +183,20 @@ def test_config4_filtered_scan_10m_bitmap_batch512(zv, ten_million):
             if len(allowed) >= k:
                 assert [kk for _, kk in allowed[:k]] == fk[i].tolist() or np.array_equal(
                     np.array([s for s, _ in allowed[:k]], np.float32), fs[i])
+        if p_keep == 0.1:
+            # ... and against the ORACLE (not the GPU's own unfiltered answer): the ~1M kept rows are brought to the host and the
+            # restated CPU scan (flat_searcher_context.h:949-963: a filtered row is skipped before its distance) runs over exactly
+            # them for the first queries of the batch — the gather variant of the wide kernel at full size
+            kept_pos = torch.nonzero(keep).squeeze(1)
+            assert kept_pos.numel() >= 900_000
+            kept_rows = base.index_select(0, kept_pos).cpu().numpy()
+            hq = q[:12].cpu().numpy()
+            ok, os_, _, oc = oracle.flat_search(kept_rows, hq, k, O.METRIC_L2, keys=kept_pos.cpu().numpy().astype(np.uint64), threads=8)
+            qn = (hq.astype(np.float64) ** 2).sum(1)
+            bn = float((kept_rows[:4096].astype(np.float64) ** 2).sum(1).max())
+            tie_tolerant_compare(fk[:12], fs[:12], fc[:12], ok, os_, oc, rtol=2e-6, atol=1e-6, select_band=4e-6 * (qn.max() + bn),
+                                 what="10M filtered (keep 10 %): gather scan vs the oracle over the kept rows")
+            del kept_rows
 
 
 @pytest.mark.parametrize("nshards", [8, 1])
