@@ -12,6 +12,8 @@
 #include <zvec/core/framework/index_dumper.h>
 #include <zvec/core/framework/index_helper.h>
 #include <zvec/core/framework/index_cluster.h>
+#include <zvec/core/framework/index_converter.h>
+#include <zvec/core/framework/index_reformer.h>
 #include <zvec/core/framework/index_factory.h>
 #include <zvec/core/framework/index_holder.h>
 #include <zvec/core/framework/index_memory.h>
@@ -495,6 +497,118 @@ void *zref_ivf_searcher_over_rows(const char *cls, const char *params_json, int 
   } while (false);
   if (rc_out) *rc_out = rc;
   return rc == 0 ? r.release() : nullptr;
+}
+
+
+// ---- boundary A's pre / post-processing around boundary B (src/core/interface/index.cc) ------------------------------------------
+// zref_build_converted: what Index::Add + Train + Dump amount to for a converted index — IndexFactory::CreateConverter(converter),
+// init(meta), TrainAndTransform over the caller's rows (index.cc:111-183: the converter's meta names the reformer), then the builder
+// over the converter's result holder with the converter's meta.
+int zref_build_converted(const char *builder_cls, const char *converter_cls, int dtype, uint32_t dim, const char *metric,
+                         const char *builder_params_json, const void *rows, const uint64_t *keys, uint64_t n, const char *target) {
+  IndexMeta meta = make_meta(dtype, dim, metric);
+  ailego::Params bparams;
+  if (!parse_params(builder_params_json, &bparams)) return -1000;
+  auto conv = IndexFactory::CreateConverter(converter_cls);
+  if (!conv) return -1001;
+  meta.set_converter(converter_cls, 0, ailego::Params());
+  int rc = conv->init(meta, ailego::Params());
+  if (rc != 0) return rc;
+  IndexHolder::Pointer holder = std::make_shared<BorrowedHolder>(meta.data_type(), dim, meta.element_size(), rows, keys, n);
+  if ((rc = IndexConverter::TrainAndTransform(conv, holder)) != 0) return rc;
+  IndexMeta cmeta = conv->meta();
+  auto builder = IndexFactory::CreateBuilder(builder_cls);
+  if (!builder) return -1002;
+  if ((rc = builder->init(cmeta, bparams)) != 0) return rc;
+  IndexHolder::Pointer conv_rows = conv->result();
+  if (!conv_rows) return -1003;
+  if ((rc = builder->train(conv_rows)) != 0 && rc != IndexError_NotImplemented) return rc;
+  if ((rc = builder->build(conv_rows)) != 0) return rc;
+  auto dumper = IndexFactory::CreateDumper("MemoryDumper");
+  if (!dumper) return -1004;
+  if ((rc = dumper->init(ailego::Params())) != 0) return rc;
+  IndexMemory::Instance()->remove(target);
+  if ((rc = dumper->create(target)) != 0) return rc;
+  if ((rc = builder->dump(dumper)) != 0) return rc;
+  return dumper->close();
+}
+
+// The search sequence of boundary A over any runner, with the reformer and the metric the index's own meta names (index.cc:87-108,
+// 179-183).  batched = 0: Index::_dense_search once per query (index.cc:596-652: reformer->transform(1), search_impl(count = 1),
+// metric->normalize, reformer->normalize) — what the product does today.  batched = 1: Index::SearchBatch of
+// patches/boundary_a.diff: ONE reformer->transform(count), ONE search_impl(count), then per query the same two normalisations.
+// `queries` are RAW (unconverted) rows of in_dtype / in_dim.  Results: [count][topk] keys / scores, counts.
+int zref_search_sequence(void *h, void *c, int in_dtype, uint32_t in_dim, const void *queries, uint32_t count, int batched,
+                         int linear, uint32_t topk, uint64_t *out_keys, float *out_scores, uint32_t *out_counts) {
+  auto *r = static_cast<Runner *>(h);
+  auto *x = static_cast<Ctx *>(c);
+  const IndexMeta &im = r->searcher ? r->searcher->meta() : r->streamer->meta();
+  auto metric = IndexFactory::CreateMetric(im.metric_name());
+  if (!metric) return -1001;
+  int rc = metric->init(im, im.metric_params());
+  if (rc != 0) return rc;
+  if (metric->query_metric()) metric = metric->query_metric();
+  IndexReformer::Pointer reformer;
+  if (!im.reformer_name().empty()) {
+    reformer = IndexFactory::CreateReformer(im.reformer_name());
+    if (!reformer) return -1002;
+    if ((rc = reformer->init(im.reformer_params())) != 0) return rc;
+  }
+  IndexQueryMeta in_meta(in_dtype ? IndexMeta::DT_FP16 : IndexMeta::DT_FP32, in_dim);
+  const size_t stride = in_meta.element_size();
+  x->c->set_topk(topk);
+  auto emit = [&](uint32_t q, IndexDocumentList list, const void *raw) -> int {
+    if (metric->support_normalize())
+      for (auto &d : list) metric->normalize(d.mutable_score());
+    if (reformer && reformer->normalize(raw, in_meta, list) != 0) return IndexError_Runtime;
+    const uint32_t m = (uint32_t)std::min<size_t>(list.size(), topk);
+    out_counts[q] = m;
+    for (uint32_t j = 0; j < m; ++j) {
+      out_keys[(size_t)q * topk + j] = list[j].key();
+      out_scores[(size_t)q * topk + j] = list[j].score();
+    }
+    return 0;
+  };
+  const char *qp = static_cast<const char *>(queries);
+  if (batched) {
+    const void *vectors = queries;
+    std::string buf;
+    IndexQueryMeta ometa = in_meta;
+    if (reformer) {
+      rc = reformer->transform(queries, in_meta, count, &buf, &ometa);
+      if (rc == IndexError_Unsupported || rc == IndexError_NotImplemented) {
+        // (CosineReformer has no batched transform, cosine_reformer.cc:146-150: one query at a time, rows concatenated)
+        buf.clear();
+        for (uint32_t q = 0; q < count; ++q) {
+          std::string one;
+          if ((rc = reformer->transform(qp + (size_t)q * stride, in_meta, &one, &ometa)) != 0) return rc;
+          buf.append(one);
+        }
+      } else if (rc != 0) {
+        return rc;
+      }
+      vectors = buf.data();
+    }
+    rc = linear ? r->get()->search_bf_impl(vectors, ometa, count, x->c) : r->get()->search_impl(vectors, ometa, count, x->c);
+    if (rc != 0) return rc;
+    for (uint32_t q = 0; q < count; ++q)
+      if ((rc = emit(q, x->c->result(q), qp + (size_t)q * stride)) != 0) return rc;
+    return 0;
+  }
+  for (uint32_t q = 0; q < count; ++q) {
+    const void *raw = qp + (size_t)q * stride;
+    const void *vector = raw;
+    std::string buf;
+    IndexQueryMeta ometa = in_meta;
+    if (reformer) {
+      if ((rc = reformer->transform(raw, in_meta, &buf, &ometa)) != 0) return rc;
+      vector = buf.data();
+    }
+    rc = linear ? r->get()->search_bf_impl(vector, ometa, 1, x->c) : r->get()->search_impl(vector, ometa, 1, x->c);
+    if (rc != 0) return rc;
+    if ((rc = emit(q, x->c->result(), raw)) != 0) return rc;
+  }
+  return 0;
 }
 
 // ---- searches: mode 0 search_impl, 1 search_bf_impl, 2 search_bf_by_p_keys_impl (index_runner.h:490-585) ----------------

@@ -59,6 +59,8 @@ def lib():
             "zref_ctx_group_count": (u32, [vp, u32]),
             "zref_ctx_group": (i32, [vp, u32, u32, P(u32), vp, vp, u32]),
             "zref_ivf_searcher_over_rows": (vp, [cp, cp, i32, u32, cp, vp, u32, vp, vp, vp, P(i32)]),
+            "zref_build_converted": (i32, [cp, cp, i32, u32, cp, cp, vp, vp, u64, cp]),
+            "zref_search_sequence": (i32, [vp, vp, i32, u32, vp, u32, i32, i32, u32, vp, vp, vp]),
             "zref_search_mt": (i32, [vp, i32, vp, i32, u32, u32, u32, cp, u32, vp, vp, vp, P(C.c_double)]),
         }
         for name, (res, args) in sig.items():
@@ -129,6 +131,17 @@ def build(cls, rows, metric, target, keys=None, params=None, column_major=False,
     if rc != 0:
         raise RuntimeError("%s build: rc %d" % (cls, rc))
     return sec.value
+
+
+def build_converted(builder, converter, rows, metric, target, keys=None, params=None):
+    """Index::Add/Train/Dump for a converted index: the converter (e.g. "CosineFp32Converter", "HalfFloatConverter") transforms the
+    rows and names the reformer in its meta (index.cc:111-183), the builder builds and dumps the converted rows."""
+    rows = np.ascontiguousarray(rows)
+    keys = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+    rc = lib().zref_build_converted(builder.encode(), converter.encode(), _dt(rows), rows.shape[1], metric.encode(), _js(params), _p(rows),
+                                    _p(keys), rows.shape[0], target.encode())
+    if rc != 0:
+        raise RuntimeError("%s + %s: rc %d" % (converter, builder, rc))
 
 
 class Context:
@@ -301,6 +314,20 @@ class Runner:
                 return rc, None
             out.append(ctx.result(0))
         return 0, out
+
+    def search_sequence(self, ctx, raw_queries, topk, batched, linear=False):
+        """boundary A's sequence around this runner with the index's own reformer / metric: batched=False = Index::_dense_search per
+        query (index.cc:596-652), batched=True = Index::SearchBatch of patches/boundary_a.diff.  raw_queries: unconverted rows."""
+        q = np.ascontiguousarray(raw_queries)
+        count = q.shape[0]
+        keys = np.zeros((count, topk), np.uint64)
+        scores = np.full((count, topk), np.inf, np.float32)
+        counts = np.zeros(count, np.uint32)
+        rc = lib().zref_search_sequence(self.h, ctx.h, _dt(q), q.shape[1], _p(q), count, int(batched), int(linear), topk, _p(keys), _p(scores),
+                                        _p(counts))
+        if rc != 0:
+            raise RuntimeError("search_sequence rc %d" % rc)
+        return keys, scores, counts
 
     def search_mt(self, q, topk, threads, mode=0, ctx_params=None):
         """Queries dealt over `threads` threads, one query per call (tools/core/bench.cc:145-245); returns arrays + wall seconds."""

@@ -334,3 +334,51 @@ def test_flat_streamer_wraps_the_reference_streamer(R):
         hip.close(), ref.close()
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+@pytest.mark.parametrize("conv,metric,builder,ref_cls,hip_cls", [
+    ("CosineFp32Converter", "Cosine", "FlatBuilder", "FlatSearcher", "HipFlatSearcher"),
+    ("HalfFloatConverter", "SquaredEuclidean", "FlatBuilder", "FlatSearcher", "HipFlatSearcher"),
+    ("CosineFp32Converter", "Cosine", "IVFBuilder", "IVFSearcher", "HipIVFSearcher"),
+    ("CosineFp16Converter", "Cosine", "IVFBuilder", "IVFSearcher", "HipIVFSearcher"),
+])
+def test_boundary_a_search_batch_sequence(R, conv, metric, builder, ref_cls, hip_cls):
+    """next-4: Index::SearchBatch of patches/boundary_a.diff, run step for step around the plugin's operators with the REFERENCE's own
+    converter, reformer and metric (oracle/ref_core_shim.cc zref_search_sequence): rows converted by the converter the product picks
+    (index.cc:111-183), raw queries through reformer->transform, ONE search_impl(count) on the GPU, per query metric->normalize and
+    reformer->normalize — against count calls of Index::_dense_search's sequence (index.cc:596-652, count = 1) on the plugin and on
+    the reference's CPU operator.  (Found by running it: CosineReformer has no batched transform, cosine_reformer.cc:146-150 — the
+    patch falls back to per-query transforms.)"""
+    rng = np.random.default_rng(16)
+    n, dim, nq, k = 8000, 40, 37, 9
+    means = rng.standard_normal((32, dim)).astype(np.float32) * 2
+    base = (means[rng.integers(0, 32, n)] + rng.standard_normal((n, dim)).astype(np.float32)).astype(np.float32)
+    q = (means[rng.integers(0, 32, nq)] + rng.standard_normal((nq, dim)).astype(np.float32)).astype(np.float32)
+    keys = rng.permutation(2 * n)[:n].astype(np.uint64)
+    ivf = builder == "IVFBuilder"
+    bparams = {"proxima.ivf.builder.centroid_count": "32", "proxima.ivf.builder.thread_count": 2} if ivf else None
+    R.build_converted(builder, conv, base, metric, "bnd_a", keys=keys, params=bparams)
+    from zvec_amd.index import container_segments, parse_index_meta
+    image = R.mem_get("bnd_a").tobytes()
+    seg = container_segments(image)
+    m = parse_index_meta(image[seg["IndexMeta"][0]:sum(seg["IndexMeta"])])
+    sdt = np.float16 if m["data_type"] == 1 else np.float32
+    sp = {"proxima.ivf.searcher.scan_ratio": 0.25, "proxima.ivf.searcher.brute_force_threshold": 10} if ivf else None
+    ref = R.Runner.searcher(ref_cls, "bnd_a", m["dimension"], sdt, params=sp)
+    hip = R.Runner.searcher(hip_cls, "bnd_a", m["dimension"], sdt, params=sp)
+    rc_, hc = ref.create_context(), hip.create_context()
+    want = ref.search_sequence(rc_, q, k, batched=False)            # the product today, on the reference's CPU operator
+    got1 = hip.search_sequence(hc, q, k, batched=False)             # the same single calls on the GPU operator
+    gotb = hip.search_sequence(hc, q, k, batched=True)              # Index::SearchBatch on the GPU operator
+    half = sdt == np.float16
+    tol = dict(rtol=4e-6, atol=2e-6) if not half else dict(rtol=4e-6, atol=2e-4)
+    band = None if metric == "Cosine" else 1e-3
+    if metric == "Cosine":
+        tol["scale"] = 1.0
+    tie_tolerant_compare(got1[0], got1[1], got1[2], want[0], want[1], want[2], what="singles: plugin vs reference", select_band=band, **tol)
+    tie_tolerant_compare(gotb[0], gotb[1], gotb[2], want[0], want[1], want[2], what="SearchBatch: plugin vs reference singles", select_band=band, **tol)
+    tie_tolerant_compare(gotb[0], gotb[1], gotb[2], got1[0], got1[1], got1[2], what="SearchBatch vs singles on the plugin", select_band=band, **tol)
+    for x in (rc_, hc):
+        x.close()
+    ref.close(), hip.close()
+    R.mem_remove("bnd_a")
