@@ -77,35 +77,27 @@ int launch_scan(const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipStr
                    : launch_scan_t<NG, M16, false, false>(a, max_items, cus, stream);
 }
 
-// the wide 128x128 flat tile; *occ_out = work-groups per CU it reaches for this k.  ZVK_WIDE_WAVES selects the form at build
-// time: 4 = scan4_kernel (4 waves, a 64 x 64 block per wave), 8 = scan8_kernel (8 waves, 64 x 32 per wave)
-#ifndef ZVK_WIDE_WAVES
-#define ZVK_WIDE_WAVES 8
-#endif
+// the 8-wave 128x128 flat tile (scan8_kernel); *occ_out = work-groups per CU it reaches for this k.  (Round 3 measured a 4-wave
+// form of the same tile — a 64 x 64 block per wave, the labelling kernel's shape — with and without an in-register tile
+// pre-filter: 118.9 / 116.1 against 124.5 TFLOP/s on one box; DESIGN.md §3.  It is not kept.)
 template <bool EXCL, bool F16, bool GATHER>
 int launch_scan8_t(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream, int *occ_out) {
   static bool attr_set[16] = {false};
   size_t lds = scan8_lds_bytes(a.k);
   int dev = 0;
   (void)hipGetDevice(&dev);
-#if ZVK_WIDE_WAVES == 4
-  auto *kern = &scan4_kernel<EXCL, F16, GATHER>;
-  constexpr unsigned threads = 256;
-#else
-  auto *kern = &scan8_kernel<EXCL, F16, GATHER>;
-  constexpr unsigned threads = 512;
-#endif
   if (!attr_set[dev & 15]) {
-    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan8_kernel<EXCL, F16, GATHER>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     attr_set[dev & 15] = true;
   }
   int occ = 0;
-  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds));
+  ZCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan8_kernel<EXCL, F16, GATHER>, 512, lds));
   if (occ < 1) occ = 1;
   if (occ_out) { *occ_out = occ; return 0; }
   uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)max_items, (uint64_t)cus * (uint64_t)occ);
   if (grid == 0) return 0;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, a);
+  hipLaunchKernelGGL((scan8_kernel<EXCL, F16, GATHER>), dim3(grid), dim3(512), lds, stream, a);
   ZCHK(hipGetLastError());
   return 0;
 }

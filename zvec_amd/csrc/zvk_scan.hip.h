@@ -720,295 +720,4 @@ __global__ void __launch_bounds__(512, 4) scan8_kernel(const ScanArgs a) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// The wide flat-scan kernel, 4-wave form (selected with -DZVK_WIDE_WAVES=4; measured in round 3): the same
-// 128-query x 128-row tile, LDS images, LDS-DMA staging, K-step and list logic as scan8_kernel, but on 256 threads = 4 waves as
-// 2 (query-row halves) x 2 (column halves), each wave owning a 64 x 64 block = 2 x 2 MFMA blocks (64 accumulators).  Per k-group
-// a wave reads 2 A + 2 B fragments for 4 MFMA chains instead of 2 A + 1 B for 2: a third fewer LDS operand bytes per MFMA — the
-// shape of the build's labelling kernel (zvk_assign.hip.h).  Two work-groups per CU, two waves per SIMD, up to 256 registers per
-// wave: room for the in-register tile pre-filter (every lane tests its 64 accumulators against the rows' bounds; only a tile
-// with a possible admission pays for the transposition and the owner-wave pass), which spills under scan8's 128-register cap.
-// ---------------------------------------------------------------------------------------------
-template <bool EXCL, bool F16, bool GATHER>
-__global__ void __launch_bounds__(256, 2) scan4_kernel(const ScanArgs a) {
-  constexpr int ROWS = W8_ROWS;
-  extern __shared__ f32x4 zvk_smem4[];
-  float *smem = reinterpret_cast<float *>(zvk_smem4);
-  float *Qs = smem;                      // [2][ROWS*32]
-  float *Bs = Qs + 2 * ROWS * TILE_K;    // [2][SLAB]
-  float *qn_s = Bs + 2 * SLAB;           // [ROWS]
-  RowState st;
-  st.tau = qn_s + ROWS;
-  st.cnt = reinterpret_cast<uint32_t *>(st.tau + ROWS);
-  uint32_t *qrow_s = st.cnt + ROWS;
-  uint32_t *slot_s = qrow_s + ROWS;
-  uint32_t *hit_s = slot_s + ROWS;       // [4 spare words] tile-epilogue flag: some score of this tile may be admitted
-  st.k = a.k;
-  st.gt = reinterpret_cast<float *>(slot_s + ROWS + 4);
-  st.tq = st.gt + ROWS;
-  st.gtau = a.gtau;
-  st.qrow = qrow_s;
-  st.Ls = st.tq + ROWS;
-  st.Li = reinterpret_cast<uint32_t *>(st.Ls + (size_t)ROWS * a.k);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wn = wave & 1, wm = wave >> 1;               // column half, query-row half
-  const int r = lane & 31, h = lane >> 5;                 // 32x32x2 operand coordinates
-  const int srow = tid >> 3, schunk = tid & 7;            // staging coordinates: rows srow + 32 j, j = 0..3
-  const int sswz = schunk ^ ((srow >> 1) & 7);
-  const uint32_t dpad = a.dpad, nks = a.nks, k = a.k;
-  const uint32_t ntiles_total = (uint32_t)((a.n + TILE_N - 1) / TILE_N);
-  const uint32_t rows_valid_total = (uint32_t)min((uint64_t)0xffffffffu, a.n);
-
-  const uint32_t vtotal = ((a.nchunks + 7) / 8) * 8 * a.nqtiles;      // XCD-aware item order, as scan8_kernel
-  for (uint32_t v = blockIdx.x; v < vtotal; v += gridDim.x) {         // uniform exit
-    const uint32_t qtile = (v >> 3) % a.nqtiles;
-    const uint32_t chunk = ((v >> 3) / a.nqtiles) * 8 + (v & 7);
-    if (chunk >= a.nchunks) continue;
-    const uint32_t tile_begin = chunk * a.tiles_per_chunk;
-    const uint32_t tile_end = min(tile_begin + a.tiles_per_chunk, ntiles_total);
-    const uint32_t r0 = qtile * ROWS;
-    const uint32_t nrows = min((uint32_t)ROWS, a.nq - r0);
-
-    for (int j = tid; j < ROWS; j += 256) {
-      const bool live = (uint32_t)j < nrows;
-      const uint32_t qrow = live ? r0 + j : r0;
-      qrow_s[j] = qrow;
-      slot_s[j] = live ? qrow * a.nchunks + chunk : IDX_NONE;
-      qn_s[j] = (a.metric == METRIC_L2) ? a.qnorm[qrow] : 0.f;
-      st.tau[j] = a.threshold;
-      st.gt[j] = a.threshold;
-      st.tq[j] = live ? a.threshold : -__builtin_inff();       // (rows past the batch never pass the tile pre-filter)
-      st.cnt[j] = 0;
-    }
-    __syncthreads();
-
-    const uint32_t nsteps = (tile_end - tile_begin) * nks;
-    uint32_t gq[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) gq[j] = qrow_s[srow + 32 * j] * dpad + (uint32_t)sswz * 4u;
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
-    uint32_t gp[4] = {0, 0, 0, 0}, gpn[4] = {0, 0, 0, 0}, gp_tile = ~0u;
-    auto gather_src = [&](uint32_t p_, uint32_t k_) {
-      const uint32_t rs = p_ & (TILE_N - 1);
-      const uint32_t chunk_ = (uint32_t)schunk ^ (uint32_t)((srow >> 1) & 7) ^ ((rs >> 1) & 7u);
-      return reinterpret_cast<const f32x4 *>(a.base + (size_t)(p_ >> 7) * TILE_N * dpad + (size_t)k_ * SLAB) + (rs * 8 + chunk_);
-    };
-    auto stage_glds = [&](uint32_t t_, uint32_t k_, float *Bb, float *Qb) {
-      char *bl = reinterpret_cast<char *>(Bb) + wave * 1024;      // wave-uniform destinations
-      char *ql = reinterpret_cast<char *>(Qb) + wave * 1024;
-      if constexpr (GATHER) {
-        if (t_ != gp_tile) {                       // uniform: first step of a new tile
-          const uint32_t tn = min(t_ + 1, tile_end - 1);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            gp[j] = (gp_tile == ~0u) ? a.gather_pos[(size_t)t_ * TILE_N + srow + 32 * j] : gpn[j];
-            gpn[j] = a.gather_pos[(size_t)tn * TILE_N + srow + 32 * j];
-          }
-          gp_tile = t_;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          __builtin_amdgcn_global_load_lds((glb_void *)gather_src(gp[j], k_), (lds_void *)(bl + 4096 * j), 16, 0, 0);
-      } else {
-        const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(a.base + (size_t)t_ * TILE_N * dpad + (size_t)k_ * SLAB) + tid;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          __builtin_amdgcn_global_load_lds((glb_void *)(bsrc + 256 * j), (lds_void *)(bl + 4096 * j), 16, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_global_load_lds((glb_void *)(a.queries + (size_t)(gq[j] + k_ * TILE_K)), (lds_void *)(ql + 4096 * j), 16, 0, 0);
-    };
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
-    uint32_t tile = tile_begin, ks = 0;          // step being computed
-    uint32_t ptile = tile_begin, pks = 0;        // next step to fetch
-    uint32_t fetched = 0;
-    auto advance = [&](uint32_t &t_, uint32_t &k_) { if (++k_ == nks) { k_ = 0; ++t_; } };
-    if (nsteps > 0) {
-      stage_glds(ptile, pks, Bs, Qs);
-      if (nsteps > 1) advance(ptile, pks);
-      fetched = 1;
-    }
-    const float m_alpha = (a.metric == METRIC_L2) ? -2.f : -1.f;
-    const float m_beta = (a.metric == METRIC_COSINE) ? 1.f : 0.f;
-    const float m_nrm = (a.metric == METRIC_L2) ? 1.f : 0.f;
-    const float m_lo = (a.metric == METRIC_L2) ? 0.f : -__builtin_inff();
-
-    float bn[2] = {0.f, 0.f};
-    uint32_t ex[2] = {0, 0};
-    for (uint32_t s0 = 0; s0 < nsteps; s0 += 2) {
-#pragma unroll
-     for (int u = 0; u < 2; ++u) {
-      const uint32_t s = s0 + u;
-      if (s >= nsteps) break;                      // uniform
-      const int buf = u;
-      const bool has_next = (s + 1 < nsteps);
-      __syncthreads();
-      if (has_next) stage_glds(ptile, pks, Bs + (buf ^ 1) * SLAB, Qs + (buf ^ 1) * ROWS * TILE_K);
-      if (fetched + 1 < nsteps) advance(ptile, pks);
-      ++fetched;
-      // One step BEFORE a tile ends the query-wide bounds are refreshed and the tile's hit flag cleared; the next step's barrier
-      // publishes both.  (A one-step tile — d <= 32 — has no such step: it always takes the full epilogue.)
-      if (nks > 1 && ks == nks - 2 && a.dump == nullptr) {
-        if (tid < ROWS) {
-          const float g_ = fkey_inv(__hip_atomic_load(&a.gtau[qrow_s[tid]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          st.gt[tid] = g_;
-          st.tq[tid] = ((uint32_t)tid < nrows) ? fminf(st.tau[tid], g_) : -__builtin_inff();
-        }
-        if (tid == 0) hit_s[0] = 0;
-      }
-      if (ks == nks - 1) {                          // column constants of this tile, landing under its last step's matrix work
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const uint32_t col = wn * 64 + ni * 32 + r;
-          if constexpr (GATHER) {
-            bn[ni] = a.bnorm[a.gather_pos[(size_t)tile * TILE_N + col]];
-          } else {
-            const uint32_t pos = tile * TILE_N + col;
-            bn[ni] = a.bnorm[(size_t)pos];
-            if constexpr (EXCL) {
-              const uint64_t d0 = min((uint64_t)pos, a.ndense - 1);
-              ex[ni] = (a.exclude[d0 >> 5] >> (d0 & 31)) & 1u;
-            }
-          }
-        }
-      }
-      {
-        const float *Qb = Qs + buf * ROWS * TILE_K + wm * 64 * TILE_K;
-        const float *Bb = Bs + buf * SLAB + wn * 64 * TILE_K;
-        const int swz = (r >> 1) & 7;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int c = (2 * kk + h) ^ swz;
-          const f32x4 a0 = *reinterpret_cast<const f32x4 *>(Qb + (r * 8 + c) * 4);
-          const f32x4 a1 = *reinterpret_cast<const f32x4 *>(Qb + ((32 + r) * 8 + c) * 4);
-          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(Bb + (r * 8 + c) * 4);
-          const f32x4 b1 = *reinterpret_cast<const f32x4 *>(Bb + ((32 + r) * 8 + c) * 4);
-          if constexpr (F16) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b0), acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b1), acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b0), acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b1), acc[1][1], 0, 0, 0);
-          } else {
-#define ZVK_MFMA4(ACC, A, B)                                                   \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B.x, ACC, 0, 0, 0);          \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B.y, ACC, 0, 0, 0);          \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B.z, ACC, 0, 0, 0);          \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B.w, ACC, 0, 0, 0);
-            ZVK_MFMA4(acc[0][0], a0, b0)
-            ZVK_MFMA4(acc[0][1], a0, b1)
-            ZVK_MFMA4(acc[1][0], a1, b0)
-            ZVK_MFMA4(acc[1][1], a1, b1)
-#undef ZVK_MFMA4
-          }
-        }
-      }
-
-      if (ks == nks - 1) {
-        const uint32_t pos0 = tile * TILE_N;
-        bool colvalid[2];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) colvalid[ni] = (pos0 + wn * 64 + ni * 32 + r < rows_valid_total) && (ex[ni] == 0);
-        bool full = true;
-        if (nks > 1 && a.dump == nullptr) {
-          bool any = false;
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            const int gbase = (wm * 2 + mi) * 32;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int row_l = (e & 3) + 8 * (e >> 2) + 4 * h;
-              const float tq_ = st.tq[gbase + row_l], qn_ = qn_s[gbase + row_l];
-#pragma unroll
-              for (int ni = 0; ni < 2; ++ni) {
-                const float sc = fmaxf(fmaf(m_alpha, acc[mi][ni][e], fmaf(m_nrm, qn_ + bn[ni], m_beta)), m_lo);
-                any |= colvalid[ni] && sc <= tq_;
-              }
-            }
-          }
-          if (__ballot(any) != 0 && lane == 0) hit_s[0] = 1;
-          __syncthreads();                                                        // (also: every wave is done reading `buf`)
-          full = hit_s[0] != 0;                                                   // uniform
-          if (!full) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-          }
-        } else {
-          if (a.dump == nullptr && tid < ROWS) {
-            const float g_ = fkey_inv(__hip_atomic_load(&a.gtau[qrow_s[tid]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            st.gt[tid] = g_;
-            st.tq[tid] = ((uint32_t)tid < nrows) ? fminf(st.tau[tid], g_) : -__builtin_inff();
-          }
-          __syncthreads();                                                        // every wave is done reading `buf`
-        }
-        float *Sc = wm ? (Qs + buf * ROWS * TILE_K) : (Bs + buf * SLAB);          // [32 rows][128 cols] per row half
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          if (!full) break;                                                       // uniform
-          const int gbase = (wm * 2 + mi) * 32;
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int row_l = (e & 3) + 8 * (e >> 2) + 4 * h;
-              const float dot = acc[mi][ni][e];
-              const float sc = fmaxf(fmaf(m_alpha, dot, fmaf(m_nrm, qn_s[gbase + row_l] + bn[ni], m_beta)), m_lo);
-              Sc[row_l * TILE_N + wn * 64 + ni * 32 + r] = colvalid[ni] ? sc : __builtin_inff();
-              acc[mi][ni][e] = 0.f;
-            }
-          __syncthreads();
-          {
-            f32x2 v = *reinterpret_cast<const f32x2 *>(Sc + wn * TILE_N + 2 * lane);
-            float t0 = st.tq[gbase + wn];
-#pragma unroll 1
-            for (int i = 0; i < 16; ++i) {
-              const int row_l = i * 2 + wn;                     // rows dealt round-robin to the 2 waves of the half
-              const int row = gbase + row_l;
-              const int nrow_l = min(row_l + 2, 31);
-              const f32x2 vn = *reinterpret_cast<const f32x2 *>(Sc + nrow_l * TILE_N + 2 * lane);
-              const float tn = st.tq[gbase + nrow_l];
-              if ((uint32_t)row < nrows) {
-                if (a.dump) *reinterpret_cast<f32x2 *>(a.dump + (size_t)qrow_s[row] * a.dump_stride + pos0 + 2 * lane) = v;
-                else owner_row(st, row, v.x, v.y, t0, pos0, lane);
-              }
-              v = vn;
-              t0 = tn;
-            }
-          }
-          __syncthreads();
-        }
-      }
-
-      advance(tile, ks);
-     }
-    }
-
-    for (uint32_t j = tid; a.dump == nullptr && j < nrows * k; j += 256) {
-      uint32_t row = j / k, t = j - row * k;
-      uint32_t c = st.cnt[row];
-      size_t o = (size_t)slot_s[row] * k + t;
-      a.part_s[o] = (t < c) ? st.Ls[(size_t)row * k + t] : __builtin_inff();
-      uint32_t pi = (t < c) ? st.Li[(size_t)row * k + t] : IDX_NONE;
-      if constexpr (GATHER) { if (pi != IDX_NONE) pi = a.gather_pos[pi]; }      // logical row -> stored position
-      a.part_i[o] = pi;
-    }
-    __syncthreads();
-  }
-}
-
 }  // namespace zvk
