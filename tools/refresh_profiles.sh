@@ -15,6 +15,10 @@ timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/flat -- python3 $R/bench.py --workload flat1m --steps 10 --warmup 2 --no-cpu-baseline > $O/${tag}_flat1m_bench_under_rocprof.json 2> $O/flat.log
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/shard8 -- python3 $R/bench.py --shard-of 8 --steps 10 --warmup 2 --no-host-path > $O/${tag}_ivf10m_shard8_bench_under_rocprof.json 2> $O/shard8.log
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s100 -- python3 $R/bench.py --workload ivf100m_fp16 --shard-of 8 --steps 10 --warmup 2 --no-host-path > $O/${tag}_ivf100m_fp16_shard8_bench_under_rocprof.json 2> $O/s100.log
+# round 3: the product's count = 1 / small-batch route, and the build's labelling kernel
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b1 -- python3 $R/bench.py --batch 1 --steps 200 --warmup 20 --no-cpu-baseline --no-host-path > $O/${tag}_ivf10m_b1_bench_under_rocprof.json 2> $O/b1.log
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b8 -- python3 $R/bench.py --batch 8 --steps 100 --warmup 10 --no-cpu-baseline --no-host-path > $O/${tag}_ivf10m_b8_bench_under_rocprof.json 2> $O/b8.log
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/label -- python3 $R/tools/time_label.py > $O/${tag}_label_time.log 2> $O/label.log
 python3 - <<PY
 import csv, glob, json, shutil
 O, tag = "$O", "$tag"
@@ -24,7 +28,10 @@ shutil.copy(one("stats/**/*kernel_stats.csv"), O + "/%s_ivf10m_kernel_stats.csv"
 shutil.copy(one("flat/**/*kernel_stats.csv"), O + "/%s_flat1m_kernel_stats.csv" % tag)
 shutil.copy(one("shard8/**/*kernel_stats.csv"), O + "/%s_ivf10m_shard8_kernel_stats.csv" % tag)
 shutil.copy(one("s100/**/*kernel_stats.csv"), O + "/%s_ivf100m_fp16_shard8_kernel_stats.csv" % tag)
-for name, d in (("ivf10m", "stats"), ("flat1m", "flat"), ("ivf10m_shard8", "shard8")):
+shutil.copy(one("b1/**/*kernel_stats.csv"), O + "/%s_ivf10m_b1_kernel_stats.csv" % tag)
+shutil.copy(one("b8/**/*kernel_stats.csv"), O + "/%s_ivf10m_b8_kernel_stats.csv" % tag)
+shutil.copy(one("label/**/*kernel_stats.csv"), O + "/%s_label_kernel_stats.csv" % tag)
+for name, d in (("ivf10m", "stats"), ("flat1m", "flat"), ("ivf10m_shard8", "shard8"), ("ivf10m_b1", "b1"), ("ivf10m_b8", "b8")):
     rows = list(csv.DictReader(open(one(d + "/**/*kernel_trace.csv"))))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     keep = ["Kernel_Name", "Start_Timestamp", "End_Timestamp", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size"]
@@ -54,5 +61,5 @@ json.dump({"kernel": "zvk::scan_kernel<1, true, false, false> - IVF list scan (1
 json.dump({"ivf10m": traffic}, open(O + "/pmc_traffic.json", "w"))
 print("traffic/algorithmic", traffic / alg)
 PY
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/flat $O/shard8 $O/s100
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/flat $O/shard8 $O/s100 $O/b1 $O/b8 $O/label
 ls -la $O
