@@ -8,9 +8,9 @@
 //
 // Shape.  256 threads = 4 waves as 2 (row halves) x 2 (centroid halves) over a 128-row x 128-centroid tile; a wave owns a
 // 64 x 64 block = 2 x 2 MFMA blocks of 32 x 32 (64 accumulators).  Compared with the search tile (8 waves, 64 x 32 per wave)
-// every operand fragment read from LDS feeds two MFMAs instead of 1.33: with f16 rows the matrix pipe retires a 32x32x16
-// MFMA in 32 cycles against 2 KB of operands, so LDS bandwidth (128 B / clk / CU), not the pipe, bounds the search tile at
-// half the peak; the 64 x 64 wave block moves that bound to 0.68.  Staging is LDS-DMA exactly as in scan8_kernel (the centroid
+// every operand fragment read from LDS feeds two MFMAs instead of 1.33 (4 ds_read_b128 per 4 MFMAs against 3 per 2): a third
+// fewer LDS operand bytes and wait points per MFMA, which counts once a 32x32x16 f16 MFMA retires in 32 cycles.  Staging is
+// LDS-DMA exactly as in scan8_kernel (the centroid
 // slab is stored as its LDS image; the row image's XOR swizzle is applied at the source), double-buffered, ONE barrier per
 // k-step, 64 KB of LDS => two work-groups per CU.
 //
