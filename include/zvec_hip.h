@@ -333,6 +333,19 @@ int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *sc
 int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_t bytes, uint64_t count, int column_major,
                                 uint32_t batch_size, const uint64_t *keys);
 
+/* The centroid index in a space of its own.  IVFBuilder trains INNER-PRODUCT indexes through a MipsConverter
+ * (src/core/algorithm/ivf/ivf_builder.cc:552-555): the nested "ivf.centroid" index of such a file holds converted centroids — more
+ * dimensions, squared-Euclidean metric, a MipsReformer named in its meta — and IVFCentroidIndex::search reforms every query before
+ * the coarse scan (ivf_centroid_index.cc:273-297), while the inverted lists keep the original rows and metric.
+ * zvec_hip_ivf_load_segments may then be given centroids = NULL; zvec_hip_ivf_set_coarse_space installs the converted centroid
+ * rows (nlist x coarse_dim elements of the index's element type, centroid-id order; coarse_metric L2 or IP) and searches go
+ * through zvec_hip_ivf_search_coarse, which takes the reformed queries ([count][coarse_dim]) beside the original ones
+ * (zvec_hip_ivf_search_bf needs neither).  IVFSearcher::search_impl otherwise, ivf_searcher.cc:183-250. */
+int zvec_hip_ivf_set_coarse_space(zvec_hip_ivf_t h, uint32_t coarse_dim, int coarse_metric, const void *centroids, uint32_t nlist);
+int zvec_hip_ivf_search_coarse(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries, const void *coarse_queries, uint32_t count,
+                               uint32_t topk, float threshold, uint32_t nprobe, uint32_t max_scan_count,
+                               const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores, uint32_t *out_counts);
+
 /* HipFlatStreamer::open over a storage the reference's FlatStreamer has written (FlatStreamerEntity, flat_streamer_entity.cc:43-47,
  * flat_streamer_entity.h:287-311, BlockHeader / DeletionMap flat_index_format.h:91-126): `blocks` = a run of `nblocks` blocks of
  * `block_size` bytes as they lie in a "flat.features<i>" segment — [block_vector_count x element][block_vector_count x u64 key]

@@ -22,6 +22,7 @@
 #include <zvec/core/framework/index_factory.h>
 #include <zvec/core/framework/index_helper.h>
 #include <zvec/core/framework/index_provider.h>
+#include <zvec/core/framework/index_reformer.h>
 #include <zvec/core/framework/index_searcher.h>
 #include <zvec/core/framework/index_segment_storage.h>
 #include <zvec/core/framework/index_streamer.h>
@@ -759,27 +760,44 @@ class HipIVFCore {
     if ((rc = nested->open(std::string(), false)) != 0) return rc;
     IndexMeta cmeta;
     if ((rc = IndexHelper::DeserializeFromStorage(nested.get(), &cmeta)) != 0) return rc;
-    if (cmeta.element_size() != elem_size_) return IndexError_Unsupported;   // (converted / quantised centroid index)
+    // The centroid index may live in a space of its own: IVFBuilder trains inner-product indexes through a MipsConverter
+    // (ivf_builder.cc:552-555), the nested index then holds converted centroids (more dimensions, squared-Euclidean) and names
+    // the reformer every query goes through before the coarse scan (IVFCentroidIndex::load / search, ivf_centroid_index.cc:
+    // 273-297,538-562).  Same element type only: quantised centroid indexes (int8 / int4 reformers) are not taken.
+    const size_t celem = cmeta.element_size();
+    creformer_.reset();
+    if (cmeta.data_type() != meta->data_type()) return IndexError_Unsupported;
+    if (!cmeta.reformer_name().empty()) {
+      creformer_ = IndexFactory::CreateReformer(cmeta.reformer_name());
+      if (!creformer_) return IndexError_NoExist;
+      if ((rc = creformer_->init(cmeta.reformer_params())) != 0) return rc;
+    } else if (celem != elem_size_) {
+      return IndexError_Unsupported;
+    }
     std::string ckeys, cfeat;
     if ((rc = read_segment(nested.get(), kFlatKeys, &ckeys)) != 0) return rc;
     if ((rc = read_segment(nested.get(), kFlatFeatures, &cfeat)) != 0) return rc;
     const size_t nlist = ckeys.size() / sizeof(uint64_t);
-    if (nlist == 0 || nlist * elem_size_ != cfeat.size()) return IndexError_Mismatch;
+    if (nlist == 0 || nlist * celem != cfeat.size()) return IndexError_Mismatch;
     std::string centroids(cfeat.size(), '\0');
     const uint64_t *ck = reinterpret_cast<const uint64_t *>(ckeys.data());
-    const size_t unit = IndexMeta::AlignSizeof(cmeta.data_type()), cols = elem_size_ / unit;
+    const size_t unit = IndexMeta::AlignSizeof(cmeta.data_type()), cols = celem / unit;
     const bool colmajor = cmeta.major_order() == IndexMeta::MO_COLUMN;
     for (size_t i = 0; i < nlist; ++i) {
       if (ck[i] >= nlist) return IndexError_InvalidFormat;
-      char *dst = &centroids[ck[i] * elem_size_];
+      char *dst = &centroids[ck[i] * celem];
       const size_t blk = i / 32, r = i % 32;
       if (colmajor && (blk + 1) * 32 <= nlist) {             // full 32-row block, transposed in units (flat_builder.cc:231-262)
-        const char *b0 = cfeat.data() + blk * 32 * elem_size_;
+        const char *b0 = cfeat.data() + blk * 32 * celem;
         for (size_t u = 0; u < cols; ++u) memcpy(dst + u * unit, b0 + (u * 32 + r) * unit, unit);
       } else {
-        memcpy(dst, cfeat.data() + i * elem_size_, elem_size_);
+        memcpy(dst, cfeat.data() + i * celem, celem);
       }
     }
+    const int cmetric = metric_of(cmeta);
+    if (creformer_ && (cmetric != ZVEC_HIP_METRIC_L2 && cmetric != ZVEC_HIP_METRIC_IP)) return IndexError_Unsupported;
+    if (creformer_ && ndev > 1) return IndexError_Unsupported;                 // (the coarse space runs on one device)
+    in_qmeta_ = IndexQueryMeta(meta->data_type(), meta->dimension());
     std::string header, lmeta, body, keys;
     if ((rc = read_segment(stg, kIvfHeader, &header)) != 0) return rc;
     if ((rc = read_segment(stg, kIvfMeta, &lmeta)) != 0) return rc;
@@ -794,7 +812,9 @@ class HipIVFCore {
     } else {
       if ((rc = zvec_hip_ivf_create(meta->dimension(), dtype, metric, device, &h_)) != 0) return rc;
       rc = zvec_hip_ivf_load_segments(h_, header.data(), header.size(), lmeta.data(), lmeta.size(), body.data(), body.size(),
-                                      keys.data(), keys.size(), centroids.data());
+                                      keys.data(), keys.size(), creformer_ ? nullptr : centroids.data());
+      if (rc == 0 && creformer_)
+        rc = zvec_hip_ivf_set_coarse_space(h_, cmeta.dimension(), cmetric, centroids.data(), (uint32_t)nlist);
     }
     if (rc != 0) return rc;
     keys_.assign(reinterpret_cast<const uint64_t *>(keys.data()),
@@ -837,10 +857,30 @@ class HipIVFCore {
       const uint32_t nprobe = std::max(static_cast<uint32_t>(std::round(nlist_ * ctx->scan_ratio_)), 1u);
       uint32_t max_scan = static_cast<uint32_t>(std::ceil(keys_.size() * ctx->scan_ratio_));
       max_scan = std::max(ctx->bruteforce_threshold_, max_scan);
-      rc = sh_ ? zvec_hip_shards_search(sh_, q, count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits, ctx->keys_.data(),
-                                        ctx->scores_.data(), ctx->counts_.data())
-               : zvec_hip_ivf_search(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits,
-                                     ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+      if (creformer_) {
+        // IVFCentroidIndex::search: the queries reformed for the coarse space — in one call where the reformer has a batched
+        // transform, one by one where it has not
+        std::string cq;
+        IndexQueryMeta ometa;
+        rc = creformer_->transform(q, in_qmeta_, count, &cq, &ometa);
+        if (rc == IndexError_Unsupported || rc == IndexError_NotImplemented) {
+          cq.clear();
+          for (uint32_t i = 0; i < count; ++i) {
+            std::string one;
+            if ((rc = creformer_->transform(static_cast<const char *>(q) + size_t(i) * elem_size_, in_qmeta_, &one, &ometa)) != 0) return rc;
+            cq.append(one);
+          }
+        } else if (rc != 0) {
+          return rc;
+        }
+        rc = zvec_hip_ivf_search_coarse(h_, ctx->h_, q, cq.data(), count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits,
+                                        ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+      } else {
+        rc = sh_ ? zvec_hip_shards_search(sh_, q, count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits, ctx->keys_.data(),
+                                          ctx->scores_.data(), ctx->counts_.data())
+                 : zvec_hip_ivf_search(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits,
+                                       ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
+      }
     }
     if (rc != 0) return rc;
     ctx->fill(count, ctx->topk(), ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
@@ -869,6 +909,8 @@ class HipIVFCore {
   }
 
   zvec_hip_ivf_t h_{nullptr};
+  IndexReformer::Pointer creformer_;      // the centroid index's reformer when it lives in a converted space (MIPS), else null
+  IndexQueryMeta in_qmeta_;               // the queries as they arrive
   zvec_hip_shards_t sh_{nullptr};         // set instead of h_ when the lists are dealt over several devices
   std::unordered_map<uint64_t, uint64_t> pos_of_key_;   // key -> list-order position
   uint32_t elem_size_{0}, nlist_{0};

@@ -228,11 +228,14 @@ def test_ivf_classes_on_reference_dumped_files(R, cls_pair):
         R.mem_remove("g_" + name)
 
 
-@pytest.mark.parametrize("metric,dt", [("SquaredEuclidean", np.float32), ("SquaredEuclidean", np.float16)])
+@pytest.mark.parametrize("metric,dt", [("SquaredEuclidean", np.float32), ("SquaredEuclidean", np.float16), ("InnerProduct", np.float32)])
 def test_ivf_built_by_the_reference_builder_searched_by_both(R, metric, dt):
     """An index TRAINED, BUILT and DUMPED by the reference's own IVFBuilder (its k-means, its labelling, its dumper) on real-valued
     data; partial probes with the max_scan_count rule live; one context handed from one index to another (magic re-bind,
-    ivf_searcher.cc:198-202); context update(params) changing the scan ratio."""
+    ivf_searcher.cc:198-202); context update(params) changing the scan ratio.  InnerProduct: the reference's builder trains through
+    a MipsConverter (ivf_builder.cc:552-555), so the nested centroid index holds CONVERTED centroids (d + 4 dimensions, squared
+    Euclidean) behind a MipsReformer: the plugin installs them as a coarse space of their own (zvec_hip_ivf_set_coarse_space) and
+    reforms every query with the reference's reformer before the coarse pass, as IVFCentroidIndex::search does."""
     rng = np.random.default_rng(14)
     n, dim, nlist = 20000, 48, 64
     means = rng.standard_normal((nlist, dim)).astype(np.float32) * 2

@@ -66,6 +66,9 @@ SYMBOLS = {
     "zvec_hip_ivf_load": (C.c_int, [_h, C.c_void_p, C.c_uint32, _u64p, C.c_void_p, _u64p]),
     "zvec_hip_flat_load_features": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _u64p]),
     "zvec_hip_flat_load_blocks": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "zvec_hip_ivf_set_coarse_space": (C.c_int, [_h, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32]),
+    "zvec_hip_ivf_search_coarse": (C.c_int, [_h, _h, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32,
+                                             _u64p, _u64p, _f32p, _u32p]),
     "zvec_hip_ivf_load_segments": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                              C.c_void_p, C.c_uint64, C.c_void_p]),
     "zvec_hip_ivf_build_dev": (C.c_int, [_h, C.c_void_p, C.c_uint64, _u64p, C.c_uint32, C.c_uint32,

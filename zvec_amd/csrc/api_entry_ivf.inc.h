@@ -245,7 +245,13 @@ static int ivf_end_lists(zvec_hip_ivf_s *h) {
 // all rows at once (load, load_segments, the one-call build): centroids + layout + rows + tables
 static int ivf_pack(zvec_hip_ivf_s *h, const void *d_rows, uint64_t n, const uint64_t *keys,
                     const std::vector<uint32_t> &labels, const void *h_centroids, uint32_t nlist, hipStream_t s) {
-  ZRET(ivf_set_centroids(h, h_centroids, nlist, s));
+  if (h_centroids) {
+    ZRET(ivf_set_centroids(h, h_centroids, nlist, s));
+  } else {                               // (load_segments without centroids: zvec_hip_ivf_set_coarse_space brings them)
+    h->nlist = nlist;
+    h->cent.n = 0;
+    h->trained = false;
+  }
   std::vector<uint32_t> sizes(nlist, 0);
   for (uint64_t i = 0; i < n; ++i) {
     if (labels[i] >= nlist) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
@@ -307,7 +313,7 @@ static int load_fail(int check, int code) {
 int zvec_hip_ivf_load_segments(zvec_hip_ivf_t h, const void *inverted_header, uint64_t header_bytes,
                                const void *inverted_meta, uint64_t meta_bytes, const void *inverted_body,
                                uint64_t body_bytes, const void *keys, uint64_t keys_bytes, const void *centroids) {
-  if (!h || !inverted_header || !inverted_meta || !centroids) return load_fail(1, ZVEC_HIP_ERR_INVALID_ARGUMENT);
+  if (!h || !inverted_header || !inverted_meta) return load_fail(1, ZVEC_HIP_ERR_INVALID_ARGUMENT);
   if (header_bytes < sizeof(RefInvertedIndexHeader) + sizeof(RefIndexMetaHeader)) return load_fail(2, ZVEC_HIP_ERR_INVALID_ARGUMENT);
   RefInvertedIndexHeader hd;
   memcpy(&hd, inverted_header, sizeof(hd));
@@ -669,14 +675,16 @@ int zvec_hip_ivf_get_vectors(zvec_hip_ivf_t h, const uint64_t *list_positions, u
 static int ivf_search_dev_locked(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const void *d_queries, uint32_t count, uint32_t topk,
                                  float threshold, uint32_t nprobe, uint32_t max_scan_count, int brute_force,
                                  const uint64_t *d_exclude, uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts,
-                                 hipStream_t s) {
+                                 hipStream_t s, const void *d_coarse_queries = nullptr) {
+  if (!h->trained && !brute_force) return ZVEC_HIP_ERR_NO_TRAINED;      // (segments loaded, coarse space still to be set)
   // 32-bit word offsets into the padded query matrix: very large batches go in slices
-  const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(h->lists.dpad, 1u));
+  const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(std::max(h->lists.dpad, h->cent.dpad), 1u));
   for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
     const uint32_t m = std::min(maxq, count - q0);
     SearchOut out{d_out_keys + (size_t)q0 * topk, d_out_scores + (size_t)q0 * topk, nullptr, d_out_counts + q0};
     ZRET(ivf_search_core(h, c, reinterpret_cast<const char *>(d_queries) + (size_t)q0 * h->lists.row_bytes(), m, topk, threshold,
-                         nprobe, max_scan_count, brute_force, d_exclude, out, s));
+                         nprobe, max_scan_count, brute_force, d_exclude, out, s,
+                         d_coarse_queries ? reinterpret_cast<const char *>(d_coarse_queries) + (size_t)q0 * h->cent.row_bytes() : nullptr));
   }
   return 0;
 }
@@ -698,7 +706,7 @@ int zvec_hip_ivf_search_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_
 static int ivf_search_host_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count, uint32_t topk,
                                 float threshold, uint32_t nprobe, uint32_t max_scan_count, int brute_force,
                                 const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
-                                uint32_t *out_counts) {
+                                uint32_t *out_counts, const void *coarse_queries = nullptr) {
   if (!h || !queries || !out_keys || !out_scores || !out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
   if (count == 0) return 0;
@@ -708,10 +716,53 @@ static int ivf_search_host_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void
   std::lock_guard<std::mutex> g(c->mu);
   ZCHK(hipSetDevice(h->device));
   ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->lists.row_bytes(), exclude_bitset, h->count_local, count, topk, c->cur));
+  const void *d_cq = nullptr;
+  if (coarse_queries && h->coarse_sep) {
+    const size_t cb = (size_t)count * h->cent.row_bytes();
+    ZRET(c->io_cq.ensure(cb));
+    ZCHK(hipMemcpyAsync(c->io_cq.p, coarse_queries, cb, hipMemcpyHostToDevice, c->cur));
+    d_cq = c->io_cq.p;
+  }
   ZRET(ivf_search_dev_locked(h, c, c->io_q.p, count, topk, threshold, nprobe, max_scan_count, brute_force,
                              exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr, c->io_keys.as<uint64_t>(),
-                             c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
+                             c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur, d_cq));
   return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, c->cur);
+}
+
+// The centroid index in a space of its own.  IVFBuilder trains INNER-PRODUCT indexes through a MipsConverter
+// (ivf_builder.cc:552-555): the nested "ivf.centroid" index then holds converted centroids — more dimensions, squared-Euclidean
+// metric, a MipsReformer named in its meta — and IVFCentroidIndex::search transforms every query with that reformer before the
+// coarse scan (ivf_centroid_index.cc:273-297), while the inverted lists keep the original rows and metric.  This entry installs
+// such a centroid store (nlist rows of `coarse_dim` elements of the index's element type, in centroid-id order); searches then
+// go through zvec_hip_ivf_search_coarse, which takes the reformed queries beside the original ones.
+int zvec_hip_ivf_set_coarse_space(zvec_hip_ivf_t h, uint32_t coarse_dim, int coarse_metric, const void *centroids, uint32_t nlist) {
+  if (!h || !centroids || coarse_dim == 0 || nlist == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (coarse_metric != ZVEC_HIP_METRIC_L2 && coarse_metric != ZVEC_HIP_METRIC_IP) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (h->loaded && nlist != h->nlist) return ZVEC_HIP_ERR_MISMATCH;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  hipStream_t s = h->defctx->own;
+  h->cent.release();
+  h->cent.configure(coarse_dim, coarse_metric, h->dtype);
+  const size_t rb = h->cent.row_bytes();
+  h->h_centroids.assign(static_cast<const char *>(centroids), static_cast<const char *>(centroids) + (size_t)nlist * rb);
+  Scoped<char> d_c;
+  ZRET(d_c.alloc((size_t)nlist * rb));
+  ZCHK(hipMemcpyAsync(d_c, centroids, (size_t)nlist * rb, hipMemcpyHostToDevice, s));
+  ZRET(store_append_dev(h->cent, d_c, nlist, nullptr, s));
+  ZCHK(hipStreamSynchronize(s));
+  h->nlist = nlist;
+  h->coarse_sep = true;
+  h->trained = true;
+  return 0;
+}
+
+int zvec_hip_ivf_search_coarse(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries, const void *coarse_queries, uint32_t count,
+                               uint32_t topk, float threshold, uint32_t nprobe, uint32_t max_scan_count,
+                               const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores, uint32_t *out_counts) {
+  if (!h || !h->coarse_sep || !coarse_queries) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  return ivf_search_host_impl(h, ctx, queries, count, topk, threshold, nprobe, max_scan_count, 0, exclude_bitset, out_keys,
+                              out_scores, out_counts, coarse_queries);
 }
 
 int zvec_hip_ivf_search(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count, uint32_t topk,

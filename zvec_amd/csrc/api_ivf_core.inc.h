@@ -4,9 +4,13 @@
 namespace {
 
 // ---- IVF search core (device pointers) ------------------------------------------------------
+// d_coarse_queries: the queries in the centroid store's own space when it has one (h->coarse_sep: an inner-product index whose
+// centroid index the reference's builder trained in MIPS-converted space, ivf_builder.cc:552-555, searched through a MipsReformer,
+// ivf_centroid_index.cc:273-297); nullptr otherwise
 int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_queries, uint32_t count, uint32_t topk,
                     float threshold, uint32_t nprobe, uint32_t max_scan_count, int brute_force,
-                    const uint64_t *d_exclude, const SearchOut &out, hipStream_t stream) {
+                    const uint64_t *d_exclude, const SearchOut &out, hipStream_t stream, const void *d_coarse_queries = nullptr) {
+  if (h->coarse_sep && !brute_force && d_coarse_queries == nullptr) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   const int cus = device_cus(ctx);
   const uint32_t nlist = h->nlist;
   if (nprobe < 1) nprobe = 1;
@@ -26,11 +30,13 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   // prepared rows (no padding: dim_in == the scanned dims == whole 128-byte k-steps; 16-byte aligned) the preparation launch is
   // skipped — one kernel and one launch gap less in a chain of eight short dependent kernels (single query, 10M x 768:
   // 5 us + gap of the ~70 us one lane needs between two of its scoring kernels).
-  const bool raw_rows = direct && h->lists.dim_in == h->lists.dscan && (size_t)h->lists.dpad * 4 == h->lists.row_bytes() &&
+  const bool sep = h->coarse_sep && !brute_force;
+  const bool raw_rows = !sep && direct && h->lists.dim_in == h->lists.dscan && (size_t)h->lists.dpad * 4 == h->lists.row_bytes() &&
                         (reinterpret_cast<uintptr_t>(d_queries) & 15u) == 0;
   const float *qrows = raw_rows ? reinterpret_cast<const float *>(d_queries) : nullptr;
   if (!raw_rows) {
-    ZRET(prep_queries(ctx, h->lists, d_queries, count, FLT_MAX, stream));   // coarse pass: no RNN radius
+    // (a separate coarse space: the coarse pass runs on the coarse queries, then the list queries are prepared in their place)
+    ZRET(prep_queries(ctx, sep ? h->cent : h->lists, sep ? d_coarse_queries : d_queries, count, FLT_MAX, stream));   // coarse pass: no RNN radius
     qrows = ctx->qpad.as<float>();
   }
 
@@ -48,10 +54,10 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
       ZRET(ctx->part_s.ensure(pairs * 4));
       if (h->cent.f16)
         hipLaunchKernelGGL(rows_score_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->cent.base,
-                           qrows, h->cent.dpad, h->metric, nlist, count, stride, ctx->part_s.as<float>());
+                           qrows, h->cent.dpad, h->cent.metric, nlist, count, stride, ctx->part_s.as<float>());
       else
         hipLaunchKernelGGL(rows_score_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->cent.base,
-                           qrows, h->cent.dpad, h->metric, nlist, count, stride, ctx->part_s.as<float>());
+                           qrows, h->cent.dpad, h->cent.metric, nlist, count, stride, ctx->part_s.as<float>());
       MergeArgs m{};
       m.part_s = ctx->part_s.as<float>(); m.slots_per_q = 1; m.slot_stride = 1; m.k = nprobe; m.slot_len = stride; m.threshold = FLT_MAX;
       m.out_keys = co.keys; m.out_scores = co.scores; m.out_idx = co.idx; m.out_counts = co.counts;
@@ -61,6 +67,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
       ZRET(flat_scan_prepared(ctx, h->cent, count, nprobe, FLT_MAX, nullptr, co, stream, false));
     }
   }
+  if (sep) ZRET(prep_queries(ctx, h->lists, d_queries, count, FLT_MAX, stream));      // from here on: the lists' own space
   if (direct) {
     // 2'. every query's probed rows as positions (same probe rule), 3'. one wave per (query, row): direct distance,
     // 4'. selection in two steps: runs of 4096 candidates -> top-k lists, those -> the result (no refinement needed:

@@ -168,6 +168,7 @@ struct zvec_hip_ctx_s {
   DevBuf qpad, qnorm, part_s, part_i, coarse_keys, coarse_scores, coarse_idx, coarse_cnt;
   DevBuf plan;        // all u32 plan arrays
   DevBuf io_q, io_ex, io_out;                          // staging for host-pointer entry points
+  DevBuf io_cq;                                        // ... the coarse-space queries of zvec_hip_ivf_search_coarse
   DevView io_keys, io_scores, io_counts;               // the result arrays inside io_out: ONE copy brings them back
   DevBuf grp_ws, grp_of, grp_out, grp_tab;
   DevBuf direct_pos, direct_keys, direct_scores, direct_idx, direct_cnt;   // small-batch IVF route: positions, stage-1 lists
@@ -239,6 +240,7 @@ struct zvec_hip_ivf_s {
   std::vector<uint32_t> h_owner;       // list -> shard (byte-balanced, identical on every rank)
   std::vector<uint64_t> h_cursor;      // streamed build: next dense position of each list
   Store cent;     // centroids as a flat store
+  bool coarse_sep = false;             // the centroid store lives in a space of its own (dimension / metric): zvec_hip_ivf_set_coarse_space
   Store lists;    // inverted lists, each padded to whole tiles
   uint64_t count_local = 0, count_global = 0;
   std::vector<uint32_t> h_size, h_size_global, h_tile0;
