@@ -496,7 +496,7 @@ def main():
         result = {
             "value": batch * args.steps / elapsed,
             "ms_per_step": ms_per_step,
-            "roofline": {"bound": "hbm", "kernel": ("zvk::pkeys_score_kernel (IVF small-batch route: a wave per four probed rows%s)" if batch <= 8 else "zvk::scan_kernel<1> (IVF list scan%s)") % (", rank 0's shard" if world > 1 or shard_mode else ""),
+            "roofline": {"bound": "hbm", "kernel": ("zvk::pkeys_topk_kernel (IVF small-batch route: a wave per four probed rows, a block keeps the k best of its 128%s)" if batch <= 8 else "zvk::scan_kernel<1> (IVF list scan%s)") % (", rank 0's shard" if world > 1 or shard_mode else ""),
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,

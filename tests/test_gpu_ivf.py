@@ -337,6 +337,40 @@ def test_same_value_rows_all_ties(zv):
                 assert len(ctx.result(qi)) == 1 and ctx.result(qi)[0].score() == float(qi * qi * dim)
 
 
+@pytest.mark.parametrize("nq,k", [(1, 10), (3, 64), (2, 65)])
+def test_small_batch_equal_scores_keep_stream_order(zv, oracle, nq, k):
+    """The small-batch route with heavy ties on a stream of several thousand candidates: equal scores come back in the
+    order the reference scans them — probe rank, then place in the list (ivf_searcher.cc:223-260 walks the lists in coarse
+    order and pushes rows in storage order) — whether the scoring blocks pre-select (k <= 64: pkeys_topk_kernel + one
+    merge) or the whole score matrix is selected from in two steps (k = 65)."""
+    rng = np.random.default_rng(811 + k)
+    n, dim, nlist = 9000, 16, 24
+    points = rng.integers(0, 6, (5, dim)).astype(np.float32)           # five distinct stored points => ~1800-way ties
+    base = points[rng.integers(0, 5, n)]
+    lab = rng.integers(0, nlist, n)
+    order = np.argsort(lab, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(lab, minlength=nlist))]).astype(np.uint64)
+    cent = rng.normal(3, 2, (nlist, dim)).astype(np.float32)           # (any centroids: the probe order only has to be untied)
+    vecs, keys = base[order], order.astype(np.uint64) * 3 + 1
+    q = rng.integers(0, 6, (nq, dim)).astype(np.float32)
+    se = zv.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=0.5, brute_force_threshold=10)
+    assert se.load(cent, offs, vecs, keys) == 0
+    nprobe, max_scan = se.probe_params()
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    assert se.search_impl(q, nq, ctx) == 0
+    _, _, _, _, _, opr = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys, want_probes=True)
+    for qi in range(nq):
+        lists = [int(l) for l in opr[qi] if l != 0xffffffff]
+        stream = np.concatenate([np.arange(offs[l], offs[l + 1]) for l in lists]).astype(np.int64)
+        assert len(stream) > 2048                                       # several runs / many scoring blocks
+        sc = ((vecs[stream] - q[qi]) ** 2).sum(1)
+        first = stream[np.argsort(sc, kind="stable")[:k]]
+        assert ctx.counts[qi] == k
+        assert np.array_equal(ctx.scores[qi], np.sort(sc, kind="stable")[:k])
+        assert np.array_equal(ctx.keys[qi], keys[first]), "tie order of query %d" % qi
+
+
 def test_boundary_a_parameter_mapping_probes_exactly_nprobe(zv):
     """SURVEY H3 / patches/boundary_a.diff: nlist = 4096 honoured (no clamp to 1024), nprobe = 32 handed over as
     scan_ratio = 32/4096 with brute_force_threshold = N - 1 => every query probes exactly 32 lists and scans exactly the

@@ -40,6 +40,30 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     qrows = ctx->qpad.as<float>();
   }
 
+  // the small-batch route: stream geometry and probe-rule arguments
+  constexpr uint32_t RUN = 1024;                                        // one gather round of merge_kernel
+  uint32_t stride = 0, runs = 0, *d_off = nullptr;
+  bool block_topk = false;
+  PlanArgs dp{};
+  if (direct) {
+    stride = (uint32_t)((direct_rows + 63) / 64 * 64);
+    if (stride > RUN) stride = (stride + RUN - 1) / RUN * RUN;          // whole runs for the two-step selection
+    runs = (stride + RUN - 1) / RUN;
+    // long streams, ordinary k: the scoring blocks keep only the k best of their PKEYS_BLOCK candidates (pkeys_topk_kernel) and
+    // ONE merge finishes; otherwise the whole score matrix is written and selected from in one or two steps
+    block_topk = runs > 1 && topk <= PKEYS_TOPK_MAX;
+    ZRET(ctx->plan.ensure(((size_t)3 * count + 8) * sizeof(uint32_t)));
+    uint32_t *pb = ctx->plan.as<uint32_t>();
+    dp.coarse_idx = ctx->coarse_idx.as<uint32_t>(); dp.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
+    dp.nq = count; dp.nprobe = nprobe; dp.nlist = nlist; dp.max_scan_count = max_scan_count; dp.brute_force = 0;
+    dp.list_size = h->d_size; dp.list_size_global = h->d_size_global;
+    dp.q_nprobe = pb; dp.q_scanned = pb + count;
+    d_off = pb + 2 * (size_t)count;
+    if (ctx->profile && ctx->nprof < PROFILE_MAX && ctx->stats.p) {       // the slot prof_begin will take for this launch
+      dp.work_stats = ctx->stats.as<unsigned long long>() + 2 * (size_t)ctx->nprof;     // (zero since the last profile reset)
+    }
+  }
+
   // 1. coarse assign: flat scan over the centroids, k = nprobe (IVFCentroidIndex::search)
   if (!brute_force) {
     ZRET(ctx->coarse_keys.ensure((size_t)count * nprobe * sizeof(uint64_t)));
@@ -49,18 +73,19 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     SearchOut co{ctx->coarse_keys.as<uint64_t>(), ctx->coarse_scores.as<float>(), ctx->coarse_idx.as<uint32_t>(),
                  ctx->coarse_cnt.as<uint32_t>()};
     if (direct) {
-      const uint32_t stride = (nlist + 63) / 64 * 64;
-      const uint64_t pairs = (uint64_t)count * stride;
-      ZRET(ctx->part_s.ensure(pairs * 4));
+      const uint32_t cstride = (nlist + 63) / 64 * 64;
+      const uint64_t cpairs = (uint64_t)count * cstride;
+      ZRET(ctx->part_s.ensure(cpairs * 4));
       if (h->cent.f16)
-        hipLaunchKernelGGL(rows_score_kernel<true>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->cent.base,
-                           qrows, h->cent.dpad, h->cent.metric, nlist, count, stride, ctx->part_s.as<float>());
+        hipLaunchKernelGGL(rows_score_kernel<true>, dim3((unsigned)((cpairs + 3) / 4)), dim3(256), 0, stream, h->cent.base,
+                           qrows, h->cent.dpad, h->cent.metric, nlist, count, cstride, ctx->part_s.as<float>());
       else
-        hipLaunchKernelGGL(rows_score_kernel<false>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, stream, h->cent.base,
-                           qrows, h->cent.dpad, h->cent.metric, nlist, count, stride, ctx->part_s.as<float>());
+        hipLaunchKernelGGL(rows_score_kernel<false>, dim3((unsigned)((cpairs + 3) / 4)), dim3(256), 0, stream, h->cent.base,
+                           qrows, h->cent.dpad, h->cent.metric, nlist, count, cstride, ctx->part_s.as<float>());
       MergeArgs m{};
-      m.part_s = ctx->part_s.as<float>(); m.slots_per_q = 1; m.slot_stride = 1; m.k = nprobe; m.slot_len = stride; m.threshold = FLT_MAX;
+      m.part_s = ctx->part_s.as<float>(); m.slots_per_q = 1; m.slot_stride = 1; m.k = nprobe; m.slot_len = cstride; m.threshold = FLT_MAX;
       m.out_keys = co.keys; m.out_scores = co.scores; m.out_idx = co.idx; m.out_counts = co.counts;
+      dp.coarse_idx = co.idx; dp.coarse_cnt = co.counts;                  // (the buffers may just have grown)
       hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(256), (size_t)nprobe * 12 + 16, stream, m);     // four waves share the row
       ZCHK(hipGetLastError());
     } else {
@@ -72,31 +97,30 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     // 2'. every query's probed rows as positions (same probe rule), 3'. one wave per (query, row): direct distance,
     // 4'. selection in two steps: runs of 4096 candidates -> top-k lists, those -> the result (no refinement needed:
     // the scores already are sum((q - b)^2))
-    constexpr uint32_t RUN = 1024;                                      // one gather round of merge_kernel
-    uint32_t stride = (uint32_t)((direct_rows + 63) / 64 * 64);
-    if (stride > RUN) stride = (stride + RUN - 1) / RUN * RUN;          // whole runs for the two-step selection
-    const uint32_t runs = (stride + RUN - 1) / RUN;
     const uint64_t pairs = (uint64_t)count * stride;
-    ZRET(ctx->plan.ensure(((size_t)3 * count + 8) * sizeof(uint32_t)));
-    uint32_t *pb = ctx->plan.as<uint32_t>();
-    PlanArgs p{};
-    p.coarse_idx = ctx->coarse_idx.as<uint32_t>(); p.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
-    p.nq = count; p.nprobe = nprobe; p.nlist = nlist; p.max_scan_count = max_scan_count; p.brute_force = 0;
-    p.list_size = h->d_size; p.list_size_global = h->d_size_global;
-    p.q_nprobe = pb; p.q_scanned = pb + count;
-    uint32_t *d_off = pb + 2 * (size_t)count;
     ZRET(ctx->direct_pos.ensure(pairs * 4));
-    ZRET(ctx->part_s.ensure(pairs * 4));
-    ZRET(ctx->part_i.ensure(pairs * 4));
-    if (ctx->profile && ctx->nprof < PROFILE_MAX && ctx->stats.p) {       // the slot prof_begin will take for this launch
-      p.work_stats = ctx->stats.as<unsigned long long>() + 2 * (size_t)ctx->nprof;     // (zero since the last profile reset)
-    }
-    hipLaunchKernelGGL(ivf_expand_direct_kernel, dim3(nprobe, count), dim3(256), 0, stream, p, h->d_tile0, h->d_dense0,
+    hipLaunchKernelGGL(ivf_expand_direct_kernel, dim3(nprobe, count), dim3(256), 0, stream, dp, h->d_tile0, h->d_dense0,
                        reinterpret_cast<const uint32_t *>(d_exclude), stride, d_off, ctx->direct_pos.as<uint32_t>());
+    if (!block_topk) {
+      ZRET(ctx->part_s.ensure(pairs * 4));
+      ZRET(ctx->part_i.ensure(pairs * 4));
+    }
     gate_enter(ctx, stream);                                              // (the radius is applied by the selection)
     const int pi = prof_begin(ctx, stream, (double)count * h->lists.dscan * h->lists.elem + (double)count * topk * 12.0, 0, 1);
     if (pi >= 0) ctx->prof_dscan[pi] = h->lists.dscan | (h->lists.f16 ? 0x80000000u : 0u);
-    if (h->lists.f16)
+    const uint32_t bpq = (stride + PKEYS_BLOCK - 1) / PKEYS_BLOCK;
+    if (block_topk) {
+      ZRET(ctx->direct_scores.ensure((uint64_t)count * bpq * topk * 4));
+      ZRET(ctx->direct_idx.ensure((uint64_t)count * bpq * topk * 4));
+      if (h->lists.f16)
+        hipLaunchKernelGGL(pkeys_topk_kernel<true>, dim3(count * bpq), dim3(256), 0, stream, h->lists.base, qrows, h->lists.dpad,
+                           h->metric, ctx->direct_pos.as<uint32_t>(), d_off, count, stride, topk, ctx->direct_scores.as<float>(),
+                           ctx->direct_idx.as<uint32_t>());
+      else
+        hipLaunchKernelGGL(pkeys_topk_kernel<false>, dim3(count * bpq), dim3(256), 0, stream, h->lists.base, qrows, h->lists.dpad,
+                           h->metric, ctx->direct_pos.as<uint32_t>(), d_off, count, stride, topk, ctx->direct_scores.as<float>(),
+                           ctx->direct_idx.as<uint32_t>());
+    } else if (h->lists.f16)
       hipLaunchKernelGGL(pkeys_score_kernel<true>, dim3(pkeys_score_blocks(count, stride)), dim3(256), 0, stream, h->lists.base,
                          qrows, h->lists.dpad, h->metric, ctx->direct_pos.as<uint32_t>(), d_off, count, stride,
                          ctx->part_s.as<float>(), ctx->part_i.as<uint32_t>());
@@ -107,6 +131,17 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     prof_end(ctx, stream, pi);
     gate_leave(ctx, stream);
     ZCHK(hipGetLastError());
+    if (block_topk) {
+      // (equal scores: list order, then entry order = the order of the candidate stream, as below)
+      MergeArgs f{};
+      f.part_s = ctx->direct_scores.as<float>(); f.part_i = ctx->direct_idx.as<uint32_t>(); f.slots_per_q = bpq; f.slot_stride = 1;
+      f.k = topk; f.slot_len = topk; f.threshold = threshold; f.order_by_ordinal = 1; f.keymap = h->lists.keys;
+      f.out_keys = out.keys; f.out_scores = out.scores; f.out_idx = out.idx; f.out_counts = out.counts;
+      hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(256), (size_t)topk * 12 + 16, stream, f);
+      ZCHK(hipGetLastError());
+      ctx->q_nprobe = dp.q_nprobe; ctx->q_scanned = dp.q_scanned; ctx->last_count = count; ctx->last_list_count = nullptr;
+      return 0;
+    }
     // equal scores keep the reference's order — probe rank, then position in the list — which here is the ORDER of the
     // candidate stream, not the order of the positions
     MergeArgs m{};
@@ -134,7 +169,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
       hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(64), (size_t)topk * 12 + 16, stream, m);
     }
     ZCHK(hipGetLastError());
-    ctx->q_nprobe = p.q_nprobe; ctx->q_scanned = p.q_scanned; ctx->last_count = count; ctx->last_list_count = nullptr;
+    ctx->q_nprobe = dp.q_nprobe; ctx->q_scanned = dp.q_scanned; ctx->last_count = count; ctx->last_list_count = nullptr;
     return 0;
   }
 

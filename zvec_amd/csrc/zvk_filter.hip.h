@@ -212,29 +212,19 @@ __global__ void __launch_bounds__(256) compact_rows_kernel(const float *src, con
 // a wave takes PKEYS_ROWS consecutive entries of one query's list: their loads are issued together (12 independent
 // 16-byte loads per lane at d = 768 instead of 3), and four times fewer waves have to be launched
 constexpr uint32_t PKEYS_ROWS = 4;
+// the wave's PKEYS_ROWS rows (positions id[], IDX_NONE = hole) against one prepared query row: every lane returns the scores
 template <bool F16>
-__global__ void __launch_bounds__(256) pkeys_score_kernel(const float *base, const float *queries, uint32_t dpadw,
-                                                          int metric, const uint32_t *pos, const uint32_t *off,
-                                                          uint32_t nq, uint32_t maxlen, float *out_s, uint32_t *out_i) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t groups = (maxlen + PKEYS_ROWS - 1) / PKEYS_ROWS;
-  const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= (uint64_t)nq * groups) return;
-  const uint32_t q = (uint32_t)(w / groups), j0 = (uint32_t)(w - (uint64_t)q * groups) * PKEYS_ROWS;
-  const uint32_t len = off[q + 1] - off[q];
-  uint32_t id[PKEYS_ROWS];
+__device__ __forceinline__ void pkeys_rows_distance(const float *base, const float *qrow, uint32_t dpadw, int metric,
+                                                    const uint32_t (&id)[PKEYS_ROWS], int lane, float (&sc)[PKEYS_ROWS]) {
   const float *trow[PKEYS_ROWS];
   uint32_t swz[PKEYS_ROWS];
 #pragma unroll
   for (uint32_t r = 0; r < PKEYS_ROWS; ++r) {
-    const uint32_t j = j0 + r;
-    id[r] = (j < len) ? pos[off[q] + j] : IDX_NONE;
     const uint32_t p = (id[r] != IDX_NONE) ? id[r] : 0u;          // (holes read row 0 and are discarded)
     const uint32_t row = p & 127;
     trow[r] = base + (size_t)(p >> 7) * TILE_N * dpadw + (size_t)(row * 8) * 4;
     swz[r] = (row >> 1) & 7;
   }
-  const float *qrow = queries + (size_t)q * dpadw;
   const uint32_t nchunks = dpadw >> 2;
   float acc[PKEYS_ROWS];
 #pragma unroll
@@ -270,16 +260,111 @@ __global__ void __launch_bounds__(256) pkeys_score_kernel(const float *base, con
   for (uint32_t r = 0; r < PKEYS_ROWS; ++r) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) acc[r] += __shfl_xor(acc[r], o);
+    sc[r] = (metric == METRIC_L2) ? acc[r] : (metric == METRIC_IP ? -acc[r] : 1.f - acc[r]);
   }
+}
+
+template <bool F16>
+__global__ void __launch_bounds__(256) pkeys_score_kernel(const float *base, const float *queries, uint32_t dpadw,
+                                                          int metric, const uint32_t *pos, const uint32_t *off,
+                                                          uint32_t nq, uint32_t maxlen, float *out_s, uint32_t *out_i) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t groups = (maxlen + PKEYS_ROWS - 1) / PKEYS_ROWS;
+  const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (uint64_t)nq * groups) return;
+  const uint32_t q = (uint32_t)(w / groups), j0 = (uint32_t)(w - (uint64_t)q * groups) * PKEYS_ROWS;
+  const uint32_t len = off[q + 1] - off[q];
+  uint32_t id[PKEYS_ROWS];
+#pragma unroll
+  for (uint32_t r = 0; r < PKEYS_ROWS; ++r) {
+    const uint32_t j = j0 + r;
+    id[r] = (j < len) ? pos[off[q] + j] : IDX_NONE;
+  }
+  float sc[PKEYS_ROWS];
+  pkeys_rows_distance<F16>(base, queries + (size_t)q * dpadw, dpadw, metric, id, lane, sc);
   if (lane < (int)PKEYS_ROWS && j0 + lane < maxlen) {
-    float a = acc[0];
+    float a = sc[0];
     uint32_t i = id[0];
 #pragma unroll
     for (uint32_t r = 1; r < PKEYS_ROWS; ++r)
-      if ((uint32_t)lane == r) { a = acc[r]; i = id[r]; }
-    const float sc = (metric == METRIC_L2) ? a : (metric == METRIC_IP ? -a : 1.f - a);
-    out_s[(size_t)q * maxlen + j0 + lane] = (i != IDX_NONE) ? sc : __builtin_inff();
+      if ((uint32_t)lane == r) { a = sc[r]; i = id[r]; }
+    out_s[(size_t)q * maxlen + j0 + lane] = (i != IDX_NONE) ? a : __builtin_inff();
     out_i[(size_t)q * maxlen + j0 + lane] = i;
+  }
+}
+
+// The same scoring with the first selection step folded in (the single-query IVF route): a block takes PKEYS_BLOCK consecutive
+// candidates of one query's stream and writes only their k best — sorted by (score, place in the stream) — as list
+// (query, block) of a [nq][blocks][k] matrix.  The stream's 4 bytes of score + 4 of position per candidate are never written,
+// and ONE merge of the lists (ordered by list, then entry = by place in the stream again) finishes the selection where the
+// score matrix needed two.  Unused entries: +inf / IDX_NONE.  k <= PKEYS_TOPK_MAX.
+constexpr uint32_t PKEYS_BLOCK = 128;
+constexpr uint32_t PKEYS_TOPK_MAX = 64;
+template <bool F16>
+__global__ void __launch_bounds__(256) pkeys_topk_kernel(const float *base, const float *queries, uint32_t dpadw, int metric,
+                                                         const uint32_t *pos, const uint32_t *off, uint32_t nq, uint32_t maxlen,
+                                                         uint32_t k, float *out_s, uint32_t *out_i) {
+  __shared__ unsigned long long s_key[PKEYS_BLOCK];      // order-preserving score key << 32 | place in the block; ~0 = hole
+  __shared__ float s_sc[PKEYS_BLOCK];
+  __shared__ uint32_t s_pos[PKEYS_BLOCK];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t bpq = (maxlen + PKEYS_BLOCK - 1) / PKEYS_BLOCK;
+  const uint32_t q = blockIdx.x / bpq, b = blockIdx.x - q * bpq;
+  const uint32_t len = min(off[q + 1] - off[q], maxlen);
+  const float *qrow = queries + (size_t)q * dpadw;
+  constexpr uint32_t PER_WAVE = PKEYS_BLOCK / 4;
+#pragma unroll 2
+  for (uint32_t g = 0; g < PER_WAVE / PKEYS_ROWS; ++g) {
+    const uint32_t t0 = wave * PER_WAVE + g * PKEYS_ROWS, j0 = b * PKEYS_BLOCK + t0;
+    if (j0 >= len) {                                       // uniform: past the stream
+      if (lane < (int)PKEYS_ROWS) s_key[t0 + lane] = ~0ull;
+      continue;
+    }
+    uint32_t id[PKEYS_ROWS];
+#pragma unroll
+    for (uint32_t r = 0; r < PKEYS_ROWS; ++r) id[r] = (j0 + r < len) ? pos[off[q] + j0 + r] : IDX_NONE;
+    float sc[PKEYS_ROWS];
+    pkeys_rows_distance<F16>(base, qrow, dpadw, metric, id, lane, sc);
+    if (lane < (int)PKEYS_ROWS) {
+      float a = sc[0];
+      uint32_t i = id[0];
+#pragma unroll
+      for (uint32_t r = 1; r < PKEYS_ROWS; ++r)
+        if ((uint32_t)lane == r) { a = sc[r]; i = id[r]; }
+      s_key[t0 + lane] = (i != IDX_NONE) ? (((unsigned long long)fkey(a + 0.f) << 32) | (t0 + lane)) : ~0ull;
+      s_sc[t0 + lane] = a;
+      s_pos[t0 + lane] = i;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  constexpr int KPL = PKEYS_BLOCK / 64;                   // keys per lane
+  unsigned long long kk[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) kk[e] = s_key[e * 64 + lane];
+  float rs = __builtin_inff();
+  uint32_t ri = IDX_NONE;
+  for (uint32_t r = 0; r < k; ++r) {                       // k rounds of a wave-wide minimum (keys are distinct)
+    unsigned long long m = kk[0];
+#pragma unroll
+    for (int e = 1; e < KPL; ++e) m = kk[e] < m ? kk[e] : m;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const uint32_t hi = __shfl_xor((uint32_t)(m >> 32), o), lo = __shfl_xor((uint32_t)m, o);
+      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+      m = other < m ? other : m;
+    }
+    if (m == ~0ull) break;                                 // uniform: nothing left
+    if ((uint32_t)lane == r) { const uint32_t t = (uint32_t)m & (PKEYS_BLOCK - 1); rs = s_sc[t]; ri = s_pos[t]; }
+#pragma unroll
+    for (int e = 0; e < KPL; ++e)
+      if (kk[e] == m) kk[e] = ~0ull;
+  }
+  if ((uint32_t)lane < k) {
+    const size_t o = ((size_t)q * bpq + b) * k + lane;
+    out_s[o] = rs;
+    out_i[o] = ri;
   }
 }
 

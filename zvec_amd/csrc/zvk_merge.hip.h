@@ -39,6 +39,7 @@ struct MergeArgs {
 // Launched with 64 threads (one wave per query) or, for small batches of partial-list merges, 256: the extra waves
 // only help gathering the survivors (the one phase that streams every candidate); wave 0 finishes alone.
 __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
+  const uint32_t q = blockIdx.x;
   extern __shared__ f32x4 zvk_smem4[];
   const uint32_t k = a.k;
   float *Ls = reinterpret_cast<float *>(zvk_smem4);          // [k]
@@ -46,7 +47,6 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
   uint32_t *Li = Lo + k;                                      // [k] idx / candidate ordinal
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const uint32_t q = blockIdx.x;
   uint32_t sb, nslots;
   if (a.slot_begin) { sb = a.slot_begin[q]; nslots = a.slot_begin[q + 1] - sb; }
   else if (a.slot_stride == 1) { sb = q * a.slots_per_q; nslots = a.slots_per_q; }
@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
   const uint32_t sl = a.slot_len;
   const uint64_t total = (uint64_t)nslots * sl;
   constexpr int U = 16;          // candidate batches fetched together: one wave per query is latency-bound on this stream
+  __shared__ float wave_min[4][64];   // the bound passes of several waves meet here
 
   // Dense rows (coarse step): a cheap, exact upper bound of the k-th score before any insertion — every
   // lane takes the minimum of its own strided elements; those are 64 distinct candidates, so the k-th
@@ -76,7 +77,6 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
       for (int u = 0; u < U; ++u) mn = fminf(mn, v[u]);
     }
     if (nwaves > 1) {      // several waves (small batches): lane l's minimum over every wave's share — still 64 disjoint subsets
-      __shared__ float wave_min[4][64];
       wave_min[wave & 3][lane] = mn;
       __syncthreads();
       for (uint32_t w = 0; w < nwaves && w < 4; ++w) mn = fminf(mn, wave_min[w][lane]);
@@ -101,8 +101,25 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
   // of every slot (768 slots x ~3 survivors overflowed the gather and sent single-query merges down the slow path).
   if (a.part_i != nullptr && a.part_keys == nullptr && a.part_counts == nullptr && a.packed_stride == 0 &&
       a.slot_stride == 1 && nslots >= 64 && k <= 64) {
+    // (every wave takes a share, four heads in flight per lane: a plain loop was a chain of nslots / 64 dependent round trips —
+    // 12 of them, most of the merge's time, for the 734 lists of a single-query IVF search)
     float mn = __builtin_inff();
-    for (uint32_t j = lane; j < nslots; j += 64) mn = fminf(mn, a.part_s[((size_t)sb + j) * sl]);
+    const uint32_t tstride = nwaves * 64;
+    for (uint32_t j0 = wave * 64 + lane; j0 < nslots; j0 += tstride * 4) {
+      float v[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t j = j0 + u * tstride;
+        v[u] = (j < nslots) ? a.part_s[((size_t)sb + j) * sl] : __builtin_inff();
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) mn = fminf(mn, v[u]);
+    }
+    if (nwaves > 1) {      // lane l's minimum over every wave's share: still 64 disjoint sets of heads
+      wave_min[wave & 3][lane] = mn;
+      __syncthreads();
+      for (uint32_t w = 0; w < nwaves && w < 4; ++w) mn = fminf(mn, wave_min[w][lane]);
+    }
     uint32_t rank = 0;
     for (int m = 0; m < 64; ++m) {
       const float o = bcast_f(mn, m);
