@@ -79,6 +79,9 @@ def parse_args():
     ap.add_argument("--intrinsic-dim", type=int, default=12)
     ap.add_argument("--target-recall", type=float, default=0.99)
     ap.add_argument("--nprobe-step", type=int, default=2, help="widening step of the recall sweep")
+    ap.add_argument("--no-gate", action="store_true",
+                    help="IVF workloads with --streams > 1: the lanes do NOT share a gate (their dominant kernels may overlap; "
+                         "the roofline kernel's HIP-event time is then that of a shared device). An experiment switch")
     ap.add_argument("--streams", type=int, default=2,
                     help="IVF workloads: consecutive (independent) batches alternate over this many contexts / HIP streams that "
                          "share a gate (zvec_hip_gate_t): list scans run back to back, everything else overlaps them (1 or 2)")
@@ -415,7 +418,7 @@ def main():
         # inside the timed region, and the scan kernel's HIP-event duration is that of an un-shared device
         lanes = [(sh, stream_ptr, None)]
         if args.streams > 1:
-            gate = zvec_amd.Gate(local_rank)
+            gate = None if args.no_gate else zvec_amd.Gate(local_rank)
             ctx.set_gate(gate)
             for _ in range(args.streams - 1):
                 s2 = torch.cuda.Stream(device=dev)
