@@ -95,8 +95,8 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   if (sep) ZRET(prep_queries(ctx, h->lists, d_queries, count, FLT_MAX, stream));      // from here on: the lists' own space
   if (direct) {
     // 2'. every query's probed rows as positions (same probe rule), 3'. one wave per (query, row): direct distance,
-    // 4'. selection in two steps: runs of 4096 candidates -> top-k lists, those -> the result (no refinement needed:
-    // the scores already are sum((q - b)^2))
+    // 4'. selection: the scoring blocks' own top-k lists -> the result, or (k > 64) two steps over the score matrix: runs of
+    // 1024 candidates -> top-k lists -> the result (no refinement needed: the scores already are sum((q - b)^2))
     const uint64_t pairs = (uint64_t)count * stride;
     ZRET(ctx->direct_pos.ensure(pairs * 4));
     hipLaunchKernelGGL(ivf_expand_direct_kernel, dim3(nprobe, count), dim3(256), 0, stream, dp, h->d_tile0, h->d_dense0,
