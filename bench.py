@@ -553,8 +553,9 @@ def committed_traffic(args, world, shard_mode):
     measured by separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (profiles/README.md) and
     corrected as MI355X_MICROARCH.md §HBM prescribes; null for any other configuration."""
     try:
-        if world == 1 and not shard_mode and not args.n and not args.batch and not args.nprobe and not args.nlist:
-            v = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+        if world == 1 and not shard_mode and not args.n and args.batch in (0, None, 1) and not args.nprobe and not args.nlist:
+            key = args.workload + ("_b1" if args.batch == 1 else "")      # (the single-query route has its own dominant kernel)
+            v = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
             if v is not None:
                 return v, "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, not this run)"
     except (OSError, ValueError):
