@@ -167,7 +167,8 @@ def test_ivf_fuzz_big(zv, oracle, seed):
     ok, os_, _, oc, osc = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys, exclude_bits=words, threads=16)
     cd = np.sort(exact_l2(cent.astype(np.float32), q.astype(np.float32)), 1)
     sel = np.nonzero((np.diff(cd[:, :min(nprobe + 1, nlist)], axis=1) != 0).all(1))[0]
-    assert len(sel) > 0
+    if len(sel) == 0:       # (integer data, one or three queries: every query can have a coarse tie — seed 41 of an 80-seed run)
+        pytest.skip("every query of this draw has a tie in its coarse ranking: the probe set is not defined")
     tie_tolerant_compare(ctx.keys[sel], ctx.scores[sel], ctx.counts[sel], ok[sel], os_[sel], oc[sel],
                          what="ivf big fuzz seed=%d n=%d d=%d nlist=%d nq=%d k=%d ratio=%g %s" % (seed, n, dim, nlist, nq, k, ratio, dt.__name__))
 
