@@ -268,8 +268,12 @@ def main():
     shard_mode = args.shard_of > 1 and world == 1 and kind == "ivf"
     if shard_mode:
         args.no_cpu_baseline = True
-    ngt = 0 if shard_mode else max(batch, args.gt_queries or batch)
-    nqueries = max(batch, ngt)
+    # small batches (the product's count = 1 calls): the timed steps ROTATE over a pool of different query batches — the same
+    # single query every step would find its ~290 MB of probed rows half-resident in the 256 MB Infinity Cache — and recall is
+    # measured on the whole pool.  (A 1024-query batch reads every list of the index each step: nothing to rotate for.)
+    qpool_n = 64 if (kind == "ivf" and batch <= 16) else 1
+    ngt = 0 if shard_mode else max(batch * qpool_n, args.gt_queries or batch)
+    nqueries = max(batch * qpool_n, ngt)
     queries = gen_corpus(torch, nqueries, dim, dev, SEED + 1, proj, tdtype)   # held-out draws (fp16: HalfFloatReformer = RNE cast)
     # BASELINE configs[1] is a flat INNER-PRODUCT scan; every other workload is L2
     flat_metric = "InnerProduct" if args.workload == "flat1m" else "SquaredEuclidean"
@@ -384,6 +388,7 @@ def main():
         sh = ShardedIVF(ivf, ctx, rank, world)
         max_scan = n        # brute_force_threshold = N-1 => exactly nprobe lists are probed
         q = queries[:batch].contiguous()
+        qpool = [queries[j * batch:(j + 1) * batch].contiguous() for j in range(qpool_n)]
 
         # recall@10 of the configuration being timed, measured on the timed queries; the metric demands >= 0.99: if
         # nprobe (BASELINE: 32) does not reach it on this corpus, widen nprobe until it does and time THAT (the
@@ -433,11 +438,12 @@ def main():
 
         def run_step(i, np_):
             sh_i, sp, ts = lanes[i % len(lanes)]
+            qi = qpool[i % qpool_n]
             if ts is None:
-                sh_i.search(q, topk, np_, max_scan, sp)
+                sh_i.search(qi, topk, np_, max_scan, sp)
             else:
                 with torch.cuda.stream(ts):
-                    sh_i.search(q, topk, np_, max_scan, sp)
+                    sh_i.search(qi, topk, np_, max_scan, sp)
 
         host_issue = [0.0]
 

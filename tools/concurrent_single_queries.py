@@ -12,14 +12,15 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import zvec_amd  # noqa: E402
-from bench import gen_corpus, SEED  # noqa: E402
+from bench import corpus_proj, gen_corpus, SEED  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 nlist = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 dim, topk, nprobe = 768, 10, 38
 dev = torch.device("cuda:0")
-base, proj = gen_corpus(torch, n, dim, dev, SEED)
-queries, _ = gen_corpus(torch, 4096, dim, dev, SEED + 1, proj=proj)
+proj = corpus_proj(torch, dim, dev, 12)
+base = gen_corpus(torch, n, dim, dev, SEED, proj, torch.float32)
+queries = gen_corpus(torch, 4096, dim, dev, SEED + 1, proj, torch.float32)
 ivf = zvec_amd.HipIVFSearcher(dim, "SquaredEuclidean", scan_ratio=(nprobe + 0.25) / nlist, brute_force_threshold=n - 1)
 zvec_amd._lib.check(ivf.build_dev(base.data_ptr(), n, nlist, kmeans_iters=10, seed=SEED), "build")
 ivf.total_count = n
