@@ -484,21 +484,26 @@ def main():
         host_qps = None
         if world == 1 and not args.no_host_path:
             hctx = ivf.create_context()
-            qh = np.ascontiguousarray(q.cpu().numpy())
+            qhs = [np.ascontiguousarray(x.cpu().numpy()) for x in qpool]      # (small batches: a different batch every call)
+            hcall = [0]
             hk = np.zeros((batch, topk), np.uint64)
             hs = np.zeros((batch, topk), np.float32)
             hc = np.zeros(batch, np.uint32)
             L = zvec_amd._lib.lib()
 
             def host_call():      # zvec_hip_ivf_search: the C ABI entry itself (no Python result objects)
+                qh = qhs[hcall[0] % len(qhs)]
+                hcall[0] += 1
                 zvec_amd._lib.check(L.zvec_hip_ivf_search(ivf._h, hctx._h, qh.ctypes.data, batch, topk, 3.4028234663852886e38,
                                                           nprobe, n - 1, None, hk.ctypes.data, hs.ctypes.data, hc.ctypes.data),
                                     "zvec_hip_ivf_search")
-            host_call()
-            th = time.perf_counter()
-            for _ in range(5):
+            nhost = 5 if batch > 16 else 200
+            for _ in range(1 if batch > 16 else 20):
                 host_call()
-            host_qps = 5 * batch / (time.perf_counter() - th)
+            th = time.perf_counter()
+            for _ in range(nhost):
+                host_call()
+            host_qps = nhost * batch / (time.perf_counter() - th)
             log("host-pointer entry zvec_hip_ivf_search (PCIe-inclusive): %.0f QPS" % host_qps)
         per_launch_ms = prof["scan_ms"] / max(prof["launches"], 1)
         bytes_per_launch = prof["bytes"] / max(prof["launches"], 1)
