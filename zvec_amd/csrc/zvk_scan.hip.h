@@ -70,6 +70,14 @@ __device__ __forceinline__ void stage_store(const StageRegs<NG> &sr, float *Bb, 
 // ---------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+#ifdef ZVK_CLOCK_STAMP
+// Diagnostic build only (tools/build_variant.sh clk -DZVK_CLOCK_STAMP): every work-group of the wide flat kernel, and of the IVF list scan, stamps
+// the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) when it starts and when it ends; the
+// in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md "DVFS give-back" item 6).  The stamps go
+// to a buffer of their own that nothing else reads.
+__device__ unsigned long long zvk_clock_stamps[1024][4];
+#endif
+
 template <int NG, bool M16>
 struct ScanShape {
   static constexpr int ROWS = M16 ? 32 : NG * QGROUP;
@@ -116,6 +124,12 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : (NG == 2 && !M16 ? 3 : 1))
   uint32_t total;
   if (a.mode == 0) total = a.nchunks * a.nqtiles;
   else total = *a.total_items;
+#ifdef ZVK_CLOCK_STAMP
+  if (tid == 0 && blockIdx.x < 1024 && a.mode == 1) {
+    zvk_clock_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime();
+    zvk_clock_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 
   for (uint32_t iter = 0;; ++iter) {
     uint32_t item;
@@ -446,6 +460,12 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : (NG == 2 && !M16 ? 3 : 1))
     }
     __syncthreads();
   }
+#ifdef ZVK_CLOCK_STAMP
+  if (tid == 0 && blockIdx.x < 1024 && a.mode == 1) {
+    zvk_clock_stamps[blockIdx.x][2] = __builtin_amdgcn_s_memtime();
+    zvk_clock_stamps[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,13 +477,6 @@ __global__ void __launch_bounds__(256, (NG >= 4 ? 2 : (NG == 2 && !M16 ? 3 : 1))
 // same base-row reuse, which is what the matrix cores need to stay busy across barriers and epilogues.
 // Flat mode only (mode 0); the IVF list scan keeps the 16-row shape above.
 // ---------------------------------------------------------------------------------------------
-#ifdef ZVK_CLOCK_STAMP
-// Diagnostic build only (tools/build_variant.sh clk -DZVK_CLOCK_STAMP): every work-group of the wide flat kernel stamps
-// the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) when it starts and when it ends; the
-// in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md "DVFS give-back" item 6).  The stamps go
-// to a buffer of their own that nothing else reads.
-__device__ unsigned long long zvk_clock_stamps[1024][4];
-#endif
 constexpr int W8_ROWS = 128;
 __host__ __device__ inline size_t scan8_lds_bytes(uint32_t k) {
   return (2 * (size_t)W8_ROWS * TILE_K + 2 * (size_t)SLAB + 7 * (size_t)W8_ROWS + 4 + 2 * (size_t)W8_ROWS * k) * 4;
