@@ -62,6 +62,20 @@ int zvec_hip_abi_version(void);
 int zvec_hip_device_count(int *count);
 const char *zvec_hip_error_string(int code); /* IndexError::What analogue */
 
+/* Process-wide options of the host-pointer entry points (also read from the environment at first use: ZVEC_HIP_WAIT,
+ * ZVEC_HIP_ZEROCOPY).  zvec calls boundary B with ONE query per call from many threads, each with its own context
+ * (src/core/interface/index.cc:24-45,605-619; tools/core/bench.cc:145-245), so how a call waits and how 3 KB travel matter:
+ *   "wait"      0 = spin in hipStreamSynchronize; 1 (default) = poll a completion word in pinned memory — spinning while the
+ *               answer is ~0.1 ms away, SLEEPING when the previous wait on the context was long (64 spinning callers exhaust a
+ *               16-CPU quota and are frozen by the scheduler for most of every period: 19.5 k searches/s at 16 threads fell to
+ *               5.2 k at 64; sleeping: 18.4 k); 2 = block on a hipEventBlockingSync event
+ *   "zerocopy"  transfers up to 256 KiB may skip the copy engine through host-mapped pinned slots of the context: bit 1 (value 2,
+ *               the default) = the last kernels write keys | scores | counts straight into host memory; bit 0 = the first kernel
+ *               reads the queries in place (measured slower than the staged copy: off by default); 0 = staged copies both ways
+ * Unsupported (-12) for an unknown name. */
+int zvec_hip_set_option(const char *name, int value);
+int zvec_hip_get_option(const char *name, int *value);
+
 /* search context: IndexRunner::create_context() (index_runner.h:400-470).  One per caller thread;
  * owns a HIP stream and the scan workspace.  Passing NULL to a search uses the handle's built-in
  * context under a mutex. */
@@ -350,8 +364,10 @@ int zvec_hip_ivf_search_coarse(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void 
  * flat_streamer_entity.h:287-311, BlockHeader / DeletionMap flat_index_format.h:91-126): `blocks` = a run of `nblocks` blocks of
  * `block_size` bytes as they lie in a "flat.features<i>" segment — [block_vector_count x element][block_vector_count x u64 key]
  * ... [DeletionMap][BlockHeader] — and keep[b] = the live rows of block b (bit r: r < vector_count, not deleted, key valid).
- * One strided copy + one launch per run instead of a provider walk row by row.  Appends, in block / row order. */
-int zvec_hip_flat_load_blocks(zvec_hip_flat_t h, const void *blocks, uint64_t nblocks, uint32_t block_size,
+ * One strided copy + one launch per run instead of a provider walk row by row.  Appends, in block / row order.
+ * `bytes` = the extent of `blocks` the caller vouches for: InvalidArgument when nblocks x block_size does not fit in it or a block
+ * is too small for its rows, keys and 16 tail bytes. */
+int zvec_hip_flat_load_blocks(zvec_hip_flat_t h, const void *blocks, uint64_t bytes, uint64_t nblocks, uint32_t block_size,
                               uint32_t block_vector_count, const uint32_t *keep);
 
 /* IVFSearcher::load from the raw payloads of the segments a dumped reference index holds (SURVEY next-2):

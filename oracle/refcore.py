@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY — ctypes face of oracle/_ref/libzvec_ref_core.so (oracle/ref_core_shim.cc): the reference's
 whole core library compiled in place, its operators driven BY REGISTERED NAME through the reference's own factories.  The
-same calls drive the plugin's operators once `load_plugin()` has brought oracle/_ref/libzvec_hip_plugin.so in through the
+same calls drive the plugin's operators once `load_plugin()` has brought plugin/build/libzvec_hip_plugin.so in through the
 reference's IndexPluginBroker.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
 import ctypes as C
 import json
@@ -10,7 +10,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CORE = os.path.join(HERE, "_ref", "libzvec_ref_core.so")
-PLUGIN = os.path.join(HERE, "_ref", "libzvec_hip_plugin.so")
+PLUGIN = os.path.join(os.path.dirname(HERE), "plugin", "build", "libzvec_hip_plugin.so")
 
 _lib = None
 _plugin_loaded = False

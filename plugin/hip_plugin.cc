@@ -42,6 +42,7 @@
 
 #include "hip_plugin_common.h"
 #include "zvec_hip.h"
+#include "zvec_hip_operator.hpp"
 
 namespace zvec {
 namespace core {
@@ -51,6 +52,10 @@ namespace {
 // parameter keys of the operators this plugin stands in for
 const std::string kParamBruteForceThreshold("proxima.ivf.searcher.brute_force_threshold");  // ivf_params.h:46-47
 const std::string kParamHipDeviceCount("proxima.hip.device_count");   // new: > 1 = shard the index over devices [device, device + count)
+// new: the micro-batcher of single-query searches (zvec_hip_operator.hpp); window_us > 0 turns it on
+const std::string kParamHipBatchWindowUs("proxima.hip.searcher.batch_window_us");
+const std::string kParamHipMaxBatch("proxima.hip.searcher.max_batch");
+const std::string kParamHipBatchLingerUs("proxima.hip.searcher.batch_linger_us");
 
 // segment ids (flat_utility.h:32-34, ivf_index_format.h:152-164)
 const std::string kFlatKeys("flat.keys"), kFlatFeatures("flat.features");
@@ -78,23 +83,10 @@ int read_segment(IndexStorage *stg, const std::string &id, std::string *out, int
 
 }  // namespace
 
-/*! Reader/writer lock that cannot starve the writer (std::shared_mutex on glibc prefers readers; searches that overlap
- *  continuously would keep add_impl waiting): everybody passes a gate, a writer keeps it while the readers drain. */
-class FairSharedMutex {
- public:
-  void lock() { gate_.lock(); rw_.lock(); gate_.unlock(); }
-  void unlock() { rw_.unlock(); }
-  void lock_shared() { gate_.lock(); rw_.lock_shared(); gate_.unlock(); }
-  void unlock_shared() { rw_.unlock_shared(); }
-
- private:
-  std::mutex gate_;
-  std::shared_mutex rw_;
-};
-
 /*! Search context: one per caller thread (index.cc:24-45 caches it thread-local per index type and may hand it to
  *  another index instance of that type => magic re-binding, flat_streamer.cc:319-321 / ivf_streamer.cc:198-202).
- *  The HIP side (stream + workspace, zvec_hip_ctx_t) is index-agnostic, so re-binding is only bookkeeping. */
+ *  The HIP side (stream + workspace, zvec_hip_ctx_t) is index-agnostic, so re-binding is only bookkeeping.  The op_*
+ *  accessors are what the shared operator logic (include/zvec_hip_operator.hpp) reads a context through. */
 class HipContext : public IndexContext {
  public:
   HipContext(int device, uint32_t magic) : magic_(magic) { rc_ = zvec_hip_ctx_create(device, &h_); }
@@ -123,15 +115,19 @@ class HipContext : public IndexContext {
   const IndexGroupDocumentList &group_result() const override { return group_results_[0]; }
   const IndexGroupDocumentList &group_result(size_t i) const override { return group_results_[i]; }
 
-  //! key/score arrays of one batched call -> per-query IndexDocumentList (topk_to_result: lists end at the
-  //! RNN threshold, which the device gate already applied)
-  void fill(uint32_t count, uint32_t k, const uint64_t *keys, const float *scores, const uint32_t *n) {
-    results_.assign(count, IndexDocumentList());
-    for (uint32_t q = 0; q < count; ++q) {
-      results_[q].reserve(n[q]);
-      for (uint32_t j = 0; j < n[q]; ++j) results_[q].emplace_back(keys[size_t(q) * k + j], scores[size_t(q) * k + j]);
-    }
-  }
+  // ---- what zvec_hip_op::FlatOperator / IVFOperator read (zvec_hip_operator.hpp, "Requirements on the template arguments")
+  zvec_hip_ctx_t hip() const { return h_; }
+  bool op_has_filter() const { return filter().is_valid(); }
+  bool op_filtered(uint64_t key) const { return filter()(key); }
+  bool op_has_group_by() const { return group_by().is_valid(); }
+  std::string op_group_of(uint64_t key) const { return group_by()(key); }
+  uint32_t op_group_num() const { return group_num_; }
+  uint32_t op_group_topk() const { return group_topk_; }
+  const uint64_t *op_preset_bits() const { return nullptr; }             // (IndexContext has no side channel for a bitmap yet)
+  const zvec_hip_doc_filter_t *op_doc_filter() const { return nullptr; }
+  zvec_hip_op::Scratch &op_scratch() { return scratch_; }
+  std::vector<IndexDocumentList> &op_results() { return results_; }
+  std::vector<IndexGroupDocumentList> &op_group_results() { return group_results_; }
 
   zvec_hip_ctx_t h_{nullptr};
   int rc_{0};
@@ -142,42 +138,25 @@ class HipContext : public IndexContext {
   std::vector<IndexDocumentList> results_{1};
   uint32_t group_num_{0}, group_topk_{0};
   std::vector<IndexGroupDocumentList> group_results_{1};
-  std::vector<uint32_t> group_of_, groups_, ngroups_;   // group number of every storage position; picked groups per query
-  std::vector<std::string> group_ids_;                  // group number -> the caller's id
-  std::vector<uint64_t> bits_, keys_;
-  std::vector<float> scores_;
-  std::vector<uint32_t> counts_;
-  std::string vectors_;                     // fetch_vector payload the documents point into (valid until the next search)
+  zvec_hip_op::Scratch scratch_;            // result arrays, swept filter / groups, the fetch_vector payload the documents point
+                                            // into (valid until the next search on this context)
   IndexContext::Pointer inner_;             // HipFlatStreamer: a context of the wrapped reference streamer (its add paths cast-check one)
 };
 
+//! the framework's document types, as the shared operator logic needs them
+struct PluginDocs {
+  using Document = IndexDocument;
+  using DocumentList = IndexDocumentList;
+  using GroupDocument = GroupIndexDocument;
+  using GroupDocumentList = IndexGroupDocumentList;
+  static Document make(uint64_t key, float score) { return IndexDocument(key, score); }
+  //! fetch_vector: the document points into the context's payload (index_document.h:207-216; valid until the next search)
+  static void attach(Document &d, uint32_t index, const char *row, size_t /*bytes*/) { d = IndexDocument(d.key(), d.score(), index, row); }
+};
+using HipFlatCore = zvec_hip_op::FlatOperator<HipContext, PluginDocs>;
+using HipIVFOp = zvec_hip_op::IVFOperator<HipContext, PluginDocs>;
+
 namespace {
-
-//! H4: IndexFilter is an opaque std::function<bool(uint64_t)> (index_filter.h:48-50, true = exclude); swept once over
-//! the keys in storage order into the 1-bit-per-position exclude set the scan kernels gate on
-const uint64_t *sweep_filter(HipContext *ctx, const uint64_t *keys, size_t n) {
-  if (!ctx->filter().is_valid()) return nullptr;
-  ctx->bits_.assign((n + 63) / 64, 0);
-  for (size_t i = 0; i < n; ++i)
-    if (ctx->filter()(keys[i])) ctx->bits_[i >> 6] |= 1ull << (i & 63);
-  return ctx->bits_.data();
-}
-
-//! IndexGroupBy is an opaque std::function<std::string(uint64_t)> too: swept once over the keys into dense group numbers
-void sweep_groups(HipContext *ctx, const uint64_t *keys, size_t n) {
-  std::unordered_map<std::string, uint32_t> number_of;
-  ctx->group_ids_.clear();
-  ctx->group_of_.resize(n);
-  for (size_t i = 0; i < n; ++i) {
-    std::string id = ctx->group_by()(keys[i]);
-    auto it = number_of.find(id);
-    if (it == number_of.end()) {
-      it = number_of.emplace(id, (uint32_t)ctx->group_ids_.size()).first;
-      ctx->group_ids_.push_back(std::move(id));
-    }
-    ctx->group_of_[i] = it->second;
-  }
-}
 
 HipContext *bind(IndexContext::Pointer &c, uint32_t magic) {
   auto *ctx = dynamic_cast<HipContext *>(c.get());
@@ -186,254 +165,25 @@ HipContext *bind(IndexContext::Pointer &c, uint32_t magic) {
   return ctx;
 }
 
-void size_outputs(HipContext *ctx, uint32_t count) {
-  const size_t k = ctx->topk();
-  ctx->keys_.resize(size_t(count) * k);
-  ctx->scores_.resize(size_t(count) * k);
-  ctx->counts_.resize(count);
+//! proxima.hip.searcher.batch_window_us (> 0 turns the micro-batcher on; off by default), .max_batch, .batch_linger_us
+zvec_hip_op::BatcherOptions batcher_options(const ailego::Params &params) {
+  zvec_hip_op::BatcherOptions bo;
+  params.get(kParamHipBatchWindowUs, &bo.window_us);
+  params.get(kParamHipMaxBatch, &bo.max_batch);
+  params.get(kParamHipBatchLingerUs, &bo.linger_us);
+  if (bo.max_batch == 0) bo.max_batch = 1024;
+  return bo;
+}
+
+//! create the flat operator for an index of `meta`
+int create_flat(HipFlatCore *core, const IndexMeta &meta, int device, uint32_t ndev, const ailego::Params &params) {
+  const int metric = metric_of(meta), dtype = dtype_of(meta);
+  if (metric < 0 || dtype < 0) return IndexError_Unsupported;
+  return core->create(meta.dimension(), dtype, metric, meta.element_size(), device, ndev, /*position_is_id=*/false,
+                      batcher_options(params));
 }
 
 }  // namespace
-
-// =====================================================================================================================
-// flat, shared by the searcher and the streamer
-// =====================================================================================================================
-class HipFlatCore {
- public:
-  ~HipFlatCore() { destroy(); }
-  //! ndev > 1: one zvec_hip_shards_t (a row-range shard, a worker thread and a stream per device) instead of one handle
-  int create(const IndexMeta &meta, int device, uint32_t ndev = 1) {
-    destroy();
-    const int metric = metric_of(meta), dtype = dtype_of(meta);
-    if (metric < 0 || dtype < 0) return IndexError_Unsupported;
-    device_ = device;
-    elem_size_ = meta.element_size();
-    if (ndev > 1) {
-      std::vector<int> devs(ndev);
-      for (uint32_t g = 0; g < ndev; ++g) devs[g] = device + (int)g;
-      return zvec_hip_shards_create(meta.dimension(), dtype, metric, ZVEC_HIP_SHARDS_FLAT, devs.data(), ndev, &sh_);
-    }
-    return zvec_hip_flat_create(meta.dimension(), dtype, metric, device, &h_);
-  }
-  void destroy() {
-    if (h_) zvec_hip_flat_destroy(h_);
-    if (sh_) zvec_hip_shards_destroy(sh_);
-    h_ = nullptr;
-    sh_ = nullptr;
-    keys_.clear();
-    pos_of_key_.clear();
-  }
-  int append(const void *rows, size_t n, const uint64_t *keys) {
-    std::unique_lock<FairSharedMutex> w(mu_);
-    int rc = sh_ ? zvec_hip_shards_flat_append(sh_, rows, n, keys) : zvec_hip_flat_append(h_, rows, n, keys);
-    if (rc != 0) return rc;
-    for (size_t i = 0; i < n; ++i) {
-      pos_of_key_.emplace(keys[i], (uint32_t)keys_.size());
-      keys_.push_back(keys[i]);
-    }
-    return 0;
-  }
-  //! group_by_search_impl / group_by_search_p_keys_impl (flat_streamer.cc:391-483): ids == nullptr scans every row
-  int group_search(const void *q, uint32_t count, HipContext *ctx, const uint32_t *ids, const uint32_t *offs) const {
-    if (!ctx->group_by().is_valid()) return IndexError_InvalidArgument;      // "Invalid group-by function"
-    if (sh_) return IndexError_Unsupported;                                   // (group-by runs on one device)
-    const uint32_t gnum = ctx->group_num_, gk = ctx->group_topk_;
-    if (gk == 0) return IndexError_InvalidArgument;
-    sweep_groups(ctx, keys_.data(), keys_.size());
-    const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());
-    const size_t rows = size_t(count) * gnum;
-    ctx->keys_.resize(rows * gk);
-    ctx->scores_.resize(rows * gk);
-    ctx->counts_.resize(rows);
-    ctx->groups_.resize(rows);
-    ctx->ngroups_.resize(count);
-    const uint32_t ngroups = std::max<uint32_t>(1u, (uint32_t)ctx->group_ids_.size());
-    const uint32_t none = 0;
-    const uint32_t *gof = ctx->group_of_.empty() ? &none : ctx->group_of_.data();
-    int rc = ids ? zvec_hip_flat_search_grouped_by_ids(h_, ctx->h_, q, count, ids, offs, gof, ngroups, gnum, gk, ctx->threshold(), bits,
-                                                       ctx->groups_.data(), ctx->ngroups_.data(), ctx->keys_.data(),
-                                                       ctx->scores_.data(), ctx->counts_.data())
-                 : zvec_hip_flat_search_grouped(h_, ctx->h_, q, count, gof, ngroups, gnum, gk, ctx->threshold(), bits,
-                                                ctx->groups_.data(), ctx->ngroups_.data(), ctx->keys_.data(), ctx->scores_.data(),
-                                                ctx->counts_.data());
-    if (rc != 0) return rc;
-    // topk_to_group_result (flat_streamer_context.h:135-180)
-    std::vector<uint64_t> pos;
-    ctx->group_results_.assign(count, IndexGroupDocumentList());
-    for (uint32_t qi = 0; qi < count; ++qi) {
-      ctx->group_results_[qi].resize(ctx->ngroups_[qi]);
-      for (uint32_t s = 0; s < ctx->ngroups_[qi]; ++s) {
-        const size_t row = size_t(qi) * gnum + s;
-        GroupIndexDocument &g = ctx->group_results_[qi][s];
-        g.set_group_id(ctx->group_ids_[ctx->groups_[row]]);
-        for (uint32_t j = 0; j < ctx->counts_[row]; ++j) {
-          g.mutable_docs()->emplace_back(ctx->keys_[row * gk + j], ctx->scores_[row * gk + j]);
-          if (ctx->fetch_vector()) pos.push_back(pos_of_key_.at(ctx->keys_[row * gk + j]));
-        }
-      }
-    }
-    if (!ctx->fetch_vector() || pos.empty()) return 0;
-    ctx->vectors_.resize(pos.size() * elem_size_);
-    if ((rc = zvec_hip_flat_get_vectors(h_, pos.data(), pos.size(), &ctx->vectors_[0])) != 0) return rc;
-    size_t j = 0;
-    for (auto &lst : ctx->group_results_)
-      for (auto &g : lst)
-        for (auto &d : *g.mutable_docs()) {
-          d = IndexDocument(d.key(), d.score(), (uint32_t)pos[j], ctx->vectors_.data() + j * elem_size_);
-          ++j;
-        }
-    return 0;
-  }
-  //! add_with_id_impl (FlatStreamerEntity::add_vector_with_id, flat_streamer_entity.cc:900-990): the document `id` is
-  //! replaced when it exists, appended otherwise.  Results carry keys, never positions, so the mirror keeps its own
-  //! id -> position map instead of the reference's "position == id" rule (no holes to pad, and a re-opened index whose
-  //! rows were compacted by the provider walk stays addressable)
-  int put(uint32_t id, const void *row) {
-    std::unique_lock<FairSharedMutex> w(mu_);
-    const uint64_t key = id;
-    auto it = pos_of_key_.find(key);
-    if (it == pos_of_key_.end()) {
-      int rc = sh_ ? zvec_hip_shards_flat_append(sh_, row, 1, &key) : zvec_hip_flat_append(h_, row, 1, &key);
-      if (rc != 0) return rc;
-      pos_of_key_.emplace(key, (uint32_t)keys_.size());
-      keys_.push_back(key);
-      return 0;
-    }
-    if (sh_) return IndexError_Unsupported;                   // (in-place replacement runs on one device)
-    const uint32_t pos = it->second;
-    return zvec_hip_flat_put(h_, &pos, 1, row, &key);
-  }
-  int search(const void *q, const IndexQueryMeta &qm, uint32_t count, HipContext *ctx) const {
-    if (!q || qm.element_size() != elem_size_) return IndexError_InvalidArgument;
-    std::shared_lock<FairSharedMutex> r(mu_);
-    if (ctx->group_by_search()) return group_search(q, count, ctx, nullptr, nullptr);   // flat_streamer.cc:323-324
-    size_outputs(ctx, count);
-    const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());
-    int rc = sh_ ? zvec_hip_shards_search(sh_, q, count, ctx->topk(), ctx->threshold(), 0, 0, bits, ctx->keys_.data(),
-                                          ctx->scores_.data(), ctx->counts_.data())
-                 : zvec_hip_flat_search(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), bits, ctx->keys_.data(),
-                                        ctx->scores_.data(), ctx->counts_.data());
-    if (rc != 0) return rc;
-    ctx->fill(count, ctx->topk(), ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
-    return attach_vectors(ctx, count);
-  }
-  //! search_bf_by_p_keys_impl (flat_streamer.cc:346-389): unknown keys are skipped, as get_vector_by_key != 0 -> continue
-  int search_by_keys(const void *q, const std::vector<std::vector<uint64_t>> &p_keys, const IndexQueryMeta &qm,
-                     uint32_t count, HipContext *ctx) const {
-    if (!q || qm.element_size() != elem_size_ || p_keys.size() != count) return IndexError_InvalidArgument;
-    std::shared_lock<FairSharedMutex> r(mu_);
-    std::vector<uint32_t> ids, offs(count + 1, 0);
-    for (uint32_t i = 0; i < count; ++i) {
-      for (uint64_t key : p_keys[i]) {
-        auto it = pos_of_key_.find(key);
-        if (it != pos_of_key_.end()) ids.push_back(it->second);
-      }
-      offs[i + 1] = (uint32_t)ids.size();
-    }
-    if (ids.empty()) ids.push_back(0);
-    if (ctx->group_by_search()) return group_search(q, count, ctx, ids.data(), offs.data());   // flat_streamer.cc:365-366
-    size_outputs(ctx, count);
-    const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());
-    int rc;
-    if (sh_) {
-      std::vector<uint64_t> wide(ids.begin(), ids.end());
-      rc = zvec_hip_shards_flat_search_by_ids(sh_, q, count, wide.data(), offs.data(), ctx->topk(), ctx->threshold(), bits,
-                                              ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
-    } else {
-      rc = zvec_hip_flat_search_by_ids(h_, ctx->h_, q, count, ids.data(), offs.data(), ctx->topk(), ctx->threshold(), bits,
-                                       ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
-    }
-    if (rc != 0) return rc;
-    ctx->fill(count, ctx->topk(), ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
-    return attach_vectors(ctx, count);
-  }
-  int vector_of_key(uint64_t key, void *out) const {
-    std::shared_lock<FairSharedMutex> r(mu_);
-    auto it = pos_of_key_.find(key);
-    return it == pos_of_key_.end() ? (int)IndexError_NoExist : vector_of_pos(it->second, out);
-  }
-  int vector_of_pos(uint32_t pos, void *out) const {
-    const uint64_t p = pos;
-    return sh_ ? zvec_hip_shards_flat_get_vectors(sh_, &p, 1, out) : zvec_hip_flat_get_vector(h_, pos, out);
-  }
-  //! FlatSearcher::load's "flat.features" payload -> HBM (one device, or dealt over the shards)
-  int load_features(const void *features, size_t bytes, size_t n, bool column_major, const uint64_t *keys) {
-    return sh_ ? zvec_hip_shards_flat_load_features(sh_, features, bytes, n, column_major, 32, keys)
-               : zvec_hip_flat_load_features(h_, features, bytes, n, column_major, 32, keys);
-  }
-  //! a run of FlatStreamerEntity blocks (one "flat.features<i>" segment) -> HBM: one strided copy + one pack launch
-  int load_blocks(const void *blocks, size_t nblocks, uint32_t block_size, uint32_t bvc, const std::vector<uint32_t> &keep) {
-    std::unique_lock<FairSharedMutex> w(mu_);
-    if (sh_) {            // sharded mirror: rows dealt by the shards' own append (no strided path there)
-      const char *p = static_cast<const char *>(blocks);
-      for (size_t b = 0; b < nblocks; ++b)
-        for (uint32_t m = keep[b]; m; m &= m - 1) {
-          const uint32_t r = (uint32_t)__builtin_ctz(m);
-          uint64_t key;
-          memcpy(&key, p + b * block_size + (size_t)bvc * elem_size_ + (size_t)r * 8, 8);
-          int rc = zvec_hip_shards_flat_append(sh_, p + b * block_size + (size_t)r * elem_size_, 1, &key);
-          if (rc != 0) return rc;
-          pos_of_key_.emplace(key, (uint32_t)keys_.size());
-          keys_.push_back(key);
-        }
-      return 0;
-    }
-    int rc = zvec_hip_flat_load_blocks(h_, blocks, nblocks, block_size, bvc, keep.data());
-    if (rc != 0) return rc;
-    const char *p = static_cast<const char *>(blocks);
-    for (size_t b = 0; b < nblocks; ++b)
-      for (uint32_t m = keep[b]; m; m &= m - 1) {
-        const uint32_t r = (uint32_t)__builtin_ctz(m);
-        uint64_t key;
-        memcpy(&key, p + b * block_size + (size_t)bvc * elem_size_ + (size_t)r * 8, 8);
-        pos_of_key_.emplace(key, (uint32_t)keys_.size());
-        keys_.push_back(key);
-      }
-    return 0;
-  }
-  size_t count() const { return keys_.size(); }
-  uint64_t key_at(size_t pos) const { return keys_[pos]; }
-  uint32_t elem_size() const { return elem_size_; }
-  //! rows of storage positions [pos0, pos0 + n) -> host (the provider's iterator)
-  int rows_at(uint64_t pos0, size_t n, void *out) const {
-    std::vector<uint64_t> pos(n);
-    for (size_t i = 0; i < n; ++i) pos[i] = pos0 + i;
-    return sh_ ? zvec_hip_shards_flat_get_vectors(sh_, pos.data(), n, out) : zvec_hip_flat_get_vectors(h_, pos.data(), n, out);
-  }
-  void adopt_keys(const uint64_t *keys, size_t n) {
-    keys_.assign(keys, keys + n);
-    for (size_t i = 0; i < n; ++i) pos_of_key_.emplace(keys[i], (uint32_t)i);
-  }
-
- private:
-  //! IndexContext::set_fetch_vector (index.cc:635-647): the stored vectors of the result documents, one gather launch
-  int attach_vectors(HipContext *ctx, uint32_t count) const {
-    if (!ctx->fetch_vector()) return 0;
-    std::vector<uint64_t> pos;
-    for (uint32_t q = 0; q < count; ++q)
-      for (auto &d : ctx->results_[q]) pos.push_back(pos_of_key_.at(d.key()));
-    ctx->vectors_.resize(pos.size() * elem_size_);
-    if (pos.empty()) return 0;
-    int rc = sh_ ? zvec_hip_shards_flat_get_vectors(sh_, pos.data(), pos.size(), &ctx->vectors_[0])
-                 : zvec_hip_flat_get_vectors(h_, pos.data(), pos.size(), &ctx->vectors_[0]);
-    if (rc != 0) return rc;
-    size_t j = 0;
-    for (uint32_t q = 0; q < count; ++q)
-      for (auto &d : ctx->results_[q]) {
-        d = IndexDocument(d.key(), d.score(), (uint32_t)pos[j], ctx->vectors_.data() + j * elem_size_);
-        ++j;
-      }
-    return 0;
-  }
-
-  zvec_hip_flat_t h_{nullptr};
-  zvec_hip_shards_t sh_{nullptr};         // set instead of h_ when the index is sharded over several devices
-  int device_{0};
-  uint32_t elem_size_{0};
-  mutable FairSharedMutex mu_;            // add (exclusive) vs search (shared): flat_streamer.cc:236-242
-  std::vector<uint64_t> keys_;            // key of every storage position
-  std::unordered_map<uint64_t, uint32_t> pos_of_key_;
-};
 
 /*! IVFIndexProvider (ivf_index_provider.h:24-106) / the flat searcher's provider over the device-resident rows: documents in
  *  storage (list) order; the iterator pulls the rows to the host 4096 at a time (one gather launch each); like the
@@ -529,11 +279,10 @@ class HipFlatSearcher : public IndexSearcher {
     if (keys.size() % sizeof(uint64_t) != 0) return IndexError_InvalidLength;
     const size_t n = keys.size() / sizeof(uint64_t);
     if (n * meta_.element_size() != features.size()) return IndexError_Mismatch;
-    if ((rc = core_.create(meta_, device_, ndev_)) != 0) return rc;
+    if ((rc = create_flat(&core_, meta_, device_, ndev_, params_)) != 0) return rc;
     rc = core_.load_features(features.data(), features.size(), n, meta_.major_order() == IndexMeta::MO_COLUMN,
                              reinterpret_cast<const uint64_t *>(keys.data()));
     if (rc != 0) return rc;
-    core_.adopt_keys(reinterpret_cast<const uint64_t *>(keys.data()), n);
     magic_ = IndexContext::GenerateMagic();
     stats_.set_loaded_count(n);
     return 0;
@@ -547,7 +296,8 @@ class HipFlatSearcher : public IndexSearcher {
   int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
   int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
     HipContext *ctx = bind(c, magic_);
-    return ctx ? core_.search(q, qm, count, ctx) : (int)IndexError_InvalidArgument;
+    if (!ctx || !q || qm.element_size() != core_.elem_size()) return IndexError_InvalidArgument;
+    return core_.search(q, count, ctx);
   }
   int search_bf_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
   int search_bf_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
@@ -560,7 +310,8 @@ class HipFlatSearcher : public IndexSearcher {
   int search_bf_by_p_keys_impl(const void *q, const std::vector<std::vector<uint64_t>> &p_keys, const IndexQueryMeta &qm,
                                uint32_t count, Context::Pointer &c) const override {
     HipContext *ctx = bind(c, magic_);
-    return ctx ? core_.search_by_keys(q, p_keys, qm, count, ctx) : (int)IndexError_InvalidArgument;
+    if (!ctx || !q || qm.element_size() != core_.elem_size()) return IndexError_InvalidArgument;
+    return core_.search_by_keys(q, p_keys, count, ctx);
   }
 
  private:
@@ -580,6 +331,7 @@ class HipFlatStreamer : public IndexStreamer {
  public:
   int init(const IndexMeta &meta, const ailego::Params &params) override {
     meta_ = meta;
+    params_ = params;
     params.get(kParamHipDevice, &device_);
     params.get(kParamHipDeviceCount, &ndev_);
     if (ndev_ == 0) ndev_ = 1;
@@ -593,7 +345,7 @@ class HipFlatStreamer : public IndexStreamer {
     stg_keep_ = stg;
     int rc = store_->open(std::move(stg));
     if (rc != 0) return rc;
-    if ((rc = core_.create(meta_, device_, ndev_)) != 0) return rc;
+    if ((rc = create_flat(&core_, meta_, device_, ndev_, params_)) != 0) return rc;
     // rows already persisted: the block runs of the storage's feature segments go to HBM whole (bulk_open); a storage whose
     // layout this reader does not recognise falls back to the reference streamer's provider walk (key, vector), row by row
     int bulk = this->bulk_open(stg_keep_.get());
@@ -650,7 +402,8 @@ class HipFlatStreamer : public IndexStreamer {
   int search_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
   int search_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
     HipContext *ctx = bind(c, magic_);
-    return ctx ? core_.search(q, qm, count, ctx) : (int)IndexError_InvalidArgument;
+    if (!ctx || !q || qm.element_size() != core_.elem_size()) return IndexError_InvalidArgument;
+    return core_.search(q, count, ctx);
   }
   int search_bf_impl(const void *q, const IndexQueryMeta &qm, Context::Pointer &c) const override { return search_impl(q, qm, 1, c); }
   int search_bf_impl(const void *q, const IndexQueryMeta &qm, uint32_t count, Context::Pointer &c) const override {
@@ -663,11 +416,13 @@ class HipFlatStreamer : public IndexStreamer {
   int search_bf_by_p_keys_impl(const void *q, const std::vector<std::vector<uint64_t>> &p_keys, const IndexQueryMeta &qm,
                                uint32_t count, Context::Pointer &c) const override {
     HipContext *ctx = bind(c, magic_);
-    return ctx ? core_.search_by_keys(q, p_keys, qm, count, ctx) : (int)IndexError_InvalidArgument;
+    if (!ctx || !q || qm.element_size() != core_.elem_size()) return IndexError_InvalidArgument;
+    return core_.search_by_keys(q, p_keys, count, ctx);
   }
 
  private:
   IndexMeta meta_;
+  ailego::Params params_;
   int device_{0};
   uint32_t ndev_{1};
   uint32_t magic_{0};
@@ -710,7 +465,7 @@ class HipFlatStreamer : public IndexStreamer {
         }
         keep[b] = m;
       }
-      int rc = core_.load_blocks(p, nblk, bs, bvc, keep);
+      int rc = core_.load_blocks(p, nblk * bs, nblk, bs, bvc, keep);       // (the extent seg->read just lent)
       if (rc != 0) return rc;
     }
     return 1;
@@ -733,26 +488,21 @@ class HipFlatStreamer : public IndexStreamer {
 // =====================================================================================================================
 // IVF-Flat
 // =====================================================================================================================
+/*! The storage side of the IVF operators: reads a dumped index through IndexStorage exactly as IVFSearcher::load does and hands
+ *  the payloads to the shared operator (zvec_hip_op::IVFOperator), which owns every search. */
 class HipIVFCore {
  public:
-  ~HipIVFCore() { destroy(); }
-  void destroy() {
-    if (h_) zvec_hip_ivf_destroy(h_);
-    if (sh_) zvec_hip_shards_destroy(sh_);
-    h_ = nullptr;
-    sh_ = nullptr;
-    keys_.clear();
-  }
+  void destroy() { op_.destroy(); creformer_.reset(); }
   //! IVFSearcher::load (ivf_searcher.cc:43-103) + IVFEntity::load (ivf_entity.cc:443-570): the centroid index is a
   //! nested flat index inside the "ivf.centroid" segment; the inverted lists come as header / meta / body / keys
   //! ndev > 1: whole inverted lists dealt over the devices (byte-balanced map), centroids replicated
-  int load(IndexStorage *stg, IndexMeta *meta, int device, uint32_t ndev = 1) {
+  int load(IndexStorage *stg, IndexMeta *meta, int device, uint32_t ndev, const ailego::Params &params) {
     destroy();
     int rc = IndexHelper::DeserializeFromStorage(stg, meta);
     if (rc != 0) return rc;
     const int metric = metric_of(*meta), dtype = dtype_of(*meta);
     if (metric < 0 || dtype < 0) return IndexError_Unsupported;
-    elem_size_ = meta->element_size();
+    const uint32_t elem_size = meta->element_size();
     // centroid rows: features of the nested FlatSearcher index, put in centroid-id order
     auto cseg = stg->get(kIvfCentroid, 0);
     if (!cseg) return IndexError_InvalidFormat;
@@ -765,13 +515,12 @@ class HipIVFCore {
     // the reformer every query goes through before the coarse scan (IVFCentroidIndex::load / search, ivf_centroid_index.cc:
     // 273-297,538-562).  Same element type only: quantised centroid indexes (int8 / int4 reformers) are not taken.
     const size_t celem = cmeta.element_size();
-    creformer_.reset();
     if (cmeta.data_type() != meta->data_type()) return IndexError_Unsupported;
     if (!cmeta.reformer_name().empty()) {
       creformer_ = IndexFactory::CreateReformer(cmeta.reformer_name());
       if (!creformer_) return IndexError_NoExist;
       if ((rc = creformer_->init(cmeta.reformer_params())) != 0) return rc;
-    } else if (celem != elem_size_) {
+    } else if (celem != elem_size) {
       return IndexError_Unsupported;
     }
     std::string ckeys, cfeat;
@@ -796,125 +545,55 @@ class HipIVFCore {
     }
     const int cmetric = metric_of(cmeta);
     if (creformer_ && (cmetric != ZVEC_HIP_METRIC_L2 && cmetric != ZVEC_HIP_METRIC_IP)) return IndexError_Unsupported;
-    if (creformer_ && ndev > 1) return IndexError_Unsupported;                 // (the coarse space runs on one device)
-    in_qmeta_ = IndexQueryMeta(meta->data_type(), meta->dimension());
     std::string header, lmeta, body, keys;
     if ((rc = read_segment(stg, kIvfHeader, &header)) != 0) return rc;
     if ((rc = read_segment(stg, kIvfMeta, &lmeta)) != 0) return rc;
     if ((rc = read_segment(stg, kIvfBody, &body)) != 0) return rc;
     if ((rc = read_segment(stg, kIvfKeys, &keys)) != 0) return rc;
-    if (ndev > 1) {
-      std::vector<int> devs(ndev);
-      for (uint32_t g = 0; g < ndev; ++g) devs[g] = device + (int)g;
-      if ((rc = zvec_hip_shards_create(meta->dimension(), dtype, metric, ZVEC_HIP_SHARDS_IVF, devs.data(), ndev, &sh_)) != 0) return rc;
-      rc = zvec_hip_shards_ivf_load_segments(sh_, header.data(), header.size(), lmeta.data(), lmeta.size(), body.data(),
-                                             body.size(), keys.data(), keys.size(), centroids.data());
-    } else {
-      if ((rc = zvec_hip_ivf_create(meta->dimension(), dtype, metric, device, &h_)) != 0) return rc;
-      rc = zvec_hip_ivf_load_segments(h_, header.data(), header.size(), lmeta.data(), lmeta.size(), body.data(), body.size(),
-                                      keys.data(), keys.size(), creformer_ ? nullptr : centroids.data());
-      if (rc == 0 && creformer_)
-        rc = zvec_hip_ivf_set_coarse_space(h_, cmeta.dimension(), cmetric, centroids.data(), (uint32_t)nlist);
-    }
-    if (rc != 0) return rc;
-    keys_.assign(reinterpret_cast<const uint64_t *>(keys.data()),
-                 reinterpret_cast<const uint64_t *>(keys.data()) + keys.size() / sizeof(uint64_t));
-    pos_of_key_.clear();
-    pos_of_key_.reserve(keys_.size());
-    for (size_t i = 0; i < keys_.size(); ++i) pos_of_key_.emplace(keys_[i], i);
-    nlist_ = (uint32_t)nlist;
-    return 0;
-  }
-  //! IVFEntity::get_vector_by_key: the stored row of a document (list-order position through the key map)
-  int vector_of_key(uint64_t key, void *out) const {
-    auto it = pos_of_key_.find(key);
-    if (it == pos_of_key_.end()) return IndexError_NoExist;
-    if (sh_) return IndexError_Unsupported;                  // (row fetches run on one device)
-    return zvec_hip_ivf_get_vector(h_, it->second, out);
-  }
-  //! rows of list-order positions [pos0, pos0 + n) -> host (the provider's iterator walks the index in chunks)
-  int rows_at(uint64_t pos0, size_t n, void *out) const {
-    if (sh_) return IndexError_Unsupported;
-    std::vector<uint64_t> pos(n);
-    for (size_t i = 0; i < n; ++i) pos[i] = pos0 + i;
-    return zvec_hip_ivf_get_vectors(h_, pos.data(), n, out);
-  }
-  uint64_t key_at(size_t pos) const { return keys_[pos]; }
-  uint32_t elem_size() const { return elem_size_; }
-  //! IVFSearcher::search_impl / search_bf_impl (ivf_searcher.cc:106-250)
-  int search(const void *q, const IndexQueryMeta &qm, uint32_t count, HipContext *ctx, bool brute_force) const {
-    if (!q || qm.element_size() != elem_size_) return IndexError_InvalidArgument;
-    size_outputs(ctx, count);
-    const uint64_t *bits = sweep_filter(ctx, keys_.data(), keys_.size());    // keys in list order (ivf_entity.cc:612)
-    int rc;
-    if (brute_force || keys_.size() <= ctx->bruteforce_threshold_) {         // ivf_searcher.cc:188-190
-      rc = sh_ ? zvec_hip_shards_search(sh_, q, count, ctx->topk(), ctx->threshold(), nlist_, 0xffffffffu, bits,     // every list
-                                        ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data())
-               : zvec_hip_ivf_search_bf(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), bits, ctx->keys_.data(),
-                                        ctx->scores_.data(), ctx->counts_.data());
-    } else {
-      // IVFSearcherContext::update (ivf_searcher_context.h:70-78): float arithmetic, std::round / std::ceil
-      const uint32_t nprobe = std::max(static_cast<uint32_t>(std::round(nlist_ * ctx->scan_ratio_)), 1u);
-      uint32_t max_scan = static_cast<uint32_t>(std::ceil(keys_.size() * ctx->scan_ratio_));
-      max_scan = std::max(ctx->bruteforce_threshold_, max_scan);
-      if (creformer_) {
-        // IVFCentroidIndex::search: the queries reformed for the coarse space — in one call where the reformer has a batched
-        // transform, one by one where it has not
-        std::string cq;
+    if ((rc = op_.create(meta->dimension(), dtype, metric, elem_size, device, ndev, batcher_options(params))) != 0) return rc;
+    HipIVFOp::CoarseReform reform;
+    if (creformer_) {
+      // IVFCentroidIndex::search: the queries reformed for the coarse space — in one call where the reformer has a batched
+      // transform, one by one where it has not.  What comes back must be rows of the installed coarse space (element type and
+      // dimension of the nested index's meta): anything else would be read past its end on the device.
+      IndexReformer::Pointer rf = creformer_;
+      const IndexQueryMeta in_qmeta(meta->data_type(), meta->dimension());
+      const IndexMeta::DataType ctype = cmeta.data_type();
+      const uint32_t cdim = cmeta.dimension();
+      reform = [rf, in_qmeta, elem_size, ctype, cdim](const void *q, uint32_t count, std::string *cq) -> int {
         IndexQueryMeta ometa;
-        rc = creformer_->transform(q, in_qmeta_, count, &cq, &ometa);
-        if (rc == IndexError_Unsupported || rc == IndexError_NotImplemented) {
-          cq.clear();
+        int rrc = rf->transform(q, in_qmeta, count, cq, &ometa);
+        if (rrc == IndexError_Unsupported || rrc == IndexError_NotImplemented) {
+          cq->clear();
           for (uint32_t i = 0; i < count; ++i) {
             std::string one;
-            if ((rc = creformer_->transform(static_cast<const char *>(q) + size_t(i) * elem_size_, in_qmeta_, &one, &ometa)) != 0) return rc;
-            cq.append(one);
+            if ((rrc = rf->transform(static_cast<const char *>(q) + size_t(i) * elem_size, in_qmeta, &one, &ometa)) != 0) return rrc;
+            cq->append(one);
           }
-        } else if (rc != 0) {
-          return rc;
+        } else if (rrc != 0) {
+          return rrc;
         }
-        rc = zvec_hip_ivf_search_coarse(h_, ctx->h_, q, cq.data(), count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits,
-                                        ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
-      } else {
-        rc = sh_ ? zvec_hip_shards_search(sh_, q, count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits, ctx->keys_.data(),
-                                          ctx->scores_.data(), ctx->counts_.data())
-                 : zvec_hip_ivf_search(h_, ctx->h_, q, count, ctx->topk(), ctx->threshold(), nprobe, max_scan, bits,
-                                       ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
-      }
+        if (ometa.data_type() != ctype || ometa.dimension() != cdim) return IndexError_Mismatch;
+        return 0;
+      };
     }
-    if (rc != 0) return rc;
-    ctx->fill(count, ctx->topk(), ctx->keys_.data(), ctx->scores_.data(), ctx->counts_.data());
-    return attach_vectors(ctx, count);
+    return op_.load_segments(header, lmeta, body, keys, centroids, (uint32_t)nlist, creformer_ ? cmeta.dimension() : 0, cmetric,
+                             std::move(reform));
   }
-  size_t count() const { return keys_.size(); }
- private:
-  //! fetch_vector (ivf_searcher_context.h:186-197: entity_->get_vector_by_key per result): one gather for the batch
-  int attach_vectors(HipContext *ctx, uint32_t count) const {
-    if (!ctx->fetch_vector()) return 0;
-    if (sh_) return IndexError_Unsupported;
-    std::vector<uint64_t> pos;
-    for (uint32_t q = 0; q < count; ++q)
-      for (auto &d : ctx->results_[q]) pos.push_back(pos_of_key_.at(d.key()));
-    ctx->vectors_.resize(pos.size() * elem_size_);
-    if (pos.empty()) return 0;
-    int rc = zvec_hip_ivf_get_vectors(h_, pos.data(), pos.size(), &ctx->vectors_[0]);
-    if (rc != 0) return rc;
-    size_t j = 0;
-    for (uint32_t q = 0; q < count; ++q)
-      for (auto &d : ctx->results_[q]) {
-        d = IndexDocument(d.key(), d.score(), (uint32_t)d.key(), ctx->vectors_.data() + j * elem_size_);
-        ++j;
-      }
-    return 0;
+  int vector_of_key(uint64_t key, void *out) const { return op_.vector_of_key(key, out); }
+  int rows_at(uint64_t pos0, size_t n, void *out) const { return op_.rows_at(pos0, n, out); }
+  uint64_t key_at(size_t pos) const { return op_.key_at(pos); }
+  uint32_t elem_size() const { return op_.elem_size(); }
+  size_t count() const { return op_.count(); }
+  //! IVFSearcher::search_impl / search_bf_impl (ivf_searcher.cc:106-250)
+  int search(const void *q, const IndexQueryMeta &qm, uint32_t count, HipContext *ctx, bool brute_force) const {
+    if (!q || qm.element_size() != op_.elem_size()) return IndexError_InvalidArgument;
+    return op_.search(q, count, ctx, brute_force, ctx->scan_ratio_, ctx->bruteforce_threshold_);
   }
 
-  zvec_hip_ivf_t h_{nullptr};
+ private:
+  HipIVFOp op_;
   IndexReformer::Pointer creformer_;      // the centroid index's reformer when it lives in a converted space (MIPS), else null
-  IndexQueryMeta in_qmeta_;               // the queries as they arrive
-  zvec_hip_shards_t sh_{nullptr};         // set instead of h_ when the lists are dealt over several devices
-  std::unordered_map<uint64_t, uint64_t> pos_of_key_;   // key -> list-order position
-  uint32_t elem_size_{0}, nlist_{0};
-  std::vector<uint64_t> keys_;
 };
 
 /*! "HipIVFSearcher": stands where IVFSearcher is registered (ivf_searcher.cc). */
@@ -930,7 +609,7 @@ class HipIVFSearcher : public IndexSearcher {
   int cleanup() override { return this->unload(); }
   int load(IndexStorage::Pointer stg, IndexMetric::Pointer /*metric*/) override {
     if (!stg) return IndexError_InvalidArgument;
-    int rc = core_.load(stg.get(), &meta_, device_, ndev_);
+    int rc = core_.load(stg.get(), &meta_, device_, ndev_, params_);
     if (rc != 0) return rc;
     magic_ = IndexContext::GenerateMagic();
     stats_.set_loaded_count(core_.count());
@@ -982,7 +661,7 @@ class HipIVFStreamer : public IndexStreamer {
   int cleanup() override { core_.destroy(); return 0; }
   int open(IndexStorage::Pointer stg) override {
     if (!stg) return IndexError_InvalidArgument;
-    int rc = core_.load(stg.get(), &meta_, device_, ndev_);
+    int rc = core_.load(stg.get(), &meta_, device_, ndev_, params_);
     if (rc != 0) return rc;
     magic_ = IndexContext::GenerateMagic();
     stats_.set_loaded_count(core_.count());

@@ -541,3 +541,60 @@ def test_context_update_overrides_probe_parameters(zv, oracle):
         nprobe, max_scan = se.probe_params(ctx)
         ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, base[order], q, k, nprobe, max_scan, keys=order.astype(np.uint64))
         tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc, what="ctx.update")
+
+
+def test_handle_reuse_after_a_separate_coarse_space(zv, oracle):
+    """zvec_hip_ivf_set_coarse_space puts the centroid store into a space of its own (MIPS-trained inner-product indexes,
+    ivf_centroid_index.cc:273-297).  While it is in force the entries that assume centroids in the rows' space refuse
+    (label / begin_lists / centroid read-back: Unsupported) instead of reading rows of the wrong width; a reload, a new set of
+    centroids or a build on the SAME handle leaves the coarse space and behaves like a fresh handle."""
+    import ctypes as C
+    from zvec_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    n, dim, nlist, k, cdim = 4000, 32, 16, 5, 36
+    base = rng.integers(-20, 20, (n, dim)).astype(np.float32)
+    cent, offs, order = kmeans_lists(rng, base, nlist)
+    cent = np.round(cent).astype(np.float32)
+    rows = np.ascontiguousarray(base[order])
+    q = np.ascontiguousarray(base[rng.integers(0, n, 12)] + 1)
+    h = C.c_void_p()
+    assert L.zvec_hip_ivf_create(dim, 0, 1, 0, C.byref(h)) == 0                       # inner product
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    offs64 = np.ascontiguousarray(offs, np.uint64)
+    assert L.zvec_hip_ivf_load(h, p(cent), nlist, offs64.ctypes.data_as(C.POINTER(C.c_uint64)), p(rows), None) == 0
+    keys = np.zeros((12, k), np.uint64); sc = np.zeros((12, k), np.float32); cn = np.zeros(12, np.uint32)
+    u32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+    def search():
+        return L.zvec_hip_ivf_search(h, None, p(q), 12, k, C.c_float(3.4e38), 4, 1 << 30, None, p(keys), p(sc), p(cn))
+    assert search() == 0
+    first = keys.copy()
+    # a coarse space of another width: plain searches now need the reformed queries
+    ccent = np.ascontiguousarray(rng.standard_normal((nlist, cdim)).astype(np.float32))
+    assert L.zvec_hip_ivf_set_coarse_space(h, cdim, 0, p(ccent), nlist) == 0
+    assert search() == -31
+    cq = np.ascontiguousarray(rng.standard_normal((12, cdim)).astype(np.float32))
+    assert L.zvec_hip_ivf_search_coarse(h, None, p(q), p(cq), 12, k, C.c_float(3.4e38), 4, 1 << 30, None, p(keys), p(sc), p(cn)) == 0
+    out = np.zeros((nlist, dim), np.float32)
+    nl = C.c_uint32()
+    assert L.zvec_hip_ivf_get_centroids(h, p(out), C.byref(nl)) == -12                # would overflow [nlist][dim]
+    assert L.zvec_hip_ivf_get_centroids(h, None, C.byref(nl)) == 0 and nl.value == nlist
+    assert L.zvec_hip_ivf_export(h, p(out), None, None) == -12
+    sizes = np.diff(offs64).astype(np.uint32)
+    assert L.zvec_hip_ivf_begin_lists(h, u32p(sizes)) == -12
+    import torch
+    d_rows = torch.from_numpy(rows).cuda()
+    d_lab = torch.zeros(n, dtype=torch.int32, device="cuda")
+    assert L.zvec_hip_ivf_label_dev(h, C.c_void_p(d_rows.data_ptr()), n, C.cast(C.c_void_p(d_lab.data_ptr()), C.POINTER(C.c_uint32)), None) == -12
+    # reload on the same handle: back in the rows' own space, everything works again
+    assert L.zvec_hip_ivf_load(h, p(cent), nlist, offs64.ctypes.data_as(C.POINTER(C.c_uint64)), p(rows), None) == 0
+    assert search() == 0 and np.array_equal(keys, first)
+    assert L.zvec_hip_ivf_get_centroids(h, p(out), C.byref(nl)) == 0 and np.array_equal(out, cent)
+    assert L.zvec_hip_ivf_label_dev(h, C.c_void_p(d_rows.data_ptr()), n, C.cast(C.c_void_p(d_lab.data_ptr()), C.POINTER(C.c_uint32)), None) == 0
+    torch.cuda.synchronize()
+    # set_coarse_space again, then new centroids in the rows' space: leaves it too
+    assert L.zvec_hip_ivf_set_coarse_space(h, cdim, 0, p(ccent), nlist) == 0
+    assert L.zvec_hip_ivf_set_centroids(h, p(cent), nlist) == 0
+    assert L.zvec_hip_ivf_get_centroids(h, p(out), C.byref(nl)) == 0 and np.array_equal(out, cent)
+    assert L.zvec_hip_ivf_destroy(h) == 0

@@ -1,7 +1,7 @@
 """The plugin's "HipIVFBuilder" (plugin/hip_ivf_builder.cc) RUN inside the reference's own framework.
 
 oracle/_ref/libzvec_ref_core.so (the reference's whole core library compiled in place, oracle/Makefile `ref_core`; test
-infrastructure) + oracle/_ref/libzvec_hip_plugin.so (plugin/*.cc linked to it and to the product library, loaded through the
+infrastructure) + plugin/build/libzvec_hip_plugin.so (plugin/*.cc linked to it and to the product library, loaded through the
 reference's IndexPluginBroker).  The driver (oracle/ref_core_shim.cc zref_build) creates the builder by its REGISTERED name through
 IndexFactory::CreateBuilder, trains / builds from a holder over the caller's rows and dumps into the reference's MemoryDumper.  Here
 the dumped FILE is opened by the product's loaders and searched: it must answer like an index built directly through the C ABI with

@@ -3,7 +3,7 @@
 oracle/_ref/libzvec_ref_core.so   = the reference's whole core library compiled in place (oracle/Makefile `ref_core`; incl.
                                     ailego::BufferHandle from its own buffer_manager.cc against the image's real Arrow —
                                     nothing stubbed) + the by-name driver oracle/ref_core_shim.cc
-oracle/_ref/libzvec_hip_plugin.so = plugin/hip_plugin.cc + hip_ivf_builder.cc linked to it and to zvec_amd/libzvec_hip.so,
+plugin/build/libzvec_hip_plugin.so = plugin/hip_plugin.cc + hip_ivf_builder.cc linked to it and to zvec_amd/libzvec_hip.so,
                                     brought in through the reference's IndexPluginBroker::emplace (dlopen + static registrars)
 Every case opens the SAME index file with the reference's class ("FlatSearcher", "IVFSearcher", "IVFStreamer", "FlatStreamer")
 and with the plugin's ("HipFlatSearcher", "HipIVFSearcher", "HipIVFStreamer", "HipFlatStreamer") created by their registered names
@@ -228,7 +228,8 @@ def test_ivf_classes_on_reference_dumped_files(R, cls_pair):
         R.mem_remove("g_" + name)
 
 
-@pytest.mark.parametrize("metric,dt", [("SquaredEuclidean", np.float32), ("SquaredEuclidean", np.float16), ("InnerProduct", np.float32)])
+@pytest.mark.parametrize("metric,dt", [("SquaredEuclidean", np.float32), ("SquaredEuclidean", np.float16), ("InnerProduct", np.float32),
+                                       ("InnerProduct", np.float16)])
 def test_ivf_built_by_the_reference_builder_searched_by_both(R, metric, dt):
     """An index TRAINED, BUILT and DUMPED by the reference's own IVFBuilder (its k-means, its labelling, its dumper) on real-valued
     data; partial probes with the max_scan_count rule live; one context handed from one index to another (magic re-bind,
@@ -385,3 +386,50 @@ def test_boundary_a_search_batch_sequence(R, conv, metric, builder, ref_cls, hip
         x.close()
     ref.close(), hip.close()
     R.mem_remove("bnd_a")
+
+
+@pytest.mark.parametrize("cls,kind", [("HipIVFSearcher", "ivf"), ("HipFlatSearcher", "flat")])
+def test_many_threads_single_queries_through_the_plugins_micro_batcher(R, cls, kind):
+    """zvec's real call pattern (index.cc:24-45,605-619; tools/core/bench.cc:145-245): T = 64 threads, each with a context of its
+    own, each calling search_impl(count = 1) on the PLUGIN class — with proxima.hip.searcher.batch_window_us set, so the calls ride
+    shared batches (include/zvec_hip_operator.hpp MicroBatcher, instantiated by plugin/hip_plugin.cc) — and, for comparison, with the
+    batcher off.  Every query's list must equal the one the reference's own CPU class returns for a single call."""
+    rng = np.random.default_rng(77)
+    n, dim, nlist, k, nq = 30000, 64, 96, 10, 640
+    means = rng.standard_normal((nlist, dim)).astype(np.float32) * 2
+    base = (means[rng.integers(0, nlist, n)] + rng.standard_normal((n, dim)).astype(np.float32)).astype(np.float32)
+    keys = (rng.permutation(2 * n)[:n]).astype(np.uint64)
+    q = (means[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, dim)).astype(np.float32)).astype(np.float32)
+    tol = dict(rtol=4e-6, atol=1e-5)
+    batch = {"proxima.hip.searcher.batch_window_us": 3000, "proxima.hip.searcher.max_batch": 48,
+             "proxima.hip.searcher.batch_linger_us": 200}
+    if kind == "ivf":
+        bp = {"proxima.ivf.builder.centroid_count": str(nlist), "proxima.ivf.builder.thread_count": 4}
+        R.build("IVFBuilder", base, "SquaredEuclidean", "mb_ivf", keys=keys, params=bp)
+        params = {"proxima.ivf.searcher.scan_ratio": 0.15, "proxima.ivf.searcher.brute_force_threshold": 100}
+        ref = R.Runner.searcher("IVFSearcher", "mb_ivf", dim, np.float32, params=params)
+        target = "mb_ivf"
+    else:
+        R.build("FlatBuilder", base, "SquaredEuclidean", "mb_flat", keys=keys)
+        params = {}
+        ref = R.Runner.searcher("FlatSearcher", "mb_flat", dim, np.float32, params=params)
+        target = "mb_flat"
+    rk, rs, rc_, _ = ref.search_mt(q, k, 8)                      # the reference's singles
+    for what, extra, threads in (("batched T=64", batch, 64), ("unbatched T=64", {}, 64), ("batched T=3", batch, 3)):
+        hip = R.Runner.searcher(cls, target, dim, np.float32, params=dict(params, **extra))
+        gk, gs, gc, sec = hip.search_mt(q, k, threads)
+        tie_tolerant_compare(gk, gs, gc, rk, rs, rc_, what="%s %s" % (cls, what), select_band=1e-4, **tol)
+        # a context with a filter / a radius bypasses the batcher and still answers alone
+        ctx = hip.create_context()
+        ctx.set_topk(k)
+        ctx.set_threshold(float(np.median(rs[:, 3])))
+        r2, lists = hip.search_lists(ctx, q[:5], 0)
+        assert r2 == 0
+        rctx = ref.create_context()
+        rctx.set_topk(k)
+        rctx.set_threshold(float(np.median(rs[:, 3])))
+        r1, rlists = ref.search_lists(rctx, q[:5], 0)
+        assert r1 == 0
+        compare(lists, rlists, k, "%s %s radius" % (cls, what), select_band=1e-4, **tol)
+        hip.close()
+    ref.close()

@@ -33,6 +33,8 @@ SYMBOLS = {
     "zvec_hip_abi_version": (C.c_int, []),
     "zvec_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "zvec_hip_error_string": (C.c_char_p, [C.c_int]),
+    "zvec_hip_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "zvec_hip_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "zvec_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_h)]),
     "zvec_hip_ctx_destroy": (C.c_int, [_h]),
     "zvec_hip_ctx_synchronize": (C.c_int, [_h]),
@@ -65,7 +67,7 @@ SYMBOLS = {
     "zvec_hip_ivf_destroy": (C.c_int, [_h]),
     "zvec_hip_ivf_load": (C.c_int, [_h, C.c_void_p, C.c_uint32, _u64p, C.c_void_p, _u64p]),
     "zvec_hip_flat_load_features": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _u64p]),
-    "zvec_hip_flat_load_blocks": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "zvec_hip_flat_load_blocks": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),
     "zvec_hip_ivf_set_coarse_space": (C.c_int, [_h, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32]),
     "zvec_hip_ivf_search_coarse": (C.c_int, [_h, _h, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32,
                                              _u64p, _u64p, _f32p, _u32p]),

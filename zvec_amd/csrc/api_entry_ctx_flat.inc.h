@@ -28,6 +28,27 @@ const char *zvec_hip_error_string(int code) {
   return "Unknown error";
 }
 
+int zvec_hip_set_option(const char *name, int value) {
+  if (!name) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (strcmp(name, "wait") == 0) {
+    if (value < 0 || value > 2) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+    ropts().wait = value;
+    return 0;
+  }
+  if (strcmp(name, "zerocopy") == 0) {
+    if (value < 0 || value > 3) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+    ropts().zerocopy = value;
+    return 0;
+  }
+  return ZVEC_HIP_ERR_UNSUPPORTED;
+}
+int zvec_hip_get_option(const char *name, int *value) {
+  if (!name || !value) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (strcmp(name, "wait") == 0) { *value = ropts().wait; return 0; }
+  if (strcmp(name, "zerocopy") == 0) { *value = ropts().zerocopy; return 0; }
+  return ZVEC_HIP_ERR_UNSUPPORTED;
+}
+
 int zvec_hip_ctx_create(int device, zvec_hip_ctx_t *out) {
   if (!out) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   return ctx_new(device, out);
@@ -237,13 +258,15 @@ int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_
 // valid) — the caller derives it from the 16 tail bytes of each block.  One strided H2D copy brings the row regions of the
 // whole run over, one pack launch appends the kept rows (in block / row order = the reference iterator's order,
 // flat_streamer_entity.cc:428-460) with the keys read from the run.
-int zvec_hip_flat_load_blocks(zvec_hip_flat_t h, const void *blocks, uint64_t nblocks, uint32_t block_size,
+int zvec_hip_flat_load_blocks(zvec_hip_flat_t h, const void *blocks, uint64_t bytes, uint64_t nblocks, uint32_t block_size,
                               uint32_t block_vector_count, const uint32_t *keep) {
   if (!h || (nblocks && (!blocks || !keep)) || block_vector_count == 0 || block_vector_count > 32) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (nblocks == 0) return 0;
   const uint64_t elem = h->st.row_bytes();
   const uint64_t rows_bytes = (uint64_t)block_vector_count * elem;
-  if (rows_bytes + (uint64_t)block_vector_count * 8 > block_size) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  // a block = rows, keys, then DeletionMap (4 B) + BlockHeader (12 B) (flat_index_format.h:91-126); the run must lie inside `bytes`
+  if (rows_bytes + (uint64_t)block_vector_count * 8 + 16 > block_size) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (nblocks > bytes / block_size) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::vector<uint64_t> src, keys;
   const char *p = static_cast<const char *>(blocks);
   for (uint64_t b = 0; b < nblocks; ++b) {
@@ -264,22 +287,28 @@ int zvec_hip_flat_load_blocks(zvec_hip_flat_t h, const void *blocks, uint64_t nb
   std::unique_lock<FairSharedMutex> w(h->rw);
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
+  // everything that can refuse comes before the first asynchronous copy out of the local arrays
+  if (h->st.n + kept >= 0xfffffff0ull) return ZVEC_HIP_ERR_OUT_OF_RANGE;
+  ZRET(h->st.reserve(h->st.n + kept, s));
   Scoped<char> d_rows;
   Scoped<uint64_t> d_src, d_keys;
   ZRET(d_rows.alloc(nblocks * rows_bytes));
   ZRET(d_src.alloc(kept));
   ZRET(d_keys.alloc(kept));
-  ZCHK(hipMemcpy2DAsync(d_rows, rows_bytes, blocks, block_size, rows_bytes, nblocks, hipMemcpyHostToDevice, s));
-  ZCHK(hipMemcpyAsync(d_src, src.data(), kept * 8, hipMemcpyHostToDevice, s));
-  ZCHK(hipMemcpyAsync(d_keys, keys.data(), kept * 8, hipMemcpyHostToDevice, s));
-  if (h->st.n + kept >= 0xfffffff0ull) return ZVEC_HIP_ERR_OUT_OF_RANGE;
-  ZRET(h->st.reserve(h->st.n + kept, s));
-  int rc = launch_pack(h->st, d_rows, kept, d_src, h->st.n, nullptr, s, h->st.keys, d_keys);
+  int rc = 0;
+  auto copies = [&]() -> int {
+    ZCHK(hipMemcpy2DAsync(d_rows, rows_bytes, blocks, block_size, rows_bytes, nblocks, hipMemcpyHostToDevice, s));
+    ZCHK(hipMemcpyAsync(d_src, src.data(), kept * 8, hipMemcpyHostToDevice, s));
+    ZCHK(hipMemcpyAsync(d_keys, keys.data(), kept * 8, hipMemcpyHostToDevice, s));
+    return 0;
+  };
+  rc = copies();
+  if (rc == 0) rc = launch_pack(h->st, d_rows, kept, d_src, h->st.n, nullptr, s, h->st.keys, d_keys);
   if (rc == 0) {
     h->st.n += kept;
     rc = flat_holes_cover(h, s);
   }
-  ZCHK(hipStreamSynchronize(s));
+  (void)hipStreamSynchronize(s);          // on every path: the copies read `src` / `keys` / `blocks`, the device temporaries go away
   return rc;
 }
 
@@ -522,7 +551,7 @@ int zvec_hip_flat_search(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *quer
   {
     std::shared_lock<FairSharedMutex> r(h->rw);      // the row count the bitset is sized for == the rows scanned
     ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->st.row_bytes(), exclude_bitset, h->st.n, count, topk, c->cur));
-    ZRET(flat_search_dev_locked(h, c, c->io_q.p, count, topk, threshold, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr,
+    ZRET(flat_search_dev_locked(h, c, c->io_qp, count, topk, threshold, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr,
                                 c->io_keys.as<uint64_t>(), c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
   }
   return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, c->cur);
@@ -558,7 +587,7 @@ int zvec_hip_flat_search_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const voi
     clean[i] = ok ? id : IDX_NONE;
   }
   ZRET(host_search_wrap_begin(c, queries, (size_t)count * st.row_bytes(), nullptr, 0, count, topk, s));
-  ZRET(prep_queries(c, st, c->io_q.p, count, threshold, s));
+  ZRET(prep_queries(c, st, c->io_qp, count, threshold, s));
   ZRET(c->plan.ensure(((size_t)total + count + 8) * sizeof(uint32_t)));
   uint32_t *d_pos = c->plan.as<uint32_t>();
   uint32_t *d_off = d_pos + std::max<uint32_t>(total, 1);

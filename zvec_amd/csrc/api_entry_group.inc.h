@@ -141,7 +141,7 @@ int zvec_hip_flat_search_grouped(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const vo
   ZRET(c->grp_of.ensure((size_t)st.n * 4));
   ZCHK(hipMemcpyAsync(c->grp_of.p, group_of_position, (size_t)st.n * 4, hipMemcpyHostToDevice, s));
   ZRET(host_search_wrap_begin(c, queries, (size_t)count * st.row_bytes(), exclude_bitset, st.n, count, 1, s));
-  ZRET(prep_queries(c, st, c->io_q.p, count, threshold, s));
+  ZRET(prep_queries(c, st, c->io_qp, count, threshold, s));
   const uint64_t ntiles = (st.n + TILE_N - 1) / TILE_N;
   const double row_bytes = (double)ntiles * TILE_N * 4.0;
   // query slices: the score matrix stays <= 1 GiB, and a slice is one grid dimension of group_best_kernel (<= 65535)
@@ -195,7 +195,7 @@ int zvec_hip_flat_search_grouped_by_ids(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, c
   ZRET(c->grp_of.ensure(std::max<size_t>((size_t)st.n, 1) * 4));
   if (st.n) ZCHK(hipMemcpyAsync(c->grp_of.p, group_of_position, (size_t)st.n * 4, hipMemcpyHostToDevice, s));
   ZRET(host_search_wrap_begin(c, queries, (size_t)count * st.row_bytes(), nullptr, 0, count, 1, s));
-  ZRET(prep_queries(c, st, c->io_q.p, count, threshold, s));
+  ZRET(prep_queries(c, st, c->io_qp, count, threshold, s));
   ZRET(c->plan.ensure(((size_t)total + count + 8) * sizeof(uint32_t)));
   uint32_t *d_pos = c->plan.as<uint32_t>();
   uint32_t *d_off = d_pos + std::max<uint32_t>(total, 1);

@@ -18,9 +18,21 @@ int zvec_hip_ivf_create(uint32_t dim, int dtype, int metric, int device, zvec_hi
   return 0;
 }
 
+// the centroid store back in the index's own space (after zvec_hip_ivf_set_coarse_space had put it into another one)
+static void ivf_leave_coarse_space(zvec_hip_ivf_s *h) {
+  if (!h->coarse_sep) return;
+  h->cent.release();
+  h->cent.n = 0;
+  h->cent.configure(h->dim, h->metric, h->dtype);
+  h->h_centroids.clear();
+  h->coarse_sep = false;
+  h->trained = false;
+}
+
 static void ivf_release(zvec_hip_ivf_s *h) {
   h->cent.release(); h->lists.release();
   h->cent.n = 0; h->lists.n = 0;
+  ivf_leave_coarse_space(h);
   if (h->d_size) (void)hipFree(h->d_size);
   if (h->d_size_global) (void)hipFree(h->d_size_global);
   if (h->d_tile0) (void)hipFree(h->d_tile0);
@@ -89,6 +101,7 @@ int zvec_hip_ivf_list_owners(zvec_hip_ivf_t h, uint32_t *owner_out) {
 
 // (re)build the centroid store from host rows; the index is "trained" afterwards
 static int ivf_set_centroids(zvec_hip_ivf_s *h, const void *h_centroids, uint32_t nlist, hipStream_t s) {
+  ivf_leave_coarse_space(h);            // centroids handed over here are rows of the index's own space
   const size_t rb = h->lists.row_bytes();
   h->nlist = nlist;
   if (h_centroids != h->h_centroids.data())
@@ -280,7 +293,7 @@ int zvec_hip_ivf_load(zvec_hip_ivf_t h, const void *centroids, uint32_t nlist, c
     ZRET(d_rows.alloc((size_t)n * h->lists.row_bytes()));
     ZCHK(hipMemcpyAsync(d_rows, vecs, (size_t)n * h->lists.row_bytes(), hipMemcpyHostToDevice, s));
   }
-  if (h->loaded || h->filling) ivf_release(h);
+  if (h->loaded || h->filling || h->coarse_sep) ivf_release(h);
   return ivf_pack(h, d_rows, n, keys, labels, centroids, nlist, s);
 }
 
@@ -378,7 +391,7 @@ int zvec_hip_ivf_load_segments(zvec_hip_ivf_t h, const void *inverted_header, ui
   std::vector<uint32_t> labels(total);
   for (uint32_t l = 0; l < nlist; ++l)
     for (uint64_t i = list_offsets[l]; i < list_offsets[l + 1]; ++i) labels[i] = l;
-  if (h->loaded || h->filling) ivf_release(h);
+  if (h->loaded || h->filling || h->coarse_sep) ivf_release(h);
   return ivf_pack(h, d_rows, total, static_cast<const uint64_t *>(keys), labels, centroids, nlist, s);
 }
 
@@ -504,7 +517,7 @@ int zvec_hip_ivf_build_dev(zvec_hip_ivf_t h, const void *d_vecs, uint64_t n, con
   const char *rows = reinterpret_cast<const char *>(d_vecs);
   const size_t rb = h->lists.row_bytes();
   if (sample_per_list == 0) sample_per_list = 256;
-  if (h->loaded || h->filling) ivf_release(h);
+  if (h->loaded || h->filling || h->coarse_sep) ivf_release(h);
 
   // ---- sample (deterministic stride) ----
   uint64_t S = std::min<uint64_t>(n, (uint64_t)sample_per_list * nlist);
@@ -556,7 +569,7 @@ int zvec_hip_ivf_train_dev(zvec_hip_ivf_t h, const void *d_sample, uint64_t n_sa
   ZCHK(hipSetDevice(h->device));
   zvec_hip_ctx_s *c = h->defctx;
   std::lock_guard<std::mutex> gc(c->mu);
-  if (h->loaded || h->filling) ivf_release(h);
+  if (h->loaded || h->filling || h->coarse_sep) ivf_release(h);
   return ivf_train(h, c, reinterpret_cast<const char *>(d_sample), n_sample, nlist, kmeans_iters, seed, pick_stream(c, stream));
 }
 
@@ -564,13 +577,14 @@ int zvec_hip_ivf_set_centroids(zvec_hip_ivf_t h, const void *centroids, uint32_t
   if (!h || !centroids || nlist == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
   ZCHK(hipSetDevice(h->device));
-  if (h->loaded || h->filling) ivf_release(h);
+  if (h->loaded || h->filling || h->coarse_sep) ivf_release(h);
   return ivf_set_centroids(h, centroids, nlist, h->defctx->own);
 }
 
 int zvec_hip_ivf_get_centroids(zvec_hip_ivf_t h, void *centroids, uint32_t *nlist) {
   if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (!h->trained) return ZVEC_HIP_ERR_NO_TRAINED;
+  if (centroids && h->coarse_sep) return ZVEC_HIP_ERR_UNSUPPORTED;      // (rows of another width than the caller's [nlist][dim])
   if (nlist) *nlist = h->nlist;
   if (centroids) memcpy(centroids, h->h_centroids.data(), h->h_centroids.size());
   return 0;
@@ -579,6 +593,7 @@ int zvec_hip_ivf_get_centroids(zvec_hip_ivf_t h, void *centroids, uint32_t *nlis
 int zvec_hip_ivf_label_dev(zvec_hip_ivf_t h, const void *d_rows, uint64_t n, uint32_t *d_labels, void *stream) {
   if (!h || (n && (!d_rows || !d_labels))) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (!h->trained) return ZVEC_HIP_ERR_NO_TRAINED;
+  if (h->coarse_sep) return ZVEC_HIP_ERR_UNSUPPORTED;      // the centroid store is not in the rows' space: nothing to label against
   if (n == 0) return 0;
   std::lock_guard<std::mutex> g(h->mu);
   ZCHK(hipSetDevice(h->device));
@@ -590,6 +605,7 @@ int zvec_hip_ivf_label_dev(zvec_hip_ivf_t h, const void *d_rows, uint64_t n, uin
 int zvec_hip_ivf_begin_lists(zvec_hip_ivf_t h, const uint32_t *list_sizes) {
   if (!h || !list_sizes) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (!h->trained) return ZVEC_HIP_ERR_NO_TRAINED;
+  if (h->coarse_sep) return ZVEC_HIP_ERR_UNSUPPORTED;      // (a streamed fill labels against centroids of the rows' own space)
   std::lock_guard<std::mutex> g(h->mu);
   ZCHK(hipSetDevice(h->device));
   if (h->loaded) {                       // a new fill replaces the lists, the centroids stay
@@ -630,6 +646,7 @@ int zvec_hip_ivf_info(zvec_hip_ivf_t h, uint64_t *count, uint32_t *nlist) {
 int zvec_hip_ivf_export(zvec_hip_ivf_t h, void *centroids, uint64_t *list_offsets, uint64_t *row_ids) {
   if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  if (centroids && h->coarse_sep) return ZVEC_HIP_ERR_UNSUPPORTED;      // (rows of another width than the caller's [nlist][dim])
   if (centroids) memcpy(centroids, h->h_centroids.data(), h->h_centroids.size());
   if (list_offsets) memcpy(list_offsets, h->h_dense0.data(), h->h_dense0.size() * 8);
   if (row_ids) memcpy(row_ids, h->h_row_ids.data(), h->h_row_ids.size() * 8);
@@ -723,7 +740,7 @@ static int ivf_search_host_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void
     ZCHK(hipMemcpyAsync(c->io_cq.p, coarse_queries, cb, hipMemcpyHostToDevice, c->cur));
     d_cq = c->io_cq.p;
   }
-  ZRET(ivf_search_dev_locked(h, c, c->io_q.p, count, topk, threshold, nprobe, max_scan_count, brute_force,
+  ZRET(ivf_search_dev_locked(h, c, c->io_qp, count, topk, threshold, nprobe, max_scan_count, brute_force,
                              exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr, c->io_keys.as<uint64_t>(),
                              c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur, d_cq));
   return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, c->cur);
@@ -743,6 +760,7 @@ int zvec_hip_ivf_set_coarse_space(zvec_hip_ivf_t h, uint32_t coarse_dim, int coa
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
   h->cent.release();
+  h->cent.n = 0;                          // (centroids of the rows' own space may have been loaded before)
   h->cent.configure(coarse_dim, coarse_metric, h->dtype);
   const size_t rb = h->cent.row_bytes();
   h->h_centroids.assign(static_cast<const char *>(centroids), static_cast<const char *>(centroids) + (size_t)nlist * rb);

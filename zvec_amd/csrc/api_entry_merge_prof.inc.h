@@ -77,8 +77,9 @@ int zvec_hip_merge_topk(zvec_hip_ctx_t ctx, const uint64_t *keys, const float *s
 int zvec_hip_ctx_profile(zvec_hip_ctx_t ctx, int enable) {
   if (!ctx) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(ctx->mu);
+  const bool was_on = ctx->profile && ctx->stats.p != nullptr;
   ctx->profile = enable != 0;
-  if (ctx->profile) {
+  if (ctx->profile && !was_on) {        // (already profiling: the recorded slots keep their counts; a reset goes through profile_read)
     ZCHK(hipSetDevice(ctx->device));
     ZRET(ctx->stats.ensure(sizeof(uint64_t) * 2 * PROFILE_MAX));
     // every launch slot starts at zero (the small-batch route ADDS its per-query row counts); zeroed here and at every reset,

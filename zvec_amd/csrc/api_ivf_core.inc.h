@@ -32,7 +32,8 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   // 5 us + gap of the ~70 us one lane needs between two of its scoring kernels).
   const bool sep = h->coarse_sep && !brute_force;
   const bool raw_rows = !sep && direct && h->lists.dim_in == h->lists.dscan && (size_t)h->lists.dpad * 4 == h->lists.row_bytes() &&
-                        (reinterpret_cast<uintptr_t>(d_queries) & 15u) == 0;
+                        (reinterpret_cast<uintptr_t>(d_queries) & 15u) == 0 &&
+                        !(ctx->pin_in.dev && d_queries == ctx->pin_in.dev);    // (rows in the host-mapped slot are read ONCE, by prep_queries)
   const float *qrows = raw_rows ? reinterpret_cast<const float *>(d_queries) : nullptr;
   if (!raw_rows) {
     // (a separate coarse space: the coarse pass runs on the coarse queries, then the list queries are prepared in their place)
@@ -92,7 +93,10 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
       ZRET(flat_scan_prepared(ctx, h->cent, count, nprobe, FLT_MAX, nullptr, co, stream, false));
     }
   }
-  if (sep) ZRET(prep_queries(ctx, h->lists, d_queries, count, FLT_MAX, stream));      // from here on: the lists' own space
+  if (sep) {
+    ZRET(prep_queries(ctx, h->lists, d_queries, count, FLT_MAX, stream));      // from here on: the lists' own space
+    qrows = ctx->qpad.as<float>();                                             // (the buffer may have grown: list rows wider than coarse rows)
+  }
   if (direct) {
     // 2'. every query's probed rows as positions (same probe rule), 3'. one wave per (query, row): direct distance,
     // 4'. selection: the scoring blocks' own top-k lists -> the result, or (k > 64) two steps over the score matrix: runs of
@@ -283,9 +287,11 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   if (ctx->profile && ctx->nprof < PROFILE_MAX && ctx->stats.p)      // the slot prof_begin will take for this launch
     p.work_stats = ctx->stats.as<unsigned long long>() + 2 * (size_t)ctx->nprof;
   hipLaunchKernelGGL(plan_wave_kernel<false>, dim3((count + 3) / 4), dim3(256), 0, stream, p);
-  // (a gated context runs beside another lane's resident list scan: a 1024-thread work-group is not dispatched until
-  // that scan drains — 714 us for this 20 us kernel in the round-2 trace — four waves are)
-  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(ctx->gate ? 256 : 1024), 0, stream, p);
+  // (a pipelined context — one of several lanes, i.e. gated or driven on a caller's stream — runs beside another lane's
+  // resident list scan: a 1024-thread work-group is not dispatched until that scan drains — 714 us for this 20 us kernel
+  // in the round-2 trace — four waves are)
+  const bool pipelined = ctx->gate != nullptr || stream != ctx->own;
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(pipelined ? 256 : 1024), 0, stream, p);
   hipLaunchKernelGGL(plan_wave_kernel<true>, dim3((count + 3) / 4), dim3(256), 0, stream, p);
   ZCHK(hipGetLastError());
 
@@ -349,12 +355,87 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
 constexpr size_t PIN_LIMIT = 256u << 10;  // staging through pinned memory up to 256 KiB per direction (above that the extra
                                           // host copy costs more than the pageable transfer: batch 1024 lost 2 %)
 
+// wait policy 1: the last thing on the stream writes the call's epoch into a pinned word the host polls
+__global__ void done_word_kernel(volatile uint32_t *word, uint32_t epoch) {
+  __threadfence_system();
+  *word = epoch;
+}
+
+// A host-pointer call waits for its stream here (RuntimeOpts::wait).  Everything the call enqueued is on `stream`.
+int host_wait(zvec_hip_ctx_s *ctx, hipStream_t stream) {
+  const int policy = ropts().wait.load(std::memory_order_relaxed);
+  if (policy == 1 && ctx->done_word.ensure(64) == 0 && ctx->done_word.dev) {
+    // a plain word in pinned memory: no runtime call (and none of its locks) per poll; a short spin for the single caller's
+    // latency, then the CPU is handed on between polls — with more callers than CPUs the waiting threads no longer hold the
+    // time slices the launching ones need
+    volatile uint32_t *w = static_cast<volatile uint32_t *>(ctx->done_word.p);
+    const uint32_t epoch = ++ctx->done_epoch ? ctx->done_epoch : ++ctx->done_epoch;      // (0 = the word's initial value)
+    hipLaunchKernelGGL(done_word_kernel, dim3(1), dim3(1), 0, stream, static_cast<volatile uint32_t *>(ctx->done_word.dev), epoch);
+    ZCHK(hipGetLastError());
+    // Spin while the answer is close, sleep while it is not.  A lone caller's search ends ~0.1 ms after its last launch: it is
+    // found by the spin.  With many callers sharing the GPU a call waits a millisecond or more; a thread that spun (or
+    // sched_yield-ed on a core of its own) through that would burn a whole CPU — 64 such callers exhaust a 16-CPU quota in a
+    // quarter of every scheduler period and are then all frozen for the rest of it (measured: p99 78 ms, throughput / 3).  So a
+    // context whose previous wait was long goes to sleep at once, in steps that follow the time it has already waited.
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint64_t last = ctx->last_wait_ns;
+    const uint64_t spin_ns = last > 300000 ? 0 : 200000;
+    uint64_t waited = 0;
+    if (spin_ns == 0) {
+      // most of the expected wait in ONE sleep, the rest in steps of 1/32 of it: the call returns within ~3 % (+ the timer slack)
+      // of its completion, at a few wake-ups per call
+      struct timespec ts = {0, (long)std::min<uint64_t>(last * 3 / 4, 50000000)};
+      nanosleep(&ts, nullptr);
+    }
+    for (uint32_t it = 0;; ++it) {
+      if (*w == epoch) {
+        waited = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        ctx->last_wait_ns = spin_ns ? waited : (last * 3 + waited) / 4;          // (smoothed while sleeping: one early finish must not bring the spin back)
+        return 0;
+      }
+      if ((it & 31) == 31 || waited >= spin_ns)
+        waited = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (waited < spin_ns) { __builtin_ia32_pause(); continue; }
+      const uint64_t step = std::min<uint64_t>(200000, std::max<uint64_t>(20000, std::max(waited, last) / 32));
+      struct timespec ts = {0, (long)step};
+      nanosleep(&ts, nullptr);
+      if ((it & 255) == 255 || waited > 2000000000ull) {
+        // a fault on the stream would leave the word unwritten for ever: ask the runtime now and then
+        hipError_t q = hipStreamQuery(stream);
+        if (q != hipSuccess && q != hipErrorNotReady) { ZCHK(q); }
+        if (q == hipSuccess && *w != epoch && waited > 5000000000ull) break;
+      }
+    }
+    ZCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  if (policy == 2) {
+    if (!ctx->block_ev) ZCHK(hipEventCreateWithFlags(&ctx->block_ev, hipEventBlockingSync | hipEventDisableTiming));
+    ZCHK(hipEventRecord(ctx->block_ev, stream));
+    ZCHK(hipEventSynchronize(ctx->block_ev));
+    return 0;
+  }
+  ZCHK(hipStreamSynchronize(stream));
+  return 0;
+}
+
+// Host-pointer entry points: queries (and an exclude set) in, keys | scores | counts out.  Small transfers skip the copy engine
+// (RuntimeOpts::zerocopy): the rows are put into the context's pinned slot, which is mapped into the device's address space,
+// and the first kernel of the search — prep_queries — reads them over the host link in place (ctx->io_qp); the result arrays
+// are views into the mapped result slot, so the last kernels of the chain (merge / re-score / re-sort) write the answer straight
+// into host memory and the call ends with ONE wait and three memcpys.  A copy command costs more than the 3 KB it moves: the
+// copy engine's own dispatch and its hand-over to the compute queue and back (single query, 10M x 768: 0.109 -> see DESIGN §3).
 int host_search_wrap_begin(zvec_hip_ctx_s *ctx, const void *queries, size_t qbytes, const uint64_t *exclude,
                            uint64_t nbits, uint32_t count, uint32_t topk, hipStream_t stream) {
+  const int zc = ropts().zerocopy.load(std::memory_order_relaxed);      // bit 0: queries read in place, bit 1: results written in place
   ZRET(ctx->io_q.ensure(qbytes));
+  ctx->io_qp = ctx->io_q.p;
   if (qbytes <= PIN_LIMIT && ctx->pin_in.ensure(qbytes) == 0) {
     memcpy(ctx->pin_in.p, queries, qbytes);              // (the previous call's transfer has been waited for)
-    ZCHK(hipMemcpyAsync(ctx->io_q.p, ctx->pin_in.p, qbytes, hipMemcpyHostToDevice, stream));
+    if ((zc & 1) && ctx->pin_in.dev)
+      ctx->io_qp = ctx->pin_in.dev;
+    else
+      ZCHK(hipMemcpyAsync(ctx->io_q.p, ctx->pin_in.p, qbytes, hipMemcpyHostToDevice, stream));
   } else {
     ZCHK(hipMemcpyAsync(ctx->io_q.p, queries, qbytes, hipMemcpyHostToDevice, stream));
   }
@@ -363,13 +444,21 @@ int host_search_wrap_begin(zvec_hip_ctx_s *ctx, const void *queries, size_t qbyt
     ZRET(ctx->io_ex.ensure(words * 8 + 8));
     ZCHK(hipMemcpyAsync(ctx->io_ex.p, exclude, words * 8, hipMemcpyHostToDevice, stream));
   }
-  // keys | scores | counts in ONE device buffer (16-byte aligned parts): a single copy brings a result back
+  // keys | scores | counts in ONE buffer (16-byte aligned parts): a single copy brings a result back — or none at all
   const size_t kb = (size_t)count * topk * sizeof(uint64_t), sb = ((size_t)count * topk * sizeof(float) + 15) & ~(size_t)15,
                cb = (size_t)count * sizeof(uint32_t);
-  ZRET(ctx->io_out.ensure(kb + sb + cb));
-  ctx->io_keys.p = ctx->io_out.p;
-  ctx->io_scores.p = ctx->io_out.as<char>() + kb;
-  ctx->io_counts.p = ctx->io_out.as<char>() + kb + sb;
+  char *o = nullptr;
+  ctx->out_mapped = false;
+  if ((zc & 2) && kb + sb + cb <= PIN_LIMIT && ctx->pin_out.ensure(kb + sb + cb) == 0 && ctx->pin_out.dev) {
+    o = static_cast<char *>(ctx->pin_out.dev);
+    ctx->out_mapped = true;
+  } else {
+    ZRET(ctx->io_out.ensure(kb + sb + cb));
+    o = ctx->io_out.as<char>();
+  }
+  ctx->io_keys.p = o;
+  ctx->io_scores.p = o + kb;
+  ctx->io_counts.p = o + kb + sb;
   return 0;
 }
 
@@ -377,10 +466,18 @@ int host_search_wrap_end(zvec_hip_ctx_s *ctx, uint32_t count, uint32_t topk, uin
                          uint32_t *out_counts, hipStream_t stream) {
   const size_t kb = (size_t)count * topk * sizeof(uint64_t), sbytes = (size_t)count * topk * sizeof(float),
                sb = (sbytes + 15) & ~(size_t)15, cb = (size_t)count * sizeof(uint32_t);
+  if (ctx->out_mapped) {
+    ZRET(host_wait(ctx, stream));
+    const char *h = static_cast<const char *>(ctx->pin_out.p);
+    memcpy(out_keys, h, kb);
+    memcpy(out_scores, h + kb, sbytes);
+    memcpy(out_counts, h + kb + sb, cb);
+    return 0;
+  }
   if (kb + sb + cb <= PIN_LIMIT && ctx->pin_out.ensure(kb + sb + cb) == 0) {
     char *h = static_cast<char *>(ctx->pin_out.p);
     ZCHK(hipMemcpyAsync(h, ctx->io_out.p, kb + sb + cb, hipMemcpyDeviceToHost, stream));
-    ZCHK(hipStreamSynchronize(stream));
+    ZRET(host_wait(ctx, stream));
     memcpy(out_keys, h, kb);
     memcpy(out_scores, h + kb, sbytes);
     memcpy(out_counts, h + kb + sb, cb);
@@ -389,7 +486,7 @@ int host_search_wrap_end(zvec_hip_ctx_s *ctx, uint32_t count, uint32_t topk, uin
   ZCHK(hipMemcpyAsync(out_keys, ctx->io_keys.p, kb, hipMemcpyDeviceToHost, stream));
   ZCHK(hipMemcpyAsync(out_scores, ctx->io_scores.p, sbytes, hipMemcpyDeviceToHost, stream));
   ZCHK(hipMemcpyAsync(out_counts, ctx->io_counts.p, cb, hipMemcpyDeviceToHost, stream));
-  ZCHK(hipStreamSynchronize(stream));
+  ZRET(host_wait(ctx, stream));
   return 0;
 }
 

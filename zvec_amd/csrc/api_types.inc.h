@@ -47,17 +47,41 @@ struct DevView {
 // and synchronised by the runtime, a pinned one is a plain asynchronous DMA)
 struct PinnedBuf {
   void *p = nullptr;
+  void *dev = nullptr;   // the same bytes as the device addresses them (host-mapped: kernels read / write the slot in place)
   size_t cap = 0;
   int ensure(size_t bytes) {
     if (bytes <= cap) return 0;
-    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    if (p) { (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
     size_t want = bytes + bytes / 4 + 256;
-    ZCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
+    ZCHK(hipHostMalloc(&p, want, hipHostMallocMapped));
+    if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }
     cap = want;
     return 0;
   }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
 };
+
+// Process-wide run-time options of the host-pointer entry points (zvec_hip_set_option; environment at first use).
+//   wait      how a host-pointer search waits for its stream.  The product calls boundary B from many threads, one query per
+//             call (index.cc:605-619): the runtime's spinning hipStreamSynchronize keeps every waiting thread on a CPU, and
+//             with more callers than CPUs the threads that have kernels to launch wait for time slices behind them.
+//             0 = spin (hipStreamSynchronize), 1 = poll a completion word in pinned memory, yielding the CPU between polls
+//             (a one-thread kernel at the end of the chain writes it), 2 = block on an event created with hipEventBlockingSync
+//   zerocopy  small transfers skip the copy engine.  bit 1 (value 2, the default): the last kernels write keys | scores | counts
+//             into the host-mapped result slot; bit 0: the first kernel reads the query rows from the host-mapped pinned slot —
+//             measured SLOWER than the staged copy (single query, 10M x 768: 0.121 against 0.104 ms per call), off by default
+struct RuntimeOpts {
+  std::atomic<int> wait{1};
+  std::atomic<int> zerocopy{2};
+  RuntimeOpts() {
+    if (const char *e = getenv("ZVEC_HIP_WAIT")) wait = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("ZVEC_HIP_ZEROCOPY")) zerocopy = std::max(0, std::min(3, atoi(e)));
+  }
+};
+inline RuntimeOpts &ropts() {
+  static RuntimeOpts o;
+  return o;
+}
 
 // scope-owned device temporary: freed on every exit path of the enclosing function
 template <typename T>
@@ -174,6 +198,12 @@ struct zvec_hip_ctx_s {
   DevBuf direct_pos, direct_keys, direct_scores, direct_idx, direct_cnt;   // small-batch IVF route: positions, stage-1 lists
   DevBuf holes_ex;                                     // caller's exclude set OR the store's holes                      // group-by search: per-group bests / lists, group of every position, results
   PinnedBuf pin_in, pin_out;                           // (transfers up to PIN_LIMIT bytes go through pinned memory)
+  const void *io_qp = nullptr;                         // where device code finds the uploaded queries: io_q or the mapped pin_in slot
+  bool out_mapped = false;                             // io_keys / io_scores / io_counts point into the mapped pin_out slot
+  PinnedBuf done_word;                                 // wait policy 1: completion word (epoch) a one-thread kernel writes
+  uint32_t done_epoch = 0;
+  uint64_t last_wait_ns = 0;                           // how long the previous call waited: spin (short) or sleep (long) next time
+  hipEvent_t block_ev = nullptr;                       // wait policy 2: hipEventBlockingSync
   DevBuf stats;       // per-launch {distinct_rows, pair_rows} u64 x PROFILE_MAX
   uint32_t *q_scanned = nullptr, *q_nprobe = nullptr;  // inside plan
   uint32_t *last_list_count = nullptr;                 // inside plan

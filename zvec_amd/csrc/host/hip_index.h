@@ -12,7 +12,9 @@
 //   IndexRunner operators        src/include/zvec/core/framework/index_runner.h:440-531
 //   FlatStreamer / FlatSearcher  src/core/algorithm/flat/flat_streamer.cc:304-389, flat_searcher.cc:162-211
 //   IVFSearcher (+Context)       src/core/algorithm/ivf/ivf_searcher.cc:183-250, ivf_searcher_context.h:61-79
-// Header-only, no framework dependency; link with -lzvec_hip.
+// Header-only, no framework dependency; link with -lzvec_hip.  The operator logic itself — sweeps, probe parameters, p_keys
+// mapping, result assembly, fetch_vector, add_with_id, the search sequences, the micro-batcher — is NOT here: it is
+// include/zvec_hip_operator.hpp, the one copy this mirror and the real plugin (plugin/hip_plugin.cc) both instantiate.
 #pragma once
 #include <cfloat>
 #include <cmath>
@@ -31,6 +33,7 @@
 #include <vector>
 
 #include "../../../include/zvec_hip.h"
+#include "../../../include/zvec_hip_operator.hpp"
 
 namespace zvec_hip_host {
 
@@ -131,19 +134,7 @@ class IndexFilter {
   std::function<bool(uint64_t)> fn_;
 };
 
-// reader/writer lock that cannot starve the writer: std::shared_mutex on glibc prefers readers, and searches that
-// overlap continuously (several threads in a loop) would keep an add_impl waiting forever.  Everybody passes a gate
-// first; a writer keeps the gate while the readers in flight drain, so new readers queue behind it.
-class FairSharedMutex {
- public:
-  void lock() { gate_.lock(); rw_.lock(); gate_.unlock(); }
-  void unlock() { rw_.unlock(); }
-  void lock_shared() { gate_.lock(); rw_.lock_shared(); gate_.unlock(); }
-  void unlock_shared() { rw_.unlock_shared(); }
- private:
-  std::mutex gate_;
-  std::shared_mutex rw_;
-};
+using zvec_hip_op::FairSharedMutex;
 
 inline int metric_from_name(const std::string &name) {
   if (name == "SquaredEuclidean") return ZVEC_HIP_METRIC_L2;
@@ -173,37 +164,13 @@ class Context {
   template <typename T> void set_group_by(T &&fn) { group_by_ = std::forward<T>(fn); }
   void reset_group_by() { group_by_ = nullptr; }
   bool group_by_search() const { return group_num_ > 0; }
-  bool group_by_valid() const { return (bool)group_by_; }
-  uint32_t group_num() const { return group_num_; }
-  uint32_t group_topk() const { return group_topk_; }
   const IndexGroupDocumentList &group_result() const { return group_results_.at(0); }
   const IndexGroupDocumentList &group_result(size_t i) const { return group_results_.at(i); }
-  std::vector<IndexGroupDocumentList> &mutable_group_results() { return group_results_; }
-  // host sweep of the group-by callback: dense group number of every storage position + the ids they stand for
-  void sweep_groups(const std::vector<uint64_t> &keys_by_position, std::vector<uint32_t> *group_of, std::vector<std::string> *ids) const {
-    std::unordered_map<std::string, uint32_t> number_of;
-    ids->clear();
-    group_of->resize(keys_by_position.size());
-    for (size_t i = 0; i < keys_by_position.size(); ++i) {
-      std::string id = group_by_(keys_by_position[i]);
-      auto it = number_of.find(id);
-      if (it == number_of.end()) {
-        it = number_of.emplace(id, (uint32_t)ids->size()).first;
-        ids->push_back(std::move(id));
-      }
-      (*group_of)[i] = it->second;
-    }
-  }
   // side channel of SURVEY H4: an already materialised predicate (1 bit per storage position)
   void set_exclude_bitset(std::vector<uint64_t> words) { bits_ = std::move(words); has_bits_ = true; has_doc_ = false; }
   // the composite document filter as data (doc_filter.cc:74-87): serialised roaring bitmaps + the forward bool
   // buffer; the index materialises it on the GPU (zvec_hip_*_build_filter) instead of sweeping a callback
   void set_doc_filter(const zvec_hip_doc_filter_t &f) { doc_ = f; has_doc_ = true; has_bits_ = false; }
-  bool has_doc_filter() const { return has_doc_; }
-  bool has_any_filter() const { return has_doc_ || has_bits_ || filter_.is_valid(); }
-  void take_single(IndexDocumentList &&list) { results_.assign(1, IndexDocumentList()); results_[0] = std::move(list); }
-  const zvec_hip_doc_filter_t &doc_filter() const { return doc_; }
-  std::vector<uint64_t> &bits() { return bits_; }
   const IndexDocumentList &result() const { return results_.at(0); }
   const IndexDocumentList &result(size_t i) const { return results_.at(i); }
   IndexDocumentList *mutable_result(size_t i) { return &results_.at(i); }
@@ -211,23 +178,20 @@ class Context {
   void set_magic(uint32_t m) { magic_ = m; }
   zvec_hip_ctx_t handle() const { return h_; }
 
-  // host sweep of the callback over the keys of the storage positions -> bitset
-  const uint64_t *materialise(const std::vector<uint64_t> &keys_by_position) {
-    if (has_bits_) return bits_.data();
-    if (!filter_.is_valid()) return nullptr;
-    bits_.assign((keys_by_position.size() + 63) / 64, 0);
-    for (size_t i = 0; i < keys_by_position.size(); ++i)
-      if (keys_by_position[i] != ~0ull && filter_(keys_by_position[i])) bits_[i >> 6] |= (1ull << (i & 63));   // (holes carry kInvalidKey)
-    return bits_.data();
-  }
-  void take(uint32_t count, uint32_t topk, const std::vector<uint64_t> &keys, const std::vector<float> &scores,
-            const std::vector<uint32_t> &counts) {
-    results_.assign(count, IndexDocumentList());
-    for (uint32_t q = 0; q < count; ++q) {
-      results_[q].reserve(counts[q]);
-      for (uint32_t j = 0; j < counts[q]; ++j) results_[q].emplace_back(keys[(size_t)q * topk + j], scores[(size_t)q * topk + j]);
-    }
-  }
+  // ---- what zvec_hip_op::FlatOperator / IVFOperator read (zvec_hip_operator.hpp, "Requirements on the template arguments")
+  zvec_hip_ctx_t hip() const { return h_; }
+  bool op_has_filter() const { return filter_.is_valid(); }
+  bool op_filtered(uint64_t key) const { return filter_(key); }
+  bool op_has_group_by() const { return (bool)group_by_; }
+  std::string op_group_of(uint64_t key) const { return group_by_(key); }
+  uint32_t op_group_num() const { return group_num_; }
+  uint32_t op_group_topk() const { return group_topk_; }
+  const uint64_t *op_preset_bits() const { return has_bits_ ? bits_.data() : nullptr; }
+  const zvec_hip_doc_filter_t *op_doc_filter() const { return has_doc_ ? &doc_ : nullptr; }
+  zvec_hip_op::Scratch &op_scratch() { return scratch_; }
+  std::vector<IndexDocumentList> &op_results() { return results_; }
+  std::vector<IndexGroupDocumentList> &op_group_results() { return group_results_; }
+
  private:
   zvec_hip_ctx_t h_{nullptr};
   int rc_{0};
@@ -244,145 +208,36 @@ class Context {
   uint32_t group_num_{0}, group_topk_{0};
   std::function<std::string(uint64_t)> group_by_;
   std::vector<IndexGroupDocumentList> group_results_{1};
+  zvec_hip_op::Scratch scratch_;
 };
 
-// fetch_vector: one gather of the stored rows of every result document (key -> position through `pos_of_key`,
-// built lazily from the keys the index holds), then the rows are attached to the documents
-template <typename GetRows>
-inline int attach_result_vectors(Context *ctx, uint32_t count, size_t row_bytes, const std::vector<uint64_t> &keys_by_pos,
-                                 std::unordered_map<uint64_t, uint64_t> *pos_of_key, std::mutex *map_mu, GetRows &&get_rows) {
-  std::vector<uint64_t> pos;
-  {
-    // searches are const and run concurrently (index_runner.h:490-531): the lazily built map is shared mutable state
-    std::lock_guard<std::mutex> g(*map_mu);
-    if (pos_of_key->size() != keys_by_pos.size()) {
-      pos_of_key->clear();
-      pos_of_key->reserve(keys_by_pos.size());
-      for (uint64_t i = 0; i < keys_by_pos.size(); ++i) pos_of_key->emplace(keys_by_pos[i], i);
-    }
-    for (uint32_t q = 0; q < count; ++q)
-      for (const auto &d : ctx->result(q)) {
-        auto it = pos_of_key->find(d.key());
-        if (it == pos_of_key->end()) return IndexError_NoExist;
-        pos.push_back(it->second);
-      }
-  }
-  if (pos.empty()) return 0;
-  std::vector<char> rows(pos.size() * row_bytes);
-  int rc = get_rows(pos.data(), pos.size(), rows.data());
-  if (rc != 0) return rc;
-  size_t o = 0;
-  for (uint32_t q = 0; q < count; ++q)
-    for (auto &d : *ctx->mutable_result(q)) d.set_vector(rows.data() + (o++) * row_bytes, row_bytes);
-  return 0;
+// the mirror's document types, as the shared operator logic needs them
+struct MirrorDocs {
+  using Document = IndexDocument;
+  using DocumentList = IndexDocumentList;
+  using GroupDocument = GroupIndexDocument;
+  using GroupDocumentList = IndexGroupDocumentList;
+  static Document make(uint64_t key, float score) { return IndexDocument(key, score); }
+  static void attach(Document &d, uint32_t /*index*/, const char *row, size_t bytes) { d.set_vector(row, bytes); }   // (owned copy)
+};
+
+inline zvec_hip_op::BatcherOptions batcher_options(const Params &params) {
+  zvec_hip_op::BatcherOptions bo;
+  double v;
+  if (params.get(PARAM_HIP_SEARCHER_BATCH_WINDOW_US, &v)) bo.window_us = (uint32_t)v;
+  if (params.get(PARAM_HIP_SEARCHER_MAX_BATCH, &v)) bo.max_batch = (uint32_t)v;
+  if (params.get(PARAM_HIP_SEARCHER_BATCH_LINGER_US, &v)) bo.linger_us = (uint32_t)v;
+  return bo;
 }
-
-// ---- micro-batcher -------------------------------------------------------------------------------
-// The product drives boundary B with ONE query per call from many threads (index.cc:617), which leaves the GPU at a
-// few thousand searches per second, while one batched call answers 1024 queries in 5 ms.  The batcher turns the
-// former into the latter behind the same single-query entry point: concurrent callers with the same topk join an open
-// batch; the first one in becomes its leader, keeps the batch open while an earlier batch is still searching (at most
-// until it is full or `window_us` has passed), runs ONE batched search and hands every caller its own result list.
-// A lone caller on an idle index is not delayed at all; under load the batches grow by themselves.  Callers with a filter / threshold / fetch_vector bypass it (their searches are not interchangeable).
-class MicroBatcher {
- public:
-  // runs a batched search of `count` queries (row-major, row_bytes each) and fills keys/scores [count][topk] + counts
-  using RunFn = std::function<int(const void *queries, uint32_t count, uint32_t topk, std::vector<uint64_t> *keys,
-                                  std::vector<float> *scores, std::vector<uint32_t> *counts)>;
-  // linger_us: how long a leader keeps its batch open even when nothing else is searching (0 = a lone caller is never
-  // delayed; a few tens of microseconds let callers that arrive in a burst share the first batch too)
-  MicroBatcher(size_t row_bytes, uint32_t max_batch, uint32_t window_us, uint32_t linger_us, RunFn fn)
-      : row_bytes_(row_bytes), max_batch_(std::max<uint32_t>(1, max_batch)), window_us_(window_us),
-        linger_us_(std::min(linger_us, window_us)), fn_(std::move(fn)) {}
-
-  int search(const void *query, uint32_t topk, IndexDocumentList *out) {
-    std::shared_ptr<Batch> b;
-    bool leader = false;
-    uint32_t slot = 0;
-    {
-      std::unique_lock<std::mutex> lk(mu_);
-      // join the open batch if it takes this topk and has room; otherwise wait for it to close and open a new one
-      while (open_ && (open_->topk != topk || open_->n >= max_batch_)) cv_.wait(lk);
-      b = open_;
-      if (!b) {
-        b = std::make_shared<Batch>();
-        b->topk = topk;
-        const auto now = std::chrono::steady_clock::now();
-        b->deadline = now + std::chrono::microseconds(window_us_);
-        b->linger = now + std::chrono::microseconds(linger_us_);
-        open_ = b;
-        leader = true;
-      }
-      slot = b->n++;
-      b->queries.insert(b->queries.end(), static_cast<const char *>(query), static_cast<const char *>(query) + row_bytes_);
-      if (b->n >= max_batch_) cv_.notify_all();
-      if (leader) {
-        // collect while an earlier batch is still searching (no added latency on an idle index: a lone caller goes
-        // at once unless a linger is configured), at most until the batch is full or the window has passed
-        while (b->n < max_batch_) {
-          const auto now = std::chrono::steady_clock::now();
-          const auto until = inflight_ > 0 ? b->deadline : b->linger;
-          if (now >= until) break;
-          cv_.wait_until(lk, until);
-        }
-        open_.reset();                    // the next arrival opens (and leads) the next batch
-        ++inflight_;
-        cv_.notify_all();
-      }
-    }
-    if (leader) {
-      const int rc = fn_(b->queries.data(), b->n, topk, &b->keys, &b->scores, &b->counts);
-      {
-        std::lock_guard<std::mutex> g(mu_);
-        --inflight_;
-        cv_.notify_all();                 // a leader that was collecting behind this batch may go now
-      }
-      {
-        std::lock_guard<std::mutex> g(b->mu); // the members of THIS batch wait on its own lock: no stampede on mu_
-        b->rc = rc;
-        b->done = true;
-      }
-      b->cv.notify_all();
-    } else {
-      std::unique_lock<std::mutex> bl(b->mu);
-      while (!b->done) b->cv.wait(bl);
-    }
-    if (b->rc != 0) return b->rc;
-    out->clear();
-    for (uint32_t j = 0; j < b->counts[slot]; ++j)
-      out->emplace_back(b->keys[(size_t)slot * topk + j], b->scores[(size_t)slot * topk + j]);
-    return 0;
-  }
-
- private:
-  struct Batch {
-    uint32_t topk = 0, n = 0;
-    bool done = false;
-    int rc = 0;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::chrono::steady_clock::time_point deadline, linger;
-    std::vector<char> queries;
-    std::vector<uint64_t> keys;
-    std::vector<float> scores;
-    std::vector<uint32_t> counts;
-  };
-  size_t row_bytes_;
-  uint32_t max_batch_, window_us_, linger_us_;
-  RunFn fn_;
-  std::mutex mu_;
-  std::condition_variable cv_;
-  std::shared_ptr<Batch> open_;
-  uint32_t inflight_ = 0;      // batches currently searching
-};
 
 // ---- flat: one class body serves the "FlatStreamer" and "FlatSearcher" registrations -------------
 class HipFlatStreamer {
  public:
   ~HipFlatStreamer() { close(); }
-  int init(const IndexMeta &meta, const Params & /*params*/) {
+  int init(const IndexMeta &meta, const Params &params) {
     meta_ = meta;
     metric_ = metric_from_name(meta.metric_name());
+    bo_ = batcher_options(params);
     if (metric_ < 0 || (meta.data_type() != IndexMeta::DT_FP32 && meta.data_type() != IndexMeta::DT_FP16)) return IndexError_Unsupported;
     return 0;
   }
@@ -390,75 +245,41 @@ class HipFlatStreamer {
     device_ = device;
     static std::atomic<uint32_t> next_magic{0x48495031u};    // IndexContext::GenerateMagic (index_context.cc:22-25)
     magic_ = next_magic.fetch_add(1);
-    return zvec_hip_flat_create(meta_.dimension(), meta_.data_type() == IndexMeta::DT_FP16 ? ZVEC_HIP_DT_FP16 : ZVEC_HIP_DT_FP32,
-                                metric_, device, &h_);
+    // add_with_id keeps the reference's "storage position == id" rule here (FlatStreamerEntity::add_vector_with_id)
+    return op_.create(meta_.dimension(), meta_.data_type() == IndexMeta::DT_FP16 ? ZVEC_HIP_DT_FP16 : ZVEC_HIP_DT_FP32, metric_,
+                      meta_.element_size(), device, 1, /*position_is_id=*/true, bo_);
   }
-  int close() { int rc = h_ ? zvec_hip_flat_destroy(h_) : 0; h_ = nullptr; return rc; }
+  int close() { op_.destroy(); return 0; }
   const IndexMeta &meta() const { return meta_; }
   uint32_t magic() const { return magic_; }
   Context::Pointer create_context() const {
-    if (!h_) return nullptr;
+    if (!op_.ready()) return nullptr;
     Context::Pointer c(new Context(device_, magic_));
     return c->ok() ? std::move(c) : nullptr;
   }
   //! Add a vector into index (index_runner.h:476-480)
   int add_impl(uint64_t key, const void *query, const IndexQueryMeta &qmeta, Context::Pointer & /*context*/) {
-    if (!h_ || !query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
-    std::unique_lock<FairSharedMutex> w(keys_mu_);    // add vs search: flat_streamer.cc:236-242, flat_streamer_entity.cc:150
-    int rc = zvec_hip_flat_append(h_, query, 1, &key);
-    if (rc == 0) keys_.push_back(key);
-    return rc;
+    if (!op_.ready() || !query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
+    return op_.append(query, 1, &key);
   }
-  //! Add a vector with id into index (index_runner.h:483-487) — the call core_interface::Index::_dense_add makes.
-  //! FlatStreamerEntity::add_vector_with_id (flat_streamer_entity.cc:900-990): position == id == key; ids beyond the count
-  //! leave holes (kInvalidKey rows no search returns), an id below the count overwrites in place
+  //! Add a vector with id into index (index_runner.h:483-487) — the call core_interface::Index::_dense_add makes
   int add_with_id_impl(uint32_t id, const void *query, const IndexQueryMeta &qmeta, Context::Pointer & /*context*/) {
-    if (!h_ || !query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
-    std::unique_lock<FairSharedMutex> w(keys_mu_);
-    int rc = zvec_hip_flat_put(h_, &id, 1, query, nullptr);
-    if (rc != 0) return rc;
-    if (keys_.size() <= id) keys_.resize((size_t)id + 1, kInvalidKey);
-    keys_[id] = id;
-    return 0;
+    if (!op_.ready() || !query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
+    return op_.put(id, query);
   }
-  static constexpr uint64_t kInvalidKey = ~0ull;              // flat_index_format.h:29
+  static constexpr uint64_t kInvalidKey = zvec_hip_op::kInvalidKey;              // flat_index_format.h:29
   //! bulk form used by FlatBuilder::build / FlatSearcher::load (flat_builder.cc:188-276)
   int add_batch(const void *vecs, uint64_t n, const uint64_t *keys) {
-    if (!h_) return IndexError_InvalidArgument;
-    std::unique_lock<FairSharedMutex> w(keys_mu_);
-    int rc = zvec_hip_flat_append(h_, vecs, n, keys);
-    if (rc == 0) for (uint64_t i = 0; i < n; ++i) keys_.push_back(keys ? keys[i] : keys_.size());
-    return rc;
+    if (!op_.ready()) return IndexError_InvalidArgument;
+    return op_.append(vecs, n, keys);
   }
   //! Similarity search (index_runner.h:490-500)
   int search_impl(const void *query, const IndexQueryMeta &qmeta, Context::Pointer &context) const {
     return search_impl(query, qmeta, 1, context);
   }
   int search_impl(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context) const {
-    if (!h_ || !query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;
-    Context *ctx = context.get();
-    if (!ctx || (ctx->topk() == 0 && !ctx->group_by_search())) return IndexError_InvalidArgument;    // flat_searcher.cc:194-198
-    if (ctx->magic() != magic_) ctx->set_magic(magic_);                 // context made by another index: re-bind
-    std::shared_lock<FairSharedMutex> r(keys_mu_);    // keys_ (filter sweep, bitset size, fetch_vector) vs add
-    if (ctx->group_by_search()) return group_search(query, count, ctx, nullptr, nullptr);   // flat_streamer.cc:323-324
-    const uint32_t k = ctx->topk();
-    std::vector<uint64_t> keys((size_t)count * k);
-    std::vector<float> scores((size_t)count * k);
-    std::vector<uint32_t> counts(count);
-    const uint64_t *bits = nullptr;
-    if (ctx->has_doc_filter()) {            // composite filter as data: materialised on the GPU
-      ctx->bits().assign((keys_.size() + 63) / 64, 0);
-      int frc = zvec_hip_flat_build_filter(h_, ctx->handle(), &ctx->doc_filter(), ctx->bits().data(), 0, nullptr);
-      if (frc != 0) return frc;
-      bits = ctx->bits().data();
-    } else {
-      bits = ctx->materialise(keys_);
-    }
-    int rc = zvec_hip_flat_search(h_, ctx->handle(), query, count, k, ctx->threshold(), bits,
-                                  keys.data(), scores.data(), counts.data());
-    if (rc != 0) return rc;
-    ctx->take(count, k, keys, scores, counts);
-    return ctx->fetch_vector() ? attach_vectors(ctx, count) : 0;
+    Context *ctx = bind(query, qmeta, context);
+    return ctx ? op_.search(query, count, ctx) : (int)IndexError_InvalidArgument;
   }
   //! Similarity brute force search (index_runner.h:520-531): the flat scan is the brute force
   int search_bf_impl(const void *query, const IndexQueryMeta &qmeta, Context::Pointer &context) const {
@@ -470,94 +291,32 @@ class HipFlatStreamer {
   //! Linear search by primary keys (index_runner.h:579-585; flat_streamer.cc:346-389): unknown keys are skipped
   int search_bf_by_p_keys_impl(const void *query, const std::vector<std::vector<uint64_t>> &p_keys, const IndexQueryMeta &qmeta,
                                uint32_t count, Context::Pointer &context) const {
-    if (!h_ || !query || qmeta.element_size() != meta_.element_size() || p_keys.size() != count) return IndexError_InvalidArgument;
-    Context *ctx = context.get();
-    if (!ctx || (ctx->topk() == 0 && !ctx->group_by_search())) return IndexError_InvalidArgument;
-    if (ctx->magic() != magic_) ctx->set_magic(magic_);
-    std::shared_lock<FairSharedMutex> r(keys_mu_);
-    std::vector<uint32_t> ids, offs(count + 1, 0);
-    {
-      std::lock_guard<std::mutex> g(map_mu_);
-      if (pos_of_key_.size() != keys_.size()) {
-        pos_of_key_.clear();
-        for (uint64_t i = 0; i < keys_.size(); ++i) pos_of_key_.emplace(keys_[i], i);
-      }
-      for (uint32_t q = 0; q < count; ++q) {
-        for (uint64_t key : p_keys[q]) {
-          auto it = pos_of_key_.find(key);
-          if (it != pos_of_key_.end()) ids.push_back((uint32_t)it->second);
-        }
-        offs[q + 1] = (uint32_t)ids.size();
-      }
-    }
-    if (ids.empty()) ids.push_back(0);
-    if (ctx->group_by_search()) return group_search(query, count, ctx, ids.data(), offs.data());   // flat_streamer.cc:365-366
-    const uint32_t k = ctx->topk();
-    std::vector<uint64_t> keys((size_t)count * k);
-    std::vector<float> scores((size_t)count * k);
-    std::vector<uint32_t> counts(count);
-    int rc = zvec_hip_flat_search_by_ids(h_, ctx->handle(), query, count, ids.data(), offs.data(), k, ctx->threshold(),
-                                         ctx->materialise(keys_), keys.data(), scores.data(), counts.data());
-    if (rc != 0) return rc;
-    ctx->take(count, k, keys, scores, counts);
-    return ctx->fetch_vector() ? attach_vectors(ctx, count) : 0;
+    Context *ctx = bind(query, qmeta, context);
+    return ctx ? op_.search_by_keys(query, p_keys, count, ctx) : (int)IndexError_InvalidArgument;
   }
   //! Fetch vector by id (index_runner.h:445-453)
   int get_vector_by_id(uint32_t id, std::vector<float> *out) const {
-    if (!h_) return IndexError_InvalidArgument;
+    if (!op_.ready()) return IndexError_InvalidArgument;
     out->resize(meta_.dimension());
-    return zvec_hip_flat_get_vector(h_, id, out->data());
+    return op_.vector_of_pos(id, out->data());
   }
-  uint64_t count() const { uint64_t n = 0; if (h_) zvec_hip_flat_count(h_, &n); return n; }
- protected:
-  //! group_by_search_impl / group_by_search_p_keys_impl (flat_streamer.cc:391-483) + topk_to_group_result
-  //! (flat_streamer_context.h:135-180); the caller holds keys_mu_ shared.  ids == nullptr: every row competes
-  int group_search(const void *query, uint32_t count, Context *ctx, const uint32_t *ids, const uint32_t *offs) const {
-    if (!ctx->group_by_valid()) return IndexError_InvalidArgument;     // "Invalid group-by function"
-    const uint32_t gnum = ctx->group_num(), gk = ctx->group_topk();
-    if (gk == 0) return IndexError_InvalidArgument;
-    std::vector<uint32_t> group_of;
-    std::vector<std::string> group_ids;
-    ctx->sweep_groups(keys_, &group_of, &group_ids);
-    const size_t rows = (size_t)count * gnum;
-    std::vector<uint64_t> keys(rows * gk);
-    std::vector<float> scores(rows * gk);
-    std::vector<uint32_t> counts(rows), groups(rows), ngroups(count);
-    const uint32_t none = 0;
-    const uint32_t *gof = group_of.empty() ? &none : group_of.data();
-    const uint32_t ng = std::max<uint32_t>(1u, (uint32_t)group_ids.size());
-    const uint64_t *bits = ctx->materialise(keys_);
-    int rc = ids ? zvec_hip_flat_search_grouped_by_ids(h_, ctx->handle(), query, count, ids, offs, gof, ng, gnum, gk, ctx->threshold(),
-                                                       bits, groups.data(), ngroups.data(), keys.data(), scores.data(), counts.data())
-                 : zvec_hip_flat_search_grouped(h_, ctx->handle(), query, count, gof, ng, gnum, gk, ctx->threshold(), bits,
-                                                groups.data(), ngroups.data(), keys.data(), scores.data(), counts.data());
-    if (rc != 0) return rc;
-    auto &res = ctx->mutable_group_results();
-    res.assign(count, IndexGroupDocumentList());
-    for (uint32_t q = 0; q < count; ++q) {
-      res[q].resize(ngroups[q]);
-      for (uint32_t s = 0; s < ngroups[q]; ++s) {
-        const size_t row = (size_t)q * gnum + s;
-        res[q][s].set_group_id(group_ids[groups[row]]);
-        for (uint32_t j = 0; j < counts[row]; ++j) res[q][s].mutable_docs()->emplace_back(keys[row * gk + j], scores[row * gk + j]);
-      }
-    }
-    return 0;
+  uint64_t count() const { uint64_t n = 0; if (op_.handle()) zvec_hip_flat_count(op_.handle(), &n); return n; }
+
+ private:
+  //! flat_searcher.cc:194-198 "Invalid context or topk not set yet"; a context made by another index is re-bound
+  Context *bind(const void *query, const IndexQueryMeta &qmeta, Context::Pointer &context) const {
+    if (!op_.ready() || !query || qmeta.element_size() != meta_.element_size()) return nullptr;
+    Context *ctx = context.get();
+    if (!ctx || (ctx->topk() == 0 && !ctx->group_by_search())) return nullptr;
+    if (ctx->magic() != magic_) ctx->set_magic(magic_);
+    return ctx;
   }
   IndexMeta meta_;
   int metric_{0};
   int device_{0};
   uint32_t magic_{0};
-  zvec_hip_flat_t h_{nullptr};
-  std::vector<uint64_t> keys_;
-  mutable FairSharedMutex keys_mu_;
-  mutable std::mutex map_mu_;
-  mutable std::unordered_map<uint64_t, uint64_t> pos_of_key_;
-  int attach_vectors(Context *ctx, uint32_t count) const {
-    zvec_hip_flat_t h = h_;
-    return attach_result_vectors(ctx, count, meta_.element_size(), keys_, &pos_of_key_, &map_mu_,
-                                 [h](const uint64_t *p, size_t n, void *out) { return zvec_hip_flat_get_vectors(h, p, n, out); });
-  }
+  zvec_hip_op::BatcherOptions bo_;
+  zvec_hip_op::FlatOperator<Context, MirrorDocs> op_;
 };
 using HipFlatSearcher = HipFlatStreamer;
 
@@ -569,9 +328,7 @@ class HipIVFSearcher {
     double v;
     if (params.get(PARAM_IVF_SEARCHER_SCAN_RATIO, &v)) scan_ratio_ = (float)v;
     if (params.get(PARAM_IVF_SEARCHER_BRUTE_FORCE_THRESHOLD, &v)) bruteforce_threshold_ = (uint32_t)v;
-    if (params.get(PARAM_HIP_SEARCHER_BATCH_WINDOW_US, &v)) batch_window_us_ = (uint32_t)v;
-    if (params.get(PARAM_HIP_SEARCHER_MAX_BATCH, &v)) max_batch_ = (uint32_t)v;
-    if (params.get(PARAM_HIP_SEARCHER_BATCH_LINGER_US, &v)) batch_linger_us_ = (uint32_t)v;
+    bo_ = batcher_options(params);
     if (scan_ratio_ <= 0.0f) return IndexError_InvalidArgument;   // ivf_searcher_context.h:65-69
     return 0;
   }
@@ -585,64 +342,24 @@ class HipIVFSearcher {
     device_ = device;
     static std::atomic<uint32_t> next_magic{0x49564631u};
     magic_ = next_magic.fetch_add(1);
-    int rc = zvec_hip_ivf_create(meta.dimension(), meta.data_type() == IndexMeta::DT_FP16 ? ZVEC_HIP_DT_FP16 : ZVEC_HIP_DT_FP32,
-                                 metric, device, &h_);
+    int rc = op_.create(meta.dimension(), meta.data_type() == IndexMeta::DT_FP16 ? ZVEC_HIP_DT_FP16 : ZVEC_HIP_DT_FP32, metric,
+                        meta.element_size(), device, 1, bo_);
     if (rc != 0) return rc;
-    rc = zvec_hip_ivf_load(h_, centroids, nlist, list_offsets, vecs, keys);
-    if (rc != 0) return rc;
-    nlist_ = nlist;
-    count_ = list_offsets[nlist];
-    keys_.resize(count_);
-    for (uint64_t i = 0; i < count_; ++i) keys_[i] = keys ? keys[i] : i;
-    if (batch_window_us_ > 0) {
-      batcher_.reset(new MicroBatcher(meta_.element_size(), max_batch_, batch_window_us_, batch_linger_us_,
-          [this](const void *q, uint32_t n, uint32_t k, std::vector<uint64_t> *ks, std::vector<float> *sc, std::vector<uint32_t> *cn) {
-            // a small pool of workspaces shared by the leaders (any thread may lead a batch; creating a context —
-            // a stream plus its buffers — per thread would cost more than the searches)
-            std::unique_ptr<Context> c;
-            {
-              std::lock_guard<std::mutex> g(pool_mu_);
-              if (!pool_.empty()) { c = std::move(pool_.back()); pool_.pop_back(); }
-            }
-            if (!c) c.reset(new Context(device_, magic_));
-            if (!c->ok()) return (int)IndexError_Runtime;
-            ks->assign((size_t)n * k, 0);
-            sc->assign((size_t)n * k, 0.f);
-            cn->assign(n, 0);
-            int rc = zvec_hip_ivf_search(h_, c->handle(), q, n, k, FLT_MAX, nprobe(), max_scan_count(), nullptr, ks->data(),
-                                         sc->data(), cn->data());
-            std::lock_guard<std::mutex> g(pool_mu_);
-            pool_.push_back(std::move(c));
-            return rc;
-          }));
-    }
-    return 0;
+    return op_.load_arrays(centroids, nlist, list_offsets, vecs, keys);
   }
-  int unload() { batcher_.reset(); pool_.clear(); int rc = h_ ? zvec_hip_ivf_destroy(h_) : 0; h_ = nullptr; return rc; }
+  int unload() { op_.destroy(); return 0; }
   Context::Pointer create_context() const {
-    if (!h_) return nullptr;                                   // "Load the index first" ivf_searcher.cc:257-260
+    if (!op_.ready()) return nullptr;                          // "Load the index first" ivf_searcher.cc:257-260
     Context::Pointer c(new Context(device_, magic_));
     return c->ok() ? std::move(c) : nullptr;
   }
   // IVFSearcherContext::update (ivf_searcher_context.h:61-79)
-  uint32_t nprobe() const { return std::max<uint32_t>((uint32_t)std::round((float)nlist_ * scan_ratio_), 1u); }
-  uint32_t max_scan_count() const {
-    uint32_t m = (uint32_t)std::ceil((float)count_ * scan_ratio_);
-    return std::max(bruteforce_threshold_, m);
-  }
+  uint32_t nprobe() const { return zvec_hip_op::probe_params(op_.nlist(), op_.count(), scan_ratio_, bruteforce_threshold_).nprobe; }
+  uint32_t max_scan_count() const { return zvec_hip_op::probe_params(op_.nlist(), op_.count(), scan_ratio_, bruteforce_threshold_).max_scan; }
   int search_impl(const void *query, const IndexQueryMeta &qmeta, Context::Pointer &context) const {
     return search_impl(query, qmeta, 1, context);
   }
   int search_impl(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context) const {
-    if (h_ && count_ <= bruteforce_threshold_) return search_bf_impl(query, qmeta, count, context);   // ivf_searcher.cc:188-190
-    Context *ctx = context.get();
-    if (batcher_ && count == 1 && h_ && query && ctx && ctx->topk() != 0 && qmeta.element_size() == meta_.element_size() &&
-        !ctx->has_any_filter() && !ctx->fetch_vector() && ctx->threshold() == FLT_MAX) {
-      IndexDocumentList r;                       // single plain query: ride a shared batch (MicroBatcher)
-      int rc = batcher_->search(query, ctx->topk(), &r);
-      if (rc == 0) ctx->take_single(std::move(r));
-      return rc;
-    }
     return run(query, qmeta, count, context, false);
   }
   int search_bf_impl(const void *query, const IndexQueryMeta &qmeta, Context::Pointer &context) const {
@@ -651,52 +368,24 @@ class HipIVFSearcher {
   int search_bf_impl(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context) const {
     return run(query, qmeta, count, context, true);
   }
+  zvec_hip_op::MicroBatcher<MirrorDocs>::Stats batcher_stats() const { return op_.batcher_stats(); }
+
  private:
   int run(const void *query, const IndexQueryMeta &qmeta, uint32_t count, Context::Pointer &context, bool bf) const {
-    if (!h_) return IndexError_NoIndexLoaded;
+    if (!op_.ready()) return IndexError_NoIndexLoaded;
     if (!query || qmeta.element_size() != meta_.element_size()) return IndexError_InvalidArgument;   // ivf_searcher.cc:191-194
     Context *ctx = context.get();
     if (!ctx || ctx->topk() == 0) return IndexError_InvalidArgument;                                 // ivf_searcher.cc:197-200
     if (ctx->magic() != magic_) ctx->set_magic(magic_);
-    const uint32_t k = ctx->topk();
-    std::vector<uint64_t> keys((size_t)count * k);
-    std::vector<float> scores((size_t)count * k);
-    std::vector<uint32_t> counts(count);
-    const uint64_t *bits = nullptr;
-    if (ctx->has_doc_filter()) {
-      ctx->bits().assign((keys_.size() + 63) / 64, 0);
-      int frc = zvec_hip_ivf_build_filter(h_, ctx->handle(), &ctx->doc_filter(), ctx->bits().data(), 0, nullptr);
-      if (frc != 0) return frc;
-      bits = ctx->bits().data();
-    } else {
-      bits = ctx->materialise(keys_);
-    }
-    int rc = bf ? zvec_hip_ivf_search_bf(h_, ctx->handle(), query, count, k, ctx->threshold(), bits, keys.data(),
-                                         scores.data(), counts.data())
-                : zvec_hip_ivf_search(h_, ctx->handle(), query, count, k, ctx->threshold(), nprobe(), max_scan_count(),
-                                      bits, keys.data(), scores.data(), counts.data());
-    if (rc != 0) return rc;
-    ctx->take(count, k, keys, scores, counts);
-    if (!ctx->fetch_vector()) return 0;
-    zvec_hip_ivf_t h = h_;
-    return attach_result_vectors(ctx, count, meta_.element_size(), keys_, &pos_of_key_, &map_mu_,
-                                 [h](const uint64_t *p, size_t n, void *out) { return zvec_hip_ivf_get_vectors(h, p, n, out); });
+    return op_.search(query, count, ctx, bf, scan_ratio_, bruteforce_threshold_);
   }
-  mutable std::mutex map_mu_;
-  mutable std::unordered_map<uint64_t, uint64_t> pos_of_key_;
-  std::unique_ptr<MicroBatcher> batcher_;
-  mutable std::mutex pool_mu_;
-  mutable std::vector<std::unique_ptr<Context>> pool_;
-  uint32_t batch_window_us_{0}, max_batch_{1024}, batch_linger_us_{0};
+  zvec_hip_op::BatcherOptions bo_;
   IndexMeta meta_;
   int device_{0};
   uint32_t magic_{0};
-  zvec_hip_ivf_t h_{nullptr};
-  uint32_t nlist_{0};
-  uint64_t count_{0};
   float scan_ratio_{0.1f};                 // kDefaultScanRatio  ivf_searcher_context.h:211
   uint32_t bruteforce_threshold_{1000u};   // kDefaultBfThreshold ivf_searcher_context.h:212
-  std::vector<uint64_t> keys_;
+  zvec_hip_op::IVFOperator<Context, MirrorDocs> op_;
 };
 
 // "IVFStreamer" is what the product instantiates (indexes/ivf_index.cc:38-39); in the reference it is the same read-only

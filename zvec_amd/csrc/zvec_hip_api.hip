@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <sched.h>
+#include <time.h>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
