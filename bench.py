@@ -74,7 +74,12 @@ def parse_args():
     ap.add_argument("--nprobe", type=int, default=0)
     ap.add_argument("--nlist", type=int, default=0)
     ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--kmeans-iters", type=int, default=10)
+    ap.add_argument("--kmeans-iters", type=int, default=0, help="0 = what --train says")
+    ap.add_argument("--train", default="auto", choices=["auto", "reference", "quick"],
+                    help="IVF training: reference = the reference trainer's setting, 20 Lloyd rounds over EVERY row (tests/golden/"
+                         "kmeans_quality.json: the GPU build then lands inside the spread of the reference's own trainer); quick = 10 rounds "
+                         "on a strided 256-rows-per-list sample (SSE 1.2 %% higher, recall@10 at equal nprobe ~3 points lower on that "
+                         "fixture); auto = reference when the raw rows fit beside the index (<= 48 GB), else quick")
     ap.add_argument("--gt-queries", type=int, default=0, help="queries recall is measured on (0 = the timed batch)")
     ap.add_argument("--intrinsic-dim", type=int, default=12)
     ap.add_argument("--target-recall", type=float, default=0.99)
@@ -88,6 +93,10 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=2,
                     help="IVF workloads: consecutive (independent) batches alternate over this many contexts / HIP streams: "
                          "the small kernels of batch i+-1 run around batch i's list scan")
+    ap.add_argument("--deal-coarse", action="store_true",
+                    help="N > 1 IVF: the coarse pass dealt over the ranks (rank r scores 1/N of the batch, one all-gather of the probe "
+                         "lists, every rank plans from them; zvec_amd.dist.ShardedIVF(deal_coarse=True)).  Off by default: it trades "
+                         "7/8 of the 67 us coarse pass for a second small collective per step, which only an N-GPU run can price")
     ap.add_argument("--keep", type=float, default=0.1, help="filter workloads: fraction of rows the bitmap keeps")
     ap.add_argument("--flat-threshold", type=float, default=None,
                     help="diagnostic: RNN radius for the flat workloads (a huge negative value admits nothing => distance-only time)")
@@ -312,7 +321,16 @@ def main():
         ivf = zvec_amd.HipIVFSearcher(dim, "SquaredEuclidean", device=local_rank, dtype=dtype)
         zvec_amd._lib.check(ivf.set_shard(shard, nshards), "set_shard")
         # ---------------- pass A: ground-truth flat shard + the k-means sample ----------------
-        S = min(n, 256 * nlist)
+        train = args.train
+        if train == "auto":
+            train = "reference" if n * dim * (2 if dtype == "fp16" else 4) <= 48e9 else "quick"
+        kmeans_iters = args.kmeans_iters or (20 if train == "reference" else 10)
+        S = n if train == "reference" else min(n, 256 * nlist)
+        extra_cfg["index_training"] = (
+            "GPU k-means, %d Lloyd rounds over %s" % (kmeans_iters, "every row (the reference trainer's setting)" if S == n else
+                                                     "a strided sample of %d rows (256 per list: the quick setting, below the reference "
+                                                     "trainer's clustering quality; QPS does not depend on it — a 1024-query batch streams "
+                                                     "every list either way — the nprobe needed for the recall target does)" % S))
         sample_ids = (np.arange(S, dtype=np.uint64) * np.uint64(n)) // np.uint64(S)    # the strided sample of zvec_hip_ivf_build
         sample = torch.empty((S, dim), device=dev, dtype=tdtype)
         flat = None
@@ -323,9 +341,12 @@ def main():
         t1 = time.time()
         for o, x in corpus_chunks(torch, n, dim, dev, SEED, proj, tdtype):
             m = x.shape[0]
-            i0, i1 = np.searchsorted(sample_ids, [o, o + m])
-            if i1 > i0:
-                sample[i0:i1] = x[torch.from_numpy((sample_ids[i0:i1] - np.uint64(o)).astype(np.int64)).to(dev)]
+            if S == n:
+                sample[o:o + m] = x
+            else:
+                i0, i1 = np.searchsorted(sample_ids, [o, o + m])
+                if i1 > i0:
+                    sample[i0:i1] = x[torch.from_numpy((sample_ids[i0:i1] - np.uint64(o)).astype(np.int64)).to(dev)]
             a, b = max(o, lo), min(o + m, hi)
             if flat is not None and a < b:
                 rows = x[a - o:b - o].contiguous()
@@ -347,14 +368,14 @@ def main():
             torch.cuda.empty_cache()
         # ---------------- train: k-means on the sample (same seed, same rows on every rank) ----------------
         t1 = time.time()
-        zvec_amd._lib.check(ivf.train_dev(sample.data_ptr(), S, nlist, kmeans_iters=args.kmeans_iters, seed=SEED, stream=stream_ptr), "ivf train")
+        zvec_amd._lib.check(ivf.train_dev(sample.data_ptr(), S, nlist, kmeans_iters=kmeans_iters, seed=SEED, stream=stream_ptr), "ivf train")
         del sample
         if world > 1:      # one set of centroids for everybody: rank 0's, bit for bit
             cent = torch.from_numpy(ivf.get_centroids().view(np.uint8)).to(dev)
             coll(dist.broadcast, cent, 0)
             if rank != 0:
                 zvec_amd._lib.check(ivf.set_centroids(cent.cpu().numpy().view(np.float16 if dtype == "fp16" else np.float32)), "set_centroids")
-        log("k-means (%d iters, %d lists, %d sample rows) in %.1fs" % (args.kmeans_iters, nlist, S, time.time() - t1))
+        log("k-means (%d iters, %d lists, %d sample rows) in %.1fs" % (kmeans_iters, nlist, S, time.time() - t1))
         # ---------------- pass B: nearest-centroid labels (chunks dealt round-robin to the ranks) ----------------
         t1 = time.time()
         labels = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -385,7 +406,7 @@ def main():
             time.time() - t1))
         ctx = ivf.create_context()
         ctx.set_stream(stream_ptr)
-        sh = ShardedIVF(ivf, ctx, rank, world)
+        sh = ShardedIVF(ivf, ctx, rank, world, deal_coarse=args.deal_coarse)
         max_scan = n        # brute_force_threshold = N-1 => exactly nprobe lists are probed
         q = queries[:batch].contiguous()
         qpool = [queries[j * batch:(j + 1) * batch].contiguous() for j in range(qpool_n)]
@@ -434,7 +455,7 @@ def main():
                 ctx2 = ivf.create_context()
                 ctx2.set_stream(s2.cuda_stream)
                 ctx2.set_gate(gate)
-                lanes.append((ShardedIVF(ivf, ctx2, rank, world), s2.cuda_stream, s2))
+                lanes.append((ShardedIVF(ivf, ctx2, rank, world, deal_coarse=args.deal_coarse), s2.cuda_stream, s2))
 
         def run_step(i, np_):
             sh_i, sp, ts = lanes[i % len(lanes)]
@@ -508,16 +529,24 @@ def main():
         per_launch_ms = prof["scan_ms"] / max(prof["launches"], 1)
         bytes_per_launch = prof["bytes"] / max(prof["launches"], 1)
         flops_per_launch = prof["flops"] / max(prof["launches"], 1)
-        achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         traffic, traffic_source = committed_traffic(args, world, shard_mode)
         ms_per_step = elapsed / args.steps * 1e3
+        # un-gated lanes: one scan fills the CUs while the previous one drains, so a launch's HIP-event time can exceed the step it
+        # belongs to; a launch cannot take longer than a step in steady state, so the roofline then divides by the STEP time
+        frac_ms, frac_basis = per_launch_ms, "kernel_ms (HIP events around the launch)"
+        if 0 < ms_per_step < per_launch_ms:
+            frac_ms, frac_basis = ms_per_step, "ms_per_step (overlapping lanes: kernel_ms > ms_per_step, see scan_overlap_ms_per_step)"
+        achieved = bytes_per_launch / (frac_ms * 1e-3) / 1e9 if frac_ms > 0 else 0.0
+        box = box_calibration(zvec_amd, local_rank)
         result = {
             "value": batch * args.steps / elapsed,
             "ms_per_step": ms_per_step,
             "roofline": {"bound": "hbm", "kernel": ("zvk::pkeys_topk_kernel (IVF small-batch route: a wave per four probed rows, a block keeps the k best of its 128%s)" if batch <= 8 else "zvk::scan_kernel<1> (IVF list scan%s)") % (", rank 0's shard" if world > 1 or shard_mode else ""),
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_source,
+                         "traffic_source": traffic_source, "frac_basis": frac_basis,
+                         "box_clock_mhz": box.get("clock_mhz"), "box_stream_gbs": box.get("stream_gbs"), "box_note": box.get("note"),
+                         "frac_of_box_stream": (achieved / box["stream_gbs"]) if box.get("stream_gbs") else None,
                          # (un-gated lanes: one scan fills the CUs while the previous one drains, so the step can be
                          # SHORTER than one scan's own HIP-event time; the difference is then reported as overlap)
                          "kernel_ms": per_launch_ms, "fixed_ms_per_step": max(ms_per_step - per_launch_ms, 0.0),
@@ -529,6 +558,8 @@ def main():
             "host_pointer_qps": host_qps,
         }
         extra_cfg["streams"] = len(lanes)
+        if world > 1:
+            extra_cfg["coarse_pass"] = "dealt over the ranks + all-gather of the probe lists" if args.deal_coarse else "replicated on every rank"
         extra_cfg.update({"recall_at_nprobe%d" % nprobe_base: recall_base, "qps_nprobe%d" % nprobe_base: qps_base if qps_base else
                           (result["value"] if nprobe == nprobe_base else None), "recall_queries": ngt})
         if shard_mode:
@@ -643,6 +674,10 @@ def cpu_baseline_flat(torch, base, q, topk, metric_name, args, gpu=None):
         for _ in range(2):
             ok, os_, oc, dt = ref.search_mt(qh, topk, threads)
             best = dt if best is None else min(best, dt)
+        n1 = min(4, nq)
+        one = n1 / ref.search_mt(qh[:n1], topk, 1)[3]
+        phys = all_physical_cores_run(lambda t: ref.search_mt(q[:max(nq, min(q.shape[0], 4 * t))].cpu().numpy(), topk, t)[3],
+                                      max(nq, min(q.shape[0], 4 * (cores.get("physical") or 0))), threads, cores)
         ref.close()
         R.mem_remove("bench_flat")
         kind, what = "reference", "the reference's own FlatBuilder + FlatSearcher::search_impl (libzvec_ref_core.so, -O2 -march=skylake-avx512)"
@@ -655,10 +690,12 @@ def cpu_baseline_flat(torch, base, q, topk, metric_name, args, gpu=None):
             dt = time.perf_counter() - t1
             best = dt if best is None else min(best, dt)
         o.use_reference_kernels(False)
+        one = phys = None
         kind, what = "port", "scan loop = oracle restatement, 1x1 distance kernel = %s" % (
             "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")
     parity = parity_vs_cpu(gpu, ok, os_, oc, nq) if gpu is not None else None
-    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": kind, "parity": parity,
+    return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": kind, "value_1_thread": one, "parity": parity,
+            "all_physical_cores": phys, "cpu_quota_cpus": cpu_quota_cpus(),
             "host_physical_cores": cores.get("physical"), "host_logical_cpus": cores.get("logical"), "host_usable_cpus": cores.get("usable"),
             "sample": "%d queries of the timed batch over the same %d rows, one query per call, %d threads across queries, best of 2; %s" % (
                 nq, host.shape[0], threads, what)}
@@ -723,8 +760,11 @@ def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, top
     f16 = args.workload.endswith("fp16")
     small = batch <= 16         # a handful of queries: the scan streams the base once => HBM-bound
     peak = MFMA_F16_PEAK_TF if f16 else MFMA_F32_PEAK_TF
+    box = box_calibration(zvec_amd, torch.cuda.current_device())
     roof = {"bound": "mfma", "kernel": "zvk::scan8_kernel (flat scan)", "achieved": tf, "peak": peak,
             "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": ms,
+            "frac_basis": "kernel_ms (HIP events around the launch)",
+            "box_clock_mhz": box.get("clock_mhz"), "box_stream_gbs": box.get("stream_gbs"), "box_note": box.get("note"),
             "fixed_ms_per_step": ms_per_step - ms, "algorithmic_bytes": by, "algorithmic_flops": fl,
             "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
     if small:
@@ -732,6 +772,52 @@ def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, top
         roof.update({"bound": "hbm", "kernel": "zvk::scan_kernel<1, M16> (flat scan, <= 16 queries)", "achieved": gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "mfma_tflops": tf})
     return {"value": batch * args.steps / elapsed, "ms_per_step": ms_per_step, "roofline": roof, "cpu_baseline": cpu}
+
+
+def box_calibration(zvec_amd, device):
+    """Per-box calibration in the same process as the timed region (zvec_hip_calibrate): what this box's HBM gives a pure streaming
+    reader (non-temporal 16-byte loads over 30 GB of scratch, best of 3) and the shader clock held under that load — so that 215 k
+    on one box and 205 k on another can be read as box or as code."""
+    import ctypes as C
+    try:
+        import torch
+        free, _ = torch.cuda.mem_get_info(device)
+        nbytes = int(min(30e9, free * 0.8)) // 4096 * 4096
+        mhz, gbs = C.c_double(0), C.c_double(0)
+        rc = zvec_amd._lib.lib().zvec_hip_calibrate(device, None, nbytes, 3, C.byref(mhz), C.byref(gbs))
+        if rc != 0:
+            return {"note": "zvec_hip_calibrate rc %d" % rc}
+        log("box calibration: streaming read %.0f GB/s over %.1f GB, shader clock %.0f MHz under that load" % (gbs.value, nbytes / 1e9, mhz.value))
+        return {"clock_mhz": mhz.value, "stream_gbs": gbs.value,
+                "note": "pure non-temporal streaming read of %.1f GB of scratch HBM in this process right after the timed region, best of 3; "
+                        "clock = d(s_memtime)/d(s_memrealtime) x 100 MHz, median over work-groups, under that load" % (nbytes / 1e9)}
+    except Exception as e:                               # noqa: BLE001 - calibration is a courtesy, never a reason to lose the line
+        return {"note": "calibration failed: %r" % (e,)}
+
+
+def cpu_quota_cpus():
+    """CPUs the cgroup lets this process burn per wall second (cpu.max), or None"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
+def all_physical_cores_run(run, nq, threads_used, cores):
+    """BASELINE.md §2 / tools/core/bench.cc:30-45: the CPU path at T = all physical cores of the node, next to T = 1 and T = the
+    box's share.  Run whenever the process may be scheduled on at least that many CPUs; the cgroup's CPU quota (cpu.max), when
+    there is one, still caps what those threads can burn per second — it is reported beside the figure, so the number reads as
+    "T physical-core threads under a Q-CPU quota", not as the node's unrestricted throughput."""
+    phys, usable = cores.get("physical") or 0, cores.get("usable") or 0
+    if phys <= threads_used or usable < phys:
+        return None
+    try:
+        dt = run(phys)
+        return {"threads": phys, "value": nq / dt, "unit": "queries/s", "queries": int(nq), "cpu_quota_cpus": cpu_quota_cpus(),
+                "note": "same leg at T = physical cores (%d); the cgroup quota above is what the threads can actually use" % phys}
+    except Exception as e:                               # noqa: BLE001
+        return {"threads": phys, "error": repr(e)}
 
 
 def host_threads():
@@ -812,6 +898,7 @@ def cpu_baseline_ivf(torch, ivf, q, topk, nprobe, max_scan, args, dtype, gpu=Non
         n1 = min(32, nq)
         _, _, _, d1 = ref.search_mt(qh[:n1], topk, 1)
         one = n1 / d1
+        phys = all_physical_cores_run(lambda t: ref.search_mt(qh, topk, t)[3], nq, threads, cores)
         ref.close()
         kind, what = "reference", "the reference's own IVFSearcher::search_impl (libzvec_ref_core.so, -O2 -march=skylake-avx512)"
     else:
@@ -828,10 +915,12 @@ def cpu_baseline_ivf(torch, ivf, q, topk, nprobe, max_scan, args, dtype, gpu=Non
         o.ivf_search(cent, offs, vecs, qh[:n1], topk, nprobe, max_scan, keys=rows, threads=1)
         one = n1 / (time.perf_counter() - t1)
         o.use_reference_kernels(False)
+        phys = None
         kind, what = "port", "scan loops = oracle restatement, 1x1 distance kernel = %s" % (
             "reference ailego AVX-512 (oracle/_ref)" if used_ref else "oracle C (-O3 -mavx2)")
     parity = parity_vs_cpu(gpu, ok, os_, oc, nq) if gpu is not None else None
     return {"value": nq / best, "unit": "queries/s", "cores": threads, "kind": kind, "value_1_thread": one, "parity": parity,
+            "all_physical_cores": phys, "cpu_quota_cpus": cpu_quota_cpus(),
             "host_physical_cores": cores.get("physical"), "host_logical_cpus": cores.get("logical"), "host_usable_cpus": cores.get("usable"),
             "sample": "%d queries of the timed batch, same IVF index (exported), one query per call, %d threads across queries "
                       "(the box's share of its host; capped by ZVEC_BENCH_CPU_THREADS), best of %d; %s" % (nq, threads, reps, what)}

@@ -76,6 +76,12 @@ const char *zvec_hip_error_string(int code); /* IndexError::What analogue */
 int zvec_hip_set_option(const char *name, int value);
 int zvec_hip_get_option(const char *name, int *value);
 
+/* Page-locked host memory for callers that assemble query batches themselves (the micro-batcher of include/zvec_hip_operator.hpp
+ * gathers the single queries of zvec's caller threads into such a block): a host-pointer search whose `queries` lie in it uploads
+ * them in one DMA instead of the runtime's staged copy of pageable memory.  NoMemory (-19) when the allocation fails. */
+int zvec_hip_host_alloc(uint64_t bytes, void **out);
+int zvec_hip_host_free(void *p);
+
 /* search context: IndexRunner::create_context() (index_runner.h:400-470).  One per caller thread;
  * owns a HIP stream and the scan workspace.  Passing NULL to a search uses the handle's built-in
  * context under a mutex. */
@@ -217,6 +223,19 @@ int zvec_hip_ivf_search_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_
                             uint32_t max_scan_count, const uint64_t *d_exclude_bitset,
                             uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts,
                             void *stream);
+/* The coarse pass apart from the rest, for a sharded index.  Every shard must plan from the SAME probe sets, and the
+ * pass (2 x Q x nlist x d flop against the replicated centroids, IVFCentroidIndex::search, ivf_centroid_index.cc:273-297) is the one
+ * part of a shard's step that does not shrink with the number of shards.  Dealt over the shards instead: shard r runs
+ * zvec_hip_ivf_coarse_dev on its slice of the batch, the probe lists — d_probe_idx [count][min(nprobe, nlist)] centroid ids in
+ * coarse-score order, d_probe_cnt [count] valid entries — are exchanged (Q x nprobe x 4 bytes), and every shard runs
+ * zvec_hip_ivf_search_probes_dev, which is zvec_hip_ivf_search_dev without its coarse pass (ivf_searcher.cc:217-247 from the
+ * given lists; the max_scan_count rule still uses the global list sizes).  Same results as zvec_hip_ivf_search_dev. */
+int zvec_hip_ivf_coarse_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t nprobe,
+                            uint32_t *d_probe_idx, uint32_t *d_probe_cnt, void *stream);
+int zvec_hip_ivf_search_probes_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,
+                                   float threshold, uint32_t nprobe, uint32_t max_scan_count, const uint32_t *d_probe_idx,
+                                   const uint32_t *d_probe_cnt, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys,
+                                   float *d_out_scores, uint32_t *d_out_counts, void *stream);
 /* IVFSearcher::search_bf_impl: every list in list-id order (ivf_entity.cc:719-745). */
 int zvec_hip_ivf_search_bf(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries,
                            uint32_t count, uint32_t topk, float threshold,
@@ -325,6 +344,10 @@ int zvec_hip_shards_flat_search_by_ids(zvec_hip_shards_t h, const void *queries,
                                        const uint32_t *offsets, uint32_t topk, float threshold, const uint64_t *exclude_bitset,
                                        uint64_t *out_keys, float *out_scores, uint32_t *out_counts);
 int zvec_hip_shards_flat_get_vectors(zvec_hip_shards_t h, const uint64_t *positions, uint64_t n, void *out);
+/* IVF: deal the coarse pass over the shards (off by default): shard g scores its 1/G of the batch against its replica of the
+ * centroids and peer-copies that slice of the probe lists into every shard's table (xGMI, Q x (nprobe + 1) x 4 bytes in all),
+ * every shard then plans from the table (zvec_hip_ivf_coarse_dev / zvec_hip_ivf_search_probes_dev).  Same results. */
+int zvec_hip_shards_deal_coarse(zvec_hip_shards_t h, int enable);
 /* search_impl(query, qmeta, count, ctx) over the shards; host pointers; FLAT ignores nprobe / max_scan_count.
  * exclude_bitset: 1 bit per GLOBAL storage position (FLAT: append order; IVF: list-order positions of the whole
  * index), sliced per shard on the host.  Results: the global top-k, as from one unsharded index. */
@@ -339,6 +362,12 @@ int zvec_hip_shards_search(zvec_hip_shards_t h, const void *queries, uint32_t co
 int zvec_hip_ctx_profile(zvec_hip_ctx_t ctx, int enable);
 int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *scan_ms,
                               double *algorithmic_bytes, double *algorithmic_flops, int reset);
+
+/* Per-box calibration for the measurement line (bench.py `roofline.box_clock_mhz` / `box_stream_gbs`): what this box's HBM delivers
+ * to a pure streaming reader (16-byte non-temporal loads over `bytes` of device memory: d_buf, or a scratch allocation when NULL),
+ * best of `reps` launches, and the shader clock held under that load (s_memtime against the constant 100 MHz s_memrealtime).  So a
+ * reader can tell a slow box from slow code: the list scan of SURVEY §8(d) streams the index the same way. */
+int zvec_hip_calibrate(int device, const void *d_buf, uint64_t bytes, uint32_t reps, double *clock_mhz, double *stream_gbs);
 
 /* FlatSearcher::load of the features segment of a dumped flat index (FlatBuilder<32>::write_row_index /
  * write_column_index, src/core/algorithm/flat/flat_builder.cc:186-276): `count` rows of the handle's element type —

@@ -34,6 +34,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -172,7 +173,9 @@ class MicroBatcher {
   //! a few tens of microseconds let callers that arrive in a burst share the first batch too)
   MicroBatcher(size_t row_bytes, uint32_t max_batch, uint32_t window_us, uint32_t linger_us, RunFn fn)
       : row_bytes_(row_bytes), max_batch_(std::max<uint32_t>(1, max_batch)), window_us_(window_us),
-        linger_us_(std::min(linger_us, window_us)), fn_(std::move(fn)) {}
+        linger_us_(std::min(linger_us, window_us)), fn_(std::move(fn)) {
+    if (const char *e = getenv("ZVEC_HIP_BATCH_EARLY_GO")) early_go_ = atoi(e) != 0;
+  }
 
   int search(const void *query, const BatchKey &key, DocumentList *out) {
     std::shared_ptr<Batch> b;
@@ -197,9 +200,10 @@ class MicroBatcher {
         leader = true;
       }
       slot = b->n++;
-      if (b->n >= max_batch_) cv_.notify_all();
+      if (returning_ > 0) --returning_;
+      if (b->n >= max_batch_ || returning_ == 0) cv_.notify_all();      // (full, or everybody a finished batch released is back: the leader may go)
     }
-    memcpy(b->queries.data() + (size_t)slot * row_bytes_, query, row_bytes_);        // outside the lock: 256 callers, 3 KB each
+    memcpy(b->queries + (size_t)slot * row_bytes_, query, row_bytes_);        // outside the lock: 256 callers, 3 KB each
     b->copied.fetch_add(1, std::memory_order_release);
     if (leader) {
       uint32_t n;
@@ -215,11 +219,15 @@ class MicroBatcher {
           // then settle into two alternating half-size batches, each streaming most of the lists (256 callers, 10M x 768: 39 k
           // searches/s in two batches of ~128 against one of 256).
           auto until = b->deadline;
-          if (inflight_ == 0) until = last_n_ > 1 ? std::min(b->deadline, std::max(b->linger, idle_since_ + std::chrono::microseconds(linger_us_))) : now;
+          if (inflight_ == 0) {
+            if (early_go_ && returning_ == 0) break;     // every caller the finished batches released is back (closed-loop callers): nothing to linger for
+            until = last_n_ > 1 ? std::min(b->deadline, std::max(b->linger, idle_since_ + std::chrono::microseconds(linger_us_))) : now;
+          }
           if (now >= until) break;
           cv_.wait_until(lk, until);
         }
         open_.reset();                      // the next arrival opens (and leads) the next batch
+        returning_ = 0;                     // (whoever has not come back by now is not awaited again)
         n = b->n;
         last_n_ = n;
         ++inflight_;
@@ -229,9 +237,10 @@ class MicroBatcher {
         cv_.notify_all();
       }
       while (b->copied.load(std::memory_order_acquire) < n) std::this_thread::yield();   // (a member still copying its row)
-      b->rc = fn_(b->queries.data(), n, key, &b->keys, &b->scores, &b->counts);
+      b->rc = fn_(b->queries, n, key, &b->keys, &b->scores, &b->counts);
       {
         std::lock_guard<std::mutex> g(mu_);
+        returning_ += n;                    // these callers are on their way back (an estimate: callers may also leave for good)
         if (--inflight_ == 0) idle_since_ = std::chrono::steady_clock::now();
         cv_.notify_all();                   // a leader that was collecting behind this batch may go now (after its linger)
       }
@@ -260,7 +269,12 @@ class MicroBatcher {
     int rc = 0;
     std::shared_mutex gate;
     std::chrono::steady_clock::time_point deadline, linger;
-    std::vector<char> queries;
+    char *queries = nullptr;               // max_batch rows, page-locked (zvec_hip_host_alloc): the upload is one DMA, not a staged copy
+    bool queries_pinned = false;
+    ~Batch() {
+      if (queries_pinned) zvec_hip_host_free(queries);
+      else delete[] queries;
+    }
     std::vector<uint64_t> keys;
     std::vector<float> scores;
     std::vector<uint32_t> counts;
@@ -271,14 +285,20 @@ class MicroBatcher {
     if (!free_.empty()) { b = std::move(free_.back()); free_.pop_back(); }
     if (!b) {
       b = std::make_shared<Batch>();
-      b->queries.resize((size_t)max_batch_ * row_bytes_);
+      void *p = nullptr;
+      if (zvec_hip_host_alloc((size_t)max_batch_ * row_bytes_, &p) == 0 && p) {
+        b->queries = static_cast<char *>(p);
+        b->queries_pinned = true;
+      } else {
+        b->queries = new char[(size_t)max_batch_ * row_bytes_];
+      }
     }
     b->left.store(0, std::memory_order_relaxed);
     return b;
   }
   void recycle(std::shared_ptr<Batch> &b) {
     std::lock_guard<std::mutex> g(mu_);
-    if (free_.size() < 4) free_.push_back(b);
+    if (free_.size() < 16) free_.push_back(b);      // (never dropped in a steady state: a batch owns a page-locked block that is dear to allocate)
   }
   size_t row_bytes_;
   uint32_t max_batch_, window_us_, linger_us_;
@@ -289,6 +309,8 @@ class MicroBatcher {
   std::vector<std::shared_ptr<Batch>> free_;
   uint32_t inflight_ = 0;      // batches currently searching
   uint32_t last_n_ = 0;        // size of the batch closed last
+  bool early_go_ = true;
+  uint64_t returning_ = 0;     // callers released by finished batches that have not come back yet (bounded by the linger)
   std::chrono::steady_clock::time_point idle_since_{};      // when the last searching batch ended
   Stats stats_;
 };

@@ -58,6 +58,19 @@ def _worker(rank, world, port, out):
         # ids equal wherever scores are not tied
         uniq = np.concatenate([[True], np.diff(fs[i, :fc[i]]) != 0]) & np.concatenate([np.diff(fs[i, :fc[i]]) != 0, [True]])
         ok = ok and np.array_equal(mk[i, :fc[i]][uniq], fk[i, :fc[i]][uniq])
+    # the DEALT coarse pass (ShardedIVF(deal_coarse=True)): every rank computes the probe lists of ITS slice of the batch only,
+    # one all-gather (zvec_amd.dist.all_gather_probe_lists) must hand every rank the probe table of the whole batch — the same
+    # table the local coarse pass writes (here: the oracle's), hence the same plan and the same results
+    from zvec_amd.dist import all_gather_probe_lists
+    per = (nq + world - 1) // world
+    lo, hi = min(nq, rank * per), min(nq, (rank + 1) * per)
+    mine = torch.zeros(per * (nprobe + 1), dtype=torch.int32)
+    if hi > lo:
+        _, _, _, _, _, pr = o.ivf_search(cent, offs, vecs, q[lo:hi], k, nprobe, n, keys=keys, want_probes=True)
+        mine[:(hi - lo) * nprobe] = torch.from_numpy(pr.astype(np.int64).reshape(-1).astype(np.int32))
+        mine[per * nprobe:per * nprobe + (hi - lo)] = nprobe
+    idx, cnt = all_gather_probe_lists(mine, per, nprobe)
+    ok = ok and np.array_equal(idx.numpy()[:nq].astype(np.uint32), probes.astype(np.uint32)) and bool((cnt[:nq] == nprobe).all())
     out[rank] = ok
     dist.barrier()
     dist.destroy_process_group()

@@ -69,6 +69,12 @@ def _worker(rank, world, port, out):
         print("rank", rank, "counts equal", bool(torch.equal(mc, fc)), "score mismatches", bad.shape[0],
               "first", bad[:3].tolist(), ms[bad[0, 0]].tolist() if bad.shape[0] else None,
               fs[bad[0, 0]].tolist() if bad.shape[0] else None, "key mismatches", int((~(same_keys | tied)).sum()), flush=True)
+    # the coarse pass DEALT over the ranks (default off): rank r scores its slice of the batch, one all-gather of the probe lists,
+    # every rank plans from them — must give the very same lists
+    dealt = ShardedIVF(sh, ctx, rank, world, deal_coarse=True)
+    dk, ds, dc = dealt.search(q, k, nprobe, n, stream)
+    torch.cuda.synchronize()
+    ok = ok and bool(torch.equal(dc, mc)) and bool(torch.equal(ds, ms)) and bool(torch.equal(dk, mk))
     out[rank] = ok
     dist.barrier()
     dist.destroy_process_group()

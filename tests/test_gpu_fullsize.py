@@ -1,5 +1,8 @@
-"""BASELINE.json full-size cases on the GPU, checked through size-independent properties (the oracle
-cannot scan 10M x 768 for hundreds of queries in seconds) plus oracle spot checks on a few queries.
+"""BASELINE.json full-size cases on the GPU, checked through size-independent properties, oracle spot checks on a few queries
+and — where oracle/_ref/libzvec_ref_core.so travelled — against THE REFERENCE ITSELF at full size: its own FlatSearcher over the
+same 1M rows for all 256 queries of configs[1], its own IVFSearcher over the exported 10M index for 256 of configs[2]'s queries and
+over one rank's exported 12.5M-row fp16 share for 64 of configs[3]'s (flat_searcher.cc:162-211, ivf_searcher.cc:183-250; the body of
+the exported index is lent to it, not copied: oracle/ref_core_shim.cc zref_ivf_searcher_over_rows).
 
   configs[0]  Flat L2, SIFT-1M-shaped (1M x 128, uint8-valued fp32), batch 1      -> bit-exact vs oracle
   configs[1]  Flat IP, 1M x 768 fp32, batch 256                                   -> self-query / order / oracle spot
@@ -17,6 +20,12 @@ from oracle import oracle as O
 from tests.util import tie_tolerant_compare
 
 pytestmark = pytest.mark.gpu
+
+
+def _refcore():
+    """the reference's own core library (oracle/_ref/libzvec_ref_core.so, compiled in place; it travels to the GPU box), or None"""
+    from oracle import refcore
+    return refcore if refcore.available() else None
 
 
 @pytest.fixture(scope="module")
@@ -89,6 +98,16 @@ def test_config1_flat_ip_1m_768_batch256_properties(zv, oracle):
     hq = q[:3].cpu().numpy()
     ok, os_, _, oc = oracle.flat_search(hb, hq, k, O.METRIC_IP, threads=8)
     tie_tolerant_compare(gk[:3], gs[:3], gc[:3], ok, os_, oc, rtol=4e-6, scale=1.0, what="config1 spot")
+    # ALL 256 queries against the reference's own FlatBuilder + FlatSearcher over the same rows (one query per call, as the product
+    # calls boundary B)
+    R = _refcore()
+    if R is not None:
+        R.build("FlatBuilder", hb, "InnerProduct", "cfg1_flat")
+        ref = R.Runner.searcher("FlatSearcher", "cfg1_flat", dim, np.float32)
+        rk, rs, rc_, _ = ref.search_mt(q.cpu().numpy(), k, 16)
+        ref.close()
+        R.mem_remove("cfg1_flat")
+        tie_tolerant_compare(gk, gs, gc, rk, rs, rc_, rtol=4e-6, scale=1.0, what="config1: all 256 queries vs the reference's FlatSearcher")
 
 
 @pytest.fixture(scope="module")
@@ -158,6 +177,24 @@ def test_config2_ivf_10m_768_batch1024_properties(zv, oracle, ten_million):
     qn = (hq.astype(np.float64) ** 2).sum(1)
     tie_tolerant_compare(gk[:2], gs[:2], gc[:2], ok, os_, oc, rtol=2e-6, atol=1e-6, select_band=4e-6 * (2 * qn.max() + 1),
                          what="10M oracle spot")
+    # 256 of the 1024 queries against the reference's own IVFSearcher over the exported index (rows brought to the host in list
+    # order; its IVFDumper writes the small segments, the 30.7 GB body is lent)
+    R = _refcore()
+    if R is not None:
+        vecs = np.empty((n, dim), np.float32)
+        for o in range(0, n, 1 << 20):
+            e = min(n, o + (1 << 20))
+            vecs[o:e] = base.index_select(0, rows_t[o:e]).cpu().numpy()
+        ratio = float(np.float32(nprobe) / np.float32(nlist))
+        ref = R.Runner.ivf_over_rows("IVFSearcher", cent, offs, vecs, rows.astype(np.uint64), "SquaredEuclidean",
+                                     params={"proxima.ivf.searcher.scan_ratio": ratio, "proxima.ivf.searcher.brute_force_threshold": n - 1})
+        m = 256
+        rk, rs, rc_, _ = ref.search_mt(q[:m].cpu().numpy(), k, 16)
+        ref.close()
+        del vecs
+        qn = (q[:m].cpu().numpy().astype(np.float64) ** 2).sum(1)
+        tie_tolerant_compare(gk[:m], gs[:m], gc[:m], rk, rs, rc_, rtol=2e-6, atol=1e-6, select_band=4e-6 * (2 * qn.max() + 1),
+                             what="config2: 256 queries vs the reference's IVFSearcher over the exported 10M index")
 
 
 def test_config4_filtered_scan_10m_bitmap_batch512(zv, oracle, ten_million):
@@ -281,3 +318,22 @@ def test_config3_ivf_100m_768_fp16_one_rank_share(zv, oracle, nshards):
     qn = (hq[:2].astype(np.float64) ** 2).sum(1)
     tie_tolerant_compare(gk[:2], gs[:2], gc[:2], ok, os_, oc, rtol=2e-6, atol=1e-6, select_band=4e-6 * (2 * qn.max() + 1),
                          what="100M fp16 shard oracle spot")
+    # one rank's share: 64 queries against the reference's own IVFSearcher over the exported shard — every centroid, the lists this
+    # rank owns (the others are empty here, as they are on the rank), fp16 rows of 1536 bytes lent as the dumped body.  The probe
+    # walk is never cut short (brute_force_threshold = rows - 1), so local and global list sizes give the same probe set.
+    R = _refcore()
+    if R is not None and nshards == 8:
+        vecs = np.empty((cnt, dim), np.float16)
+        for o in range(0, cnt, 1 << 20):
+            e = min(cnt, o + (1 << 20))
+            vecs[o:e] = ivf.get_vectors_by_ids(np.arange(o, e, dtype=np.uint64))
+        ratio = float(np.float32(nprobe) / np.float32(nlist))
+        ref = R.Runner.ivf_over_rows("IVFSearcher", cent, offs, vecs, rows.astype(np.uint64), "SquaredEuclidean",
+                                     params={"proxima.ivf.searcher.scan_ratio": ratio, "proxima.ivf.searcher.brute_force_threshold": cnt - 1})
+        m = 64
+        rk, rs, rc_, _ = ref.search_mt(hq[:m], k, 16)
+        ref.close()
+        del vecs
+        qn = (hq[:m].astype(np.float64) ** 2).sum(1)
+        tie_tolerant_compare(gk[:m], gs[:m], gc[:m], rk, rs, rc_, rtol=2e-6, atol=1e-6, select_band=4e-6 * (2 * qn.max() + 1),
+                             what="config3 share: 64 queries vs the reference's IVFSearcher over the exported shard")

@@ -290,6 +290,18 @@ def test_in_process_shards_ivf_equals_one_index(oracle, ndev):
     gk, gs, gc = sh.search(q, k, nprobe=nprobe, max_scan=n, exclude=O.pack_bits(mask))
     ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, n, keys=keys, exclude_bits=O.pack_bits(mask))
     tie_tolerant_compare(gk[sel], gs[sel], gc[sel], ok[sel], os_[sel], oc[sel], what="in-process ivf shards, filter")
+    # the coarse pass DEALT over the shards (peer copies of the probe-list slices, zvec_hip_shards_deal_coarse): the very same lists,
+    # also for a batch smaller than the shard count and with the filter on
+    plain = sh.search(q, k, nprobe=nprobe, max_scan=n)
+    assert sh.deal_coarse(True) == 0
+    for qq, ex in ((q, None), (q[:2], None), (q, O.pack_bits(mask))):
+        a = sh.search(qq, k, nprobe=nprobe, max_scan=n, exclude=ex)
+        assert sh.deal_coarse(False) == 0
+        b = sh.search(qq, k, nprobe=nprobe, max_scan=n, exclude=ex)
+        assert sh.deal_coarse(True) == 0
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert sh.deal_coarse(False) == 0
+    assert all(np.array_equal(x, y) for x, y in zip(sh.search(q, k, nprobe=nprobe, max_scan=n), plain))
     # (2) sharded build == unsharded build (same sample / seed rule): same answers as one zvec_hip_ivf_build index
     one = zvec_amd.HipIVFSearcher(dim, "SquaredEuclidean")
     assert one.build(base, nlist, kmeans_iters=4, sample_per_list=64, seed=11) == 0

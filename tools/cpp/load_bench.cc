@@ -86,6 +86,8 @@ struct Searcher {
   virtual void free_context(void *c) = 0;
   // one search of `count` queries; keys[count][topk] (missing entries ~0)
   virtual int search(void *c, const float *q, uint32_t count, uint64_t *keys) = 0;
+  // micro-batcher counters so far (batches run, queries in them, largest batch); false when the backend cannot tell
+  virtual bool batch_stats(uint64_t *batches, uint64_t *queries, uint64_t *largest) { (void)batches; (void)queries; (void)largest; return false; }
 };
 
 struct MirrorSearcher : Searcher {
@@ -99,6 +101,11 @@ struct MirrorSearcher : Searcher {
     return new zvec_hip_host::Context::Pointer(std::move(c));
   }
   void free_context(void *c) override { delete static_cast<zvec_hip_host::Context::Pointer *>(c); }
+  bool batch_stats(uint64_t *batches, uint64_t *queries, uint64_t *largest) override {
+    const auto st = s.batcher_stats();
+    *batches = st.batches; *queries = st.queries; *largest = st.largest;
+    return true;
+  }
   int search(void *c, const float *q, uint32_t count, uint64_t *keys) override {
     auto &ctx = *static_cast<zvec_hip_host::Context::Pointer *>(c);
     int rc = s.search_impl(q, qm, count, ctx);
@@ -141,7 +148,8 @@ struct RunResult {
   uint32_t threads = 0, window_us = 0;
   int wait = -1;
   uint64_t calls = 0, mismatched = 0;
-  double seconds = 0, qps = 0, p50_us = 0, p90_us = 0, p99_us = 0, mean_us = 0, cpus_busy = 0;
+  double seconds = 0, qps = 0, p50_us = 0, p90_us = 0, p99_us = 0, mean_us = 0, cpus_busy = 0, mean_batch = 0;
+  uint64_t largest_batch = 0;
   int rc = 0;
 };
 
@@ -188,6 +196,8 @@ RunResult run_load(Searcher *s, const std::vector<float> &pool, const std::vecto
     return u.ru_utime.tv_sec + u.ru_stime.tv_sec + 1e-6 * (u.ru_utime.tv_usec + u.ru_stime.tv_usec);
   };
   const double cpu0 = cpu_now();
+  uint64_t b0 = 0, q0 = 0, l0 = 0;
+  const bool have_stats = s->batch_stats(&b0, &q0, &l0);
   const auto t0 = Clock::now();
   go.store(true, std::memory_order_release);
   std::this_thread::sleep_for(std::chrono::duration<double>(a.seconds));
@@ -196,6 +206,12 @@ RunResult run_load(Searcher *s, const std::vector<float> &pool, const std::vecto
   r.seconds = std::chrono::duration<double>(Clock::now() - t0).count();
   r.cpus_busy = (cpu_now() - cpu0) / r.seconds;             // process CPU time per wall second: what the callers cost the host
   r.rc = err.load();
+  if (have_stats) {
+    uint64_t b1 = 0, q1 = 0, l1 = 0;
+    s->batch_stats(&b1, &q1, &l1);
+    r.mean_batch = b1 > b0 ? (double)(q1 - q0) / (double)(b1 - b0) : 0.0;
+    r.largest_batch = l1;
+  }
   std::vector<uint32_t> all;
   for (uint32_t t = 0; t < threads; ++t) {
     all.insert(all.end(), lat[t].begin(), lat[t].end());
@@ -373,6 +389,7 @@ int main(int argc, char **argv) {
         zvec_hip_get_option("wait", &r.wait);
         printf("T %4u  window %5u us  wait %d : %9.0f searches/s   p50 %8.1f  p90 %8.1f  p99 %8.1f us  %5.1f CPUs busy  (%llu calls, %llu differ, rc %d)\n",
                t, w, r.wait, r.qps, r.p50_us, r.p90_us, r.p99_us, r.cpus_busy, (unsigned long long)r.calls, (unsigned long long)r.mismatched, r.rc);
+        if (r.mean_batch > 0) printf("        micro-batcher: mean batch %.1f queries (largest so far %llu)\n", r.mean_batch, (unsigned long long)r.largest_batch);
         fflush(stdout);
         results.push_back(r);
         if (r.rc != 0) return 1;
@@ -388,8 +405,8 @@ int main(int argc, char **argv) {
       for (size_t i = 0; i < results.size(); ++i) {
         const RunResult &r = results[i];
         fprintf(f, "%s\n  {\"threads\": %u, \"batch_window_us\": %u, \"wait\": %d, \"searches_per_s\": %.1f, \"p50_us\": %.1f, \"p90_us\": %.1f, "
-                   "\"p99_us\": %.1f, \"mean_us\": %.1f, \"cpus_busy\": %.2f, \"calls\": %llu, \"answers_differing\": %llu}",
-                i ? "," : "", r.threads, r.window_us, r.wait, r.qps, r.p50_us, r.p90_us, r.p99_us, r.mean_us, r.cpus_busy,
+                   "\"p99_us\": %.1f, \"mean_us\": %.1f, \"cpus_busy\": %.2f, \"mean_batch\": %.1f, \"calls\": %llu, \"answers_differing\": %llu}",
+                i ? "," : "", r.threads, r.window_us, r.wait, r.qps, r.p50_us, r.p90_us, r.p99_us, r.mean_us, r.cpus_busy, r.mean_batch,
                 (unsigned long long)r.calls, (unsigned long long)r.mismatched);
       }
       fprintf(f, "\n]}\n");

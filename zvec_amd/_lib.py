@@ -35,6 +35,9 @@ SYMBOLS = {
     "zvec_hip_error_string": (C.c_char_p, [C.c_int]),
     "zvec_hip_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "zvec_hip_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "zvec_hip_calibrate": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "zvec_hip_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
+    "zvec_hip_host_free": (C.c_int, [C.c_void_p]),
     "zvec_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_h)]),
     "zvec_hip_ctx_destroy": (C.c_int, [_h]),
     "zvec_hip_ctx_synchronize": (C.c_int, [_h]),
@@ -68,6 +71,9 @@ SYMBOLS = {
     "zvec_hip_ivf_load": (C.c_int, [_h, C.c_void_p, C.c_uint32, _u64p, C.c_void_p, _u64p]),
     "zvec_hip_flat_load_features": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _u64p]),
     "zvec_hip_flat_load_blocks": (C.c_int, [_h, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "zvec_hip_ivf_coarse_dev": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zvec_hip_ivf_search_probes_dev": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zvec_hip_ivf_set_coarse_space": (C.c_int, [_h, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32]),
     "zvec_hip_ivf_search_coarse": (C.c_int, [_h, _h, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32,
                                              _u64p, _u64p, _f32p, _u32p]),
@@ -118,6 +124,7 @@ SYMBOLS = {
     "zvec_hip_shards_flat_search_by_ids": (C.c_int, [_h, C.c_void_p, C.c_uint32, _u64p, _u32p, C.c_uint32, C.c_float, _u64p,
                                                      _u64p, _f32p, _u32p]),
     "zvec_hip_shards_flat_get_vectors": (C.c_int, [_h, _u64p, C.c_uint64, C.c_void_p]),
+    "zvec_hip_shards_deal_coarse": (C.c_int, [_h, C.c_int]),
     "zvec_hip_shards_search": (C.c_int, [_h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, _u64p,
                                          _u64p, _f32p, _u32p]),
     "zvec_hip_flat_build_filter": (C.c_int, [_h, _h, C.POINTER(DocFilterDesc), _u64p, C.c_int, C.c_void_p]),

@@ -49,6 +49,18 @@ int zvec_hip_get_option(const char *name, int *value) {
   return ZVEC_HIP_ERR_UNSUPPORTED;
 }
 
+int zvec_hip_host_alloc(uint64_t bytes, void **out) {
+  if (!out || bytes == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return ZVEC_HIP_ERR_NO_MEMORY; }
+  *out = p;
+  return 0;
+}
+int zvec_hip_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+  return 0;
+}
+
 int zvec_hip_ctx_create(int device, zvec_hip_ctx_t *out) {
   if (!out) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   return ctx_new(device, out);

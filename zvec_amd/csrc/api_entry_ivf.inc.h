@@ -692,18 +692,62 @@ int zvec_hip_ivf_get_vectors(zvec_hip_ivf_t h, const uint64_t *list_positions, u
 static int ivf_search_dev_locked(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const void *d_queries, uint32_t count, uint32_t topk,
                                  float threshold, uint32_t nprobe, uint32_t max_scan_count, int brute_force,
                                  const uint64_t *d_exclude, uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts,
-                                 hipStream_t s, const void *d_coarse_queries = nullptr) {
+                                 hipStream_t s, const void *d_coarse_queries = nullptr, const CoarseSplit &coarse = CoarseSplit()) {
   if (!h->trained && !brute_force) return ZVEC_HIP_ERR_NO_TRAINED;      // (segments loaded, coarse space still to be set)
+  const uint32_t np = std::max<uint32_t>(1u, std::min(nprobe, h->nlist));      // (the row stride of the probe lists)
   // 32-bit word offsets into the padded query matrix: very large batches go in slices
   const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(std::max(h->lists.dpad, h->cent.dpad), 1u));
   for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
     const uint32_t m = std::min(maxq, count - q0);
-    SearchOut out{d_out_keys + (size_t)q0 * topk, d_out_scores + (size_t)q0 * topk, nullptr, d_out_counts + q0};
+    SearchOut out{d_out_keys ? d_out_keys + (size_t)q0 * topk : nullptr, d_out_scores ? d_out_scores + (size_t)q0 * topk : nullptr, nullptr,
+                  d_out_counts ? d_out_counts + q0 : nullptr};
+    CoarseSplit cs = coarse;
+    if (cs.given_idx) { cs.given_idx += (size_t)q0 * np; cs.given_cnt += q0; }
+    if (cs.out_idx) { cs.out_idx += (size_t)q0 * np; cs.out_cnt += q0; }
     ZRET(ivf_search_core(h, c, reinterpret_cast<const char *>(d_queries) + (size_t)q0 * h->lists.row_bytes(), m, topk, threshold,
                          nprobe, max_scan_count, brute_force, d_exclude, out, s,
-                         d_coarse_queries ? reinterpret_cast<const char *>(d_coarse_queries) + (size_t)q0 * h->cent.row_bytes() : nullptr));
+                         d_coarse_queries ? reinterpret_cast<const char *>(d_coarse_queries) + (size_t)q0 * h->cent.row_bytes() : nullptr, cs));
   }
   return 0;
+}
+
+// The coarse pass on its own, and a search from given probe lists (see CoarseSplit): what a rank of a sharded index runs when the
+// coarse pass is DEALT over the ranks — rank r scores queries [r x Q / G, (r + 1) x Q / G) against the replicated centroids, the
+// probe lists (Q x nprobe x 4 bytes: 128 KB at 1024 x 32) are all-gathered, every rank plans from the gathered lists
+// (IVFCentroidIndex::search, ivf_centroid_index.cc:273-297, then ivf_searcher.cc:217-247 per shard as
+// combined_vector_column_indexer.cc:140-232 does per block).
+int zvec_hip_ivf_coarse_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t nprobe,
+                            uint32_t *d_probe_idx, uint32_t *d_probe_cnt, void *stream) {
+  if (!h || !d_queries || !d_probe_idx || !d_probe_cnt) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->trained) return ZVEC_HIP_ERR_NO_TRAINED;
+  if (h->coarse_sep) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (count == 0) return 0;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  ZCHK(hipSetDevice(h->device));
+  CoarseSplit cs;
+  cs.out_idx = d_probe_idx;
+  cs.out_cnt = d_probe_cnt;
+  return ivf_search_dev_locked(h, c, d_queries, count, 1, FLT_MAX, nprobe, 0xffffffffu, 0, nullptr, nullptr, nullptr, nullptr,
+                               pick_stream(c, stream), nullptr, cs);
+}
+
+int zvec_hip_ivf_search_probes_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,
+                                   float threshold, uint32_t nprobe, uint32_t max_scan_count, const uint32_t *d_probe_idx,
+                                   const uint32_t *d_probe_cnt, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys,
+                                   float *d_out_scores, uint32_t *d_out_counts, void *stream) {
+  if (!h || !d_queries || !d_probe_idx || !d_probe_cnt || !d_out_keys || !d_out_scores || !d_out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  if (count == 0) return 0;
+  if (topk == 0) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  ZCHK(hipSetDevice(h->device));
+  CoarseSplit cs;
+  cs.given_idx = d_probe_idx;
+  cs.given_cnt = d_probe_cnt;
+  return ivf_search_dev_locked(h, c, d_queries, count, topk, threshold, nprobe, max_scan_count, 0, d_exclude_bitset, d_out_keys,
+                               d_out_scores, d_out_counts, pick_stream(c, stream), nullptr, cs);
 }
 
 int zvec_hip_ivf_search_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,

@@ -128,6 +128,87 @@ int zvec_hip_ctx_profile_read(zvec_hip_ctx_t ctx, uint64_t *launches, double *sc
   return 0;
 }
 
+// ---- per-box calibration ----------------------------------------------------------------------
+// Boxes of one pool differ (power state, clocks: the same binary's list scan was timed at 4.67 - 5.07 ms, one box at 6.1 - 6.4):
+// a bench line must let a reader tell box from code.  Two figures, measured in the same process as the timed region:
+//   stream_gbs  what this box's HBM delivers to the simplest possible reader — every lane streams 16-byte non-temporal loads
+//               over `bytes` of device memory, nothing else (the list scan's ceiling: it reads the same way, then computes)
+//   clock_mhz   the shader clock the chip holds under that load: d(s_memtime) / d(s_memrealtime) x 100 MHz, median over the
+//               work-groups (MI355X_MICROARCH.md, DVFS: the constant 100 MHz counter against the shader-clock counter)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) stream_read_kernel(const u32x4_t *p, unsigned long long n16, unsigned int *sink,
+                                                          unsigned long long *stamps) {
+  unsigned long long t0 = 0, r0 = 0;
+  if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  u32x4_t acc = {0, 0, 0, 0};
+  const unsigned long long stride = (unsigned long long)gridDim.x * 1024ull;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 1024ull + threadIdx.x; i + 768 < n16; i += stride) {
+    const u32x4_t a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + 256),
+                  c = __builtin_nontemporal_load(p + i + 512), d = __builtin_nontemporal_load(p + i + 768);
+    acc ^= a ^ b ^ c ^ d;
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u && sink) *sink = acc.x;     // (keeps the loads alive; practically never taken)
+  if (threadIdx.x == 0 && stamps) {
+    stamps[4 * (size_t)blockIdx.x + 0] = t0; stamps[4 * (size_t)blockIdx.x + 1] = r0;
+    stamps[4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime(); stamps[4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+int zvec_hip_calibrate(int device, const void *d_buf, uint64_t bytes, uint32_t reps, double *clock_mhz, double *stream_gbs) {
+  if (bytes < (1u << 20) || reps == 0 || reps > 64) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  ZCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  ZCHK(hipGetDeviceProperties(&prop, device));
+  Scoped<char> own;
+  if (!d_buf) {                               // (contents do not matter to a reader)
+    ZRET(own.alloc(bytes));
+    d_buf = own;
+  }
+  const unsigned grid = (unsigned)prop.multiProcessorCount * 8u;
+  Scoped<unsigned long long> d_st;
+  Scoped<unsigned int> d_sink;
+  ZRET(d_st.alloc((size_t)grid * 4));
+  ZRET(d_sink.alloc(1));
+  hipStream_t s = nullptr;
+  ZCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = 0;
+  double best_ms = 1e30;
+  auto run = [&]() -> int {
+    ZCHK(hipEventCreate(&e0));
+    ZCHK(hipEventCreate(&e1));
+    const unsigned long long n16 = bytes / 16;
+    for (uint32_t r = 0; r <= reps; ++r) {      // (the first launch warms up and is not counted)
+      ZCHK(hipEventRecord(e0, s));
+      hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(256), 0, s, static_cast<const u32x4_t *>(d_buf), n16, (unsigned int *)d_sink,
+                         (unsigned long long *)d_st);
+      ZCHK(hipGetLastError());
+      ZCHK(hipEventRecord(e1, s));
+      ZCHK(hipEventSynchronize(e1));
+      float ms = 0;
+      ZCHK(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0 && ms > 0 && ms < best_ms) best_ms = ms;
+    }
+    std::vector<unsigned long long> st((size_t)grid * 4);
+    ZCHK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> mhz;
+    for (unsigned b = 0; b < grid; ++b) {
+      const double dt = (double)(st[4 * (size_t)b + 2] - st[4 * (size_t)b]), dr = (double)(st[4 * (size_t)b + 3] - st[4 * (size_t)b + 1]);
+      if (dr > 0) mhz.push_back(dt / dr * 100.0);
+    }
+    std::sort(mhz.begin(), mhz.end());
+    if (clock_mhz) *clock_mhz = mhz.empty() ? 0.0 : mhz[mhz.size() / 2];
+    if (stream_gbs) *stream_gbs = best_ms < 1e29 ? (double)bytes / (best_ms * 1e-3) / 1e9 : 0.0;
+    return 0;
+  };
+  rc = run();
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipStreamSynchronize(s);
+  (void)hipStreamDestroy(s);
+  return rc;
+}
+
 #ifdef ZVK_CLOCK_STAMP
 // diagnostic build only: in-kernel clock (MHz, median over work-groups) of the LAST wide flat launch and the spread of
 // the work-groups' start / end times in ms relative to the earliest start: out[0] clock, [1] median lifetime,

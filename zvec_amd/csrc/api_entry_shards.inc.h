@@ -37,6 +37,8 @@ struct zvec_hip_shards_s {
   std::vector<zvec_hip_ivf_s *> ivf;
   std::vector<zvec_hip_ctx_s *> ctx;              // one context (stream + workspace) per shard
   std::vector<DevBuf> d_q, d_ex, d_packed;        // per shard: staged queries, exclude words, packed candidate lists
+  std::vector<DevBuf> d_probe;                    // per shard: the probe lists of the whole batch (dealt coarse pass)
+  bool deal_coarse = false;                       // IVF: the coarse pass dealt over the shards (zvec_hip_shards_deal_coarse)
   DevBuf d_gather, d_ok, d_os, d_oc;              // on devices[0]
   std::vector<std::vector<ShardRange>> ranges;    // flat: global position runs of every shard
   struct DirEntry { uint64_t global0, len, local0; uint32_t g; };
@@ -123,7 +125,7 @@ int zvec_hip_shards_create(uint32_t dim, int dtype, int metric, int kind, const 
   h->dim = dim; h->dtype = dtype; h->metric = metric; h->kind = kind; h->G = ndev;
   h->devices.assign(devices, devices + ndev);
   h->row_bytes = (size_t)dim * (dtype == ZVEC_HIP_DT_FP16 ? 2 : 4);
-  h->d_q.resize(ndev); h->d_ex.resize(ndev); h->d_packed.resize(ndev); h->ranges.resize(ndev);
+  h->d_q.resize(ndev); h->d_ex.resize(ndev); h->d_packed.resize(ndev); h->d_probe.resize(ndev); h->ranges.resize(ndev);
   int rc = 0;
   for (uint32_t g = 0; g < ndev && rc == 0; ++g) {
     zvec_hip_ctx_s *c = nullptr;
@@ -347,6 +349,13 @@ int zvec_hip_shards_flat_load_features(zvec_hip_shards_t h, const void *features
   return 0;
 }
 
+int zvec_hip_shards_deal_coarse(zvec_hip_shards_t h, int enable) {
+  if (!h || h->kind != ZVEC_HIP_SHARDS_IVF) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->deal_coarse = enable != 0;
+  return 0;
+}
+
 // the search of CombinedVectorColumnIndexer::Search over device shards (flat: nprobe / max_scan_count ignored).
 // exclude_bitset: 1 bit per GLOBAL storage position (flat: append order; IVF: list-order positions of the whole index).
 int zvec_hip_shards_search(zvec_hip_shards_t h, const void *queries, uint32_t count, uint32_t topk, float threshold,
@@ -369,13 +378,50 @@ int zvec_hip_shards_search(zvec_hip_shards_t h, const void *queries, uint32_t co
   ZRET(h->d_os.ensure(sb));
   ZRET(h->d_oc.ensure((size_t)count * 4));
   char *gather = h->d_gather.as<char>();
+  // The coarse pass DEALT over the shards (off by default; see zvec_hip_ivf_coarse_dev): shard g scores queries
+  // [g x per, (g + 1) x per) against its replica of the centroids and peer-copies that slice of the probe lists (ids, then counts)
+  // into every shard's table; the search proper then plans from the table instead of running the whole coarse pass G times.
+  const bool dealt = is_ivf && h->deal_coarse && h->G > 1 && !h->ivf[0]->coarse_sep;
+  const uint32_t np = is_ivf ? std::max<uint32_t>(1u, std::min(nprobe, h->ivf[0]->nlist)) : 0;
+  const uint32_t per = (count + h->G - 1) / h->G;
+  if (dealt) {
+    for (uint32_t g = 0; g < h->G; ++g) {          // every table exists before the first peer copy into it
+      ZCHK(hipSetDevice(h->devices[g]));
+      ZRET(h->d_probe[g].ensure(((size_t)count * np + count) * 4));
+      ZRET(h->d_q[g].ensure((size_t)count * h->row_bytes));
+    }
+    ZRET(shards_parallel(h, [&](uint32_t g) -> int {
+      ZCHK(hipSetDevice(h->devices[g]));
+      zvec_hip_ctx_s *c = h->ctx[g];
+      hipStream_t s = c->own;
+      ZCHK(hipMemcpyAsync(h->d_q[g].p, queries, (size_t)count * h->row_bytes, hipMemcpyHostToDevice, s));
+      const uint32_t lo = std::min(count, g * per), hi = std::min(count, (g + 1) * per);
+      if (hi > lo) {
+        uint32_t *idx = h->d_probe[g].as<uint32_t>() + (size_t)lo * np, *cnt = h->d_probe[g].as<uint32_t>() + (size_t)count * np + lo;
+        ZRET(zvec_hip_ivf_coarse_dev(h->ivf[g], c, h->d_q[g].as<char>() + (size_t)lo * h->row_bytes, hi - lo, nprobe, idx, cnt, s));
+        for (uint32_t o = 0; o < h->G; ++o) {
+          if (o == g) continue;
+          uint32_t *oidx = h->d_probe[o].as<uint32_t>() + (size_t)lo * np, *ocnt = h->d_probe[o].as<uint32_t>() + (size_t)count * np + lo;
+          if (h->devices[o] == h->devices[g]) {
+            ZCHK(hipMemcpyAsync(oidx, idx, (size_t)(hi - lo) * np * 4, hipMemcpyDeviceToDevice, s));
+            ZCHK(hipMemcpyAsync(ocnt, cnt, (size_t)(hi - lo) * 4, hipMemcpyDeviceToDevice, s));
+          } else {
+            ZCHK(hipMemcpyPeerAsync(oidx, h->devices[o], idx, h->devices[g], (size_t)(hi - lo) * np * 4, s));
+            ZCHK(hipMemcpyPeerAsync(ocnt, h->devices[o], cnt, h->devices[g], (size_t)(hi - lo) * 4, s));
+          }
+        }
+      }
+      ZCHK(hipStreamSynchronize(s));            // every slice has landed everywhere before any shard plans
+      return 0;
+    }));
+  }
   ZRET(shards_parallel(h, [&](uint32_t g) -> int {
     ZCHK(hipSetDevice(h->devices[g]));
     zvec_hip_ctx_s *c = h->ctx[g];
     hipStream_t s = c->own;
     ZRET(h->d_q[g].ensure((size_t)count * h->row_bytes));
     ZRET(h->d_packed[g].ensure(pb));
-    ZCHK(hipMemcpyAsync(h->d_q[g].p, queries, (size_t)count * h->row_bytes, hipMemcpyHostToDevice, s));
+    if (!dealt) ZCHK(hipMemcpyAsync(h->d_q[g].p, queries, (size_t)count * h->row_bytes, hipMemcpyHostToDevice, s));
     // this shard's slice of the global exclude set
     const uint64_t *d_ex = nullptr;
     if (exclude_bitset) {
@@ -405,7 +451,10 @@ int zvec_hip_shards_search(zvec_hip_shards_t h, const void *queries, uint32_t co
     uint64_t *dk = reinterpret_cast<uint64_t *>(p);
     float *ds = reinterpret_cast<float *>(p + kb);
     uint32_t *dc = reinterpret_cast<uint32_t *>(p + kb + sb);
-    int rc = is_ivf ? zvec_hip_ivf_search_dev(h->ivf[g], c, h->d_q[g].p, count, topk, threshold, nprobe, max_scan_count, d_ex, dk, ds,
+    int rc = dealt ? zvec_hip_ivf_search_probes_dev(h->ivf[g], c, h->d_q[g].p, count, topk, threshold, nprobe, max_scan_count,
+                                                    h->d_probe[g].as<uint32_t>(), h->d_probe[g].as<uint32_t>() + (size_t)count * np, d_ex,
+                                                    dk, ds, dc, s)
+           : is_ivf ? zvec_hip_ivf_search_dev(h->ivf[g], c, h->d_q[g].p, count, topk, threshold, nprobe, max_scan_count, d_ex, dk, ds,
                                               dc, s)
                     : zvec_hip_flat_search_dev(h->flat[g], c, h->d_q[g].p, count, topk, threshold, d_ex, dk, ds, dc, s);
     if (rc != 0) return rc;

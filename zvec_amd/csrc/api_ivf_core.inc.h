@@ -7,10 +7,22 @@ namespace {
 // d_coarse_queries: the queries in the centroid store's own space when it has one (h->coarse_sep: an inner-product index whose
 // centroid index the reference's builder trained in MIPS-converted space, ivf_builder.cc:552-555, searched through a MipsReformer,
 // ivf_centroid_index.cc:273-297); nullptr otherwise
+// The coarse pass may be taken apart from the rest (sharded IVF, SURVEY §8(e): every rank needs the same probe sets, and the
+// pass — 2 x Q x nlist x d flop against replicated centroids — is the one piece of a rank's step that does not shrink with the
+// number of ranks): `coarse` with out_idx set = run ONLY the coarse pass and leave the probe lists there ([count][nprobe] centroid
+// ids in coarse-score order + [count] valid entries); with given_idx set = skip the coarse pass and plan from those lists.
+struct CoarseSplit {
+  const uint32_t *given_idx = nullptr, *given_cnt = nullptr;
+  uint32_t *out_idx = nullptr, *out_cnt = nullptr;
+};
+
 int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_queries, uint32_t count, uint32_t topk,
                     float threshold, uint32_t nprobe, uint32_t max_scan_count, int brute_force,
-                    const uint64_t *d_exclude, const SearchOut &out, hipStream_t stream, const void *d_coarse_queries = nullptr) {
-  if (h->coarse_sep && !brute_force && d_coarse_queries == nullptr) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+                    const uint64_t *d_exclude, const SearchOut &out, hipStream_t stream, const void *d_coarse_queries = nullptr,
+                    const CoarseSplit &coarse = CoarseSplit()) {
+  const bool given = coarse.given_idx != nullptr, coarse_only = coarse.out_idx != nullptr;
+  if ((given || coarse_only) && brute_force) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (h->coarse_sep && !brute_force && !given && d_coarse_queries == nullptr) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   const int cus = device_cus(ctx);
   const uint32_t nlist = h->nlist;
   if (nprobe < 1) nprobe = 1;
@@ -22,7 +34,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   const uint64_t direct_rows = h->h_rows_of_largest.size() > nprobe ? std::max<uint64_t>(1, h->h_rows_of_largest[nprobe]) : ~0ull;
   // (measured, 2M x 768 fp32, nprobe 32 of 2048 lists, host-pointer calls: 1 query 223 -> 116 us, 2: 244 -> 153, 4: 290 -> 222,
   // 8: 390 -> 369, 16: 586 -> 655 — the direct route costs the same for every query, the tile route shares the lists)
-  const bool direct = !brute_force && count <= (uint32_t)knobs().ivf_direct_q && (uint64_t)count * direct_rows <= (4u << 20) &&
+  const bool direct = !brute_force && !coarse_only && count <= (uint32_t)knobs().ivf_direct_q && (uint64_t)count * direct_rows <= (4u << 20) &&
                       (double)count * (double)direct_rows * (double)h->lists.row_bytes() <= 2.5e9 &&
                       (size_t)topk * 12 + 16 <= 60 * 1024 && (size_t)nprobe * 12 + 16 <= 60 * 1024;
 
@@ -30,7 +42,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   // prepared rows (no padding: dim_in == the scanned dims == whole 128-byte k-steps; 16-byte aligned) the preparation launch is
   // skipped — one kernel and one launch gap less in a chain of eight short dependent kernels (single query, 10M x 768:
   // 5 us + gap of the ~70 us one lane needs between two of its scoring kernels).
-  const bool sep = h->coarse_sep && !brute_force;
+  const bool sep = h->coarse_sep && !brute_force && !given;      // (given probe lists: no coarse pass, only the lists' own space)
   const bool raw_rows = !sep && direct && h->lists.dim_in == h->lists.dscan && (size_t)h->lists.dpad * 4 == h->lists.row_bytes() &&
                         (reinterpret_cast<uintptr_t>(d_queries) & 15u) == 0 &&
                         !(ctx->pin_in.dev && d_queries == ctx->pin_in.dev);    // (rows in the host-mapped slot are read ONCE, by prep_queries)
@@ -66,13 +78,16 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   }
 
   // 1. coarse assign: flat scan over the centroids, k = nprobe (IVFCentroidIndex::search)
-  if (!brute_force) {
+  const uint32_t *probe_idx = coarse.given_idx, *probe_cnt = coarse.given_cnt;
+  if (given) { dp.coarse_idx = probe_idx; dp.coarse_cnt = probe_cnt; }
+  if (!brute_force && !given) {
     ZRET(ctx->coarse_keys.ensure((size_t)count * nprobe * sizeof(uint64_t)));
     ZRET(ctx->coarse_scores.ensure((size_t)count * nprobe * sizeof(float)));
     ZRET(ctx->coarse_idx.ensure((size_t)count * nprobe * sizeof(uint32_t)));
     ZRET(ctx->coarse_cnt.ensure((size_t)count * sizeof(uint32_t)));
-    SearchOut co{ctx->coarse_keys.as<uint64_t>(), ctx->coarse_scores.as<float>(), ctx->coarse_idx.as<uint32_t>(),
-                 ctx->coarse_cnt.as<uint32_t>()};
+    SearchOut co{ctx->coarse_keys.as<uint64_t>(), ctx->coarse_scores.as<float>(),
+                 coarse_only ? coarse.out_idx : ctx->coarse_idx.as<uint32_t>(), coarse_only ? coarse.out_cnt : ctx->coarse_cnt.as<uint32_t>()};
+    probe_idx = co.idx; probe_cnt = co.counts;
     if (direct) {
       const uint32_t cstride = (nlist + 63) / 64 * 64;
       const uint64_t cpairs = (uint64_t)count * cstride;
@@ -92,6 +107,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     } else {
       ZRET(flat_scan_prepared(ctx, h->cent, count, nprobe, FLT_MAX, nullptr, co, stream, false));
     }
+    if (coarse_only) return 0;
   }
   if (sep) {
     ZRET(prep_queries(ctx, h->lists, d_queries, count, FLT_MAX, stream));      // from here on: the lists' own space
@@ -186,7 +202,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     // route: expand every query's probed lists into positions, score each (query, row) pair directly, select.
     if ((size_t)topk * 12 + 16 > 60 * 1024) return ZVEC_HIP_ERR_UNSUPPORTED;
     PlanArgs p{};
-    p.coarse_idx = ctx->coarse_idx.as<uint32_t>(); p.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
+    p.coarse_idx = probe_idx; p.coarse_cnt = probe_cnt;
     p.nq = count; p.nprobe = nprobe; p.nlist = nlist; p.max_scan_count = max_scan_count; p.brute_force = brute_force;
     p.list_size = h->d_size; p.list_size_global = h->d_size_global;
     ZRET(ctx->plan.ensure(((size_t)2 * count + 8) * sizeof(uint32_t)));
@@ -274,7 +290,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     ZCHK(hipGetLastError());
   }
   PlanArgs p{};
-  p.coarse_idx = ctx->coarse_idx.as<uint32_t>(); p.coarse_cnt = ctx->coarse_cnt.as<uint32_t>();
+  p.coarse_idx = probe_idx; p.coarse_cnt = probe_cnt;
   p.nq = count; p.nprobe = nprobe; p.nlist = nlist; p.max_scan_count = max_scan_count; p.brute_force = brute_force;
   p.list_size = h->d_size; p.list_size_global = h->d_size_global; p.list_order = h->d_order;
   p.list_tpc = pb + o_ltpc;
@@ -378,32 +394,46 @@ int host_wait(zvec_hip_ctx_s *ctx, hipStream_t stream) {
     // quarter of every scheduler period and are then all frozen for the rest of it (measured: p99 78 ms, throughput / 3).  So a
     // context whose previous wait was long goes to sleep at once, in steps that follow the time it has already waited.
     const auto t0 = std::chrono::steady_clock::now();
-    const uint64_t last = ctx->last_wait_ns;
-    const uint64_t spin_ns = last > 300000 ? 0 : 200000;
-    uint64_t waited = 0;
-    if (spin_ns == 0) {
-      // most of the expected wait in ONE sleep, the rest in steps of 1/32 of it: the call returns within ~3 % (+ the timer slack)
-      // of its completion, at a few wake-ups per call
-      struct timespec ts = {0, (long)std::min<uint64_t>(last * 3 / 4, 50000000)};
+    auto elapsed = [&]() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
+    const uint64_t est = ctx->last_wait_ns;                 // how long this context's waits have been taking
+    if (est > 300000) {
+      // sleeping mode.  HALF the expected wait in one sleep, the rest in steps of 1/32 of it: the completion is then noticed within
+      // ~3 % (+ the timer slack) and MEASURED (it falls into the polled half), so the estimate follows the truth both ways.  A
+      // sleep that wakes to a finished call has only learnt "at most this long": the estimate is halved — it must never feed on
+      // its own oversleeping (an estimate of 60 ms once, from a first call that allocated its workspace, would otherwise hold
+      // every later 5 ms call for 45 ms).
+      const uint64_t first = std::min<uint64_t>(est / 2, 20000000);
+      struct timespec ts = {0, (long)first};
       nanosleep(&ts, nullptr);
-    }
-    for (uint32_t it = 0;; ++it) {
-      if (*w == epoch) {
-        waited = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-        ctx->last_wait_ns = spin_ns ? waited : (last * 3 + waited) / 4;          // (smoothed while sleeping: one early finish must not bring the spin back)
-        return 0;
+      if (*w == epoch) { ctx->last_wait_ns = first; return 0; }
+      const uint64_t step = std::min<uint64_t>(200000, std::max<uint64_t>(20000, est / 32));
+      for (uint32_t it = 0;; ++it) {
+        struct timespec t2 = {0, (long)step};
+        nanosleep(&t2, nullptr);
+        if (*w == epoch) { ctx->last_wait_ns = elapsed(); return 0; }
+        if ((it & 63) == 63) {
+          // a fault on the stream would leave the word unwritten for ever: ask the runtime now and then
+          hipError_t q = hipStreamQuery(stream);
+          if (q != hipSuccess && q != hipErrorNotReady) { ZCHK(q); }
+          if (q == hipSuccess && *w != epoch && elapsed() > 5000000000ull) break;
+        }
       }
-      if ((it & 31) == 31 || waited >= spin_ns)
-        waited = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-      if (waited < spin_ns) { __builtin_ia32_pause(); continue; }
-      const uint64_t step = std::min<uint64_t>(200000, std::max<uint64_t>(20000, std::max(waited, last) / 32));
-      struct timespec ts = {0, (long)step};
-      nanosleep(&ts, nullptr);
-      if ((it & 255) == 255 || waited > 2000000000ull) {
-        // a fault on the stream would leave the word unwritten for ever: ask the runtime now and then
-        hipError_t q = hipStreamQuery(stream);
-        if (q != hipSuccess && q != hipErrorNotReady) { ZCHK(q); }
-        if (q == hipSuccess && *w != epoch && waited > 5000000000ull) break;
+    } else {
+      // spinning mode: the answer is ~0.1 ms away
+      for (uint32_t it = 0;; ++it) {
+        if (*w == epoch) { ctx->last_wait_ns = elapsed(); return 0; }
+        __builtin_ia32_pause();
+        if ((it & 63) == 63 && elapsed() > 400000) { ctx->last_wait_ns = 600000; break; }     // longer than a lone call: sleep from now on
+      }
+      for (uint32_t it = 0;; ++it) {
+        struct timespec t2 = {0, 50000};
+        nanosleep(&t2, nullptr);
+        if (*w == epoch) { ctx->last_wait_ns = elapsed(); return 0; }
+        if ((it & 63) == 63) {
+          hipError_t q = hipStreamQuery(stream);
+          if (q != hipSuccess && q != hipErrorNotReady) { ZCHK(q); }
+          if (q == hipSuccess && *w != epoch && elapsed() > 5000000000ull) break;
+        }
       }
     }
     ZCHK(hipStreamSynchronize(stream));

@@ -52,6 +52,27 @@ def all_gather_candidates(keys, scores, counts, group=None):
     return unpack_candidates(out, world, count, topk)
 
 
+def all_gather_probe_lists(mine, per, np_, group=None, out=None):
+    """The exchange of a DEALT coarse pass: `mine` = this rank's slice of the probe lists, int32 [per x np_] centroid ids (coarse-score
+    order) followed by [per] valid counts, for queries [rank x per, (rank + 1) x per) of the batch.  ONE all-gather; returns
+    (idx [world x per][np_], cnt [world x per]) in query order — rank-major slices are query order.  Any backend (RCCL on the GPUs,
+    gloo staged through the host in the CPU tests / one-GPU rehearsals)."""
+    world = dist.get_world_size(group)
+    if mine.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(world * mine.numel(), dtype=mine.dtype)
+        dist.all_gather_into_tensor(host, mine.cpu(), group=group)
+        gathered = host.to(mine.device)
+    else:
+        gathered = out["gathered"] if out is not None else torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+    g = gathered.view(world, per * (np_ + 1))
+    idx = out["idx"] if out is not None else torch.empty((world * per, np_), dtype=mine.dtype, device=mine.device)
+    cnt = out["cnt"] if out is not None else torch.empty((world * per,), dtype=mine.dtype, device=mine.device)
+    idx.view(world, per * np_).copy_(g[:, :per * np_])
+    cnt.view(world, per).copy_(g[:, per * np_:])
+    return idx, cnt
+
+
 class _Sharded:
     """rank-local shard + the exchange/merge step.
 
@@ -125,13 +146,60 @@ class _Sharded:
 
 class ShardedIVF(_Sharded):
     """IVF: the shard holds the inverted lists the byte-balanced list -> shard map gives this rank
-    (zvec_hip_ivf_keep_shard / zvec_hip_ivf_shard_map), centroids replicated; probe sets are global."""
+    (zvec_hip_ivf_keep_shard / zvec_hip_ivf_shard_map), centroids replicated; probe sets are global.
+
+    deal_coarse (default off): the coarse pass — the one part of a rank's step that does not shrink with the number of ranks
+    (2 x Q x nlist x d flop against the replicated centroids; 67 us of nearly whole-chip MFMA work at 1024 x 4096 x 768, which
+    cannot share a CU with the resident list scan: DESIGN §7) — is DEALT over the ranks: rank r scores queries
+    [r x ceil(Q / G), (r + 1) x ceil(Q / G)), ONE all-gather brings every rank the probe lists of the whole batch
+    (Q x (nprobe + 1) x 4 bytes: 132 KB at 1024 x 32), every rank plans from them (zvec_hip_ivf_search_probes_dev).  Identical
+    results (the probe lists are the same arrays the local pass would have written); a second small collective per step is the
+    price, which only a run on N GPUs can weigh against 7/8 of the coarse pass — cost model in DESIGN §7."""
+
+    def __init__(self, searcher, ctx, rank, world, group=None, deal_coarse=False):
+        super().__init__(searcher, ctx, rank, world, group)
+        self.deal_coarse = bool(deal_coarse)
+        self._probe = {}
+
+    def _probe_buffers(self, count, nprobe, device):
+        key = (count, nprobe)
+        if key not in self._probe:
+            nlist = int(self.searcher.info()[1])
+            np_ = max(1, min(nprobe, nlist))
+            per = (count + self.world - 1) // self.world
+            self._probe[key] = dict(
+                np=np_, per=per,
+                mine=torch.zeros(per * (np_ + 1), dtype=torch.int32, device=device),                # [per][np] ids, then [per] counts
+                gathered=torch.zeros(self.world * per * (np_ + 1), dtype=torch.int32, device=device),
+                idx=torch.zeros((self.world * per, np_), dtype=torch.int32, device=device),
+                cnt=torch.zeros((self.world * per,), dtype=torch.int32, device=device))
+        return self._probe[key]
 
     def _local_search(self, d_queries, count, topk, b, stream_ptr, nprobe, max_scan):
         from . import _lib
-        rc = self.searcher.search_dev(d_queries.data_ptr(), count, topk, nprobe, max_scan, b["keys"].data_ptr(),
-                                      b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx, stream=stream_ptr)
-        _lib.check(rc, "zvec_hip_ivf_search_dev")
+        if not (self.deal_coarse and self.world > 1):
+            rc = self.searcher.search_dev(d_queries.data_ptr(), count, topk, nprobe, max_scan, b["keys"].data_ptr(),
+                                          b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx, stream=stream_ptr)
+            _lib.check(rc, "zvec_hip_ivf_search_dev")
+            return
+        p = self._probe_buffers(count, nprobe, d_queries.device)
+        per, np_ = p["per"], p["np"]
+        lo, hi = min(count, self.rank * per), min(count, (self.rank + 1) * per)
+        if hi > lo:
+            row_bytes = d_queries.shape[1] * d_queries.element_size()
+            rc = self.searcher.coarse_dev(d_queries.data_ptr() + lo * row_bytes, hi - lo, nprobe, p["mine"].data_ptr(),
+                                          p["mine"].data_ptr() + per * np_ * 4, self.ctx, stream=stream_ptr)
+            _lib.check(rc, "zvec_hip_ivf_coarse_dev")
+        legacy = not stream_ptr
+        if legacy:
+            self.ctx.synchronize()
+        all_gather_probe_lists(p["mine"], per, np_, self.group, out=p)
+        if legacy:
+            torch.cuda.current_stream().synchronize()
+        rc = self.searcher.search_probes_dev(d_queries.data_ptr(), count, topk, nprobe, max_scan, p["idx"].data_ptr(), p["cnt"].data_ptr(),
+                                             b["keys"].data_ptr(), b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx,
+                                             stream=stream_ptr)
+        _lib.check(rc, "zvec_hip_ivf_search_probes_dev")
 
     def search(self, d_queries, topk, nprobe, max_scan, stream_ptr):
         return super().search(d_queries, topk, nprobe, max_scan, stream_ptr=stream_ptr)

@@ -835,6 +835,19 @@ class HipIVFSearcher:
             C.c_void_p(d_exclude) if d_exclude else None, C.c_void_p(d_out_keys), C.c_void_p(d_out_scores),
             C.c_void_p(d_out_counts), C.c_void_p(stream) if stream else None)
 
+    def coarse_dev(self, d_queries, count, nprobe, d_probe_idx, d_probe_cnt, ctx, stream=None):
+        """the coarse pass alone (zvec_hip_ivf_coarse_dev): probe lists [count][min(nprobe, nlist)] u32 + [count] u32, device pointers"""
+        return _lib.lib().zvec_hip_ivf_coarse_dev(self._h, ctx._h, C.c_void_p(d_queries), count, nprobe, C.c_void_p(d_probe_idx),
+                                                  C.c_void_p(d_probe_cnt), C.c_void_p(stream) if stream else None)
+
+    def search_probes_dev(self, d_queries, count, topk, nprobe, max_scan, d_probe_idx, d_probe_cnt, d_out_keys, d_out_scores,
+                          d_out_counts, ctx, threshold=FLT_MAX, d_exclude=None, stream=None):
+        """zvec_hip_ivf_search_dev without its coarse pass: plans from the given probe lists (zvec_hip_ivf_search_probes_dev)"""
+        return _lib.lib().zvec_hip_ivf_search_probes_dev(
+            self._h, ctx._h, C.c_void_p(d_queries), count, topk, threshold, nprobe, max_scan, C.c_void_p(d_probe_idx),
+            C.c_void_p(d_probe_cnt), C.c_void_p(d_exclude) if d_exclude else None, C.c_void_p(d_out_keys), C.c_void_p(d_out_scores),
+            C.c_void_p(d_out_counts), C.c_void_p(stream) if stream else None)
+
     def last_stats(self, ctx, count):
         scanned = np.zeros(count, np.uint32)
         probes = np.zeros(count, np.uint32)
@@ -1025,6 +1038,10 @@ class HipShardedIndex:
         out = np.empty((pos.size, self.dim), self.np_dtype)
         rc = _lib.lib().zvec_hip_shards_flat_get_vectors(self._h, _np_ptr(pos), pos.size, _np_ptr(out))
         return rc, out
+
+    def deal_coarse(self, enable):
+        """IVF: deal the coarse pass over the shards (zvec_hip_shards_deal_coarse; off by default)"""
+        return _lib.lib().zvec_hip_shards_deal_coarse(self._h, int(bool(enable)))
 
     def search(self, queries, topk, nprobe=1, max_scan=0xffffffff, threshold=FLT_MAX, exclude=None):
         q = np.ascontiguousarray(queries, self.np_dtype)
