@@ -207,3 +207,40 @@ def test_kmeans_quality_vs_reference_trainer(zv):
     assert rec >= low_rec - 0.01
     assert spread <= worst_spread * 1.15
     assert (sizes == 0).sum() == 0
+
+
+@pytest.mark.parametrize("metric", ["SquaredEuclidean", "InnerProduct"])
+@pytest.mark.parametrize("n,dim,nlist", [(5000, 64, 300), (4097, 100, 513), (1024, 768, 256), (777 + 512, 40, 1000), (3000, 192, 192)])
+def test_fp16_labelling_on_the_256_tile_is_exact_on_lattice_data(zv, metric, n, dim, nlist):
+    """The fp16 labelling kernel on the 256 x 256 multi-phase tile (zvk_assign256.hip.h; taken for >= 512 rows and >= 192 centroids)
+    against an exact integer arg-min: small-integer rows and centroids make every product and every fp32 sum exact, so the label must
+    be THE nearest centroid, lowest id on ties (IVFBuilder::label, ivf_builder.h:253-274; heap.h:103-114) — ragged row counts (the
+    last work item is moved back), odd numbers of 128-centroid tiles (the second tile of the last pair is missing), centroid counts
+    that are no multiple of 16, dimensions that are no multiple of the 64-half k-step, duplicate centroids; and the same labels as
+    the 128 x 128 one-barrier kernel it replaces (option "assign256" = 0)."""
+    import ctypes as C
+    import torch
+    from zvec_amd import _lib
+    rng = np.random.default_rng(n + nlist)
+    base = rng.integers(-5, 6, (n, dim)).astype(np.float16)
+    cent = rng.integers(-5, 6, (nlist, dim)).astype(np.float16)
+    cent[nlist - 1] = cent[1]                            # duplicate centroid: the later id must never be chosen
+    se = zv.HipIVFSearcher(dim, metric, dtype="fp16")
+    assert se.set_centroids(cent) == 0
+    d_base = torch.from_numpy(base).cuda()
+    labs = []
+    L = _lib.lib()
+    for opt in (1, 0):
+        assert L.zvec_hip_set_option(b"assign256", opt) == 0
+        d_lab = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        assert se.label_dev(d_base.data_ptr(), n, d_lab.data_ptr()) == 0
+        torch.cuda.synchronize()
+        labs.append(d_lab.cpu().numpy().astype(np.int64))
+    assert L.zvec_hip_set_option(b"assign256", 1) == 0
+    b64, c64 = base.astype(np.int64), cent.astype(np.int64)
+    ip = b64 @ c64.T
+    sc = (b64 ** 2).sum(1)[:, None] + (c64 ** 2).sum(1)[None] - 2 * ip if metric == "SquaredEuclidean" else -ip
+    want = sc.argmin(1)                                   # numpy's argmin returns the FIRST minimum
+    assert np.array_equal(labs[0], want), (np.nonzero(labs[0] != want)[0][:8], labs[0][labs[0] != want][:8], want[labs[0] != want][:8])
+    assert np.array_equal(labs[1], want)
+    assert (labs[0] != nlist - 1).all()

@@ -40,12 +40,14 @@ int zvec_hip_set_option(const char *name, int value) {
     ropts().zerocopy = value;
     return 0;
   }
+  if (strcmp(name, "assign256") == 0) { ropts().assign256 = value != 0; return 0; }
   return ZVEC_HIP_ERR_UNSUPPORTED;
 }
 int zvec_hip_get_option(const char *name, int *value) {
   if (!name || !value) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   if (strcmp(name, "wait") == 0) { *value = ropts().wait; return 0; }
   if (strcmp(name, "zerocopy") == 0) { *value = ropts().zerocopy; return 0; }
+  if (strcmp(name, "assign256") == 0) { *value = ropts().assign256; return 0; }
   return ZVEC_HIP_ERR_UNSUPPORTED;
 }
 

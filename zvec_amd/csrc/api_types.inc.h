@@ -73,8 +73,10 @@ struct PinnedBuf {
 struct RuntimeOpts {
   std::atomic<int> wait{1};
   std::atomic<int> zerocopy{2};
+  std::atomic<int> assign256{1};     // fp16 labelling on the 256 x 256 multi-phase tile (0: always the 128 x 128 one-barrier tile)
   RuntimeOpts() {
     if (const char *e = getenv("ZVEC_HIP_WAIT")) wait = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("ZVEC_HIP_ASSIGN256")) assign256 = atoi(e) != 0;
     if (const char *e = getenv("ZVEC_HIP_ZEROCOPY")) zerocopy = std::max(0, std::min(3, atoi(e)));
   }
 };
