@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage (on the GPU box): tools/pmc_label.sh <tag>
 # PMC passes over tools/time_label.py (each its own run, --kernel-trace only, as gpurun requires) for the labelling kernel
-# assign_kernel<true> (fp16 rows, 2M x 16384 x 768: the launches longer than 5 ms: one chunk of rows each) and assign_kernel<false> (fp32, 1M x 4096):
+# assign256_f16_kernel / assign_kernel<true> (fp16 rows, 2M x 16384 x 768: the long launches, one chunk of rows each; ZVEC_HIP_ASSIGN256=0 selects
+# the latter) and assign_kernel<false> (fp32, 1M x 4096):
 # per-launch averages, the MFMA-busy share of the launch and the effective clock (MI355X_MICROARCH.md "DVFS give-back").
 # Writes gpurun_out/pmcl_<tag>.json.
 cd /tmp && export TMPDIR=/tmp
@@ -15,7 +16,7 @@ done
 python3 - <<PY
 import csv,glob,collections,json
 res={}
-for kern, lo in (("assign_kernel<true>", 5000.0), ("assign_kernel<false>", 5000.0)):
+for kern, lo in (("assign256_f16_kernel", 3000.0), ("assign_kernel<true>", 5000.0), ("assign_kernel<false>", 5000.0)):
     out={}
     for i in range(1,5):
         agg=collections.defaultdict(list)

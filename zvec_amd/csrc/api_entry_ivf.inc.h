@@ -412,7 +412,7 @@ static int ivf_label_rows(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const Store &cs,
     a.dpad = cs.dpad; a.nks = cs.dpad / TILE_K; a.metric = cs.metric; a.nq = m; a.n = (uint32_t)cs.n;
     a.out_label = d_labels + o; a.out_score = nullptr;
     // fp16: the 256 x 256 multi-phase tile when there is a tile's worth of rows and centroids; the 128 x 128 tile otherwise
-    const bool big = cs.f16 && ropts().assign256.load(std::memory_order_relaxed) != 0 && m >= 2u * A256_ROWS && cs.n >= 192;
+    const bool big = cs.f16 && ropts().assign256.load(std::memory_order_relaxed) != 0 && m >= 2u * A256_ROWS && cs.n >= 192 && a.nks >= 2;
     ZRET(big ? launch_assign256_f16(a, cus, s) : cs.f16 ? launch_assign<true>(a, cus, s) : launch_assign<false>(a, cus, s));
   }
   ZCHK(hipStreamSynchronize(s));      // callers read the labels with plain copies (the context's stream is non-blocking)

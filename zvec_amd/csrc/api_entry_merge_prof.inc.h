@@ -209,6 +209,22 @@ int zvec_hip_calibrate(int device, const void *d_buf, uint64_t bytes, uint32_t r
   return rc;
 }
 
+#ifdef ZVK_A256_STAMPS
+// diagnostic build only: shader-clock cycles the waves 0 / 4 of work-group 0 of assign256_f16_kernel spent, summed over every step
+// since the last call, in [group][phase 1..4][section]: 0 = from the previous stamp to the phase start (the barrier that ended the
+// previous phase; for phase 1 also the fold), 1 = fragment reads + DMA issue + counted wait, 2 = the mid barrier (staggered builds),
+// 3 = issuing the 16 MFMAs.  out[2*5*4] cycles; resets the counters.
+int zvec_hip_debug_a256_stamps(double *out) {
+  unsigned long long h[2][5][4];
+  ZCHK(hipDeviceSynchronize());
+  ZCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(zvk::zvk_a256_acc), sizeof(h)));
+  for (int g = 0; g < 2; ++g) for (int p = 0; p < 5; ++p) for (int x = 0; x < 4; ++x) out[(g * 5 + p) * 4 + x] = (double)h[g][p][x];
+  memset(h, 0, sizeof(h));
+  ZCHK(hipMemcpyToSymbol(HIP_SYMBOL(zvk::zvk_a256_acc), h, sizeof(h)));
+  return 0;
+}
+#endif
+
 #ifdef ZVK_CLOCK_STAMP
 // diagnostic build only: in-kernel clock (MHz, median over work-groups) of the LAST wide flat launch and the spread of
 // the work-groups' start / end times in ms relative to the earliest start: out[0] clock, [1] median lifetime,

@@ -134,20 +134,24 @@ int launch_assign(const AssignArgs &a, int cus, hipStream_t s) {
 
 // fp16 rows on the 256 x 256 multi-phase tile (zvk_assign256.hip.h): one work item = 256 rows x every centroid, ONE work-group
 // of 8 waves per CU (129 KiB of LDS)
-int launch_assign256_f16(const AssignArgs &a, int cus, hipStream_t s) {
+template <bool L2>
+int launch_assign256_f16_t(const AssignArgs &a, int cus, hipStream_t s) {
   static bool attr_set[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_set[dev & 15]) {
-    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&assign256_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A256_LDS));
+    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&assign256_f16_kernel<L2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A256_LDS));
     attr_set[dev & 15] = true;
   }
   const uint32_t items = (a.nq + A256_ROWS - 1) / A256_ROWS;
   const uint32_t grid = std::min<uint32_t>(items, (uint32_t)cus);
   if (grid == 0) return 0;
-  hipLaunchKernelGGL(assign256_f16_kernel, dim3(grid), dim3(512), A256_LDS, s, a);
+  hipLaunchKernelGGL(assign256_f16_kernel<L2>, dim3(grid), dim3(512), A256_LDS, s, a);
   ZCHK(hipGetLastError());
   return 0;
+}
+int launch_assign256_f16(const AssignArgs &a, int cus, hipStream_t s) {
+  return a.metric == METRIC_L2 ? launch_assign256_f16_t<true>(a, cus, s) : launch_assign256_f16_t<false>(a, cus, s);
 }
 
 // ng == 0 selects the 16-row-halves (16x16 MFMA) shape

@@ -35,14 +35,18 @@ namespace zvk {
 
 constexpr int A256_ROWS = 256;
 constexpr size_t A256_BUF = 64 * 1024;                                // one k-step image: A0 | A1 | B0 | B1
-constexpr size_t A256_LDS = 2 * A256_BUF + 1024;                      // + the row norms of the item (256 floats)
+constexpr size_t A256_LDS = 2 * A256_BUF + 2048;                      // + the squared norms of two centroid pairs (2 x 256 floats)
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
+#ifdef ZVK_A256_STAMPS
+__device__ unsigned long long zvk_a256_acc[2][5][4];
+#endif
 
+template <bool L2>
 __global__ void __launch_bounds__(512, 1) assign256_f16_kernel(const AssignArgs a) {
   extern __shared__ f32x4 zvk_smem4[];
   char *smem = reinterpret_cast<char *>(zvk_smem4);
-  float *qn_lds = reinterpret_cast<float *>(smem + 2 * A256_BUF);
+  float *bn_lds = reinterpret_cast<float *>(smem + 2 * A256_BUF);      // [pair & 1][256]: |c|^2 of the pair's centroids, by LDS-DMA
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -57,10 +61,8 @@ __global__ void __launch_bounds__(512, 1) assign256_f16_kernel(const AssignArgs 
   const uint32_t nsteps = npairs * nks;
   const uint32_t nitems = (a.nq + A256_ROWS - 1) / A256_ROWS;
 
-  const float m_alpha = (a.metric == METRIC_L2) ? -2.f : -1.f;
-  const float m_beta = (a.metric == METRIC_COSINE) ? 1.f : 0.f;
-  const float m_lo = (a.metric == METRIC_L2) ? 0.f : -__builtin_inff();
-  const bool l2 = a.metric == METRIC_L2;
+  const float m_beta = (a.metric == METRIC_COSINE) ? 1.f : 0.f;      // (scores: L2 max(|q|^2 + |c|^2 - 2 q.c, 0), IP -q.c, cosine 1 - q.c)
+  constexpr bool l2 = L2;
 
   // ---- fragment read offsets inside one buffer (bytes) ----
   // A fragment (i, kh): row = wr*64 + i*16 + lr of the 256-row image -> half wr >> 1, row-in-half rh = (wr&1)*64 + i*16 + lr; chunk
@@ -77,6 +79,27 @@ __global__ void __launch_bounds__(512, 1) assign256_f16_kernel(const AssignArgs 
   asm volatile("" ::: "memory");         \
   __builtin_amdgcn_s_barrier();          \
   asm volatile("" ::: "memory")
+// the barrier between a phase's reads / DMA issue / wait and its MFMAs exists for the staggered schedule only
+#ifdef ZVK_A256_LOCKSTEP
+#define ZVK_A256_MID_BARRIER()
+#else
+#define ZVK_A256_MID_BARRIER() ZVK_A256_BARRIER()
+#endif
+#ifdef ZVK_A256_STAMPS      // (diagnostic builds: where a step's time goes — shader-clock stamps of wave 0 / wave 4 of work-group 0)
+#define ZVK_A256_STAMP(P, X)                                                                                  \
+  if (blockIdx.x == 0 && (wave & 3) == 0) {                                                                    \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                               \
+    if (lane == 0) atomicAdd(&zvk_a256_acc[wc][(P)][(X)], t_ - stamp_prev);                                   \
+    stamp_prev = t_;                                                                                           \
+  }
+#else
+#define ZVK_A256_STAMP(P, X)
+#endif
+#ifdef ZVK_A256_NOWAIT      // (diagnostic builds: timing without the counted waits — results are then wrong)
+#define ZVK_A256_VMCNT8()
+#else
+#define ZVK_A256_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#endif
 
   // ---- staging geometry: a group = 2 LDS-DMA instructions of 512 lanes x 16 B (8 KiB each) ----
   // A groups: instruction j covers the image half j; threads 0..255 -> piece of row quarter 2j, 256..511 -> quarter 2j+1;
@@ -94,34 +117,63 @@ __global__ void __launch_bounds__(512, 1) assign256_f16_kernel(const AssignArgs 
     // source of this thread's A chunk: row r0 + j*128 + g*32 + ap_row; the row's swizzle term is the same for g = 0, 1 (a step
     // of 32 rows), so ONE per-thread offset serves all four (g, j) pieces with wave-uniform addends
     const uint32_t a_src0 = (r0 + (uint32_t)ap_row) * dpad + (uint32_t)((ap_pos ^ ((ap_row >> 1) & 7)) * 4);      // floats
-    // group g of step s: 0 = a0, 1 = b0, 2 = a1, 3 = b1 (the order they are issued in).  Steps past the end re-stage the last
-    // one (into regions nobody reads again) so that the counted waits stay exact to the very last phase.
-    auto stage = [&](int g, uint32_t s) {
-      s = min(s, nsteps - 1);
-      const uint32_t pair = s / nks, ks = s - pair * nks;
-      char *buf = smem + (s & 1) * A256_BUF;
+    // A step's staging cursor: the wave-uniform source bases of its k-step (advanced by additions, no multiplications in the loop)
+    struct Cursor {
+      uint32_t pair, ks, par;
+      const char *a;              // a.queries + ks * 128 bytes            (row block offsets are added per piece)
+      const char *b[2];           // the k-step slab of store tile 2 * pair + j (the last tile again when that one is missing)
+    };
+    const size_t tile_bytes = (size_t)TILE_N * dpad * 4, slab_bytes = (size_t)SLAB * 4;
+    const uint32_t a_piece[2][2] = {{0u, 128u * dpad * 4u}, {32u * dpad * 4u, (128u + 32u) * dpad * 4u}};      // [gi][j] bytes
+    auto cursor_at0 = [&]() {
+      Cursor c;
+      c.pair = 0; c.ks = 0; c.par = 0;
+      c.a = reinterpret_cast<const char *>(a.queries);
+      c.b[0] = reinterpret_cast<const char *>(a.base);
+      c.b[1] = reinterpret_cast<const char *>(a.base) + (size_t)min(1u, ntiles - 1) * tile_bytes;
+      return c;
+    };
+    // the step after c; past the end it stays on the last one (re-staged into regions nobody reads again, so that the counted
+    // waits stay exact to the very last phase)
+    auto next_step = [&](Cursor &c) {
+      if (c.pair == npairs - 1 && c.ks == nks - 1) return;
+      c.par ^= 1;
+      if (++c.ks == nks) {
+        c.ks = 0;
+        ++c.pair;
+        c.a = reinterpret_cast<const char *>(a.queries);
+        c.b[0] = reinterpret_cast<const char *>(a.base) + (size_t)min(2 * c.pair, ntiles - 1) * tile_bytes;
+        c.b[1] = reinterpret_cast<const char *>(a.base) + (size_t)min(2 * c.pair + 1, ntiles - 1) * tile_bytes;
+      } else {
+        c.a += 128;
+        c.b[0] += slab_bytes;
+        c.b[1] += slab_bytes;
+      }
+    };
+    // group g of the step at cursor c: 0 = a0, 1 = b0, 2 = a1, 3 = b1 (the order they are issued in)
+    auto stage = [&](int g, const Cursor &c) {
+#ifdef ZVK_A256_NODMA
+      if (c.pair + c.ks > 1) return;
+#endif
+      char *buf = smem + c.par * A256_BUF;
       const int gi = g >> 1;
       if ((g & 1) == 0) {
         // A: uniform base (row block, k-step) + ONE 32-bit per-thread offset
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           char *dst = buf + j * 16384 + gi * 4096 + (wave >> 2) * 8192 + (wave & 3) * 1024;                 // wave-uniform
-          const char *base = reinterpret_cast<const char *>(a.queries) + ((size_t)(j * 128 + gi * 32) * dpad + (size_t)ks * TILE_K) * 4;
-          __builtin_amdgcn_global_load_lds((glb_void *)(base + a_src0 * 4u), (lds_void *)dst, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((glb_void *)(c.a + a_piece[gi][j] + a_src0 * 4u), (lds_void *)dst, 16, 0, 0);
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const uint32_t tile = min(2 * pair + (uint32_t)j, ntiles - 1);
-          const char *base = reinterpret_cast<const char *>(a.base + (size_t)tile * TILE_N * dpad + (size_t)ks * SLAB) + gi * 8192;
           char *dst = buf + 32768 + j * 16384 + gi * 8192 + wave * 1024;                                    // wave-uniform
-          __builtin_amdgcn_global_load_lds((glb_void *)(base + b_lds0), (lds_void *)dst, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((glb_void *)(c.b[j] + gi * 8192 + b_lds0), (lds_void *)dst, 16, 0, 0);
         }
       }
     };
 
     __syncthreads();                       // the previous item's reduction scratch / norms are free again
-    if (tid < A256_ROWS) qn_lds[tid] = l2 ? a.qnorm[r0 + (uint32_t)tid] : 0.f;
     float best_s[4][4];
     uint32_t best_i[4][4];
     floatx4_t acc[4][8];
@@ -134,15 +186,33 @@ __global__ void __launch_bounds__(512, 1) assign256_f16_kernel(const AssignArgs 
     }
 
     // ---- prologue: step 0 whole, a0 / b0 of step 1; a0(0), b0(0) retired and published ----
-    stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0); stage(0, 1); stage(1, 1);
+    uint32_t pair = 0, ks = 0;                       // the step being multiplied (buffer s & 1)
+    Cursor c1 = cursor_at0();                        // step s + 1
+    {
+      const Cursor c0 = c1;
+      stage(0, c0); stage(1, c0); stage(2, c0); stage(3, c0);
+    }
+    next_step(c1);
+    Cursor c2 = c1;                                  // step s + 2
+    next_step(c2);
+    stage(0, c1); stage(1, c1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     ZVK_A256_BARRIER();
 
+#ifndef ZVK_A256_LOCKSTEP
+    // The two centroid halves' wave groups (waves 0-3 / 4-7: the two waves of every SIMD) run ONE barrier apart: while one group
+    // multiplies, the other reads its fragments, issues its DMA and sits out its counted wait.  Group 1 takes one barrier more
+    // here, group 0 one more after the loop.
+    if (wc == 1) { ZVK_A256_BARRIER(); }
+#endif
     f16x8 fa[4][2], fb[4][2];
+#ifdef ZVK_A256_STAMPS
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
     for (uint32_t s = 0; s < nsteps; ++s) {
       const char *buf = smem + (s & 1) * A256_BUF;
-      const uint32_t pair = s / nks, ks = s - pair * nks;
       // ---------------- phase 1: A rows i = 0,1 (kept for phase 4) + B columns n = 0..3; quadrant (i 0-1, n 0-3) ----------------
+      ZVK_A256_STAMP(1, 0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -151,39 +221,83 @@ __global__ void __launch_bounds__(512, 1) assign256_f16_kernel(const AssignArgs 
       for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) fb[n][kh] = ZVK_A256_FB(n, kh);
-      stage(2, s + 1);                                     // a1(s+1)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // a1(s) has landed (this wave's pieces)
+      if (l2 && ks == 0 && wave < 4) {
+        // the pair's column norms, one dword per lane of waves 0-3, into the parity slot of bn_lds: in flight for at least a whole
+        // k-step before the fold reads them (nks >= 2: the host takes the 128 x 128 kernel otherwise); the extra operation only
+        // makes these waves' counted waits more conservative
+        const uint32_t colg = min(pair * 256 + (uint32_t)tid, ntiles * TILE_N - 1);
+        __builtin_amdgcn_global_load_lds((glb_void *)(a.bnorm + colg), (lds_void *)(bn_lds + (pair & 1) * 256 + wave * 64), 4, 0, 0);
+      }
+      stage(2, c1);                                        // a1(s+1)
+      ZVK_A256_VMCNT8();                                   // a1(s) has landed (this wave's pieces)
+      ZVK_A256_STAMP(1, 1);
+      ZVK_A256_MID_BARRIER();
+      ZVK_A256_STAMP(1, 2);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
+      for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][kh], fb[n][kh], acc[i][n], 0, 0, 0);
+#ifndef ZVK_A256_LOCKSTEP
+        // phase 2's fragments (a1: retired before this phase's mid barrier) are fetched UNDER this phase's MFMAs: their registers are free
+        if (kh == 0) {
+#pragma unroll
+          for (int i = 2; i < 4; ++i)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) fa[i][k2] = ZVK_A256_FA(i, k2);
+        }
+#endif
+      }
       __builtin_amdgcn_s_setprio(0);
+      ZVK_A256_STAMP(1, 3);
       ZVK_A256_BARRIER();
       // ---------------- phase 2: A rows i = 2,3; quadrant (i 2-3, n 0-3) ----------------
+      ZVK_A256_STAMP(2, 0);
+#ifdef ZVK_A256_LOCKSTEP
 #pragma unroll
       for (int i = 2; i < 4; ++i)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) fa[i][kh] = ZVK_A256_FA(i, kh);
-      stage(3, s + 1);                                     // b1(s+1)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // b1(s) has landed
+#endif
+      stage(3, c1);                                        // b1(s+1)
+      ZVK_A256_VMCNT8();                                   // b1(s) has landed
+      ZVK_A256_STAMP(2, 1);
+      ZVK_A256_MID_BARRIER();
+      ZVK_A256_STAMP(2, 2);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
+      for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
         for (int i = 2; i < 4; ++i)
 #pragma unroll
           for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][kh], fb[n][kh], acc[i][n], 0, 0, 0);
+#ifndef ZVK_A256_LOCKSTEP
+        // the first k-half of phase 3's B fragments (b1: retired before this phase's mid barrier) over the registers the MFMAs above
+        // have just consumed, under the second k-half's MFMAs
+        if (kh == 0) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) fb[n][0] = ZVK_A256_FB(4 + n, 0);
+        }
+#endif
+      }
       __builtin_amdgcn_s_setprio(0);
+      ZVK_A256_STAMP(2, 3);
       ZVK_A256_BARRIER();
       // ---------------- phase 3: B columns n = 4..7 (over the registers of n = 0..3); quadrant (i 2-3, n 4-7) ----------------
+      ZVK_A256_STAMP(3, 0);
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) fb[n][kh] = ZVK_A256_FB(4 + n, kh);
-      stage(0, s + 2);                                     // a0(s+2): its region was last read in phase 1
+      for (int n = 0; n < 4; ++n) {
+#ifdef ZVK_A256_LOCKSTEP
+        fb[n][0] = ZVK_A256_FB(4 + n, 0);
+#endif
+        fb[n][1] = ZVK_A256_FB(4 + n, 1);
+      }
+      stage(0, c2);                                        // a0(s+2): its region was last read in phase 1
+      ZVK_A256_STAMP(3, 1);
+      ZVK_A256_MID_BARRIER();
+      ZVK_A256_STAMP(3, 2);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
@@ -192,18 +306,15 @@ __global__ void __launch_bounds__(512, 1) assign256_f16_kernel(const AssignArgs 
 #pragma unroll
           for (int n = 0; n < 4; ++n) acc[i][4 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][kh], fb[n][kh], acc[i][4 + n], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+      ZVK_A256_STAMP(3, 3);
       ZVK_A256_BARRIER();
       // ---------------- phase 4: no reads; quadrant (i 0-1, n 4-7) ----------------
-      stage(1, s + 2);                                     // b0(s+2)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // a0(s+1), b0(s+1) have landed
-      float bn[8];
-      if (ks == nks - 1 && l2) {                           // column norms of this centroid pair, landing under the last MFMAs
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-          const uint32_t col = pair * 256 + (uint32_t)(wc * 128 + n * 16 + lr);
-          bn[n] = a.bnorm[min(col, ntiles * TILE_N - 1)];
-        }
-      }
+      ZVK_A256_STAMP(4, 0);
+      stage(1, c2);                                        // b0(s+2)
+      ZVK_A256_VMCNT8();                                   // a0(s+1), b0(s+1) have landed
+      ZVK_A256_STAMP(4, 1);
+      ZVK_A256_MID_BARRIER();
+      ZVK_A256_STAMP(4, 2);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
@@ -212,33 +323,49 @@ __global__ void __launch_bounds__(512, 1) assign256_f16_kernel(const AssignArgs 
 #pragma unroll
           for (int n = 0; n < 4; ++n) acc[i][4 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][kh], fb[n][kh], acc[i][4 + n], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+      ZVK_A256_STAMP(4, 3);
       // ---- end of a centroid pair: fold the 64 x 128 block into the running arg-min (registers only) ----
+#ifdef ZVK_A256_NOFOLD
+      if (ks == nks - 1 && a.n == 0xffffffffu) {
+#else
       if (ks == nks - 1) {
+#endif
+        // Compared per row: t = |c|^2 - 2 q.c (L2) or -q.c (IP / cosine) — the row's own |q|^2 (and cosine's 1) is common to all
+        // its candidates and joins the winner when the item ends; padding columns of the last tile (or of a missing second tile)
+        // carry +inf and never win.
+        float cadd[8];
+        uint32_t col[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          col[n] = pair * 256 + (uint32_t)(wc * 128 + n * 16 + lr);
+          const float nb = l2 ? bn_lds[(pair & 1) * 256 + wc * 128 + n * 16 + lr] : 0.f;
+          cadd[n] = col[n] < a.n ? nb : __builtin_inff();
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const f32x4 q4 = *reinterpret_cast<const f32x4 *>(qn_lds + wr * 64 + i * 16 + lq * 4);
 #pragma unroll
           for (int n = 0; n < 8; ++n) {
-            const uint32_t col = pair * 256 + (uint32_t)(wc * 128 + n * 16 + lr);
-            const bool valid = col < a.n;                  // padding columns of the last tile (or of a missing second tile) never win
-            const float nb = l2 ? bn[n] : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float dot = acc[i][n][j];
-              float sc = fmaxf(fmaf(m_alpha, dot, l2 ? q4[j] + nb : m_beta), m_lo);
-              sc = valid ? sc : __builtin_inff();
-              if (sc < best_s[i][j]) {                     // strict: a lane's columns come in ascending order, the first stays
-                best_s[i][j] = sc;
-                best_i[i][j] = col;
+              const float t = fmaf(l2 ? -2.f : -1.f, acc[i][n][j], cadd[n]);
+              if (t < best_s[i][j]) {                      // strict: a lane's columns come in ascending order, the first stays
+                best_s[i][j] = t;
+                best_i[i][j] = col[n];
               }
               acc[i][n][j] = 0.f;
             }
           }
         }
       }
+      pair = c1.pair; ks = c1.ks;
+      c1 = c2;
+      next_step(c2);
       ZVK_A256_BARRIER();
     }
 
+#ifndef ZVK_A256_LOCKSTEP
+    if (wc == 0) { ZVK_A256_BARRIER(); }
+#endif
     // ---- end of the item: the 16 lanes sharing a row slot (xor-shuffles over lr), then the two centroid halves through LDS ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-staged tail has landed: the operand buffers become scratch
 #pragma unroll
@@ -277,7 +404,7 @@ __global__ void __launch_bounds__(512, 1) assign256_f16_kernel(const AssignArgs 
       const uint32_t i1 = red_i[A256_ROWS + tid];
       if (s1 < s_ || (s1 == s_ && i1 < i_)) { s_ = s1; i_ = i1; }
       a.out_label[r0 + tid] = i_;
-      if (a.out_score) a.out_score[r0 + tid] = s_;
+      if (a.out_score) a.out_score[r0 + tid] = l2 ? fmaxf(a.qnorm[r0 + tid] + s_, 0.f) : s_ + m_beta;
     }
   }
 }
@@ -285,5 +412,7 @@ __global__ void __launch_bounds__(512, 1) assign256_f16_kernel(const AssignArgs 
 #undef ZVK_A256_FA
 #undef ZVK_A256_FB
 #undef ZVK_A256_BARRIER
+#undef ZVK_A256_MID_BARRIER
+#undef ZVK_A256_VMCNT8
 
 }  // namespace zvk
