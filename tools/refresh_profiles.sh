@@ -19,6 +19,8 @@ timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s10
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b1 -- python3 $R/bench.py --batch 1 --steps 200 --warmup 20 --no-cpu-baseline --no-host-path > $O/${tag}_ivf10m_b1_bench_under_rocprof.json 2> $O/b1.log
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b8 -- python3 $R/bench.py --batch 8 --steps 100 --warmup 10 --no-cpu-baseline --no-host-path > $O/${tag}_ivf10m_b8_bench_under_rocprof.json 2> $O/b8.log
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/label -- python3 $R/tools/time_label.py > $O/${tag}_label_time.log 2> $O/label.log
+# round 4: the wide flat tile on fp16 rows (its fraction of the f16 peak must be recomputable from a committed summary)
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/flat16 -- python3 $R/bench.py --workload flat1m_fp16 --steps 10 --warmup 2 --no-cpu-baseline > $O/${tag}_flat1m_fp16_bench_under_rocprof.json 2> $O/flat16.log
 python3 - <<PY
 import csv, glob, json, shutil
 O, tag = "$O", "$tag"
@@ -31,6 +33,7 @@ shutil.copy(one("s100/**/*kernel_stats.csv"), O + "/%s_ivf100m_fp16_shard8_kerne
 shutil.copy(one("b1/**/*kernel_stats.csv"), O + "/%s_ivf10m_b1_kernel_stats.csv" % tag)
 shutil.copy(one("b8/**/*kernel_stats.csv"), O + "/%s_ivf10m_b8_kernel_stats.csv" % tag)
 shutil.copy(one("label/**/*kernel_stats.csv"), O + "/%s_label_kernel_stats.csv" % tag)
+shutil.copy(one("flat16/**/*kernel_stats.csv"), O + "/%s_flat1m_fp16_kernel_stats.csv" % tag)
 for name, d in (("ivf10m", "stats"), ("flat1m", "flat"), ("ivf10m_shard8", "shard8"), ("ivf10m_b1", "b1"), ("ivf10m_b8", "b8")):
     rows = list(csv.DictReader(open(one(d + "/**/*kernel_trace.csv"))))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
