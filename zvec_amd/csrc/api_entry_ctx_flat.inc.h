@@ -41,6 +41,11 @@ int zvec_hip_set_option(const char *name, int value) {
     return 0;
   }
   if (strcmp(name, "assign256") == 0) { ropts().assign256 = value != 0; return 0; }
+  if (strcmp(name, "scan256") == 0) {
+    if (value < 0 || value > 2) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+    ropts().scan256 = value;
+    return 0;
+  }
   return ZVEC_HIP_ERR_UNSUPPORTED;
 }
 int zvec_hip_get_option(const char *name, int *value) {
@@ -48,6 +53,7 @@ int zvec_hip_get_option(const char *name, int *value) {
   if (strcmp(name, "wait") == 0) { *value = ropts().wait; return 0; }
   if (strcmp(name, "zerocopy") == 0) { *value = ropts().zerocopy; return 0; }
   if (strcmp(name, "assign256") == 0) { *value = ropts().assign256; return 0; }
+  if (strcmp(name, "scan256") == 0) { *value = ropts().scan256; return 0; }
   return ZVEC_HIP_ERR_UNSUPPORTED;
 }
 

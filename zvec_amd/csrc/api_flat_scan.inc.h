@@ -25,6 +25,7 @@ struct Knobs {
   int ivf_occ_cap = 0;        // ZVEC_HIP_IVF_OCC_CAP   IVF list scan: at most this many persistent work-groups per CU (0 = all)
   bool no_wide_dump = false;  // ZVEC_HIP_NO_WIDE_DUMP  dense-score path (IVF coarse step): never take the 8-wave tile
   int ivf_direct_q = 8;       // ZVEC_HIP_IVF_DIRECT_Q  IVF searches of at most this many queries take the direct (wave per row) route
+  int seed_rows256 = 4096;    // ZVEC_HIP_SEED_ROWS256  rows of the bound-seeding prefix in front of the 256 x 256 fp16 tile (multiple of 128)
   Knobs() {
 #ifdef ZVEC_HIP_TUNING
     if (const char *e = getenv("ZVEC_HIP_MAX_NG")) max_ng = std::max(1, std::min(4, atoi(e)));
@@ -38,6 +39,7 @@ struct Knobs {
     if (const char *e = getenv("ZVEC_HIP_IVF_OCC_CAP")) ivf_occ_cap = std::max(0, atoi(e));
     if (const char *e = getenv("ZVEC_HIP_IVF_HEAD_PCT")) ivf_head_pct = std::max(0, std::min(75, atoi(e)));
     if (const char *e = getenv("ZVEC_HIP_IVF_DIRECT_Q")) ivf_direct_q = std::max(0, atoi(e));
+    if (const char *e = getenv("ZVEC_HIP_SEED_ROWS256")) seed_rows256 = std::max(128, atoi(e) / 128 * 128);
 #endif
   }
 };
@@ -112,6 +114,24 @@ int launch_scan8(const ScanArgs &a, bool f16, uint32_t max_items, int cus, hipSt
                      : launch_scan8_t<false, true, false>(a, max_items, cus, stream, occ_out);
   return a.exclude ? launch_scan8_t<true, false, false>(a, max_items, cus, stream, occ_out)
                    : launch_scan8_t<false, false, false>(a, max_items, cus, stream, occ_out);
+}
+
+// wide fp16 flat scan on the 256 x 256 multi-phase tile (zvk_scan256.hip.h): ONE work-group of 8 waves per CU
+int launch_scan256_f16(const ScanArgs &a, uint32_t max_items, int cus, hipStream_t stream) {
+  static bool attr_set[16] = {false};
+  const size_t lds = scan256_lds_bytes(a.k);
+  if (lds > LDS_LIMIT || a.nq < (uint32_t)S256_ROWS || a.nks < 2) return ZVEC_HIP_ERR_UNSUPPORTED;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set[dev & 15]) {
+    ZCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan256_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    attr_set[dev & 15] = true;
+  }
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)max_items, (uint64_t)cus);
+  if (grid == 0) return 0;
+  hipLaunchKernelGGL(scan256_f16_kernel, dim3(grid), dim3(512), lds, stream, a);
+  ZCHK(hipGetLastError());
+  return 0;
 }
 
 // nearest-centroid assignment (zvk_assign.hip.h): one work item = 128 rows x every centroid, two work-groups per CU
@@ -429,7 +449,10 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     const double row_bytes_d = (double)ntiles_d * TILE_N * 4.0;
     const bool small_base = (double)st.n * st.dpad * 4.0 <= 64.0 * 1024 * 1024;
     const bool k_fits_merge = (size_t)topk * 12 + 16 <= 60 * 1024;
-    const bool want_a = small_base && d_exclude == nullptr && topk > 8 && row_bytes_d * count <= 128.0 * 1024 * 1024;
+    // (tests force the 256 x 256 tile onto small bases: option scan256 = 2)
+    const bool forced256 = ropts().scan256.load(std::memory_order_relaxed) == 2 && st.f16 && count >= (uint32_t)S256_ROWS &&
+                           st.dpad / TILE_K >= 2 && scan256_lds_bytes(topk) <= LDS_LIMIT;
+    const bool want_a = small_base && d_exclude == nullptr && topk > 8 && row_bytes_d * count <= 128.0 * 1024 * 1024 && !forced256;
     const bool want_b = pick_ng(count, topk) < 1;
     if (want_b && !k_fits_merge) return ZVEC_HIP_ERR_UNSUPPORTED;
     if ((want_a || want_b) && k_fits_merge) {
@@ -453,12 +476,22 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
       return 0;
     }
   }
+  // The fused shapes: a base that stays in the 256 MiB Infinity Cache (IVF centroids, k-means codebooks) can be re-read by
+  // every query tile for free and prefers many small query tiles; wide batches over a streamed base take the 8-wave 128 x 128
+  // tile; fp16 rows under at least 256 queries with a short list the 256 x 256 multi-phase tile (one work-group per CU).
+  const bool cache_resident = (double)st.n * st.dpad * 4.0 <= 64.0 * 1024 * 1024;
+  const int opt256 = ropts().scan256.load(std::memory_order_relaxed);      // (2: on cache-resident bases too — the tests' small cases)
+  const bool can256 = opt256 != 0 && st.f16 && d_exclude == nullptr && count >= (uint32_t)S256_ROWS && st.dpad / TILE_K >= 2 &&
+                      scan256_lds_bytes(topk) <= LDS_LIMIT && (uint64_t)count * st.dpad * 4ull < (1ull << 32);   // (32-bit query offsets)
+  const bool wide = !knobs().no_wide && (!cache_resident || knobs().force_wide || (opt256 == 2 && can256)) && pick_ng(count, topk) == 4 &&
+                    count > 2 * QGROUP && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
+  const bool wide256 = wide && can256;
   // Bound seeding: every work-group of the fused scan starts its lists empty, and filling a list costs ~k ln(rows/k)
   // sorted insertions per (query, chunk) — with hundreds of chunks in flight that warm-up is most of the admission
   // work.  A scan of a small prefix first (its k-th score bounds the final k-th from above) lets every chunk start
   // with a bound that only ~k * chunk_rows / sample_rows of its rows pass.
-  constexpr uint64_t SEED_ROWS = 4096;
-  if (!knobs().no_seed && st.n >= 64 * SEED_ROWS && topk <= 64 && count >= 16) {
+  const uint64_t SEED_ROWS = wide256 ? (uint64_t)knobs().seed_rows256 : 4096;
+  if (!knobs().no_seed && st.n >= 64 * 4096 && topk <= 64 && count >= 16) {
     ZRET(ctx->seed_keys.ensure((size_t)count * topk * sizeof(uint64_t)));
     ZRET(ctx->seed_scores.ensure((size_t)count * topk * sizeof(float)));
     ZRET(ctx->seed_counts.ensure((size_t)count * sizeof(uint32_t)));
@@ -474,10 +507,6 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     ZCHK(hipGetLastError());
   }
   int ng = pick_ng(count, topk);
-  // a base that stays in the 256 MiB Infinity Cache (IVF centroids, k-means codebooks) can be re-read by
-  // every query tile for free: prefer many small query tiles (more work-groups, each with a long run of
-  // tiles per top-k warm-up) over few large ones
-  const bool cache_resident = (double)st.n * st.dpad * 4.0 <= 64.0 * 1024 * 1024;
   if (cache_resident && ng > 1) ng = 1;
   if (ng < 1) return ZVEC_HIP_ERR_UNSUPPORTED;
   // a handful of queries (the product's count = 1): the 16-row MFMA shape (the IVF list-scan kernel in flat mode) does
@@ -485,22 +514,24 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
   // (1 query over 1M x 768: scan 0.64 -> 0.50 ms = 6.1 TB/s; 1M x 128: 0.155 -> 0.126 ms)
   const bool m16_small = knobs().m16_small && ng == 1 && count <= 16;
   const int cus = device_cus(ctx);
-  // wide batches over a streamed base: the 8-wave 128x128 tile (two work-groups per CU while its lists fit)
-  const bool wide = !knobs().no_wide && (!cache_resident || knobs().force_wide) && pick_ng(count, topk) == 4 && count > 2 * QGROUP && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
   int occ8 = 1;
   ScanArgs probe{};
   probe.k = topk; probe.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
-  if (wide) ZRET(launch_scan8(probe, st.f16, 0, cus, stream, &occ8));
-  const uint32_t rows = wide ? W8_ROWS : ng * QGROUP;
+  if (wide && !wide256) ZRET(launch_scan8(probe, st.f16, 0, cus, stream, &occ8));
+  const uint32_t rows = wide256 ? (uint32_t)S256_ROWS : wide ? W8_ROWS : ng * QGROUP;
   const uint32_t nqtiles = (count + rows - 1) / rows;
   const uint64_t ntiles = (st.n + TILE_N - 1) / TILE_N;
-  uint64_t resident = wide ? (uint64_t)cus * occ8
+  uint64_t resident = wide256 ? (uint64_t)cus : wide ? (uint64_t)cus * occ8
                            : (uint64_t)cus * (ng >= 4 ? 2 : (ng == 2 ? 2 : 3));   // work-groups per CU each shape reaches
   // items are equal-sized in a flat scan, so ONE wave of work-groups (items == resident slots) is the balanced
   // choice and gives the longest tile runs per top-k warm-up
   FlatSplit fs;
   if (wide) {
     fs = flat_split(ntiles, nqtiles, resident);
+    if (wide256 && (fs.tpc & 1)) {          // the kernel walks the chunk in PAIRS of tiles
+      fs.tpc += 1;
+      fs.nchunks = (uint32_t)((ntiles + fs.tpc - 1) / fs.tpc);
+    }
   } else {
     uint64_t want_chunks = std::max<uint64_t>(1, (resident + nqtiles - 1) / nqtiles);
     uint64_t tpc1 = std::max<uint64_t>(1, (ntiles + want_chunks - 1) / want_chunks);
@@ -531,7 +562,8 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     pi = prof_begin(ctx, stream, bytes, flops, 0);
   }
   int lrc;
-  if (wide) lrc = launch_scan8(a, st.f16, ((nchunks + 7) / 8) * 8 * nqtiles, cus, stream);   // ids padded to whole XCD groups
+  if (wide256) lrc = launch_scan256_f16(a, ((nchunks + 7) / 8) * 8 * nqtiles, cus, stream);
+  else if (wide) lrc = launch_scan8(a, st.f16, ((nchunks + 7) / 8) * 8 * nqtiles, cus, stream);   // ids padded to whole XCD groups
   else lrc = launch_scan_ng(m16_small ? 0 : ng, a, st.f16, nchunks * nqtiles, cus, stream);
   prof_end(ctx, stream, pi);
   if (profile_it) gate_leave(ctx, stream);

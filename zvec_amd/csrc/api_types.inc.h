@@ -74,7 +74,9 @@ struct RuntimeOpts {
   std::atomic<int> wait{1};
   std::atomic<int> zerocopy{2};
   std::atomic<int> assign256{1};     // fp16 labelling on the 256 x 256 multi-phase tile (0: always the 128 x 128 one-barrier tile)
+  std::atomic<int> scan256{1};       // wide fp16 flat scans (>= 256 queries, k <= 11) on the 256 x 256 multi-phase tile (0: scan8_kernel; 2: on cache-resident bases too)
   RuntimeOpts() {
+    if (const char *e = getenv("ZVEC_HIP_SCAN256")) scan256 = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("ZVEC_HIP_WAIT")) wait = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("ZVEC_HIP_ASSIGN256")) assign256 = atoi(e) != 0;
     if (const char *e = getenv("ZVEC_HIP_ZEROCOPY")) zerocopy = std::max(0, std::min(3, atoi(e)));

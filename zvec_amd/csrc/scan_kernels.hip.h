@@ -24,6 +24,7 @@
 #include "zvk_scan.hip.h"
 #include "zvk_assign.hip.h"
 #include "zvk_assign256.hip.h"
+#include "zvk_scan256.hip.h"
 #include "zvk_merge.hip.h"
 #include "zvk_rows.hip.h"
 #include "zvk_filter.hip.h"
