@@ -774,7 +774,13 @@ def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, top
     small = batch <= 16         # a handful of queries: the scan streams the base once => HBM-bound
     peak = MFMA_F16_PEAK_TF if f16 else MFMA_F32_PEAK_TF
     box = box_calibration(zvec_amd, torch.cuda.current_device())
-    roof = {"bound": "mfma", "kernel": "zvk::scan8_kernel (flat scan)", "achieved": tf, "peak": peak,
+    # which wide kernel the dispatch takes (api_flat_scan.inc.h: fp16 rows, >= 256 queries, k <= 11, unfiltered, option scan256 on)
+    import ctypes as C
+    opt256 = C.c_int(0)
+    zvec_amd._lib.lib().zvec_hip_get_option(b"scan256", C.byref(opt256))
+    on256 = f16 and opt256.value != 0 and batch >= 256 and topk <= 11 and doc_filter is None and dim > 64
+    kname = "zvk::scan256_f16_kernel (flat scan, 256 x 256 multi-phase tile)" if on256 else "zvk::scan8_kernel (flat scan)"
+    roof = {"bound": "mfma", "kernel": kname, "achieved": tf, "peak": peak,
             "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": ms,
             "frac_basis": "kernel_ms (HIP events around the launch)",
             "box_clock_mhz": box.get("clock_mhz"), "box_stream_gbs": box.get("stream_gbs"), "box_note": box.get("note"),

@@ -72,7 +72,11 @@ const char *zvec_hip_error_string(int code); /* IndexError::What analogue */
  *   "zerocopy"  transfers up to 256 KiB may skip the copy engine through host-mapped pinned slots of the context: bit 1 (value 2,
  *               the default) = the last kernels write keys | scores | counts straight into host memory; bit 0 = the first kernel
  *               reads the queries in place (measured slower than the staged copy: off by default); 0 = staged copies both ways
- * Unsupported (-12) for an unknown name. */
+ *   "assign256" 1 (default) = fp16 labelling / k-means assignment on the 256 x 256 multi-phase tile; 0 = the 128 x 128 tile
+ *   "scan256"   1 (default) = flat scans of fp16 rows by at least 256 queries with k <= 11 and no filter take the 256 x 256
+ *               multi-phase tile when the base is streamed (past the Infinity Cache); 2 = on small bases too (tests); 0 = the
+ *               128 x 128 tile always.  Same results either way (ZVEC_HIP_ASSIGN256 / ZVEC_HIP_SCAN256 in the environment).
+ * Unsupported (-12) for an unknown name, invalid argument (-1) for a value outside the option's range. */
 int zvec_hip_set_option(const char *name, int value);
 int zvec_hip_get_option(const char *name, int *value);
 

@@ -53,36 +53,44 @@ __device__ __forceinline__ void lds_store_f32(float *p, float v) { lds_store_u32
 // same admission rule and the same kept set as owner_row / sorted_insert (zvk_common.hip.h): s <= min(tau, gt), ascending
 // (score, position), the k smallest kept.
 __device__ __forceinline__ void lane_insert(const RowState &st, int row, float s, uint32_t pos) {
+  constexpr int KMAX = 11;                                  // (scan256_lds_bytes: the lists of a longer k do not fit)
   const uint32_t k = st.k;
   float tl = st.tau[row];
   const float tg = st.gt[row];
-  if (!(s <= fminf(tl, tg))) return;
   uint32_t c = st.cnt[row];
   float *L = st.Ls + (size_t)row * k;
   uint32_t *I = st.Li + (size_t)row * k;
-  uint32_t j;
-  if (c == k) {
-    const float es = L[k - 1];
-    const uint32_t ei = I[k - 1];
-    if (!(s < es || (s == es && pos < ei))) return;       // k entries precede it
-    j = k - 1;
-  } else {
-    j = c;
-    ++c;
+  // the whole list in one round of loads: the number of entries in front of the candidate, then the tail moves up by stores only
+  float es[KMAX];
+  uint32_t ei[KMAX];
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t) {
+    const bool in = (uint32_t)t < c;
+    es[t] = in ? L[t] : 0.f;
+    ei[t] = in ? I[t] : 0u;
   }
-  while (j > 0) {
-    const float es = L[j - 1];
-    const uint32_t ei = I[j - 1];
-    if (es < s || (es == s && ei < pos)) break;
-    L[j] = es;
-    I[j] = ei;
-    --j;
+  if (!(s <= fminf(tl, tg))) return;
+  uint32_t p = 0;
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t) p += ((uint32_t)t < c && (es[t] < s || (es[t] == s && ei[t] < pos))) ? 1u : 0u;
+  if (p >= k) return;                                       // k entries precede it
+  const uint32_t hi = min(c, k - 1);                        // entries [p, hi) move up by one
+#pragma unroll
+  for (int t = 0; t < KMAX - 1; ++t) {
+    if ((uint32_t)t >= p && (uint32_t)t < hi) {
+      L[t + 1] = es[t];
+      I[t + 1] = ei[t];
+    }
   }
-  L[j] = s;
-  I[j] = pos;
+  L[p] = s;
+  I[p] = pos;
+  c = min(c + 1, k);
   st.cnt[row] = c;
   if (c == k) {
-    tl = L[k - 1];
+    tl = s;                                                 // the new k-th: the candidate, or the old (k-1)-th it pushed up
+#pragma unroll
+    for (int t = 0; t < KMAX - 1; ++t)
+      if (p != k - 1 && (uint32_t)t + 2 == k) tl = es[t];
     st.tau[row] = tl;
     if (tl < tg) atomicMin(&st.gtau[st.qrow[row]], fkey(tl));
   }
@@ -373,34 +381,36 @@ __global__ void __launch_bounds__(512, 1) scan256_f16_kernel(const ScanArgs a) {
           for (int i = 0; i < 4; ++i) {
             const f32x4 tq4 = *reinterpret_cast<const f32x4 *>(st.tq + row0 + i * 16);
             const f32x4 qn4 = *reinterpret_cast<const f32x4 *>(qn_s + row0 + i * 16);      // (0 unless L2)
-            // The unrolled test runs in the shifted form alpha q.b + |b|^2 <= (bound - |q|^2) + slack: two packed FMAs and four
-            // compares per 4 scores.  The slack, 2^-19 (|bound| + |q|^2), covers the roundings of both forms (a passing L2 score has
-            // |b|^2 <= 2 (|q|^2 + bound), so every term is within a few 2^-24 of that scale); the exact score and the exact test
-            // follow on the taken side.  +inf bounds stay +inf; the -inf of a dead row becomes NaN and never passes.
-            f32x4 tqs;
+            // The unrolled test runs in the shifted form  min_j (alpha q.b_j - (bound_j - |q_j|^2 + slack_j)) <= -(|b|^2)  over the 4
+            // rows a lane holds of one column: two packed FMAs, two minima, ONE compare and branch per 4 scores.  The slack,
+            // 2^-19 (|bound| + |q|^2), covers the roundings of both forms (a passing L2 score has |b|^2 <= 2 (|q|^2 + bound), so
+            // every term is within a few 2^-24 of that scale); the exact scores and the exact tests follow on the taken side.
+            // +inf bounds stay +inf; the -inf of a dead row becomes NaN, which the minima drop and no compare passes.
+            f32x4 nts;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tqs[j] = (tq4[j] - qn4[j]) + (__builtin_fabsf(tq4[j]) + qn4[j]) * 0x1p-19f;
+            for (int j = 0; j < 4; ++j) nts[j] = -((tq4[j] - qn4[j]) + (__builtin_fabsf(tq4[j]) + qn4[j]) * 0x1p-19f);
             const uint32_t qhalf = lds_off(sc + slot_addr((wr * 2 + (i >> 1)) * 4) + wc * (S256_QHALF * 8));
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
-              const f32x2 in2 = {inner[n], inner[n]};
               const f32x2 al2 = {m_alpha, m_alpha};
-              const f32x2 y01 = al2 * f32x2{acc[i][n][0], acc[i][n][1]} + in2;
-              const f32x2 y23 = al2 * f32x2{acc[i][n][2], acc[i][n][3]} + in2;
-              const float y_[4] = {y01.x, y01.y, y23.x, y23.y};
+              const f32x2 w01 = al2 * f32x2{acc[i][n][0], acc[i][n][1]} + f32x2{nts[0], nts[1]};
+              const f32x2 w23 = al2 * f32x2{acc[i][n][2], acc[i][n][3]} + f32x2{nts[2], nts[3]};
+              const float wmin = __builtin_fminf(__builtin_fminf(w01.x, w01.y), __builtin_fminf(w23.x, w23.y));
+              if (__ballot(wmin <= -inner[n]) != 0) {      // (wave-uniform)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                if (__ballot(y_[j] <= tqs[j]) != 0) {      // (wave-uniform)
+                for (int j = 0; j < 4; ++j) {
                   // the same operations as the transposing path below: fma(alpha, dot, fma(nrm, |q|^2 + |b|^2, beta)), clamped at the
                   // metric's floor (a NaN — a column past the rows — must not be laundered by the clamp)
                   const float x_ = fmaf(m_alpha, acc[i][n][j], qn4[j] + inner[n]);
                   const float v_ = fmaxf(x_, m_lo);
                   const bool ok = x_ <= tq4[j] && v_ <= tq4[j];
                   const uint64_t m_ = __ballot(ok);
-                  const uint32_t e_ = nput[i >> 1] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));
-                  if (ok && e_ < (uint32_t)S256_QHALF)
-                    lds_store_u64(qhalf + e_ * 8, (uint64_t)__builtin_bit_cast(uint32_t, v_) | ((uint64_t)(code0 + (uint32_t)(((i * 16 + j) << 8) + n * 16)) << 32));
-                  nput[i >> 1] += (uint32_t)__popcll(m_);
+                  if (m_ != 0) {
+                    const uint32_t e_ = nput[i >> 1] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));
+                    if (ok && e_ < (uint32_t)S256_QHALF)
+                      lds_store_u64(qhalf + e_ * 8, (uint64_t)__builtin_bit_cast(uint32_t, v_) | ((uint64_t)(code0 + (uint32_t)(((i * 16 + j) << 8) + n * 16)) << 32));
+                    nput[i >> 1] += (uint32_t)__popcll(m_);
+                  }
                 }
               }
             }
