@@ -111,3 +111,30 @@ def test_streamed_base_with_seeded_bounds(zv, oracle):
             tie_tolerant_compare(g[0], g[1], g[2], b[0], b[1], b[2], what="scan256 against scan8, streamed %s" % name)
     finally:
         assert L.zvec_hip_set_option(b"scan256", 1) == 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_seeded_sweep(zv, oracle, forced256, seed):
+    """random shapes on the 256 x 256 tile: ragged batches, odd tile counts, every k it holds, remapped keys, a radius"""
+    rng = np.random.default_rng(9100 + seed)
+    dim = int(rng.choice([65, 96, 128, 200, 384, 520, 768, 1000]))
+    n = int(rng.choice([130, 257, 1000, 4097, 12000, 30000]))
+    nq = int(rng.choice([256, 257, 300, 383, 512, 600]))
+    k = int(rng.integers(1, 12))
+    name, metric = [("SquaredEuclidean", O.METRIC_L2), ("InnerProduct", O.METRIC_IP)][int(rng.integers(0, 2))]
+    hi = 12 if dim > 200 else 30
+    base = rng.integers(-hi, hi + 1, (n, dim)).astype(np.float16)
+    q = rng.integers(-hi, hi + 1, (nq, dim)).astype(np.float16)
+    keys = rng.permutation(2 * n)[:n].astype(np.uint64)
+    se = zv.HipFlatSearcher(dim, name, dtype="fp16")
+    assert se.load(base, keys) == 0
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    thr = O.FLT_MAX
+    if rng.random() < 0.4:
+        thr = float(np.median(oracle.flat_search(base, q[:1], min(3 * k, n), metric, threads=8)[1]))
+        ctx.set_threshold(thr)
+    assert se.search_impl(q, nq, ctx) == 0
+    ok, os_, _, oc = oracle.flat_search(base, q, k, metric, keys=keys, threshold=thr, threads=16)
+    tie_tolerant_compare(ctx.keys, ctx.scores, ctx.counts, ok, os_, oc,
+                         what="scan256 sweep seed=%d n=%d d=%d nq=%d k=%d thr=%g %s" % (seed, n, dim, nq, k, thr, name))
