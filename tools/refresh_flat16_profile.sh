@@ -1,9 +1,10 @@
 #!/bin/bash
 # usage (on the GPU box): tools/refresh_flat16_profile.sh [tag]
 # The evidence of the wide fp16 flat scan (bench.py --workload flat1m_fp16: 1M x 768 fp16, k = 10), for 256 and 1024 queries:
-#   <tag>_flat1m_fp16[_b1024]_bench.json                 the plain bench line (256 x 256 tile)
-#   <tag>_flat1m_fp16[_b1024]_scan8_bench.json           the same with option scan256 = 0 (the 128 x 128 tile of rounds 2-3)
-#   <tag>_flat1m_fp16[_b1024]_kernel_stats.csv / _kernel_trace_tail.csv / _bench_under_rocprof.json   rocprofv3 --kernel-trace --stats
+#   <tag>_flat1m_fp16[_b1024]_bench.json                 the plain bench line (256 x 256 tile; two lanes, the default)
+#   <tag>_flat1m_fp16[_b1024]_streams1_bench.json        the same on ONE lane (--streams 1: kernel_ms is then one launch alone)
+#   <tag>_flat1m_fp16[_b1024]_scan8_bench.json           one lane with option scan256 = 0 (the 128 x 128 tile of rounds 2-3)
+#   <tag>_flat1m_fp16[_b1024]_kernel_stats.csv / _kernel_trace_tail.csv / _bench_under_rocprof.json   rocprofv3 --kernel-trace --stats, one lane
 #   <tag>_flat1m_fp16_pmc.json                            MFMA-busy share / waits / LDS conflicts / effective clock of scan256_f16_kernel
 # -> gpurun_out/profiles_new/
 set -e
@@ -15,9 +16,10 @@ mkdir -p $O
 for b in 256 1024; do
   v=""; [ $b != 256 ] && v="_b$b"
   python3 $R/bench.py --workload flat1m_fp16 --batch $b --steps 30 --warmup 5 --no-cpu-baseline > $O/${tag}_flat1m_fp16${v}_bench.json 2> $O/f16$v.log
-  ZVEC_HIP_SCAN256=0 python3 $R/bench.py --workload flat1m_fp16 --batch $b --steps 30 --warmup 5 --no-cpu-baseline > $O/${tag}_flat1m_fp16${v}_scan8_bench.json 2>> $O/f16$v.log
+  python3 $R/bench.py --workload flat1m_fp16 --batch $b --steps 30 --warmup 5 --no-cpu-baseline --streams 1 > $O/${tag}_flat1m_fp16${v}_streams1_bench.json 2>> $O/f16$v.log
+  ZVEC_HIP_SCAN256=0 python3 $R/bench.py --workload flat1m_fp16 --batch $b --steps 30 --warmup 5 --no-cpu-baseline --streams 1 > $O/${tag}_flat1m_fp16${v}_scan8_bench.json 2>> $O/f16$v.log
   rm -rf $O/f16prof
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/f16prof -- python3 $R/bench.py --workload flat1m_fp16 --batch $b --steps 10 --warmup 2 --no-cpu-baseline > $O/${tag}_flat1m_fp16${v}_bench_under_rocprof.json 2>> $O/f16$v.log
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/f16prof -- python3 $R/bench.py --workload flat1m_fp16 --batch $b --steps 10 --warmup 2 --no-cpu-baseline --streams 1 > $O/${tag}_flat1m_fp16${v}_bench_under_rocprof.json 2>> $O/f16$v.log
   python3 - <<PY
 import csv, glob, shutil
 O, tag, v = "$O", "$tag", "$v"
@@ -39,7 +41,7 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_WAVES"; do
   i=$((i+1))
   rm -rf $O/f16pmc_$i
-  timeout -k 10 280 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/f16pmc_$i -- python3 $R/bench.py --workload flat1m_fp16 --steps 10 --warmup 2 --no-cpu-baseline > $O/f16pmc_$i.log 2>&1 || exit 1
+  timeout -k 10 280 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/f16pmc_$i -- python3 $R/bench.py --workload flat1m_fp16 --steps 10 --warmup 2 --no-cpu-baseline --streams 1 > $O/f16pmc_$i.log 2>&1 || exit 1
 done
 python3 - <<PY
 import csv, glob, collections, json

@@ -12,7 +12,7 @@ rm -rf $O && mkdir -p $O
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/${tag}_ivf10m_bench_under_rocprof.json 2> $O/stats.log
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.log
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.log
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/flat -- python3 $R/bench.py --workload flat1m --steps 10 --warmup 2 --no-cpu-baseline > $O/${tag}_flat1m_bench_under_rocprof.json 2> $O/flat.log
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/flat -- python3 $R/bench.py --workload flat1m --steps 10 --warmup 2 --no-cpu-baseline --streams 1 > $O/${tag}_flat1m_bench_under_rocprof.json 2> $O/flat.log
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/shard8 -- python3 $R/bench.py --shard-of 8 --steps 10 --warmup 2 --no-host-path > $O/${tag}_ivf10m_shard8_bench_under_rocprof.json 2> $O/shard8.log
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s100 -- python3 $R/bench.py --workload ivf100m_fp16 --shard-of 8 --steps 10 --warmup 2 --no-host-path > $O/${tag}_ivf100m_fp16_shard8_bench_under_rocprof.json 2> $O/s100.log
 # round 3: the product's count = 1 / small-batch route, and the build's labelling kernel
@@ -20,7 +20,7 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b1 
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b8 -- python3 $R/bench.py --batch 8 --steps 100 --warmup 10 --no-cpu-baseline --no-host-path > $O/${tag}_ivf10m_b8_bench_under_rocprof.json 2> $O/b8.log
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/label -- python3 $R/tools/time_label.py > $O/${tag}_label_time.log 2> $O/label.log
 # round 4: the wide flat tile on fp16 rows (its fraction of the f16 peak must be recomputable from a committed summary)
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/flat16 -- python3 $R/bench.py --workload flat1m_fp16 --steps 10 --warmup 2 --no-cpu-baseline > $O/${tag}_flat1m_fp16_bench_under_rocprof.json 2> $O/flat16.log
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/flat16 -- python3 $R/bench.py --workload flat1m_fp16 --steps 10 --warmup 2 --no-cpu-baseline --streams 1 > $O/${tag}_flat1m_fp16_bench_under_rocprof.json 2> $O/flat16.log
 python3 - <<PY
 import csv, glob, json, shutil
 O, tag = "$O", "$tag"
