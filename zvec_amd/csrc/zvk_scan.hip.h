@@ -666,7 +666,11 @@ __global__ void __launch_bounds__(512, 4) scan8_kernel(const ScanArgs a) {
       // ---- tile epilogue: two rounds; in round gi the row half wm transposes its group 2*wm+gi through 16 KiB of
       // the operand buffer this step has just finished with (half 0: its base slab, half 1: its query rows) and the
       // 4 waves of the half admit its 32 rows (row i of the group belongs to wave i % 4 of the half)
+#ifdef ZVK_SCAN8_NOEPI      // (diagnostic builds: the matrix loop of the wide kernel alone — results are then wrong)
+      if (ks == nks - 1 && a.n == 0xffffffffffffffffull) {
+#else
       if (ks == nks - 1) {
+#endif
         if (a.dump == nullptr && tid < ROWS) {
           const float g_ = fkey_inv(__hip_atomic_load(&a.gtau[qrow_s[tid]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           st.gt[tid] = g_;
