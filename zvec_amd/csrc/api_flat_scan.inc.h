@@ -25,7 +25,7 @@ struct Knobs {
   int ivf_occ_cap = 0;        // ZVEC_HIP_IVF_OCC_CAP   IVF list scan: at most this many persistent work-groups per CU (0 = all)
   bool no_wide_dump = false;  // ZVEC_HIP_NO_WIDE_DUMP  dense-score path (IVF coarse step): never take the 8-wave tile
   int ivf_direct_q = 8;       // ZVEC_HIP_IVF_DIRECT_Q  IVF searches of at most this many queries take the direct (wave per row) route
-  int seed_rows256 = 4096;    // ZVEC_HIP_SEED_ROWS256  rows of the bound-seeding prefix in front of the 256 x 256 fp16 tile (multiple of 128)
+  int seed_rows256 = 16384;   // ZVEC_HIP_SEED_ROWS256  rows of the bound-seeding prefix in front of the 256 x 256 fp16 tile (multiple of 128; 4096 elsewhere)
   Knobs() {
 #ifdef ZVEC_HIP_TUNING
     if (const char *e = getenv("ZVEC_HIP_MAX_NG")) max_ng = std::max(1, std::min(4, atoi(e)));
