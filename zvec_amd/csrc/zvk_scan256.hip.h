@@ -7,20 +7,32 @@
 // merge_kernel.  The 128 x 128 one-barrier tile reaches 0.2 of the dense-f16 peak on a 256-query batch (profiles/
 // r3_flat1m_fp16_*): this kernel gives the scan the matrix loop of assign256_f16_kernel (zvk_assign256.hip.h — 8 waves as
 // 4 x 2 over 256 queries x 256 base rows, k-steps of 64 halves in four phases of 16 x v_mfma_f32_16x16x32_f16, LDS-DMA issued
-// two k-steps ahead behind counted `s_waitcnt vmcnt(8)`) and keeps scan8's list logic for what happens when a pair of base
-// tiles ends:
+// two k-steps ahead behind counted `s_waitcnt vmcnt(8)`) with the BASE as the streamed operand and the 256 query rows as the
+// re-read one, and does this when a pair of base tiles ends (256 x 256 scores, 128 accumulators per lane):
 //
-//   * the 256 x 256 scores leave the accumulators in EIGHT rounds of 32 query rows through 32 KiB of LDS that the matrix loop
-//     is not using at that moment — the a1 / b1 regions of the k-step buffer just multiplied (their next DMA is issued in
-//     phases 1 / 2 of the following k-step, after the barrier that ends the epilogue);
-//   * in a round every wave stores 8 rows x 128 columns of its block (row-slot i, two of the four j) and then OWNS four of the
-//     32 rows: it reads the row back as two spans of 128 columns, 2 per lane, and admits it with owner_row (zvk_common.hip.h)
-//     — one ballot against min(the list's k-th score, the query-wide bound gtau) for almost every row once the bounds are
-//     seeded, a sorted insertion otherwise.
+//   1. every lane tests its scores where they are, against min(its row's k-th score, the query-wide bound gtau) — rows' bounds
+//      read once per epilogue, the test in a shifted form that costs two packed FMAs, two minima and one compare per 4 scores,
+//      the exact score and the exact test on the (rare) taken side;
+//   2. a passing score is appended to the queue of the wave that OWNS its row (rows [32 q, 32 q + 32) -> wave q): owner q is fed
+//      by exactly two waves, each appending to its own half of q's queue at (wave-uniform count + rank among the passing lanes) —
+//      no atomics.  The queues live in 32 KiB of LDS the matrix loop is not using at that moment: the a1 / b1 regions of the k-step
+//      buffer just multiplied (their next DMA is issued in phases 1 / 2 of the following k-step, after the epilogue's last barrier);
+//   3. after one barrier every wave drains its own queue, 64 entries at a time, one LANE per entry: entries of the same row are
+//      serialised through a claim word (ds_min of the lane id), a lane inserts into its row's sorted list on its own (lane_insert:
+//      the list in registers after one round of loads, the tail moved by stores) — the same admission rule and kept set as
+//      owner_row / sorted_insert (zvk_common.hip.h; heap.h:103-114);
+//   4. a queue that would overflow (lists filling from empty without seeded bounds: small bases, the first pairs) sends the whole
+//      pair down scan8's epilogue instead — eight rounds of 32 query rows transposed through the same 32 KiB, owner waves admitting
+//      whole rows with owner_row.  The accumulators are cleared only after that decision.
+//
+// The base rows' norms and the rows' gtau keys arrive by 4-byte LDS-DMA one k-step ahead of the epilogue, and the LDS stores in front
+// of the drain are written as asm: the compiler puts a full `vmcnt(0)` in front of every LDS store it can see while LDS-DMA is in
+// flight, which would drain the staged k-steps at every epilogue.
 //
 // LDS: 2 x 64 KiB operand buffers, 2 KiB of base-row norms, 7 KiB of row state, 2 KiB per unit of k for the lists: k <= 11 fits
 // the CU's 160 KiB (the host takes scan8 otherwise, and for filtered scans, fewer than 256 queries or a single k-step).
-// The waves run in lockstep (one barrier per phase): the epilogue needs all eight in the same round.
+// The waves run in lockstep (one barrier per phase): the epilogue needs all eight in the same place.
+// Measured steps from the first version (scan8's epilogue alone: no faster than scan8) to this one: DESIGN.md §3.
 #pragma once
 #include "zvk_assign256.hip.h"
 
