@@ -52,63 +52,6 @@ constexpr int S256_QHALF = 224;
 constexpr int S256_QCLAIM = 2 * S256_QHALF * 8;       // byte offsets inside the 4 KiB
 constexpr int S256_QCNT = S256_QCLAIM + 32 * 4;
 
-// LDS stores the compiler does not see (no `vmcnt(0)` in front of them while LDS-DMA is in flight); the caller waits on lgkmcnt
-// before the barrier that publishes them.
-__device__ __forceinline__ uint32_t lds_off(const void *p) {
-  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
-}
-__device__ __forceinline__ void lds_store_u32(uint32_t off, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(off), "v"(v) : "memory"); }
-__device__ __forceinline__ void lds_store_u64(uint32_t off, uint64_t v) { asm volatile("ds_write_b64 %0, %1" ::"v"(off), "v"(v) : "memory"); }
-__device__ __forceinline__ void lds_store_f32(float *p, float v) { lds_store_u32(lds_off(p), __builtin_bit_cast(uint32_t, v)); }
-
-// One lane inserts candidate (s, pos) into the sorted list of `row` (the lanes of a wave work on different rows at once).  The
-// same admission rule and the same kept set as owner_row / sorted_insert (zvk_common.hip.h): s <= min(tau, gt), ascending
-// (score, position), the k smallest kept.
-__device__ __forceinline__ void lane_insert(const RowState &st, int row, float s, uint32_t pos) {
-  constexpr int KMAX = 11;                                  // (scan256_lds_bytes: the lists of a longer k do not fit)
-  const uint32_t k = st.k;
-  float tl = st.tau[row];
-  const float tg = st.gt[row];
-  uint32_t c = st.cnt[row];
-  float *L = st.Ls + (size_t)row * k;
-  uint32_t *I = st.Li + (size_t)row * k;
-  // the whole list in one round of loads: the number of entries in front of the candidate, then the tail moves up by stores only
-  float es[KMAX];
-  uint32_t ei[KMAX];
-#pragma unroll
-  for (int t = 0; t < KMAX; ++t) {
-    const bool in = (uint32_t)t < c;
-    es[t] = in ? L[t] : 0.f;
-    ei[t] = in ? I[t] : 0u;
-  }
-  if (!(s <= fminf(tl, tg))) return;
-  uint32_t p = 0;
-#pragma unroll
-  for (int t = 0; t < KMAX; ++t) p += ((uint32_t)t < c && (es[t] < s || (es[t] == s && ei[t] < pos))) ? 1u : 0u;
-  if (p >= k) return;                                       // k entries precede it
-  const uint32_t hi = min(c, k - 1);                        // entries [p, hi) move up by one
-#pragma unroll
-  for (int t = 0; t < KMAX - 1; ++t) {
-    if ((uint32_t)t >= p && (uint32_t)t < hi) {
-      L[t + 1] = es[t];
-      I[t + 1] = ei[t];
-    }
-  }
-  L[p] = s;
-  I[p] = pos;
-  c = min(c + 1, k);
-  st.cnt[row] = c;
-  if (c == k) {
-    tl = s;                                                 // the new k-th: the candidate, or the old (k-1)-th it pushed up
-#pragma unroll
-    for (int t = 0; t < KMAX - 1; ++t)
-      if (p != k - 1 && (uint32_t)t + 2 == k) tl = es[t];
-    st.tau[row] = tl;
-    if (tl < tg) atomicMin(&st.gtau[st.qrow[row]], fkey(tl));
-  }
-  st.tq[row] = fminf(tl, tg);
-}
-
 __global__ void __launch_bounds__(512, 1) scan256_f16_kernel(const ScanArgs a) {
   extern __shared__ f32x4 zvk_smem4[];
   char *smem = reinterpret_cast<char *>(zvk_smem4);
