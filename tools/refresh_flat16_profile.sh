@@ -6,6 +6,7 @@
 #   <tag>_flat1m_fp16[_b1024]_scan8_bench.json           one lane with option scan256 = 0 (the 128 x 128 tile of rounds 2-3)
 #   <tag>_flat1m_fp16[_b1024]_kernel_stats.csv / _kernel_trace_tail.csv / _bench_under_rocprof.json   rocprofv3 --kernel-trace --stats, one lane
 #   <tag>_flat1m_fp16_pmc.json                            MFMA-busy share / waits / LDS conflicts / effective clock of scan256_f16_kernel
+#   <tag>_flat1m_fp16_traffic.json                        its HBM-side bytes per launch (FETCH_SIZE / WRITE_SIZE passes) against the algorithmic bytes
 # -> gpurun_out/profiles_new/
 set -e
 tag=${1:-r4}
@@ -72,3 +73,33 @@ json.dump({kern: out}, open(O + "/%s_flat1m_fp16_pmc.json" % tag, "w"), indent=1
 print(json.dumps(out, indent=1))
 PY
 rm -rf $O/f16pmc_*
+# HBM-side traffic of the scan kernel (MI355X_MICROARCH.md, HBM section: separate passes, FETCH_SIZE doubled on gfx950 for 16 B / lane reads)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $O/f16t_$c
+  timeout -k 10 280 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/f16t_$c -- python3 $R/bench.py --workload flat1m_fp16 --steps 10 --warmup 2 --no-cpu-baseline --streams 1 > $O/f16t_$c.json 2> $O/f16t_$c.log || exit 1
+done
+python3 - <<PY
+import csv, glob, json
+O, tag = "$O", "$tag"
+def per_launch(c):
+    vals = []
+    for f in glob.glob(O + "/f16t_%s/**/*counter_collection.csv" % c, recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "scan256_f16_kernel" in row["Kernel_Name"] and row["Counter_Name"] == c:
+                vals.append(float(row["Counter_Value"]))
+    vals = vals[-10:]
+    return sum(vals) / len(vals), len(vals)
+fetch, nf = per_launch("FETCH_SIZE")
+write, nw = per_launch("WRITE_SIZE")
+b = json.loads(open(O + "/f16t_FETCH_SIZE.json").read().strip().splitlines()[-1])
+alg = b["roofline"]["algorithmic_bytes"]
+traffic = fetch * 1024 * 2 + write * 1024
+json.dump({"kernel": "zvk::scan256_f16_kernel - wide flat scan of fp16 rows (base tiles and query rows by LDS-DMA, 16 B per lane)",
+           "workload": b["config"]["workload"], "launches_averaged": nf,
+           "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
+           "correction": "bytes = FETCH_SIZE*1024*2 (gfx950 tallies the 128-B requests of 16 B/lane reads at 64 B: MI355X_MICROARCH.md HBM section) + WRITE_SIZE*1024",
+           "hbm_traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": traffic / alg},
+          open(O + "/%s_flat1m_fp16_traffic.json" % tag, "w"), indent=1)
+print("flat1m_fp16 traffic/algorithmic", traffic / alg, "fetch KiB", fetch, "write KiB", write)
+PY
+rm -rf $O/f16t_*
