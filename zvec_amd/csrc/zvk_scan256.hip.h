@@ -99,6 +99,16 @@ __global__ void __launch_bounds__(512, 1) scan256_f16_kernel(const ScanArgs a) {
   __builtin_amdgcn_s_barrier();          \
   asm volatile("" ::: "memory")
 #define ZVK_S256_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#ifdef ZVK_A256_STAMPS      // (diagnostic builds: shader-clock cycles wave 0 of work-group 0 spends in the sections of a pair's end; tools/flat_stamps.py)
+#define ZVK_S256_STAMP(X)                                                                                      \
+  if (blockIdx.x == 0 && wave == 0) {                                                                          \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                               \
+    if (lane == 0) atomicAdd(&zvk_a256_acc[0][(X) >> 2][(X) & 3], t_ - stamp_prev);                           \
+    stamp_prev = t_;                                                                                           \
+  }
+#else
+#define ZVK_S256_STAMP(X)
+#endif
 
   const int ap_row = ((tid >> 8) & 1) * 64 + ((tid & 255) >> 3);
   const int ap_pos = tid & 7;
@@ -113,10 +123,6 @@ __global__ void __launch_bounds__(512, 1) scan256_f16_kernel(const ScanArgs a) {
     return s_ < 16 ? (uint32_t)((s_ >> 3) * 16384 + ((s_ >> 2) & 1) * 8192 + 4096 + (s_ & 3) * 1024)
                    : (uint32_t)(32768 + ((s_ - 16) >> 3) * 16384 + 8192 + ((s_ - 16) & 7) * 1024);
   };
-  uint32_t wslot[2];
-#pragma unroll
-  for (int jb = 0; jb < 2; ++jb) wslot[jb] = slot_addr(wr * 8 + jb * 4 + lq) + (uint32_t)(((wc * 128 + lr) ^ (lq * 16)) * 4);
-
   const uint32_t vtotal = ((a.nchunks + 7) / 8) * 8 * a.nqtiles;      // XCD-aware item order: see scan8_kernel
   for (uint32_t v = blockIdx.x; v < vtotal; v += gridDim.x) {         // uniform exit
     const uint32_t qtile = (v >> 3) % a.nqtiles;
@@ -213,6 +219,210 @@ __global__ void __launch_bounds__(512, 1) scan256_f16_kernel(const ScanArgs a) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __syncthreads();                                  // (also publishes the row state)
 
+    // ---- end of a pair of base tiles: 256 x 256 scores against the rows' bounds; the few that pass into the lists ----
+#ifdef ZVK_A256_STAMPS
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
+    auto pair_end = [&](uint32_t s) {
+      ZVK_S256_STAMP(0);                                   // 0: the matrix loop since the last stamp
+      // (the lane's coordinates are re-derived here from an opaque copy: everything the epilogue computes from them would otherwise be
+      // hoisted out of the matrix loop and held in registers across it — slot offsets, queue codes, column ids)
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const int lr = lane_o & 15, lq = lane_o >> 4;
+        // the very last step re-stages itself into THIS buffer (next_step stays put): those copies must have landed before their
+        // regions become scratch
+        if (s == nsteps - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        char *sc = smem + (s & 1) * A256_BUF;
+        // (LDS stores the compiler can see are given a full `vmcnt(0)` while LDS-DMA is in flight; the ones in front of the drain go
+        // out as asm so that the k-steps staged ahead keep landing under the tests)
+        if (tid < S256_ROWS) {
+          const float g_ = fkey_inv(gk_lds[tid]);
+          lds_store_f32(st.gt + tid, g_);
+          lds_store_f32(st.tq + tid, fminf(st.tau[tid], g_));
+        }
+        const uint32_t pos0 = (tile_begin + 2 * pair) * (uint32_t)TILE_N;
+        // per column: what joins alpha * q.b — |b|^2 (L2), 1 (cosine), 0 (IP); NaN for a column past the rows (never passes)
+        float inner[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const uint32_t col = (uint32_t)(wc * 128 + n * 16 + lr);
+          const float bn_ = l2 ? bn_lds[(pair & 1) * 256 + col] : m_beta;
+          inner[n] = pos0 + col < pos_end ? bn_ : __builtin_nanf("");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ZVK_S256_BARRIER();                                // every wave is past its reads of this buffer's a1 / b1; bounds published
+        ZVK_S256_STAMP(1);                                 // 1: bounds refresh + first barrier
+        // ---- test in registers: score <= min(list's k-th, query-wide bound) of its row.  A passing score goes to the wave that owns
+        // its row (rows [32 q, 32 q + 32) -> wave q) as {score, row << 8 | column}.  Owner q is fed by exactly two waves (row quarter
+        // q >> 1, both column halves), each appending to its OWN half of q's queue: the append position is a wave-uniform counter
+        // plus the lane's rank among the passing lanes — no atomics, no LDS round trip under the 128 unrolled tests.  A half that
+        // would overflow (lists still filling without seeded bounds) sends the whole pair down the transposing path.
+        {
+          // (the lane's bases pass through an empty asm here so that the 128 unrolled tests below derive their constants inside the
+          // epilogue instead of holding 128 loop-invariant registers across the matrix loop)
+          uint32_t code0 = (uint32_t)((wr * 64 + lq * 4) << 8) | (uint32_t)(wc * 128 + lr);
+          uint32_t row0 = (uint32_t)(wr * 64 + lq * 4);
+          asm volatile("" : "+v"(code0), "+v"(row0));
+          uint32_t nput[2] = {0u, 0u};                     // entries this wave has appended for owners 2 wr, 2 wr + 1 (wave-uniform)
+#ifdef ZVK_S256_NOTEST      // (diagnostic builds: the epilogue's fixed part alone — results are then wrong)
+          if (a.n == 0xffffffffu)
+#endif
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 tq4 = *reinterpret_cast<const f32x4 *>(st.tq + row0 + i * 16);
+            const f32x4 qn4 = *reinterpret_cast<const f32x4 *>(qn_s + row0 + i * 16);      // (0 unless L2)
+            // The unrolled test runs in the shifted form  min_j (alpha q.b_j - (bound_j - |q_j|^2 + slack_j)) <= -(|b|^2)  over the 4
+            // rows a lane holds of one column: two packed FMAs, two minima, ONE compare and branch per 4 scores.  The slack,
+            // 2^-19 (|bound| + |q|^2), covers the roundings of both forms (a passing L2 score has |b|^2 <= 2 (|q|^2 + bound), so
+            // every term is within a few 2^-24 of that scale); the exact scores and the exact tests follow on the taken side.
+            // +inf bounds stay +inf; the -inf of a dead row becomes NaN, which the minima drop and no compare passes.
+            f32x4 nts;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nts[j] = -((tq4[j] - qn4[j]) + (__builtin_fabsf(tq4[j]) + qn4[j]) * 0x1p-19f);
+            const uint32_t qhalf = lds_off(sc + slot_addr((wr * 2 + (i >> 1)) * 4) + wc * (S256_QHALF * 8));
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+              const f32x2 al2 = {m_alpha, m_alpha};
+              const f32x2 w01 = al2 * f32x2{acc[i][n][0], acc[i][n][1]} + f32x2{nts[0], nts[1]};
+              const f32x2 w23 = al2 * f32x2{acc[i][n][2], acc[i][n][3]} + f32x2{nts[2], nts[3]};
+              const float wmin = __builtin_fminf(__builtin_fminf(w01.x, w01.y), __builtin_fminf(w23.x, w23.y));
+              if (__ballot(wmin <= -inner[n]) != 0) {      // (wave-uniform)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  // the same operations as the transposing path below: fma(alpha, dot, fma(nrm, |q|^2 + |b|^2, beta)), clamped at the
+                  // metric's floor (a NaN — a column past the rows — must not be laundered by the clamp)
+                  const float x_ = fmaf(m_alpha, acc[i][n][j], qn4[j] + inner[n]);
+                  const float v_ = fmaxf(x_, m_lo);
+                  const bool ok = x_ <= tq4[j] && v_ <= tq4[j];
+                  const uint64_t m_ = __ballot(ok);
+                  if (m_ != 0) {
+                    const uint32_t e_ = nput[i >> 1] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));
+                    if (ok && e_ < (uint32_t)S256_QHALF)
+                      lds_store_u64(qhalf + e_ * 8, (uint64_t)__builtin_bit_cast(uint32_t, v_) | ((uint64_t)(code0 + (uint32_t)(((i * 16 + j) << 8) + n * 16)) << 32));
+                    nput[i >> 1] += (uint32_t)__popcll(m_);
+                  }
+                }
+              }
+            }
+          }
+          if (lane == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) lds_store_u32(lds_off(sc + slot_addr((wr * 2 + h) * 4) + S256_QCNT + wc * 4), nput[h]);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm stores above, in front of the barrier that publishes them
+        }
+        ZVK_S256_STAMP(2);                                 // 2: the tests and appends
+        ZVK_S256_BARRIER();
+        ZVK_S256_STAMP(3);                                 // 3: second barrier
+        uint32_t qn_a, qn_b;                               // this wave's queue: entries in its two halves
+        bool overflow;
+        {
+          const uint32_t c_ = *reinterpret_cast<const uint32_t *>(sc + slot_addr((lane & 7) * 4) + S256_QCNT + ((lane >> 3) & 1) * 4);
+          overflow = __ballot(c_ > (uint32_t)S256_QHALF) != 0;
+          qn_a = (uint32_t)__builtin_amdgcn_readlane((int)c_, wave);
+          qn_b = (uint32_t)__builtin_amdgcn_readlane((int)c_, wave + 8);
+        }
+#ifdef ZVK_S256_NOINS
+        if (a.n != 0xffffffffu) { qn_a = 0; qn_b = 0; }
+#endif
+        if (!overflow) {
+          // ---- drain: this wave's queue, 64 entries at a time, one lane per entry.  Entries of the same row are serialised through a
+          // claim word per row (the lowest lane goes first); a lane inserts into its row's sorted list on its own.
+          const char *qbase = sc + slot_addr(wave * 4);
+          uint32_t *claim = reinterpret_cast<uint32_t *>(sc + slot_addr(wave * 4) + S256_QCLAIM);
+          if (lane < 32) claim[lane] = 0xffffffffu;
+          const uint32_t qn_mine = qn_a + qn_b;
+          for (uint32_t e0 = 0; e0 < qn_mine; e0 += 64) {      // (wave-uniform)
+            const uint32_t e_ = e0 + (uint32_t)lane;
+            bool pending = e_ < qn_mine;
+            uint2 ent = make_uint2(0u, 0u);
+            if (pending) ent = *reinterpret_cast<const uint2 *>(qbase + (e_ < qn_a ? e_ : e_ - qn_a + (uint32_t)S256_QHALF) * 8);
+            const int row = (int)(ent.y >> 8);
+            const float es_ = __builtin_bit_cast(float, ent.x);
+            const uint32_t epos = pos0 + (ent.y & 255u);
+            while (__ballot(pending) != 0) {
+              if (pending) __hip_atomic_fetch_min(&claim[row & 31], (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+              __builtin_amdgcn_wave_barrier();
+              const bool mine = pending && __hip_atomic_load(&claim[row & 31], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (uint32_t)lane;
+              if (mine) {
+                lane_insert(st, row, es_, epos);
+                __hip_atomic_store(&claim[row & 31], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pending = false;
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) acc[i][n] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+          ZVK_S256_STAMP(4);                               // 4: drain + clearing the accumulators
+        } else {
+          // ---- the transposing path (scan8's epilogue): eight rounds of 32 rows through the scratch, owner waves admit whole rows.
+          // Round R: rows wr*64 + (R >> 1)*16 + lq*4 + 2 (R & 1) + {0, 1}
+          uint32_t wslot[2];
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb) wslot[jb] = slot_addr(wr * 8 + jb * 4 + lq) + (uint32_t)(((wc * 128 + lr) ^ (lq * 16)) * 4);
+          float bnv[8];
+          uint32_t valid = 0;
+#pragma unroll
+          for (int n = 0; n < 8; ++n) {
+            const uint32_t col = (uint32_t)(wc * 128 + n * 16 + lr);
+            bnv[n] = l2 ? bn_lds[(pair & 1) * 256 + col] : 0.f;
+            valid |= (pos0 + col < pos_end ? 1u : 0u) << n;
+          }
+          ZVK_S256_BARRIER();                              // every wave has read the queue counters
+#pragma unroll
+          for (int R = 0; R < 8; ++R) {
+            {
+              const int i = R >> 1, jj = R & 1;
+#pragma unroll
+              for (int jb = 0; jb < 2; ++jb) {
+                const int j = 2 * jj + jb;
+                const float qn = qn_s[wr * 64 + i * 16 + lq * 4 + j];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                  const float v_ = fmaxf(fmaf(m_alpha, acc[i][n][j], fmaf(m_nrm, qn + bnv[n], m_beta)), m_lo);
+                  *reinterpret_cast<float *>(sc + (wslot[jb] ^ (uint32_t)(n * 64))) = ((valid >> n) & 1u) ? v_ : __builtin_inff();
+                  acc[i][n][j] = 0.f;
+                }
+              }
+            }
+            ZVK_S256_BARRIER();
+            // this wave's four rows of the round (slot wave * 4 + t), each as two spans of 128 columns, 2 per lane: all eight spans
+            // are read and tested against the rows' bounds at once; only a span with a passing score goes through owner_row
+            {
+              const int row_b = (wave >> 1) * 64 + (wave & 1) + (R >> 1) * 16 + 2 * (R & 1);
+              constexpr int row_step = 4;                  // the row of slot wave * 4 + t is row_b + row_step * t
+              auto span = [&](int u_) -> const f32x2 * {
+                const int t_ = u_ >> 1, hc_ = u_ & 1;
+                const int swz_ = t_ * 16;
+                return reinterpret_cast<const f32x2 *>(sc + slot_addr(wave * 4 + t_) + (uint32_t)(((hc_ * 128 + 2 * lane) ^ swz_) * 4));
+              };
+              uint32_t hits = 0;
+              float tqv[4];
+              f32x2 vv[8];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) tqv[t] = st.tq[row_b + row_step * t];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) vv[u] = *span(u);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) hits |= (__ballot(vv[u].x <= tqv[u >> 1] || vv[u].y <= tqv[u >> 1]) != 0 ? 1u : 0u) << u;
+              while (hits != 0) {                          // (wave-uniform)
+                const int u = __builtin_ctz(hits);
+                hits &= hits - 1;
+                const int row = row_b + row_step * (u >> 1);
+                const f32x2 v2 = *span(u);
+                owner_row(st, row, v2.x, v2.y, st.tq[row], pos0 + (uint32_t)((u & 1) * 128), lane);
+              }
+            }
+            ZVK_S256_BARRIER();
+          }
+        }
+    };
     f16x8 fa[4][2], fb[4][2];
     for (uint32_t s = 0; s < nsteps; ++s) {
       const char *buf = smem + (s & 1) * A256_BUF;
@@ -289,195 +499,12 @@ __global__ void __launch_bounds__(512, 1) scan256_f16_kernel(const ScanArgs a) {
           for (int n = 0; n < 4; ++n) acc[i][4 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][kh], fb[n][kh], acc[i][4 + n], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
 
-      // ---- end of a pair of base tiles: 256 x 256 scores against the rows' bounds; the few that pass into the lists ----
+      // ---- end of a pair of base tiles ----
 #ifdef ZVK_S256_NOEPI      // (diagnostic builds: the matrix loop alone — results are then wrong)
-      if (ks == nks - 1 && a.n == 0xffffffffu) {
+      if (ks == nks - 1 && a.n == 0xffffffffu) pair_end(s);
 #else
-      if (ks == nks - 1) {
+      if (ks == nks - 1) pair_end(s);
 #endif
-        // the very last step re-stages itself into THIS buffer (next_step stays put): those copies must have landed before their
-        // regions become scratch
-        if (s == nsteps - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        char *sc = smem + (s & 1) * A256_BUF;
-        // (LDS stores the compiler can see are given a full `vmcnt(0)` while LDS-DMA is in flight; the ones in front of the drain go
-        // out as asm so that the k-steps staged ahead keep landing under the tests)
-        if (tid < S256_ROWS) {
-          const float g_ = fkey_inv(gk_lds[tid]);
-          lds_store_f32(st.gt + tid, g_);
-          lds_store_f32(st.tq + tid, fminf(st.tau[tid], g_));
-        }
-        const uint32_t pos0 = (tile_begin + 2 * pair) * (uint32_t)TILE_N;
-        // per column: what joins alpha * q.b — |b|^2 (L2), 1 (cosine), 0 (IP); NaN for a column past the rows (never passes)
-        float inner[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-          const uint32_t col = (uint32_t)(wc * 128 + n * 16 + lr);
-          const float bn_ = l2 ? bn_lds[(pair & 1) * 256 + col] : m_beta;
-          inner[n] = pos0 + col < pos_end ? bn_ : __builtin_nanf("");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ZVK_S256_BARRIER();                                // every wave is past its reads of this buffer's a1 / b1; bounds published
-        // ---- test in registers: score <= min(list's k-th, query-wide bound) of its row.  A passing score goes to the wave that owns
-        // its row (rows [32 q, 32 q + 32) -> wave q) as {score, row << 8 | column}.  Owner q is fed by exactly two waves (row quarter
-        // q >> 1, both column halves), each appending to its OWN half of q's queue: the append position is a wave-uniform counter
-        // plus the lane's rank among the passing lanes — no atomics, no LDS round trip under the 128 unrolled tests.  A half that
-        // would overflow (lists still filling without seeded bounds) sends the whole pair down the transposing path.
-        {
-          // (the lane's bases pass through an empty asm here so that the 128 unrolled tests below derive their constants inside the
-          // epilogue instead of holding 128 loop-invariant registers across the matrix loop)
-          uint32_t code0 = (uint32_t)((wr * 64 + lq * 4) << 8) | (uint32_t)(wc * 128 + lr);
-          uint32_t row0 = (uint32_t)(wr * 64 + lq * 4);
-          asm volatile("" : "+v"(code0), "+v"(row0));
-          uint32_t nput[2] = {0u, 0u};                     // entries this wave has appended for owners 2 wr, 2 wr + 1 (wave-uniform)
-#ifdef ZVK_S256_NOTEST      // (diagnostic builds: the epilogue's fixed part alone — results are then wrong)
-          if (a.n == 0xffffffffu)
-#endif
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f32x4 tq4 = *reinterpret_cast<const f32x4 *>(st.tq + row0 + i * 16);
-            const f32x4 qn4 = *reinterpret_cast<const f32x4 *>(qn_s + row0 + i * 16);      // (0 unless L2)
-            // The unrolled test runs in the shifted form  min_j (alpha q.b_j - (bound_j - |q_j|^2 + slack_j)) <= -(|b|^2)  over the 4
-            // rows a lane holds of one column: two packed FMAs, two minima, ONE compare and branch per 4 scores.  The slack,
-            // 2^-19 (|bound| + |q|^2), covers the roundings of both forms (a passing L2 score has |b|^2 <= 2 (|q|^2 + bound), so
-            // every term is within a few 2^-24 of that scale); the exact scores and the exact tests follow on the taken side.
-            // +inf bounds stay +inf; the -inf of a dead row becomes NaN, which the minima drop and no compare passes.
-            f32x4 nts;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) nts[j] = -((tq4[j] - qn4[j]) + (__builtin_fabsf(tq4[j]) + qn4[j]) * 0x1p-19f);
-            const uint32_t qhalf = lds_off(sc + slot_addr((wr * 2 + (i >> 1)) * 4) + wc * (S256_QHALF * 8));
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-              const f32x2 al2 = {m_alpha, m_alpha};
-              const f32x2 w01 = al2 * f32x2{acc[i][n][0], acc[i][n][1]} + f32x2{nts[0], nts[1]};
-              const f32x2 w23 = al2 * f32x2{acc[i][n][2], acc[i][n][3]} + f32x2{nts[2], nts[3]};
-              const float wmin = __builtin_fminf(__builtin_fminf(w01.x, w01.y), __builtin_fminf(w23.x, w23.y));
-              if (__ballot(wmin <= -inner[n]) != 0) {      // (wave-uniform)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  // the same operations as the transposing path below: fma(alpha, dot, fma(nrm, |q|^2 + |b|^2, beta)), clamped at the
-                  // metric's floor (a NaN — a column past the rows — must not be laundered by the clamp)
-                  const float x_ = fmaf(m_alpha, acc[i][n][j], qn4[j] + inner[n]);
-                  const float v_ = fmaxf(x_, m_lo);
-                  const bool ok = x_ <= tq4[j] && v_ <= tq4[j];
-                  const uint64_t m_ = __ballot(ok);
-                  if (m_ != 0) {
-                    const uint32_t e_ = nput[i >> 1] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));
-                    if (ok && e_ < (uint32_t)S256_QHALF)
-                      lds_store_u64(qhalf + e_ * 8, (uint64_t)__builtin_bit_cast(uint32_t, v_) | ((uint64_t)(code0 + (uint32_t)(((i * 16 + j) << 8) + n * 16)) << 32));
-                    nput[i >> 1] += (uint32_t)__popcll(m_);
-                  }
-                }
-              }
-            }
-          }
-          if (lane == 0) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) lds_store_u32(lds_off(sc + slot_addr((wr * 2 + h) * 4) + S256_QCNT + wc * 4), nput[h]);
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm stores above, in front of the barrier that publishes them
-        }
-        ZVK_S256_BARRIER();
-        uint32_t qn_a, qn_b;                               // this wave's queue: entries in its two halves
-        bool overflow;
-        {
-          const uint32_t c_ = *reinterpret_cast<const uint32_t *>(sc + slot_addr((lane & 7) * 4) + S256_QCNT + ((lane >> 3) & 1) * 4);
-          overflow = __ballot(c_ > (uint32_t)S256_QHALF) != 0;
-          qn_a = (uint32_t)__builtin_amdgcn_readlane((int)c_, wave);
-          qn_b = (uint32_t)__builtin_amdgcn_readlane((int)c_, wave + 8);
-        }
-#ifdef ZVK_S256_NOINS
-        if (a.n != 0xffffffffu) { qn_a = 0; qn_b = 0; }
-#endif
-        if (!overflow) {
-          // ---- drain: this wave's queue, 64 entries at a time, one lane per entry.  Entries of the same row are serialised through a
-          // claim word per row (the lowest lane goes first); a lane inserts into its row's sorted list on its own.
-          const char *qbase = sc + slot_addr(wave * 4);
-          uint32_t *claim = reinterpret_cast<uint32_t *>(sc + slot_addr(wave * 4) + S256_QCLAIM);
-          if (lane < 32) claim[lane] = 0xffffffffu;
-          const uint32_t qn_mine = qn_a + qn_b;
-          for (uint32_t e0 = 0; e0 < qn_mine; e0 += 64) {      // (wave-uniform)
-            const uint32_t e_ = e0 + (uint32_t)lane;
-            bool pending = e_ < qn_mine;
-            uint2 ent = make_uint2(0u, 0u);
-            if (pending) ent = *reinterpret_cast<const uint2 *>(qbase + (e_ < qn_a ? e_ : e_ - qn_a + (uint32_t)S256_QHALF) * 8);
-            const int row = (int)(ent.y >> 8);
-            const float es_ = __builtin_bit_cast(float, ent.x);
-            const uint32_t epos = pos0 + (ent.y & 255u);
-            while (__ballot(pending) != 0) {
-              if (pending) __hip_atomic_fetch_min(&claim[row & 31], (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-              __builtin_amdgcn_wave_barrier();
-              const bool mine = pending && __hip_atomic_load(&claim[row & 31], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (uint32_t)lane;
-              if (mine) {
-                lane_insert(st, row, es_, epos);
-                __hip_atomic_store(&claim[row & 31], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                pending = false;
-              }
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-              __builtin_amdgcn_wave_barrier();
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int n = 0; n < 8; ++n) acc[i][n] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-        } else {
-          // ---- the transposing path (scan8's epilogue): eight rounds of 32 rows through the scratch, owner waves admit whole rows
-          float bnv[8];
-          uint32_t valid = 0;
-#pragma unroll
-          for (int n = 0; n < 8; ++n) {
-            const uint32_t col = (uint32_t)(wc * 128 + n * 16 + lr);
-            bnv[n] = l2 ? bn_lds[(pair & 1) * 256 + col] : 0.f;
-            valid |= (pos0 + col < pos_end ? 1u : 0u) << n;
-          }
-          ZVK_S256_BARRIER();                              // every wave has read the queue counters
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-#pragma unroll
-              for (int jb = 0; jb < 2; ++jb) {
-                const int j = 2 * jj + jb;
-                const float qn = qn_s[wr * 64 + i * 16 + lq * 4 + j];
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                  const float v_ = fmaxf(fmaf(m_alpha, acc[i][n][j], fmaf(m_nrm, qn + bnv[n], m_beta)), m_lo);
-                  *reinterpret_cast<float *>(sc + (wslot[jb] ^ (uint32_t)(n * 64))) = ((valid >> n) & 1u) ? v_ : __builtin_inff();
-                  acc[i][n][j] = 0.f;
-                }
-              }
-              ZVK_S256_BARRIER();
-              // this wave's four rows of the round (slot wave * 4 + t), each as two spans of 128 columns, 2 per lane: all eight spans
-              // are read and tested against the rows' bounds at once; only a span with a passing score goes through owner_row
-              {
-                const int row_b = (wave >> 1) * 64 + (wave & 1) + i * 16 + 2 * jj;      // + 4 t
-                auto span = [&](int u_) -> const f32x2 * {
-                  const int t_ = u_ >> 1, hc_ = u_ & 1;
-                  return reinterpret_cast<const f32x2 *>(sc + slot_addr(wave * 4 + t_) + (uint32_t)(((hc_ * 128 + 2 * lane) ^ (t_ * 16)) * 4));
-                };
-                uint32_t hits = 0;
-                float tqv[4];
-                f32x2 vv[8];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) tqv[t] = st.tq[row_b + 4 * t];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) vv[u] = *span(u);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) hits |= (__ballot(vv[u].x <= tqv[u >> 1] || vv[u].y <= tqv[u >> 1]) != 0 ? 1u : 0u) << u;
-                while (hits != 0) {                        // (wave-uniform)
-                  const int u = __builtin_ctz(hits);
-                  hits &= hits - 1;
-                  const int row = row_b + 4 * (u >> 1);
-                  const f32x2 v2 = *span(u);
-                  owner_row(st, row, v2.x, v2.y, st.tq[row], pos0 + (uint32_t)((u & 1) * 128), lane);
-                }
-              }
-              ZVK_S256_BARRIER();
-            }
-          }
-        }
-      }
       pair = c1.pair; ks = c1.ks;
       c1 = c2;
       next_step(c2);
@@ -505,5 +532,6 @@ __global__ void __launch_bounds__(512, 1) scan256_f16_kernel(const ScanArgs a) {
 #undef ZVK_S256_FB
 #undef ZVK_S256_BARRIER
 #undef ZVK_S256_VMCNT8
+#undef ZVK_S256_STAMP
 
 }  // namespace zvk
