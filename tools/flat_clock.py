@@ -10,6 +10,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["ZVEC_HIP_LIBRARY"] = os.path.join(ROOT, "zvec_amd", "_variants", "libzvec_hip_clk.so")
+DT = sys.argv[1] if len(sys.argv) > 1 else "fp32"          # fp16: the 256 x 256 tile (scan256_f16_kernel), L2 metric
 import torch  # noqa: E402
 import zvec_amd  # noqa: E402
 
@@ -19,9 +20,10 @@ s = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(s)
 g = torch.Generator(device=dev)
 g.manual_seed(1)
-base = torch.randn((n, dim), generator=g, device=dev)
-q = torch.randn((nq, dim), generator=g, device=dev)
-flat = zvec_amd.HipFlatSearcher(dim, "InnerProduct")
+tdt = torch.float16 if DT == "fp16" else torch.float32
+base = torch.randn((n, dim), generator=g, device=dev).to(tdt)
+q = torch.randn((nq, dim), generator=g, device=dev).to(tdt)
+flat = zvec_amd.HipFlatSearcher(dim, "InnerProduct" if DT == "fp32" else "SquaredEuclidean", dtype=DT)
 sp = s.cuda_stream
 zvec_amd._lib.check(flat.add_batch_dev(base.data_ptr(), n, stream=sp), "append")
 ctx = flat.create_context()

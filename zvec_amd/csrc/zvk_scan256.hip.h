@@ -123,6 +123,12 @@ __global__ void __launch_bounds__(512, 1) scan256_f16_kernel(const ScanArgs a) {
     return s_ < 16 ? (uint32_t)((s_ >> 3) * 16384 + ((s_ >> 2) & 1) * 8192 + 4096 + (s_ & 3) * 1024)
                    : (uint32_t)(32768 + ((s_ - 16) >> 3) * 16384 + 8192 + ((s_ - 16) & 7) * 1024);
   };
+#ifdef ZVK_CLOCK_STAMP      // (diagnostic builds: start / end stamps of every work-group, tools/flat_clock.py fp16)
+  if (tid == 0 && blockIdx.x < 1024) {
+    zvk_clock_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime();
+    zvk_clock_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   const uint32_t vtotal = ((a.nchunks + 7) / 8) * 8 * a.nqtiles;      // XCD-aware item order: see scan8_kernel
   for (uint32_t v = blockIdx.x; v < vtotal; v += gridDim.x) {         // uniform exit
     const uint32_t qtile = (v >> 3) % a.nqtiles;
@@ -526,6 +532,12 @@ __global__ void __launch_bounds__(512, 1) scan256_f16_kernel(const ScanArgs a) {
     }
     __syncthreads();
   }
+#ifdef ZVK_CLOCK_STAMP
+  if (tid == 0 && blockIdx.x < 1024) {
+    zvk_clock_stamps[blockIdx.x][2] = __builtin_amdgcn_s_memtime();
+    zvk_clock_stamps[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 #undef ZVK_S256_FA
