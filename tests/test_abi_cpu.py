@@ -155,3 +155,25 @@ def test_header_is_plain_c_and_a_c_program_links():
                                os.path.join(root, "examples", "flat_search.c"), "-L" + os.path.join(root, "zvec_amd"), "-lzvec_hip",
                                "-Wl,-rpath," + os.path.join(root, "zvec_amd")])
         assert os.path.exists(exe)
+
+
+def test_runtime_options_round_trip_without_a_gpu():
+    """zvec_hip_set_option / zvec_hip_get_option (include/zvec_hip.h): process-wide switches, no device call behind them — every
+    documented name takes its documented range, reads back, refuses values outside it and unknown names."""
+    import ctypes as C
+    from zvec_amd import _lib
+    L = _lib.lib()
+    v = C.c_int(-1)
+    for name, ok_values, bad in ((b"wait", (0, 1, 2), 3), (b"zerocopy", (0, 1, 2, 3), 4), (b"scan256", (0, 1, 2), 3)):
+        assert L.zvec_hip_get_option(name, C.byref(v)) == 0
+        before = v.value
+        for x in ok_values:
+            assert L.zvec_hip_set_option(name, x) == 0
+            assert L.zvec_hip_get_option(name, C.byref(v)) == 0 and v.value == x
+        assert L.zvec_hip_set_option(name, bad) != 0 and L.zvec_hip_set_option(name, -1) != 0
+        assert L.zvec_hip_get_option(name, C.byref(v)) == 0 and v.value == ok_values[-1]
+        assert L.zvec_hip_set_option(name, before) == 0
+    assert L.zvec_hip_set_option(b"assign256", 0) == 0 and L.zvec_hip_get_option(b"assign256", C.byref(v)) == 0 and v.value == 0
+    assert L.zvec_hip_set_option(b"assign256", 1) == 0
+    assert L.zvec_hip_set_option(b"no-such-option", 1) != 0 and L.zvec_hip_get_option(b"no-such-option", C.byref(v)) != 0
+    assert L.zvec_hip_set_option(None, 1) != 0
