@@ -110,6 +110,51 @@ def test_config1_flat_ip_1m_768_batch256_properties(zv, oracle):
         tie_tolerant_compare(gk, gs, gc, rk, rs, rc_, rtol=4e-6, scale=1.0, what="config1: all 256 queries vs the reference's FlatSearcher")
 
 
+def test_flat_l2_1m_768_fp16_batch256_on_the_256_tile(zv, oracle):
+    """bench.py --workload flat1m_fp16 at full size: 1M x 768 fp16 rows (HalfFloatConverter output), L2, 256 queries — the shape
+    that takes scan256_f16_kernel with seeded bounds.  Size-independent properties, an oracle spot check, the 128 x 128 kernel on
+    the same search, and 64 of the queries against the reference's own FlatBuilder + FlatSearcher over the same fp16 rows."""
+    stream = _stream()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260325)
+    n, dim, nq, k = 1_000_000, 768, 256, 10
+    base = torch.randn((n, dim), generator=g, device=dev).half()
+    sel = torch.randint(0, n, (nq,), generator=g, device=dev)
+    q = base[sel].contiguous()                                                    # self-queries: distance 0 to their own row
+    flat = zv.HipFlatSearcher(dim, "SquaredEuclidean", dtype="fp16")
+    assert flat.add_batch_dev(base.data_ptr(), n, stream=stream) == 0
+    ctx = flat.create_context()
+    ctx.set_stream(stream)
+    gk, gs, gc = _search_dev(flat, ctx, q, k, stream)
+    assert (gc == k).all()
+    assert np.array_equal(gk[:, 0], sel.cpu().numpy().astype(np.uint64)) and np.all(gs[:, 0] == 0.0)
+    assert np.all(np.diff(gs, axis=1) >= 0)
+    rk, rs, rc = _search_dev(flat, ctx, q.flip(0).contiguous(), k, stream)      # no cross-query leakage
+    assert np.array_equal(rk[::-1], gk) and np.array_equal(rs[::-1], gs)
+    from zvec_amd import _lib
+    L = _lib.lib()
+    assert L.zvec_hip_set_option(b"scan256", 0) == 0                             # the 128 x 128 kernel on the same search
+    try:
+        bk, bs, bc = _search_dev(flat, ctx, q, k, stream)
+    finally:
+        assert L.zvec_hip_set_option(b"scan256", 1) == 0
+    tie_tolerant_compare(gk, gs, gc, bk, bs, bc, rtol=2e-6, atol=1e-4, what="fp16 1M: 256 x 256 tile vs 128 x 128 tile")
+    hb = base.cpu().numpy()
+    hq = q.cpu().numpy()
+    ok, os_, _, oc = oracle.flat_search(hb, hq[:3], k, O.METRIC_L2, threads=8)
+    tie_tolerant_compare(gk[:3], gs[:3], gc[:3], ok, os_, oc, rtol=2e-6, atol=1e-4, what="fp16 1M spot")
+    R = _refcore()
+    if R is not None:
+        R.build("FlatBuilder", hb, "SquaredEuclidean", "f16_flat")
+        ref = R.Runner.searcher("FlatSearcher", "f16_flat", dim, np.float16)
+        rk, rs, rc_, _ = ref.search_mt(hq[:64], k, 16)
+        ref.close()
+        R.mem_remove("f16_flat")
+        tie_tolerant_compare(gk[:64], gs[:64], gc[:64], rk, rs, rc_, rtol=2e-6, atol=1e-4,
+                             what="fp16 1M: 64 queries vs the reference's FlatSearcher")
+
+
 @pytest.fixture(scope="module")
 def ten_million(zv):
     stream = _stream()
