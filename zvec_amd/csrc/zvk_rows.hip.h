@@ -179,6 +179,48 @@ __global__ void seed_gtau_kernel(uint32_t *gtau, const float *scores, const uint
 }
 
 
+// Bound seeding without a selection: the scores of a prefix of the base ([query][stride], `len` valid columns) -> an upper bound
+// of every query's final k-th score.  Each of the block's 256 threads keeps the minimum of its own strided share of the row; those
+// are 256 disjoint sets, so the k-th smallest of the 256 minima is >= the k-th smallest of the row (and within a rank or two of
+// it: the row's best k land in different shares but for the odd collision).  Same slack as seed_gtau_kernel, from the norms of the
+// k candidates that carry the bound.  One block per query; k <= 256.
+__global__ void __launch_bounds__(256) seed_bound_kernel(const float *dump, uint32_t stride, uint32_t len, uint32_t *gtau, const float *qnorm,
+                                                         const float *bnorm, int metric, uint32_t k) {
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const float *row = dump + (size_t)q * stride;
+  float mn = __builtin_inff();
+  uint32_t mi = 0;
+  for (uint32_t e0 = tid; e0 < len; e0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t e = e0 + (uint32_t)u * 256;
+      v[u] = e < len ? row[e] : __builtin_inff();
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (v[u] < mn) { mn = v[u]; mi = e0 + (uint32_t)u * 256; }
+  }
+  __shared__ float sm[256];
+  __shared__ uint32_t bmax_bits;
+  sm[tid] = mn;
+  if (tid == 0) bmax_bits = 0u;
+  __syncthreads();
+  uint32_t rank = 0;
+  for (uint32_t m = 0; m < 256; ++m) {
+    const float o = sm[m];
+    rank += (o < mn || (o == mn && m < tid)) ? 1u : 0u;
+  }
+  if (rank < k && mn < __builtin_inff()) atomicMax(&bmax_bits, __builtin_bit_cast(uint32_t, fmaxf(bnorm[mi], 0.f)));      // (non-negative floats order as their bits)
+  __syncthreads();
+  if (rank == k - 1) {
+    const float bmax = __builtin_bit_cast(float, bmax_bits);
+    const float mag = (metric == 0) ? qnorm[q] + bmax : sqrtf(qnorm[q] * bmax);
+    const float b = mn + 8e-6f * mag + fabsf(mn) * 1e-6f + 1e-30f;
+    if (b == b) atomicMin(&gtau[q], fkey(b));
+  }
+}
+
 // exclude set of a search over a store with holes: the caller's bits OR the store's hole bits
 __global__ void or_bits_kernel(uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t words) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
