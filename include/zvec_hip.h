@@ -240,6 +240,23 @@ int zvec_hip_ivf_search_probes_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const v
                                    float threshold, uint32_t nprobe, uint32_t max_scan_count, const uint32_t *d_probe_idx,
                                    const uint32_t *d_probe_cnt, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys,
                                    float *d_out_scores, uint32_t *d_out_counts, void *stream);
+/* Half-width pre-selection for an fp32 L2 / inner-product index ("shadow lists"): same results, about half the bytes per search.
+ * IVFSearcher::search_impl scores every row of the probed lists in fp32 (ivf_searcher.cc:217-247, ivf_entity.cc:664-717); on the
+ * GPU that scan is bound by the bytes of the lists.  zvec_hip_ivf_set_shadow(h, 1, preselect) stores every row a second time rounded
+ * to fp16 (HalfFloatConverter's rounding) at the same positions; searches of more than a handful of queries (no radius, k <= 32) then
+ * scan the fp16 rows for `preselect` rows per query (0: max(32, 3k); <= 64), re-score those on the fp32 rows with the kernel that
+ * refines the fp32 route's final lists, keep the k best and CERTIFY them: a row that was left out cannot beat the k-th kept one once
+ * the measured rounding of the two conversions (max over the stored rows of |b - b16|, per query |q - q16|; triangle inequality for
+ * L2, Cauchy-Schwarz for IP) and the accumulation error are allowed for.  Queries that fail the certificate are re-run on the fp32
+ * lists: by zvec_hip_ivf_search itself (host pointers), or — device pointers, where the search call only enqueues — by
+ * zvec_hip_ivf_shadow_certify, which the caller runs on the same context with the same arguments before it reads the results
+ * (*rerun = queries re-run; a call with no shadow search pending returns 0 at once).  Unsupported: fp16 / cosine indexes, rows
+ * beyond the half range.  enable = 0 frees the copy.  zvec_hip_ivf_shadow_info: state, bytes held, max |b - b16|, max |b16|. */
+int zvec_hip_ivf_set_shadow(zvec_hip_ivf_t h, int enable, uint32_t preselect);
+int zvec_hip_ivf_shadow_info(zvec_hip_ivf_t h, int *enabled, uint64_t *bytes, float *max_row_error, float *max_row_norm);
+int zvec_hip_ivf_shadow_certify(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,
+                                uint32_t nprobe, uint32_t max_scan_count, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys,
+                                float *d_out_scores, uint32_t *d_out_counts, void *stream, uint32_t *rerun);
 /* IVFSearcher::search_bf_impl: every list in list-id order (ivf_entity.cc:719-745). */
 int zvec_hip_ivf_search_bf(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries,
                            uint32_t count, uint32_t topk, float threshold,

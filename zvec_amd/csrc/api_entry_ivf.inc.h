@@ -29,7 +29,17 @@ static void ivf_leave_coarse_space(zvec_hip_ivf_s *h) {
   h->trained = false;
 }
 
+static void ivf_drop_shadow(zvec_hip_ivf_s *h) {
+  h->shadow.keys = nullptr; h->shadow.extra = nullptr;      // (never its own)
+  h->shadow.release();
+  h->shadow.n = 0;
+  if (h->d_shadow_facts) (void)hipFree(h->d_shadow_facts);
+  h->d_shadow_facts = nullptr;
+  h->shadow_on = false;
+}
+
 static void ivf_release(zvec_hip_ivf_s *h) {
+  ivf_drop_shadow(h);
   h->cent.release(); h->lists.release();
   h->cent.n = 0; h->lists.n = 0;
   ivf_leave_coarse_space(h);
@@ -699,6 +709,10 @@ static int ivf_search_dev_locked(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const voi
   const uint32_t np = std::max<uint32_t>(1u, std::min(nprobe, h->nlist));      // (the row stride of the probe lists)
   // 32-bit word offsets into the padded query matrix: very large batches go in slices
   const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(std::max(h->lists.dpad, h->cent.dpad), 1u));
+  // (the flags of a shadow search belong to ONE call of the core: a sliced batch reads the fp32 lists)
+  struct SkipGuard { zvec_hip_ctx_s *c; bool old; ~SkipGuard() { c->shadow_skip = old; } } guard{c, c->shadow_skip};
+  if (count > maxq) c->shadow_skip = true;
+  c->sh_count = 0;
   for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
     const uint32_t m = std::min(maxq, count - q0);
     SearchOut out{d_out_keys ? d_out_keys + (size_t)q0 * topk : nullptr, d_out_scores ? d_out_scores + (size_t)q0 * topk : nullptr, nullptr,
@@ -766,6 +780,123 @@ int zvec_hip_ivf_search_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_
                                d_out_keys, d_out_scores, d_out_counts, pick_stream(c, stream));
 }
 
+// The second half of a search through the shadow lists: waits for it, reads how many queries could not be certified and runs those
+// again on the fp32 lists (same probe rule, same exclude set), their results replacing the uncertified ones.  The caller holds c->mu.
+static int ivf_shadow_certify_locked(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const void *d_queries, uint32_t count, uint32_t topk,
+                                     uint32_t nprobe, uint32_t max_scan_count, const uint64_t *d_exclude, uint64_t *d_out_keys,
+                                     float *d_out_scores, uint32_t *d_out_counts, hipStream_t s, const void *d_coarse_queries,
+                                     uint32_t *rerun_out) {
+  if (rerun_out) *rerun_out = 0;
+  if (c->sh_count == 0) return 0;                      // the last search on this context did not use the shadow lists
+  if (c->sh_count != count) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  c->sh_count = 0;
+  uint32_t nflag = 0;
+  ZCHK(hipMemcpyAsync(&nflag, c->sh_flags.as<uint32_t>() + count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  ZCHK(hipStreamSynchronize(s));
+  if (nflag == 0) return 0;
+  std::vector<uint32_t> flags(count);
+  ZCHK(hipMemcpyAsync(flags.data(), c->sh_flags.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  ZCHK(hipStreamSynchronize(s));
+  std::vector<uint32_t> which;
+  for (uint32_t q = 0; q < count; ++q) if (flags[q]) which.push_back(q);
+  const uint32_t m = (uint32_t)which.size();
+  if (m == 0) return 0;
+  const size_t rb = h->lists.row_bytes(), crb = h->cent.row_bytes();
+  Scoped<char> tq, tcq;
+  Scoped<uint64_t> tk;
+  Scoped<float> ts;
+  Scoped<uint32_t> tc;
+  ZRET(tq.alloc((size_t)m * rb));
+  ZRET(tk.alloc((size_t)m * topk));
+  ZRET(ts.alloc((size_t)m * topk));
+  ZRET(tc.alloc(m));
+  if (d_coarse_queries) ZRET(tcq.alloc((size_t)m * crb));
+  for (uint32_t i = 0; i < m; ++i) {
+    ZCHK(hipMemcpyAsync(tq.p + (size_t)i * rb, static_cast<const char *>(d_queries) + (size_t)which[i] * rb, rb, hipMemcpyDeviceToDevice, s));
+    if (d_coarse_queries)
+      ZCHK(hipMemcpyAsync(tcq.p + (size_t)i * crb, static_cast<const char *>(d_coarse_queries) + (size_t)which[i] * crb, crb, hipMemcpyDeviceToDevice, s));
+  }
+  const bool old = c->shadow_skip;
+  c->shadow_skip = true;
+  const int rc = ivf_search_dev_locked(h, c, tq.p, m, topk, FLT_MAX, nprobe, max_scan_count, 0, d_exclude, tk, ts, tc, s,
+                                       d_coarse_queries ? tcq.p : nullptr);
+  c->shadow_skip = old;
+  ZRET(rc);
+  for (uint32_t i = 0; i < m; ++i) {
+    const size_t o = (size_t)which[i] * topk;
+    ZCHK(hipMemcpyAsync(d_out_keys + o, tk.p + (size_t)i * topk, (size_t)topk * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+    ZCHK(hipMemcpyAsync(d_out_scores + o, ts.p + (size_t)i * topk, (size_t)topk * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ZCHK(hipMemcpyAsync(d_out_counts + which[i], tc.p + i, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  }
+  ZCHK(hipStreamSynchronize(s));                       // (the temporaries are freed on return)
+  if (rerun_out) *rerun_out = m;
+  return 0;
+}
+
+int zvec_hip_ivf_set_shadow(zvec_hip_ivf_t h, int enable, uint32_t preselect) {
+  if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  ZCHK(hipSetDevice(h->device));
+  if (!enable) {
+    ZCHK(hipDeviceSynchronize());
+    ivf_drop_shadow(h);
+    return 0;
+  }
+  if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  if (h->dtype != ZVEC_HIP_DT_FP32 || h->metric == ZVEC_HIP_METRIC_COSINE) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (preselect > 64) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (h->shadow_on) { h->shadow_kp = preselect; return 0; }
+  hipStream_t s = h->defctx->own;
+  Store &sh = h->shadow;
+  sh = Store();
+  sh.configure(h->dim, h->metric, ZVEC_HIP_DT_FP16);
+  const uint64_t tiles = (h->lists.n + TILE_N - 1) / TILE_N;
+  if (tiles == 0) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  if (hipMalloc(&sh.base, (size_t)tiles * TILE_N * sh.dpad * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); sh.base = nullptr; return ZVEC_HIP_ERR_NO_MEMORY; }
+  if (hipMalloc(&sh.bnorm, (size_t)tiles * TILE_N * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); ivf_drop_shadow(h); return ZVEC_HIP_ERR_NO_MEMORY; }
+  if (hipMalloc(&h->d_shadow_facts, sizeof(ShadowFacts)) != hipSuccess) { (void)hipGetLastError(); ivf_drop_shadow(h); return ZVEC_HIP_ERR_NO_MEMORY; }
+  sh.cap_tiles = tiles;
+  sh.n = tiles * TILE_N;
+  ZCHK(hipMemsetAsync(h->d_shadow_facts, 0, sizeof(ShadowFacts), s));
+  // every position of the used tiles; the padding rows behind a list's last row become zero rows
+  const uint64_t npos = tiles * TILE_N;
+  hipLaunchKernelGGL(shadow_rows_kernel, dim3((unsigned)((npos + 3) / 4)), dim3(256), 0, s, h->lists.base, h->lists.dpad, sh.dscan,
+                     sh.base, sh.dpad, sh.bnorm, npos, h->d_tile0, h->d_size, h->nlist, static_cast<ShadowFacts *>(h->d_shadow_facts));
+  ZCHK(hipGetLastError());
+  ShadowFacts f{};
+  ZCHK(hipMemcpyAsync(&f, h->d_shadow_facts, sizeof(f), hipMemcpyDeviceToHost, s));
+  ZCHK(hipStreamSynchronize(s));
+  const float mx = __builtin_bit_cast(float, f.max_abs);
+  if (!(mx < 65504.f)) { ivf_drop_shadow(h); return ZVEC_HIP_ERR_UNSUPPORTED; }     // rows beyond the half range (or nan)
+  h->shadow_max_err = __builtin_bit_cast(float, f.max_err);
+  h->shadow_max_norm = __builtin_bit_cast(float, f.max_norm);
+  h->shadow_kp = preselect;
+  h->shadow_on = true;
+  return 0;
+}
+
+int zvec_hip_ivf_shadow_info(zvec_hip_ivf_t h, int *enabled, uint64_t *bytes, float *max_row_error, float *max_row_norm) {
+  if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  if (enabled) *enabled = h->shadow_on ? 1 : 0;
+  if (bytes) *bytes = h->shadow_on ? (uint64_t)h->shadow.cap_tiles * TILE_N * (h->shadow.dpad + 1) * sizeof(float) : 0;
+  if (max_row_error) *max_row_error = h->shadow_on ? h->shadow_max_err : 0.f;
+  if (max_row_norm) *max_row_norm = h->shadow_on ? h->shadow_max_norm : 0.f;
+  return 0;
+}
+
+int zvec_hip_ivf_shadow_certify(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,
+                                uint32_t nprobe, uint32_t max_scan_count, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys,
+                                float *d_out_scores, uint32_t *d_out_counts, void *stream, uint32_t *rerun) {
+  if (!h || !d_queries || !d_out_keys || !d_out_scores || !d_out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  ZCHK(hipSetDevice(h->device));
+  return ivf_shadow_certify_locked(h, c, d_queries, count, topk, nprobe, max_scan_count, d_exclude_bitset, d_out_keys, d_out_scores,
+                                   d_out_counts, pick_stream(c, stream), nullptr, rerun);
+}
+
 static int ivf_search_host_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *queries, uint32_t count, uint32_t topk,
                                 float threshold, uint32_t nprobe, uint32_t max_scan_count, int brute_force,
                                 const uint64_t *exclude_bitset, uint64_t *out_keys, float *out_scores,
@@ -789,6 +920,9 @@ static int ivf_search_host_impl(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void
   ZRET(ivf_search_dev_locked(h, c, c->io_qp, count, topk, threshold, nprobe, max_scan_count, brute_force,
                              exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr, c->io_keys.as<uint64_t>(),
                              c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur, d_cq));
+  if (c->sh_count)       // shadow lists: the queries whose result could not be certified are re-run on the fp32 lists
+    ZRET(ivf_shadow_certify_locked(h, c, c->io_qp, count, topk, nprobe, max_scan_count, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr,
+                                   c->io_keys.as<uint64_t>(), c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur, d_cq, nullptr));
   return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, c->cur);
 }
 

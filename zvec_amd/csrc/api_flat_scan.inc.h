@@ -708,7 +708,7 @@ void ctx_free(zvec_hip_ctx_s *c) {
   c->gtau.release(); c->ridx.release(); c->seed_keys.release(); c->seed_scores.release(); c->seed_counts.release(); c->seed_idx.release(); c->cmp_base.release(); c->cmp_norm.release(); c->cmp_extra.release(); c->cmp_keys.release(); c->cmp_pos.release(); c->cmp_cnt.release(); c->qpad.release(); c->qnorm.release(); c->part_s.release(); c->part_i.release();
   c->coarse_keys.release(); c->coarse_scores.release(); c->coarse_idx.release(); c->coarse_cnt.release();
   c->plan.release(); c->io_q.release(); c->io_ex.release(); c->io_out.release(); c->io_cq.release();
-  c->grp_ws.release(); c->grp_of.release(); c->grp_out.release(); c->grp_tab.release(); c->holes_ex.release(); c->direct_pos.release(); c->direct_keys.release(); c->direct_scores.release(); c->direct_idx.release(); c->direct_cnt.release(); c->stats.release(); c->pin_in.release(); c->pin_out.release(); c->done_word.release();
+  c->grp_ws.release(); c->grp_of.release(); c->grp_out.release(); c->grp_tab.release(); c->holes_ex.release(); c->direct_pos.release(); c->direct_keys.release(); c->direct_scores.release(); c->direct_idx.release(); c->direct_cnt.release(); c->stats.release(); c->sh_q16.release(); c->sh_qn16.release(); c->sh_qinfo.release(); c->sh_keys.release(); c->sh_scores.release(); c->sh_true.release(); c->sh_idx.release(); c->sh_counts.release(); c->sh_flags.release(); c->pin_in.release(); c->pin_out.release(); c->done_word.release();
   if (c->block_ev) (void)hipEventDestroy(c->block_ev);
   for (auto e : c->ev0) (void)hipEventDestroy(e);
   for (auto e : c->ev1) (void)hipEventDestroy(e);

@@ -253,6 +253,18 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     ctx->q_nprobe = nullptr; ctx->q_scanned = nullptr; ctx->last_count = 0;
     return 0;
   }
+  // Half-width pre-selection (zvk_shadow.hip.h): the scan reads the fp16 twin of the lists and keeps k' > k rows per query, which
+  // are re-scored on the fp32 rows and certified below.  Not with an RNN radius (it would have to be widened by the rounding bound),
+  // not for search_bf, not on the certify step's own re-run.
+  uint32_t kp = 0;
+  if (h->shadow_on && h->shadow.base && !ctx->shadow_skip && !brute_force && !(threshold < FLT_MAX) && topk <= 32) {
+    kp = h->shadow_kp ? h->shadow_kp : std::max<uint32_t>(32, 3 * topk);
+    kp = std::min<uint32_t>(kp, 64);                                     // (shadow_select_kernel: one candidate per lane)
+    if (kp <= topk || scan_lds_bytes(1, kp, true) > LDS_LIMIT - 1024) kp = 0;
+  }
+  const bool use_shadow = kp != 0;
+  const uint32_t ks = use_shadow ? kp : topk;                            // k of the list scan and of its merge
+  ctx->sh_count = 0;
   const uint32_t rows_per_group = 32;
   const uint64_t npairs = (uint64_t)count * (brute_force ? nlist : nprobe);
   // layout of the plan buffer (u32 words)
@@ -329,13 +341,24 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     slots_bound = s * count;
   }
   if (slots_bound == 0) slots_bound = 1;
-  ZRET(ctx->part_s.ensure(slots_bound * topk * sizeof(float)));
-  ZRET(ctx->part_i.ensure(slots_bound * topk * sizeof(uint32_t)));
+  ZRET(ctx->part_s.ensure(slots_bound * ks * sizeof(float)));
+  ZRET(ctx->part_i.ensure(slots_bound * ks * sizeof(uint32_t)));
 
+  const Store &sst = use_shadow ? h->shadow : h->lists;                  // the store the list scan streams
   ScanArgs a{};
-  a.base = h->lists.base; a.bnorm = h->lists.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
+  a.base = sst.base; a.bnorm = sst.bnorm; a.exclude = reinterpret_cast<const uint32_t *>(d_exclude);
   a.queries = ctx->qpad.as<float>(); a.qnorm = ctx->qnorm.as<float>();
-  a.dpad = h->lists.dpad; a.nks = h->lists.dpad / TILE_K; a.metric = h->metric; a.k = topk; a.threshold = threshold;
+  if (use_shadow) {
+    ZRET(ctx->sh_q16.ensure((size_t)count * sst.dpad * sizeof(float)));
+    ZRET(ctx->sh_qn16.ensure((size_t)count * sizeof(float)));
+    ZRET(ctx->sh_qinfo.ensure((size_t)count * sizeof(f32x2)));
+    hipLaunchKernelGGL(shadow_prep_queries_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, reinterpret_cast<const float *>(d_queries),
+                       count, h->lists.dim_in, sst.dscan, sst.dpad, ctx->sh_q16.as<float>(), ctx->sh_qn16.as<float>(),
+                       ctx->sh_qinfo.as<f32x2>());
+    ZCHK(hipGetLastError());
+    a.queries = ctx->sh_q16.as<float>(); a.qnorm = ctx->sh_qn16.as<float>();
+  }
+  a.dpad = sst.dpad; a.nks = sst.dpad / TILE_K; a.metric = h->metric; a.k = ks; a.threshold = threshold;
   a.gtau = ctx->gtau.as<uint32_t>();
   a.mode = 1; a.nq = count; a.n = h->lists.n; a.ndense = h->count_local; a.tiles_per_chunk = tpc; a.list_tpc = pb + o_ltpc;
   a.total_items = p.total_items; a.queue = pb + o_queue; a.list_order = h->d_order; a.item_off = p.item_off; a.list_tile0 = h->d_tile0; a.list_size = h->d_size;
@@ -344,9 +367,9 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   // algorithmic bytes of the list scan = rows of the DISTINCT probed lists (counted on device from
   // the plan: plan_scan_kernel's work_stats) + the query rows + the result lists
   gate_enter(ctx, stream);
-  int pi = prof_begin(ctx, stream, (double)count * h->lists.dscan * h->lists.elem + (double)count * topk * 12.0, 0, 1);
-  if (pi >= 0) ctx->prof_dscan[pi] = h->lists.dscan | (h->lists.f16 ? 0x80000000u : 0u);
-  const int lrc = launch_scan_ng(ng, a, h->lists.f16, 0x7fffffffu, cus, stream);
+  int pi = prof_begin(ctx, stream, (double)count * sst.dscan * sst.elem + (double)count * ks * 12.0, 0, 1);
+  if (pi >= 0) ctx->prof_dscan[pi] = sst.dscan | (sst.f16 ? 0x80000000u : 0u);
+  const int lrc = launch_scan_ng(ng, a, sst.f16, 0x7fffffffu, cus, stream);
   prof_end(ctx, stream, pi);
   gate_leave(ctx, stream);
   ZRET(lrc);
@@ -354,8 +377,34 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   // 4. merge the per-(query, probe, chunk) partial lists in probe order
   MergeArgs m{};
   m.part_s = a.part_s; m.part_i = a.part_i; m.part_keys = nullptr; m.slot_begin = p.slot_begin; m.slots_per_q = 0;
-  m.slot_stride = 1; m.part_counts = nullptr; m.k = topk; m.slot_len = topk; m.threshold = threshold; m.keymap = h->lists.keys;
+  m.slot_stride = 1; m.part_counts = nullptr; m.k = ks; m.slot_len = ks; m.threshold = threshold; m.keymap = h->lists.keys;
   m.bound_keys = a.gtau;
+  if (use_shadow) {
+    // the k' pre-selected rows of every query in shadow-score order -> their true scores -> the k best + the certificate
+    const size_t ck = (size_t)count * kp;
+    ZRET(ctx->sh_keys.ensure(ck * sizeof(uint64_t)));
+    ZRET(ctx->sh_scores.ensure(ck * sizeof(float)));
+    ZRET(ctx->sh_true.ensure(ck * sizeof(float)));
+    ZRET(ctx->sh_idx.ensure(ck * sizeof(uint32_t)));
+    ZRET(ctx->sh_counts.ensure((size_t)count * sizeof(uint32_t)));
+    ZRET(ctx->sh_flags.ensure(((size_t)count + 4) * sizeof(uint32_t)));
+    m.out_keys = ctx->sh_keys.as<uint64_t>(); m.out_scores = ctx->sh_scores.as<float>(); m.out_idx = ctx->sh_idx.as<uint32_t>();
+    m.out_counts = ctx->sh_counts.as<uint32_t>();
+    hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(merge_threads(count)), (size_t)kp * 12 + 16, stream, m);
+    hipLaunchKernelGGL(shadow_rescore_kernel<false>, dim3((unsigned)((ck + 3) / 4)), dim3(256), 0, stream, h->lists.base,
+                       ctx->qpad.as<float>(), h->lists.dpad, h->metric, m.out_idx, m.out_counts, count, kp, ctx->sh_true.as<float>());
+    ZCHK(hipMemsetAsync(ctx->sh_flags.as<uint32_t>() + count, 0, sizeof(uint32_t), stream));
+    ShadowSelectArgs sa{};
+    sa.c_keys = m.out_keys; sa.c_shadow = m.out_scores; sa.c_true = ctx->sh_true.as<float>(); sa.c_idx = m.out_idx;
+    sa.c_counts = m.out_counts; sa.qinfo = ctx->sh_qinfo.as<f32x2>(); sa.facts = static_cast<const ShadowFacts *>(h->d_shadow_facts);
+    sa.kp = kp; sa.k = topk; sa.dscan = h->lists.dscan; sa.metric = h->metric;
+    sa.out_keys = out.keys; sa.out_scores = out.scores; sa.out_idx = out.idx; sa.out_counts = out.counts;
+    sa.flags = ctx->sh_flags.as<uint32_t>(); sa.nflag = sa.flags + count;
+    hipLaunchKernelGGL(shadow_select_kernel, dim3(count), dim3(64), 0, stream, sa);
+    ZCHK(hipGetLastError());
+    ctx->sh_count = count;
+    return 0;
+  }
   uint32_t *ridx = out.idx;
   if (h->metric == ZVEC_HIP_METRIC_L2 && ridx == nullptr) {
     ZRET(ctx->ridx.ensure((size_t)count * topk * sizeof(uint32_t)));

@@ -200,6 +200,11 @@ struct zvec_hip_ctx_s {
   DevView io_keys, io_scores, io_counts;               // the result arrays inside io_out: ONE copy brings them back
   DevBuf grp_ws, grp_of, grp_out, grp_tab;
   DevBuf direct_pos, direct_keys, direct_scores, direct_idx, direct_cnt;   // small-batch IVF route: positions, stage-1 lists
+  // half-width pre-selection (zvec_hip_ivf_set_shadow): fp16 query rows + norms, per-query rounding facts, the k' pre-selected rows
+  // of every query (keys | shadow scores | true scores | positions | counts), flags [count] + the flagged count [1]
+  DevBuf sh_q16, sh_qn16, sh_qinfo, sh_keys, sh_scores, sh_true, sh_idx, sh_counts, sh_flags;
+  uint32_t sh_count = 0;                               // queries of the last search that went through the shadow lists (0: none)
+  bool shadow_skip = false;                            // the certify step's re-run: this search must read the fp32 lists
   DevBuf holes_ex;                                     // caller's exclude set OR the store's holes                      // group-by search: per-group bests / lists, group of every position, results
   PinnedBuf pin_in, pin_out;                           // (transfers up to PIN_LIMIT bytes go through pinned memory)
   const void *io_qp = nullptr;                         // where device code finds the uploaded queries: io_q or the mapped pin_in slot
@@ -276,6 +281,12 @@ struct zvec_hip_ivf_s {
   Store cent;     // centroids as a flat store
   bool coarse_sep = false;             // the centroid store lives in a space of its own (dimension / metric): zvec_hip_ivf_set_coarse_space
   Store lists;    // inverted lists, each padded to whole tiles
+  // fp16 twin of `lists` at the same positions (own base + bnorm; keys / geometry are the lists'): zvec_hip_ivf_set_shadow
+  Store shadow;
+  bool shadow_on = false;
+  uint32_t shadow_kp = 0;              // rows pre-selected per query (0: from k)
+  void *d_shadow_facts = nullptr;      // zvk::ShadowFacts
+  float shadow_max_err = 0.f, shadow_max_norm = 0.f;
   uint64_t count_local = 0, count_global = 0;
   std::vector<uint32_t> h_size, h_size_global, h_tile0;
   std::vector<uint64_t> h_rows_of_largest;   // [i] = rows of the i largest local lists (bound of what i probes can scan)

@@ -27,6 +27,7 @@
 #include "zvk_scan256.hip.h"
 #include "zvk_merge.hip.h"
 #include "zvk_rows.hip.h"
+#include "zvk_shadow.hip.h"
 #include "zvk_filter.hip.h"
 #include "zvk_plan.hip.h"
 #include "zvk_build.hip.h"

@@ -159,6 +159,7 @@ class ShardedIVF(_Sharded):
     def __init__(self, searcher, ctx, rank, world, group=None, deal_coarse=False):
         super().__init__(searcher, ctx, rank, world, group)
         self.deal_coarse = bool(deal_coarse)
+        self.shadow_reruns = 0
         self._probe = {}
 
     def _probe_buffers(self, count, nprobe, device):
@@ -181,6 +182,11 @@ class ShardedIVF(_Sharded):
             rc = self.searcher.search_dev(d_queries.data_ptr(), count, topk, nprobe, max_scan, b["keys"].data_ptr(),
                                           b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx, stream=stream_ptr)
             _lib.check(rc, "zvec_hip_ivf_search_dev")
+            if self.world > 1:
+                # an index with shadow lists (zvec_hip_ivf_set_shadow): the local lists must be certified (uncertified queries re-run
+                # on the fp32 lists) BEFORE they are exchanged; returns at once when the search did not use the shadow lists
+                self.shadow_reruns += self.searcher.shadow_certify(d_queries.data_ptr(), count, topk, nprobe, max_scan, b["keys"].data_ptr(),
+                                                                   b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx, stream=stream_ptr)
             return
         p = self._probe_buffers(count, nprobe, d_queries.device)
         per, np_ = p["per"], p["np"]
@@ -200,6 +206,8 @@ class ShardedIVF(_Sharded):
                                              b["keys"].data_ptr(), b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx,
                                              stream=stream_ptr)
         _lib.check(rc, "zvec_hip_ivf_search_probes_dev")
+        self.shadow_reruns += self.searcher.shadow_certify(d_queries.data_ptr(), count, topk, nprobe, max_scan, b["keys"].data_ptr(),
+                                                           b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx, stream=stream_ptr)
 
     def search(self, d_queries, topk, nprobe, max_scan, stream_ptr):
         return super().search(d_queries, topk, nprobe, max_scan, stream_ptr=stream_ptr)

@@ -835,6 +835,28 @@ class HipIVFSearcher:
             C.c_void_p(d_exclude) if d_exclude else None, C.c_void_p(d_out_keys), C.c_void_p(d_out_scores),
             C.c_void_p(d_out_counts), C.c_void_p(stream) if stream else None)
 
+    def set_shadow(self, enable=True, preselect=0):
+        """half-width pre-selection (zvec_hip_ivf_set_shadow): an fp16 twin of the fp32 lists is scanned for `preselect` rows per
+        query, those are re-scored in fp32 and the result is certified; uncertified queries are re-run on the fp32 lists"""
+        _lib.check(_lib.lib().zvec_hip_ivf_set_shadow(self._h, int(bool(enable)), int(preselect)), "zvec_hip_ivf_set_shadow")
+
+    def shadow_info(self):
+        on, nbytes, err, norm = C.c_int(0), C.c_uint64(0), C.c_float(0), C.c_float(0)
+        _lib.check(_lib.lib().zvec_hip_ivf_shadow_info(self._h, C.byref(on), C.byref(nbytes), C.byref(err), C.byref(norm)),
+                   "zvec_hip_ivf_shadow_info")
+        return {"enabled": bool(on.value), "bytes": int(nbytes.value), "max_row_error": float(err.value), "max_row_norm": float(norm.value)}
+
+    def shadow_certify(self, d_queries, count, topk, nprobe, max_scan, d_out_keys, d_out_scores, d_out_counts, ctx,
+                       d_exclude=None, stream=None):
+        """the second half of search_dev on an index with shadow lists: waits, re-runs the uncertified queries on the fp32 lists;
+        returns how many were re-run"""
+        n = C.c_uint32(0)
+        _lib.check(_lib.lib().zvec_hip_ivf_shadow_certify(
+            self._h, ctx._h, C.c_void_p(d_queries), count, topk, nprobe, max_scan, C.c_void_p(d_exclude) if d_exclude else None,
+            C.c_void_p(d_out_keys), C.c_void_p(d_out_scores), C.c_void_p(d_out_counts), C.c_void_p(stream) if stream else None,
+            C.byref(n)), "zvec_hip_ivf_shadow_certify")
+        return int(n.value)
+
     def coarse_dev(self, d_queries, count, nprobe, d_probe_idx, d_probe_cnt, ctx, stream=None):
         """the coarse pass alone (zvec_hip_ivf_coarse_dev): probe lists [count][min(nprobe, nlist)] u32 + [count] u32, device pointers"""
         return _lib.lib().zvec_hip_ivf_coarse_dev(self._h, ctx._h, C.c_void_p(d_queries), count, nprobe, C.c_void_p(d_probe_idx),
