@@ -403,6 +403,10 @@ struct BatcherOptions {
   uint32_t window_us = 0;      // proxima.hip.searcher.batch_window_us: > 0 turns the micro-batcher on
   uint32_t max_batch = 1024;   // proxima.hip.searcher.max_batch
   uint32_t linger_us = 0;      // proxima.hip.searcher.batch_linger_us
+  // IVF, fp32 L2 / inner-product indexes on one device: searches pre-select on an fp16 twin of the lists, re-score in fp32 and
+  // certify the result (zvec_hip_ivf_set_shadow: same results, about half the bytes per search, + half the index size in HBM)
+  uint32_t shadow = 0;             // proxima.hip.searcher.half_width_preselect: != 0 turns it on (off by default)
+  uint32_t shadow_preselect = 0;   // proxima.hip.searcher.preselect_rows: rows pre-selected per query (0: max(32, 3k); <= 64)
 };
 
 //! a few workspaces (stream + buffers) shared by the batch leaders: any caller thread may lead a batch, and a context per
@@ -848,6 +852,11 @@ class IVFOperator {
   }
   int loaded(uint32_t nlist) {
     nlist_ = nlist;
+    if (bo_.shadow && !sh_) {
+      // (an index the shadow lists cannot serve — fp16 rows, cosine, elements beyond the half range — keeps searching its own lists)
+      const int rc = zvec_hip_ivf_set_shadow(h_, 1, std::min<uint32_t>(bo_.shadow_preselect, 64));
+      if (rc != 0 && rc != ZVEC_HIP_ERR_UNSUPPORTED) return rc;
+    }
     if (bo_.window_us > 0)
       batcher_.reset(new MicroBatcher<DT>(elem_size_, bo_.max_batch, bo_.window_us, bo_.linger_us,
           [this](const void *q, uint32_t n, const BatchKey &key, std::vector<uint64_t> *ks, std::vector<float> *sc, std::vector<uint32_t> *cn) {

@@ -56,6 +56,9 @@ const std::string kParamHipDeviceCount("proxima.hip.device_count");   // new: > 
 const std::string kParamHipBatchWindowUs("proxima.hip.searcher.batch_window_us");
 const std::string kParamHipMaxBatch("proxima.hip.searcher.max_batch");
 const std::string kParamHipBatchLingerUs("proxima.hip.searcher.batch_linger_us");
+// new: IVF searches pre-select on an fp16 twin of the fp32 lists, re-score in fp32, certify (zvec_hip_ivf_set_shadow); off by default
+const std::string kParamHipHalfWidthPreselect("proxima.hip.searcher.half_width_preselect");
+const std::string kParamHipPreselectRows("proxima.hip.searcher.preselect_rows");
 
 // segment ids (flat_utility.h:32-34, ivf_index_format.h:152-164)
 const std::string kFlatKeys("flat.keys"), kFlatFeatures("flat.features");
@@ -171,6 +174,8 @@ zvec_hip_op::BatcherOptions batcher_options(const ailego::Params &params) {
   params.get(kParamHipBatchWindowUs, &bo.window_us);
   params.get(kParamHipMaxBatch, &bo.max_batch);
   params.get(kParamHipBatchLingerUs, &bo.linger_us);
+  params.get(kParamHipHalfWidthPreselect, &bo.shadow);
+  params.get(kParamHipPreselectRows, &bo.shadow_preselect);
   if (bo.max_batch == 0) bo.max_batch = 1024;
   return bo;
 }

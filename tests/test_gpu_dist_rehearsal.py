@@ -75,6 +75,15 @@ def _worker(rank, world, port, out):
     dk, ds, dc = dealt.search(q, k, nprobe, n, stream)
     torch.cuda.synchronize()
     ok = ok and bool(torch.equal(dc, mc)) and bool(torch.equal(ds, ms)) and bool(torch.equal(dk, mk))
+    # every rank's shard with shadow lists (zvec_hip_ivf_set_shadow): pre-selected on fp16 twins of the local lists, re-scored in fp32,
+    # certified (uncertified queries re-run on the fp32 lists) BEFORE the exchange — the merged lists must be the very same, with the
+    # replicated and with the dealt coarse pass
+    sh.set_shadow(True)
+    for variant in (sharded, dealt):
+        hk, hs, hc = variant.search(q, k, nprobe, n, stream)
+        torch.cuda.synchronize()
+        ok = ok and bool(torch.equal(hc, mc)) and bool(torch.equal(hs, ms)) and bool(((hk == mk) | tied).all())
+    sh.set_shadow(False)
     out[rank] = ok
     dist.barrier()
     dist.destroy_process_group()

@@ -190,6 +190,21 @@ def test_config2_ivf_10m_768_batch1024_properties(zv, oracle, ten_million):
     assert (gk[:, 0] == sel.cpu().numpy().astype(np.uint64)).mean() > 0.999
     scanned, probes = ivf.last_stats(ctx, nq)
     assert (probes == nprobe).all()
+    # the half-width pre-selection (zvec_hip_ivf_set_shadow) on all 1024 queries: fp16 shadow lists, fp32 re-scoring, certificate,
+    # fp32 re-run of what it cannot certify == the fp32 route, keys and score BITS (which the rest of this test ties to the oracle
+    # and to the reference's own IVFSearcher)
+    ivf.set_shadow(True)
+    sk = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    ss = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    sc = torch.empty((nq,), dtype=torch.int32, device=dev)
+    assert ivf.search_dev(q.data_ptr(), nq, k, nprobe, n, sk.data_ptr(), ss.data_ptr(), sc.data_ptr(), ctx, stream=stream) == 0
+    rerun = ivf.shadow_certify(q.data_ptr(), nq, k, nprobe, n, sk.data_ptr(), ss.data_ptr(), sc.data_ptr(), ctx, stream=stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(sk.cpu().numpy().astype(np.uint64), gk) and np.array_equal(sc.cpu().numpy().astype(np.uint32), gc)
+    assert np.array_equal(ss.cpu().numpy().view(np.uint32), gs.view(np.uint32))
+    print("config2 through the shadow lists: %d of %d queries re-run in fp32" % (rerun, nq))
+    ivf.set_shadow(False)
+    del sk, ss, sc
     # shard union: lists l%2==0 / l%2==1 searched separately and merged == the unsharded answer
     parts = []
     for r in range(2):

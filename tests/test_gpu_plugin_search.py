@@ -275,6 +275,48 @@ def test_ivf_built_by_the_reference_builder_searched_by_both(R, metric, dt):
         r.close()
 
 
+@pytest.mark.parametrize("metric,dt", [("SquaredEuclidean", np.float32), ("InnerProduct", np.float32), ("SquaredEuclidean", np.float16)])
+def test_ivf_half_width_preselect_through_the_plugin(R, metric, dt):
+    """proxima.hip.searcher.half_width_preselect = 1: the plugin class pre-selects on an fp16 twin of the lists, re-scores in fp32,
+    certifies and re-runs what it cannot certify (zvec_hip_ivf_set_shadow) — and must answer like the reference's IVFSearcher over
+    an index the reference's own builder made, and like the plugin class without the parameter.  (fp16 index: the parameter is
+    accepted and the index keeps searching its own lists.)"""
+    rng = np.random.default_rng(15)
+    n, dim, nlist = 20000, 48, 64
+    means = rng.standard_normal((nlist, dim)).astype(np.float32) * 2
+    base = (means[rng.integers(0, nlist, n)] + rng.standard_normal((n, dim)).astype(np.float32)).astype(dt)
+    keys = (rng.permutation(3 * n)[:n]).astype(np.uint64)
+    q = (means[rng.integers(0, nlist, 64)] + rng.standard_normal((64, dim)).astype(np.float32)).astype(dt)
+    R.build("IVFBuilder", base, metric, "built_hw", keys=keys, params={"proxima.ivf.builder.centroid_count": str(nlist),
+                                                                        "proxima.ivf.builder.thread_count": 4})
+    params = {"proxima.ivf.searcher.scan_ratio": 0.1, "proxima.ivf.searcher.brute_force_threshold": 100}
+    half = dict(params, **{"proxima.hip.searcher.half_width_preselect": 1})
+    tol = dict(rtol=4e-6, atol=1e-5) if dt == np.float32 else dict(rtol=4e-6, atol=1e-4)
+    k = 10
+    ref = R.Runner.searcher("IVFSearcher", "built_hw", dim, dt, params=params)
+    hip = R.Runner.searcher("HipIVFSearcher", "built_hw", dim, dt, params=params)
+    hw = R.Runner.searcher("HipIVFSearcher", "built_hw", dim, dt, params=half)
+    rc_, hc, wc = ref.create_context(), hip.create_context(), hw.create_context()
+    for c in (rc_, hc, wc):
+        c.set_topk(k)
+    band = 1e-4 if metric == "SquaredEuclidean" else None
+    r1, l1 = ref.search_lists(rc_, q, 0)
+    r2, l2 = hip.search_lists(hc, q, 0)
+    r3, l3 = hw.search_lists(wc, q, 0)
+    assert r1 == 0 and r2 == 0 and r3 == 0
+    compare(l3, l1, k, "half-width vs reference", select_band=band, **tol)
+    compare(l3, l2, k, "half-width vs fp32 route", select_band=band, **tol)
+    if metric == "SquaredEuclidean":
+        a, b = lists_to_arrays(l3, k), lists_to_arrays(l2, k)                     # same keys, same score bits
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2])
+    r4, l4 = hw.search_lists(wc, q[:1], 0)                 # the product's count = 1 call: the small-batch route, fp32 lists
+    r5, l5 = ref.search_lists(rc_, q[:1], 0)
+    assert r4 == 0 and r5 == 0
+    compare(l4, l5, k, "half-width single", select_band=band, **tol)
+    for r in (ref, hip, hw):
+        r.close()
+
+
 def test_flat_streamer_wraps_the_reference_streamer(R):
     """HipFlatStreamer: add_impl / add_with_id_impl persist through the wrapped reference FlatStreamer and mirror into HBM;
     searches run on the GPU; close + re-open reads the persisted rows back (flat_streamer.cc:236-483)."""

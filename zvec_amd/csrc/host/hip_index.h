@@ -92,6 +92,8 @@ static const char *const PARAM_IVF_SEARCHER_BRUTE_FORCE_THRESHOLD = "proxima.ivf
 static const char *const PARAM_HIP_SEARCHER_BATCH_WINDOW_US = "proxima.hip.searcher.batch_window_us";
 static const char *const PARAM_HIP_SEARCHER_MAX_BATCH = "proxima.hip.searcher.max_batch";
 static const char *const PARAM_HIP_SEARCHER_BATCH_LINGER_US = "proxima.hip.searcher.batch_linger_us";
+static const char *const PARAM_HIP_SEARCHER_HALF_WIDTH_PRESELECT = "proxima.hip.searcher.half_width_preselect";
+static const char *const PARAM_HIP_SEARCHER_PRESELECT_ROWS = "proxima.hip.searcher.preselect_rows";
 
 class IndexDocument {
  public:
@@ -227,6 +229,8 @@ inline zvec_hip_op::BatcherOptions batcher_options(const Params &params) {
   if (params.get(PARAM_HIP_SEARCHER_BATCH_WINDOW_US, &v)) bo.window_us = (uint32_t)v;
   if (params.get(PARAM_HIP_SEARCHER_MAX_BATCH, &v)) bo.max_batch = (uint32_t)v;
   if (params.get(PARAM_HIP_SEARCHER_BATCH_LINGER_US, &v)) bo.linger_us = (uint32_t)v;
+  if (params.get(PARAM_HIP_SEARCHER_HALF_WIDTH_PRESELECT, &v)) bo.shadow = (uint32_t)v;
+  if (params.get(PARAM_HIP_SEARCHER_PRESELECT_ROWS, &v)) bo.shadow_preselect = (uint32_t)v;
   return bo;
 }
 
