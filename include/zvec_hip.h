@@ -252,6 +252,16 @@ int zvec_hip_ivf_search_probes_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const v
  * zvec_hip_ivf_shadow_certify, which the caller runs on the same context with the same arguments before it reads the results
  * (*rerun = queries re-run; a call with no shadow search pending returns 0 at once).  Unsupported: fp16 / cosine indexes, rows
  * beyond the half range.  enable = 0 frees the copy.  zvec_hip_ivf_shadow_info: state, bytes held, max |b - b16|, max |b16|. */
+/* The same for a flat store (FlatSearcher::search_impl / search_bf_impl, flat_searcher.cc:162-211: every row scored in fp32): an fp16
+ * twin of the rows present at the call; searches (no radius, k <= 32, any batch size) pre-select on it, re-score in fp32, certify.  A
+ * single query's scan is bound by the bytes of the rows (halved), a wide batch's by the fp32 matrix rate (fp16 instead).  ANY later
+ * mutation of the store (append / put / load / reserve) drops the twin; set it again when the rows have settled.  Host-pointer
+ * searches certify inside the call, zvec_hip_flat_search_dev is followed by zvec_hip_flat_shadow_certify. */
+int zvec_hip_flat_set_shadow(zvec_hip_flat_t h, int enable, uint32_t preselect);
+int zvec_hip_flat_shadow_info(zvec_hip_flat_t h, int *enabled, uint64_t *bytes, float *max_row_error, float *max_row_norm);
+int zvec_hip_flat_shadow_certify(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,
+                                 const uint64_t *d_exclude_bitset, uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts,
+                                 void *stream, uint32_t *rerun);
 int zvec_hip_ivf_set_shadow(zvec_hip_ivf_t h, int enable, uint32_t preselect);
 int zvec_hip_ivf_shadow_info(zvec_hip_ivf_t h, int *enabled, uint64_t *bytes, float *max_row_error, float *max_row_norm);
 int zvec_hip_ivf_shadow_certify(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,

@@ -173,3 +173,85 @@ def test_shadow_refusals(zv):
     assert lib.zvec_hip_ivf_set_shadow(cs._h, 1, 0) == zv.IndexError_.Unsupported
     n = C.c_uint32(7)
     assert lib.zvec_hip_ivf_shadow_certify(se._h, None, None, 1, 1, 1, 1, None, None, None, None, None, C.byref(n)) == zv.IndexError_.InvalidArgument
+
+
+# ---- flat stores -------------------------------------------------------------------------------------------------------------------
+def _flat_search(se, q, k, exclude=None):
+    ctx = se.create_context()
+    ctx.set_topk(k)
+    if exclude is not None:
+        ctx.set_filter(exclude)
+    assert se.search_impl(q, len(q), ctx) == 0
+    return ctx.keys.copy(), ctx.scores.copy(), ctx.counts.copy()
+
+
+def _flat_search_dev(se, q, k):
+    import torch
+    dq = torch.from_numpy(q).cuda()
+    nq = len(q)
+    keys = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+    scores = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+    counts = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    ctx = se.create_context()
+    torch.cuda.synchronize()
+    assert se.search_dev(dq.data_ptr(), nq, k, keys.data_ptr(), scores.data_ptr(), counts.data_ptr(), ctx) == 0
+    rerun = se.shadow_certify(dq.data_ptr(), nq, k, keys.data_ptr(), scores.data_ptr(), counts.data_ptr(), ctx)
+    assert se.shadow_certify(dq.data_ptr(), nq, k, keys.data_ptr(), scores.data_ptr(), counts.data_ptr(), ctx) == 0
+    torch.cuda.synchronize()
+    return keys.cpu().numpy().astype(np.uint64), scores.cpu().numpy(), counts.cpu().numpy().astype(np.uint32), rerun
+
+
+@pytest.mark.parametrize("metric", ["SquaredEuclidean", "InnerProduct"])
+@pytest.mark.parametrize("n,dim,nq,k", [(300000, 128, 256, 10), (150000, 96, 1, 10), (150000, 96, 8, 5), (40000, 64, 300, 32)])
+def test_flat_shadow_equals_the_fp32_route(zv, metric, n, dim, nq, k):
+    """wide batches (the 8-wave tile over fp16 rows), a handful of queries (the 16-row shape), a cache-resident base — every shape of
+    flat_scan_prepared under the shadow rows returns what the fp32 rows return"""
+    rng = np.random.default_rng(n + nq)
+    cl = rng.standard_normal((200, dim)).astype(np.float32) * 2
+    base = (cl[rng.integers(0, 200, n)] + rng.standard_normal((n, dim)).astype(np.float32)).astype(np.float32)
+    q = (cl[rng.integers(0, 200, nq)] + rng.standard_normal((nq, dim)).astype(np.float32)).astype(np.float32)
+    se = zv.HipFlatSearcher(dim, metric)
+    assert se.load(base) == 0
+    k0, s0, c0 = _flat_search(se, q, k)
+    se.set_shadow(True)
+    assert se.shadow_info()["enabled"]
+    k1, s1, c1 = _flat_search(se, q, k)
+    k2, s2, c2, rerun = _flat_search_dev(se, q, k)
+    assert rerun < max(nq // 2, 1) + 1
+    for kk, ss, cc in ((k1, s1, c1), (k2, s2, c2)):
+        assert np.array_equal(cc, c0)
+        if metric == "SquaredEuclidean":
+            assert np.array_equal(kk, k0) and np.array_equal(ss.view(np.uint32), s0.view(np.uint32))
+        else:
+            tie_tolerant_compare(kk, ss, cc, k0, s0, c0, atol=4e-6 * dim * 8, what="flat shadow ip")
+    # with a filter
+    f0 = _flat_search(se, q, k, exclude=lambda key: key % 4 == 1)
+    assert se.shadow_info()["enabled"]
+    se.set_shadow(False)
+    f1 = _flat_search(se, q, k, exclude=lambda key: key % 4 == 1)
+    assert np.array_equal(f0[2], f1[2]) and not (f0[0][:, 0] % 4 == 1).any()
+    if metric == "SquaredEuclidean":
+        assert np.array_equal(f0[0], f1[0]) and np.array_equal(f0[1].view(np.uint32), f1[1].view(np.uint32))
+
+
+def test_flat_shadow_integer_data_vs_the_oracle_and_mutation(zv, oracle):
+    rng = np.random.default_rng(31)
+    n, dim, nq, k = 100000, 64, 64, 10
+    base = rng.integers(0, 32, (n, dim)).astype(np.float32)
+    q = rng.integers(0, 32, (nq, dim)).astype(np.float32)
+    se = zv.HipFlatStreamer(dim, "SquaredEuclidean")
+    assert se.add_batch(base[: n // 2], np.arange(n // 2, dtype=np.uint64)) == 0
+    se.set_shadow(True)
+    assert se.shadow_info()["max_row_error"] == 0.0
+    gk, gs, gc, _ = _flat_search_dev(se, q, k)
+    ok, os_, _, oc = oracle.flat_search(base[: n // 2], q, k)
+    tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="flat shadow int")
+    # a mutation drops the twin: the store searches its own (now longer) rows
+    assert se.add_batch(base[n // 2:], np.arange(n // 2, n, dtype=np.uint64)) == 0
+    assert not se.shadow_info()["enabled"]
+    gk, gs, gc = _flat_search(se, q, k)
+    ok, os_, _, oc = oracle.flat_search(base, q, k)
+    tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="flat after growth")
+    se.set_shadow(True)
+    gk, gs, gc = _flat_search(se, q, k)
+    tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="flat shadow after growth")

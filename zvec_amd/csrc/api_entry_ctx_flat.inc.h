@@ -126,10 +126,21 @@ int zvec_hip_flat_create(uint32_t dim, int dtype, int metric, int device, zvec_h
   return 0;
 }
 
+static void flat_drop_shadow(zvec_hip_flat_s *h) {
+  if (!h->shadow.base && !h->d_shadow_facts) { h->shadow_on = false; return; }
+  h->shadow.keys = nullptr; h->shadow.extra = nullptr;      // (never its own)
+  h->shadow.release();
+  h->shadow.n = 0;
+  if (h->d_shadow_facts) (void)hipFree(h->d_shadow_facts);
+  h->d_shadow_facts = nullptr;
+  h->shadow_on = false;
+}
+
 int zvec_hip_flat_destroy(zvec_hip_flat_t h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
+  flat_drop_shadow(h);
   h->st.release();
   h->d_holes.release();
   h->ring.release();
@@ -145,6 +156,7 @@ int zvec_hip_flat_reserve(zvec_hip_flat_t h, uint64_t capacity) {
   if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
   std::unique_lock<FairSharedMutex> w(h->rw);
+  flat_drop_shadow(h);                               // (any mutation: the fp16 twin no longer mirrors the store)
   ZCHK(hipSetDevice(h->device));
   return h->st.reserve(capacity, h->defctx->own);
 }
@@ -217,6 +229,7 @@ int zvec_hip_flat_append_dev(zvec_hip_flat_t h, const void *d_vecs, uint64_t n, 
   if (!h || (!d_vecs && n)) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
   std::unique_lock<FairSharedMutex> w(h->rw);
+  flat_drop_shadow(h);                               // (any mutation: the fp16 twin no longer mirrors the store)
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = pick_stream(h->defctx, stream);
   ZRET(flat_order_after_appends(h, s));                                    // (an earlier append on another stream)
@@ -244,6 +257,7 @@ int zvec_hip_flat_load_features(zvec_hip_flat_t h, const void *features, uint64_
   if (bytes < count * elem) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(h->mu);
   std::unique_lock<FairSharedMutex> w(h->rw);
+  flat_drop_shadow(h);                               // (any mutation: the fp16 twin no longer mirrors the store)
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
   Scoped<uint8_t> d_body;
@@ -305,6 +319,7 @@ int zvec_hip_flat_load_blocks(zvec_hip_flat_t h, const void *blocks, uint64_t by
   if (kept == 0) return 0;
   std::lock_guard<std::mutex> g(h->mu);
   std::unique_lock<FairSharedMutex> w(h->rw);
+  flat_drop_shadow(h);                               // (any mutation: the fp16 twin no longer mirrors the store)
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
   // everything that can refuse comes before the first asynchronous copy out of the local arrays
@@ -337,6 +352,7 @@ int zvec_hip_flat_append(zvec_hip_flat_t h, const void *vecs, uint64_t n, const 
   if (n == 0) return 0;
   std::lock_guard<std::mutex> g(h->mu);
   std::unique_lock<FairSharedMutex> w(h->rw);
+  flat_drop_shadow(h);                               // (any mutation: the fp16 twin no longer mirrors the store)
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
   const size_t rb = h->st.row_bytes();
@@ -384,6 +400,7 @@ int zvec_hip_flat_put(zvec_hip_flat_t h, const uint32_t *ids, uint64_t n, const 
     if (ids[i] >= 0xfffffff0u) return ZVEC_HIP_ERR_OUT_OF_RANGE;
   std::lock_guard<std::mutex> g(h->mu);
   std::unique_lock<FairSharedMutex> w(h->rw);
+  flat_drop_shadow(h);                               // (any mutation: the fp16 twin no longer mirrors the store)
   ZCHK(hipSetDevice(h->device));
   hipStream_t s = h->defctx->own;
   Store &st = h->st;
@@ -534,6 +551,56 @@ static int flat_search_dev_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, const v
   ZRET(flat_effective_exclude(h, c, d_exclude_bitset, s, &d_exclude_bitset));
   // the kernels address the padded query matrix with 32-bit word offsets: very large batches go in slices
   const uint32_t maxq = std::max<uint32_t>(1u, 0x7fffffffu / std::max<uint32_t>(h->st.dpad, 1u));
+  c->sh_count = 0;
+  // Half-width pre-selection (zvk_shadow.hip.h, as for the IVF lists): the scan streams the fp16 twin of the store for k' rows per
+  // query — half the bytes of a small batch's HBM-bound scan, and fp16 matrix work instead of fp32 for a wide one —, those are
+  // re-scored on the fp32 rows, the k best certified; zvec_hip_flat_shadow_certify re-runs what fails.
+  if (h->shadow_on && h->shadow.base && h->shadow.n == h->st.n && !c->shadow_skip && !(threshold < FLT_MAX) && topk <= 32 &&
+      count <= maxq && h->st.n > 0) {
+    uint32_t kp = h->shadow_kp ? h->shadow_kp : std::max<uint32_t>(32, 3 * topk);
+    kp = std::min<uint32_t>(kp, 64);
+    if (kp > topk) {
+      ZRET(prep_queries(c, h->st, d_queries, count, threshold, s));            // fp32 rows for the re-scoring; resets the shared bounds
+      const Store &sst = h->shadow;
+      const size_t ck = (size_t)count * kp;
+      ZRET(c->sh_q16.ensure((size_t)count * sst.dpad * sizeof(float)));
+      ZRET(c->sh_qn16.ensure((size_t)count * sizeof(float)));
+      ZRET(c->sh_qinfo.ensure((size_t)count * sizeof(f32x2)));
+      ZRET(c->sh_keys.ensure(ck * sizeof(uint64_t)));
+      ZRET(c->sh_scores.ensure(ck * sizeof(float)));
+      ZRET(c->sh_true.ensure(ck * sizeof(float)));
+      ZRET(c->sh_idx.ensure(ck * sizeof(uint32_t)));
+      ZRET(c->sh_counts.ensure((size_t)count * sizeof(uint32_t)));
+      ZRET(c->sh_flags.ensure(((size_t)count + 4) * sizeof(uint32_t)));
+      hipLaunchKernelGGL(shadow_prep_queries_kernel, dim3((count + 3) / 4), dim3(256), 0, s, reinterpret_cast<const float *>(d_queries),
+                         count, h->st.dim_in, sst.dscan, sst.dpad, c->sh_q16.as<float>(), c->sh_qn16.as<float>(), c->sh_qinfo.as<f32x2>());
+      ZCHK(hipGetLastError());
+      Store view = sst;                          // the shadow rows under the store's keys (a view: owns nothing)
+      view.keys = h->st.keys;
+      SearchOut so{c->sh_keys.as<uint64_t>(), c->sh_scores.as<float>(), c->sh_idx.as<uint32_t>(), c->sh_counts.as<uint32_t>()};
+      std::swap(c->qpad, c->sh_q16);             // the scan reads the context's prepared queries: the fp16 ones for this call
+      std::swap(c->qnorm, c->sh_qn16);
+      c->shadow_scan = true;
+      const int rc = flat_scan_prepared(c, view, count, kp, FLT_MAX, d_exclude_bitset, so, s, false);
+      c->shadow_scan = false;
+      std::swap(c->qpad, c->sh_q16);
+      std::swap(c->qnorm, c->sh_qn16);
+      ZRET(rc);
+      hipLaunchKernelGGL(shadow_rescore_kernel<false>, dim3((unsigned)((ck + 3) / 4)), dim3(256), 0, s, h->st.base, c->qpad.as<float>(),
+                         h->st.dpad, h->st.metric, so.idx, so.counts, count, kp, c->sh_true.as<float>());
+      ZCHK(hipMemsetAsync(c->sh_flags.as<uint32_t>() + count, 0, sizeof(uint32_t), s));
+      ShadowSelectArgs sa{};
+      sa.c_keys = so.keys; sa.c_shadow = so.scores; sa.c_true = c->sh_true.as<float>(); sa.c_idx = so.idx; sa.c_counts = so.counts;
+      sa.qinfo = c->sh_qinfo.as<f32x2>(); sa.facts = static_cast<const ShadowFacts *>(h->d_shadow_facts);
+      sa.kp = kp; sa.k = topk; sa.dscan = h->st.dscan; sa.metric = h->st.metric;
+      sa.out_keys = d_out_keys; sa.out_scores = d_out_scores; sa.out_idx = nullptr; sa.out_counts = d_out_counts;
+      sa.flags = c->sh_flags.as<uint32_t>(); sa.nflag = sa.flags + count;
+      hipLaunchKernelGGL(shadow_select_kernel, dim3(count), dim3(64), 0, s, sa);
+      ZCHK(hipGetLastError());
+      c->sh_count = count;
+      return 0;
+    }
+  }
   for (uint32_t q0 = 0; q0 < count; q0 += maxq) {
     const uint32_t m = std::min(maxq, count - q0);
     ZRET(prep_queries(c, h->st, reinterpret_cast<const char *>(d_queries) + (size_t)q0 * h->st.row_bytes(), m, threshold, s));
@@ -541,6 +608,112 @@ static int flat_search_dev_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, const v
     ZRET(flat_scan_prepared(c, h->st, m, topk, threshold, d_exclude_bitset, out, s, true));
   }
   return 0;
+}
+
+// the second half of a search through the shadow rows (as ivf_shadow_certify_locked): the caller holds c->mu and h->rw (shared)
+static int flat_shadow_certify_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, const void *d_queries, uint32_t count, uint32_t topk,
+                                      const uint64_t *d_exclude, uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts,
+                                      hipStream_t s, uint32_t *rerun_out) {
+  if (rerun_out) *rerun_out = 0;
+  if (c->sh_count == 0) return 0;
+  if (c->sh_count != count) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  c->sh_count = 0;
+  uint32_t nflag = 0;
+  ZCHK(hipMemcpyAsync(&nflag, c->sh_flags.as<uint32_t>() + count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  ZCHK(hipStreamSynchronize(s));
+  if (nflag == 0) return 0;
+  std::vector<uint32_t> flags(count);
+  ZCHK(hipMemcpyAsync(flags.data(), c->sh_flags.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  ZCHK(hipStreamSynchronize(s));
+  std::vector<uint32_t> which;
+  for (uint32_t q = 0; q < count; ++q) if (flags[q]) which.push_back(q);
+  const uint32_t m = (uint32_t)which.size();
+  if (m == 0) return 0;
+  const size_t rb = h->st.row_bytes();
+  Scoped<char> tq;
+  Scoped<uint64_t> tk;
+  Scoped<float> ts;
+  Scoped<uint32_t> tc;
+  ZRET(tq.alloc((size_t)m * rb));
+  ZRET(tk.alloc((size_t)m * topk));
+  ZRET(ts.alloc((size_t)m * topk));
+  ZRET(tc.alloc(m));
+  for (uint32_t i = 0; i < m; ++i)
+    ZCHK(hipMemcpyAsync(tq.p + (size_t)i * rb, static_cast<const char *>(d_queries) + (size_t)which[i] * rb, rb, hipMemcpyDeviceToDevice, s));
+  const bool old = c->shadow_skip;
+  c->shadow_skip = true;
+  const int rc = flat_search_dev_locked(h, c, tq.p, m, topk, FLT_MAX, d_exclude, tk, ts, tc, s);
+  c->shadow_skip = old;
+  ZRET(rc);
+  for (uint32_t i = 0; i < m; ++i) {
+    const size_t o = (size_t)which[i] * topk;
+    ZCHK(hipMemcpyAsync(d_out_keys + o, tk.p + (size_t)i * topk, (size_t)topk * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+    ZCHK(hipMemcpyAsync(d_out_scores + o, ts.p + (size_t)i * topk, (size_t)topk * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ZCHK(hipMemcpyAsync(d_out_counts + which[i], tc.p + i, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  }
+  ZCHK(hipStreamSynchronize(s));
+  if (rerun_out) *rerun_out = m;
+  return 0;
+}
+
+int zvec_hip_flat_set_shadow(zvec_hip_flat_t h, int enable, uint32_t preselect) {
+  if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->mu);
+  std::unique_lock<FairSharedMutex> w_(h->rw);
+  ZCHK(hipSetDevice(h->device));
+  ZCHK(hipDeviceSynchronize());
+  flat_drop_shadow(h);
+  if (!enable) return 0;
+  if (h->dtype != ZVEC_HIP_DT_FP32 || h->st.metric == ZVEC_HIP_METRIC_COSINE) return ZVEC_HIP_ERR_UNSUPPORTED;
+  if (preselect > 64) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  if (h->st.n == 0) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
+  hipStream_t s = h->defctx->own;
+  ZRET(flat_wait_appends(h, s));
+  Store &sh = h->shadow;
+  sh = Store();
+  sh.configure(h->st.dim_in, h->st.metric, ZVEC_HIP_DT_FP16);
+  const uint64_t tiles = (h->st.n + TILE_N - 1) / TILE_N;
+  if (hipMalloc(&sh.base, (size_t)tiles * TILE_N * sh.dpad * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); sh.base = nullptr; return ZVEC_HIP_ERR_NO_MEMORY; }
+  if (hipMalloc(&sh.bnorm, (size_t)tiles * TILE_N * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); flat_drop_shadow(h); return ZVEC_HIP_ERR_NO_MEMORY; }
+  if (hipMalloc(&h->d_shadow_facts, sizeof(ShadowFacts)) != hipSuccess) { (void)hipGetLastError(); flat_drop_shadow(h); return ZVEC_HIP_ERR_NO_MEMORY; }
+  sh.cap_tiles = tiles;
+  sh.n = h->st.n;
+  ZCHK(hipMemsetAsync(h->d_shadow_facts, 0, sizeof(ShadowFacts), s));
+  const uint64_t npos = tiles * TILE_N;
+  hipLaunchKernelGGL(shadow_rows_kernel, dim3((unsigned)((npos + 3) / 4)), dim3(256), 0, s, h->st.base, h->st.dpad, sh.dscan, sh.base, sh.dpad,
+                     sh.bnorm, npos, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, h->st.n, static_cast<ShadowFacts *>(h->d_shadow_facts));
+  ZCHK(hipGetLastError());
+  ShadowFacts f{};
+  ZCHK(hipMemcpyAsync(&f, h->d_shadow_facts, sizeof(f), hipMemcpyDeviceToHost, s));
+  ZCHK(hipStreamSynchronize(s));
+  if (!(__builtin_bit_cast(float, f.max_abs) < 65504.f)) { flat_drop_shadow(h); return ZVEC_HIP_ERR_UNSUPPORTED; }
+  h->shadow_max_err = __builtin_bit_cast(float, f.max_err);
+  h->shadow_max_norm = __builtin_bit_cast(float, f.max_norm);
+  h->shadow_kp = preselect;
+  h->shadow_on = true;
+  return 0;
+}
+
+int zvec_hip_flat_shadow_info(zvec_hip_flat_t h, int *enabled, uint64_t *bytes, float *max_row_error, float *max_row_norm) {
+  if (!h) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  std::shared_lock<FairSharedMutex> r(h->rw);
+  if (enabled) *enabled = h->shadow_on ? 1 : 0;
+  if (bytes) *bytes = h->shadow_on ? (uint64_t)h->shadow.cap_tiles * TILE_N * (h->shadow.dpad + 1) * sizeof(float) : 0;
+  if (max_row_error) *max_row_error = h->shadow_on ? h->shadow_max_err : 0.f;
+  if (max_row_norm) *max_row_norm = h->shadow_on ? h->shadow_max_norm : 0.f;
+  return 0;
+}
+
+int zvec_hip_flat_shadow_certify(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,
+                                 const uint64_t *d_exclude_bitset, uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts,
+                                 void *stream, uint32_t *rerun) {
+  if (!h || !d_queries || !d_out_keys || !d_out_scores || !d_out_counts) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  zvec_hip_ctx_s *c = ctx ? ctx : h->defctx;
+  std::lock_guard<std::mutex> g(c->mu);
+  std::shared_lock<FairSharedMutex> r(h->rw);
+  ZCHK(hipSetDevice(h->device));
+  return flat_shadow_certify_locked(h, c, d_queries, count, topk, d_exclude_bitset, d_out_keys, d_out_scores, d_out_counts,
+                                    pick_stream(c, stream), rerun);
 }
 
 int zvec_hip_flat_search_dev(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count,
@@ -573,6 +746,9 @@ int zvec_hip_flat_search(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *quer
     ZRET(host_search_wrap_begin(c, queries, (size_t)count * h->st.row_bytes(), exclude_bitset, h->st.n, count, topk, c->cur));
     ZRET(flat_search_dev_locked(h, c, c->io_qp, count, topk, threshold, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr,
                                 c->io_keys.as<uint64_t>(), c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur));
+    if (c->sh_count)       // shadow rows: the queries whose result could not be certified are re-run on the fp32 rows
+      ZRET(flat_shadow_certify_locked(h, c, c->io_qp, count, topk, exclude_bitset ? c->io_ex.as<uint64_t>() : nullptr,
+                                      c->io_keys.as<uint64_t>(), c->io_scores.as<float>(), c->io_counts.as<uint32_t>(), c->cur, nullptr));
   }
   return host_search_wrap_end(c, count, topk, out_keys, out_scores, out_counts, c->cur);
 }

@@ -861,7 +861,7 @@ int zvec_hip_ivf_set_shadow(zvec_hip_ivf_t h, int enable, uint32_t preselect) {
   // every position of the used tiles; the padding rows behind a list's last row become zero rows
   const uint64_t npos = tiles * TILE_N;
   hipLaunchKernelGGL(shadow_rows_kernel, dim3((unsigned)((npos + 3) / 4)), dim3(256), 0, s, h->lists.base, h->lists.dpad, sh.dscan,
-                     sh.base, sh.dpad, sh.bnorm, npos, h->d_tile0, h->d_size, h->nlist, static_cast<ShadowFacts *>(h->d_shadow_facts));
+                     sh.base, sh.dpad, sh.bnorm, npos, h->d_tile0, h->d_size, h->nlist, 0ull, static_cast<ShadowFacts *>(h->d_shadow_facts));
   ZCHK(hipGetLastError());
   ShadowFacts f{};
   ZCHK(hipMemcpyAsync(&f, h->d_shadow_facts, sizeof(f), hipMemcpyDeviceToHost, s));

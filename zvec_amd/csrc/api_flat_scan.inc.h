@@ -374,7 +374,8 @@ int flat_dense_scores(zvec_hip_ctx_s *ctx, const Store &st, uint32_t q0, uint32_
 // coarse pass and the k-means labelling, which only need the ranking
 int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uint32_t topk, float threshold,
                        const uint64_t *d_exclude, const SearchOut &out_in, hipStream_t stream, bool user_facing) {
-  const bool profile_it = user_facing;
+  const bool profile_it = user_facing || ctx->shadow_scan;      // (the scan over a shadow store IS the search's dominant scan)
+  ctx->shadow_scan = false;                                     // (... its nested seeding pre-pass is not)
   SearchOut out = out_in;
   if (user_facing && st.metric == ZVEC_HIP_METRIC_L2 && out.idx == nullptr) {
     ZRET(ctx->ridx.ensure((size_t)count * topk * sizeof(uint32_t)));

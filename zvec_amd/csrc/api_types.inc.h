@@ -205,6 +205,7 @@ struct zvec_hip_ctx_s {
   DevBuf sh_q16, sh_qn16, sh_qinfo, sh_keys, sh_scores, sh_true, sh_idx, sh_counts, sh_flags;
   uint32_t sh_count = 0;                               // queries of the last search that went through the shadow lists (0: none)
   bool shadow_skip = false;                            // the certify step's re-run: this search must read the fp32 lists
+  bool shadow_scan = false;                            // flat_scan_prepared is running over a shadow store: profiled / gated like a user-facing scan
   DevBuf holes_ex;                                     // caller's exclude set OR the store's holes                      // group-by search: per-group bests / lists, group of every position, results
   PinnedBuf pin_in, pin_out;                           // (transfers up to PIN_LIMIT bytes go through pinned memory)
   const void *io_qp = nullptr;                         // where device code finds the uploaded queries: io_q or the mapped pin_in slot
@@ -231,6 +232,13 @@ struct zvec_hip_flat_s {
   int device = 0;
   int dtype = 0;
   Store st;
+  // fp16 twin of `st` at the same positions (own base + bnorm): zvec_hip_flat_set_shadow.  Built for the rows present at that moment;
+  // any mutation of the store drops it (the store then searches its own rows until it is set again)
+  Store shadow;
+  bool shadow_on = false;
+  uint32_t shadow_kp = 0;
+  void *d_shadow_facts = nullptr;      // zvk::ShadowFacts
+  float shadow_max_err = 0.f, shadow_max_norm = 0.f;
   zvec_hip_ctx_s *defctx = nullptr;
   std::mutex mu;            // serialises the calls that use defctx's workspace (appends, get_vector)
   // The streamer is searched while it grows (flat_streamer_test.cc TestConcurrentAddAndSearch): searches hold `rw`

@@ -37,18 +37,21 @@ struct ShadowFacts {
 // (the padding rows behind a list's last row are never written in the fp32 lists: they become zero rows here and feed no fact)
 __global__ void __launch_bounds__(256) shadow_rows_kernel(const float *base32, uint32_t dpad32, uint32_t dscan, float *base16,
                                                           uint32_t dpad16, float *bnorm16, uint64_t n, const uint32_t *list_tile0,
-                                                          const uint32_t *list_size, uint32_t nlist, ShadowFacts *facts) {
+                                                          const uint32_t *list_size, uint32_t nlist, uint64_t nvalid, ShadowFacts *facts) {
   const int lane = threadIdx.x & 63;
   const uint64_t pos = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pos >= n) return;
-  // the list that owns this tile: the last one whose first tile is <= it (empty lists share their successor's first tile)
-  const uint32_t tile = (uint32_t)(pos >> 7);
-  uint32_t lo = 0, hi = nlist;
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (list_tile0[mid] <= tile) lo = mid; else hi = mid;
+  bool valid = pos < nvalid;                         // flat store (list_tile0 == nullptr): the first nvalid positions
+  if (list_tile0) {
+    // IVF: the list that owns this tile — the last one whose first tile is <= it (empty lists share their successor's first tile)
+    const uint32_t tile = (uint32_t)(pos >> 7);
+    uint32_t lo = 0, hi = nlist;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (list_tile0[mid] <= tile) lo = mid; else hi = mid;
+    }
+    valid = pos - (uint64_t)list_tile0[lo] * TILE_N < (uint64_t)list_size[lo];
   }
-  const bool valid = pos - (uint64_t)list_tile0[lo] * TILE_N < (uint64_t)list_size[lo];
   const uint32_t nelem = dpad16 * 2u;
   float acc = 0.f, err = 0.f, mx = 0.f;
   for (uint32_t c = lane; c < nelem; c += 64) {

@@ -230,6 +230,9 @@ class ShardedFlat(_Sharded):
         rc = self.searcher.search_dev(d_queries.data_ptr(), count, topk, b["keys"].data_ptr(), b["scores"].data_ptr(),
                                       b["counts"].data_ptr(), self.ctx, d_exclude=d_exclude, stream=stream_ptr, **kw)
         _lib.check(rc, "zvec_hip_flat_search_dev")
+        if self.world > 1:      # a store with shadow rows: certified (uncertified queries re-run in fp32) BEFORE the exchange
+            self.searcher.shadow_certify(d_queries.data_ptr(), count, topk, b["keys"].data_ptr(), b["scores"].data_ptr(),
+                                         b["counts"].data_ptr(), self.ctx, d_exclude=d_exclude, stream=stream_ptr)
 
     def search(self, d_queries, topk, stream_ptr, d_exclude=None, threshold=None):
         return super().search(d_queries, topk, stream_ptr=stream_ptr, d_exclude=d_exclude, threshold=threshold)

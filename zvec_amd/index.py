@@ -531,6 +531,28 @@ class _FlatBase:
             C.c_void_p(d_out_scores), C.c_void_p(d_out_counts), C.c_void_p(stream) if stream else None)
 
 
+    def set_shadow(self, enable=True, preselect=0):
+        """half-width pre-selection (zvec_hip_flat_set_shadow): an fp16 twin of the rows present now is scanned for `preselect` rows
+        per query, those are re-scored in fp32 and the result is certified; any later mutation of the store drops the twin"""
+        _lib.check(_lib.lib().zvec_hip_flat_set_shadow(self._h, int(bool(enable)), int(preselect)), "zvec_hip_flat_set_shadow")
+
+    def shadow_info(self):
+        on, nbytes, err, norm = C.c_int(0), C.c_uint64(0), C.c_float(0), C.c_float(0)
+        _lib.check(_lib.lib().zvec_hip_flat_shadow_info(self._h, C.byref(on), C.byref(nbytes), C.byref(err), C.byref(norm)),
+                   "zvec_hip_flat_shadow_info")
+        return {"enabled": bool(on.value), "bytes": int(nbytes.value), "max_row_error": float(err.value), "max_row_norm": float(norm.value)}
+
+    def shadow_certify(self, d_queries, count, topk, d_out_keys, d_out_scores, d_out_counts, ctx, d_exclude=None, stream=None):
+        """the second half of search_dev on a store with shadow rows: waits, re-runs the uncertified queries on the fp32 rows;
+        returns how many were re-run"""
+        n = C.c_uint32(0)
+        _lib.check(_lib.lib().zvec_hip_flat_shadow_certify(
+            self._h, ctx._h, C.c_void_p(d_queries), count, topk, C.c_void_p(d_exclude) if d_exclude else None, C.c_void_p(d_out_keys),
+            C.c_void_p(d_out_scores), C.c_void_p(d_out_counts), C.c_void_p(stream) if stream else None, C.byref(n)),
+            "zvec_hip_flat_shadow_certify")
+        return int(n.value)
+
+
 class HipFlatStreamer(_FlatBase):
     """stands where "FlatStreamer" is registered (flat_streamer.cc:486-489): mutable, add + search."""
 
