@@ -450,6 +450,8 @@ class FlatOperator {
     device_ = device;
     elem_size_ = elem_size;
     position_is_id_ = position_is_id;
+    shadow_ = bo.shadow;
+    shadow_preselect_ = std::min<uint32_t>(bo.shadow_preselect, 64);
     int rc;
     if (ndev > 1) {
       std::vector<int> devs(ndev);
@@ -591,6 +593,13 @@ class FlatOperator {
                  : zvec_hip_flat_load_features(h_, features, bytes, n, column_major, 32, keys);
     if (rc != 0) return rc;
     if (keys) dir_.adopt(keys, n); else dir_.adopt_identity(n);
+    // FlatSearcher's one-shot load: the rows have settled — proxima.hip.searcher.half_width_preselect puts an fp16 twin beside them
+    // (a store it cannot serve — fp16 rows, cosine, elements beyond the half range — keeps searching its own rows; a streamer's
+    // later appends drop the twin: zvec_hip_flat_set_shadow)
+    if (shadow_ && h_ && n > 0) {
+      rc = zvec_hip_flat_set_shadow(h_, 1, shadow_preselect_);
+      if (rc != 0 && rc != ZVEC_HIP_ERR_UNSUPPORTED) return rc;
+    }
     return 0;
   }
   //! a run of FlatStreamerEntity blocks (one "flat.features<i>" segment: [bvc x element][bvc x key] ... [DeletionMap]
@@ -717,6 +726,7 @@ class FlatOperator {
   bool position_is_id_{false};
   mutable FairSharedMutex mu_;            // add (exclusive) vs search (shared): flat_streamer.cc:236-242
   KeyDirectory dir_;                      // key of every storage position
+  uint32_t shadow_{0}, shadow_preselect_{0};      // BatcherOptions::shadow / shadow_preselect
   std::unique_ptr<MicroBatcher<DT>> batcher_;
   mutable CtxPool pool_;
 };

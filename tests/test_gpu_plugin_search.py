@@ -134,6 +134,36 @@ def test_flat_searcher_on_reference_dumped_files(R):
         R.mem_remove("g_" + name)
 
 
+def test_flat_searcher_half_width_preselect_through_the_plugin(R):
+    """proxima.hip.searcher.half_width_preselect = 1 on HipFlatSearcher (zvec_hip_flat_set_shadow after the load): the golden flat
+    files — integer data, exact in fp16 — answered like the reference's FlatSearcher, filter included; fp16 files accept the
+    parameter and keep searching their own rows"""
+    rng = np.random.default_rng(12)
+    half = {"proxima.hip.searcher.half_width_preselect": 1}
+    for name, dt, base, keys, dim, image, _, _ in golden():
+        if not name.startswith("flat"):
+            continue
+        R.mem_put("g_" + name, image)
+        ref = R.Runner.searcher("FlatSearcher", "g_" + name, dim, dt)
+        hip = R.Runner.searcher("HipFlatSearcher", "g_" + name, dim, dt, params=half)
+        q = rng.integers(-8, 9, (40, dim)).astype(dt)
+        k = 5
+        rc_, hc = ref.create_context(), hip.create_context()
+        rc_.set_topk(k), hc.set_topk(k)
+        r1, l1 = ref.search_lists(rc_, q, 0)
+        r2, l2 = hip.search_lists(hc, q, 0)
+        assert r1 == 0 and r2 == 0, (name, r1, r2)
+        compare(l2, l1, k, name + " half-width")
+        ex = np.zeros(int(keys.max()) + 1, np.uint8)
+        ex[keys[rng.random(len(keys)) < 0.4]] = 1
+        rc_.set_filter(ex), hc.set_filter(ex)
+        _, l1 = ref.search_lists(rc_, q)
+        _, l2 = hip.search_lists(hc, q)
+        compare(l2, l1, k, name + " half-width filter")
+        ref.close(), hip.close()
+        R.mem_remove("g_" + name)
+
+
 def test_flat_searcher_group_by_vs_reference(R):
     """group_by_search_impl (flat_searcher.cc:178-179,205-206 -> flat_searcher_context.h:1005-1043) on a reference-dumped file."""
     rng = np.random.default_rng(12)
