@@ -43,7 +43,7 @@ struct Args {
   uint32_t dim = 768, nlist = 4096, nprobe = 36, topk = 10, pool = 4096;
   double seconds = 3.0;
   std::string backend = "mirror", framework, plugin, json, threads = "1,16,64,256", windows = "0,2000", waits = "";
-  uint32_t max_batch = 1024, linger_us = 100;
+  uint32_t max_batch = 1024, linger_us = 100, half_width = 0;
   int device = 0;
 };
 
@@ -263,6 +263,7 @@ int main(int argc, char **argv) {
     else if (k == "--waits") a.waits = v;
     else if (k == "--max-batch") a.max_batch = atoi(v.c_str());
     else if (k == "--linger-us") a.linger_us = atoi(v.c_str());
+    else if (k == "--half-width") a.half_width = atoi(v.c_str());     // proxima.hip.searcher.half_width_preselect
     else if (k == "--json") a.json = v;
     else if (k == "--device") a.device = atoi(v.c_str());
     else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
@@ -329,12 +330,12 @@ int main(int argc, char **argv) {
     const auto t0 = Clock::now();
     std::unique_ptr<Searcher> out;
     if (a.backend == "plugin") {
-      char params[512];
+      char params[768];
       snprintf(params, sizeof(params),
                "{\"proxima.ivf.searcher.scan_ratio\": %.9g, \"proxima.ivf.searcher.brute_force_threshold\": %llu, "
                "\"proxima.hip.device\": %d, \"proxima.hip.searcher.batch_window_us\": %u, \"proxima.hip.searcher.max_batch\": %u, "
-               "\"proxima.hip.searcher.batch_linger_us\": %u}",
-               (double)ratio, (unsigned long long)(a.rows - 1), a.device, window_us, a.max_batch, a.linger_us);
+               "\"proxima.hip.searcher.batch_linger_us\": %u, \"proxima.hip.searcher.half_width_preselect\": %u}",
+               (double)ratio, (unsigned long long)(a.rows - 1), a.device, window_us, a.max_batch, a.linger_us, (unsigned)a.half_width);
       auto p = std::make_unique<PluginSearcher>();
       p->d = &doors;
       p->dim = a.dim;
@@ -352,6 +353,7 @@ int main(int argc, char **argv) {
       p.set(zvec_hip_host::PARAM_HIP_SEARCHER_BATCH_WINDOW_US, window_us);
       p.set(zvec_hip_host::PARAM_HIP_SEARCHER_MAX_BATCH, a.max_batch);
       p.set(zvec_hip_host::PARAM_HIP_SEARCHER_BATCH_LINGER_US, a.linger_us);
+      p.set(zvec_hip_host::PARAM_HIP_SEARCHER_HALF_WIDTH_PRESELECT, a.half_width);
       if (m->s.init(p) != 0) return nullptr;
       zvec_hip_host::IndexMeta meta(zvec_hip_host::IndexMeta::DT_FP32, a.dim);
       meta.set_metric("SquaredEuclidean");
