@@ -278,10 +278,15 @@ static int TestMicroBatcher() {
   pb.set(PARAM_HIP_SEARCHER_BATCH_WINDOW_US, 2000);
   pb.set(PARAM_HIP_SEARCHER_MAX_BATCH, 64);
   pb.set(PARAM_HIP_SEARCHER_BATCH_LINGER_US, 40);
-  HipIVFSearcher plain, batched;
-  ASSERT(0 == plain.init(pa) && 0 == batched.init(pb));
+  // ... and the shared batches through the certified half-width pre-selection (proxima.hip.searcher.half_width_preselect:
+  // fp16 twin of the lists, fp32 re-scoring, certificate, fp32 re-run of what it cannot certify): the same lists again
+  Params pc = pb;
+  pc.set(PARAM_HIP_SEARCHER_HALF_WIDTH_PRESELECT, 1);
+  HipIVFSearcher plain, batched, half;
+  ASSERT(0 == plain.init(pa) && 0 == batched.init(pb) && 0 == half.init(pc));
   ASSERT(0 == plain.load(meta, cent.data(), nlist, offs.data(), base.data(), keys.data()));
   ASSERT(0 == batched.load(meta, cent.data(), nlist, offs.data(), base.data(), keys.data()));
+  ASSERT(0 == half.load(meta, cent.data(), nlist, offs.data(), base.data(), keys.data()));
   IndexQueryMeta qmeta(IndexMeta::DT_FP32, dim);
   std::vector<float> queries((size_t)threads * per_thread * dim);
   for (auto &v : queries) v = rnd() + 20.0f * (float)((seed >> 20) % nlist);
@@ -294,8 +299,8 @@ static int TestMicroBatcher() {
       want[i] = ctx->result();
     }
   }
-  for (int pass = 0; pass < 2; ++pass) {
-    HipIVFSearcher &se = pass ? batched : plain;
+  for (int pass = 0; pass < 3; ++pass) {
+    HipIVFSearcher &se = pass == 2 ? half : pass ? batched : plain;
     std::atomic<int> bad{0};
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
@@ -329,7 +334,8 @@ static int TestMicroBatcher() {
       });
     for (auto &x : th) x.join();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("  %u threads x %u single queries, %s: %.0f searches/s\n", threads, per_thread, pass ? "micro-batched" : "direct",
+    printf("  %u threads x %u single queries, %s: %.0f searches/s\n", threads, per_thread,
+           pass == 2 ? "micro-batched, half-width pre-selection" : pass ? "micro-batched" : "direct",
            threads * per_thread / dt);
     EXPECT(bad.load() == 0);
   }

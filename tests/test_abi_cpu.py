@@ -177,3 +177,18 @@ def test_runtime_options_round_trip_without_a_gpu():
     assert L.zvec_hip_set_option(b"assign256", 1) == 0
     assert L.zvec_hip_set_option(b"no-such-option", 1) != 0 and L.zvec_hip_get_option(b"no-such-option", C.byref(v)) != 0
     assert L.zvec_hip_set_option(None, 1) != 0
+
+
+def test_shadow_entry_points_refuse_null_handles_without_a_gpu():
+    """the half-width pre-selection entry points (zvec_hip_ivf_set_shadow / zvec_hip_flat_set_shadow and their _info / _certify
+    companions) validate their arguments before any device call"""
+    import ctypes as C
+    from zvec_amd import _lib
+    L = _lib.lib()
+    n = C.c_uint32(5)
+    on = C.c_int(7)
+    for pre in ("zvec_hip_ivf", "zvec_hip_flat"):
+        assert getattr(L, pre + "_set_shadow")(None, 1, 0) == -31
+        assert getattr(L, pre + "_shadow_info")(None, C.byref(on), None, None, None) == -31
+    assert L.zvec_hip_ivf_shadow_certify(None, None, None, 1, 1, 1, 1, None, None, None, None, None, C.byref(n)) == -31
+    assert L.zvec_hip_flat_shadow_certify(None, None, None, 1, 1, None, None, None, None, None, C.byref(n)) == -31
