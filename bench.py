@@ -941,8 +941,11 @@ def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, top
                      "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "mfma_tflops": tf})
     # ---------------- second measurement: the same steps through the half-width pre-selection (zvec_hip_flat_set_shadow) ----------------
     shadow_leg = None
-    if not f16 and world == 1 and doc_filter is None and thr is None and not args.no_shadow_leg:
-        ref32 = [x.clone() for x in lanes[0][0].search(q, topk, lanes[0][2], d_exclude=None, threshold=None)]
+    if not f16 and world == 1 and thr is None and not args.no_shadow_leg:
+        ex_ptr = excl.data_ptr() if excl is not None else None      # (filter workloads: the exclude set every step materialises)
+        if doc_filter is not None:
+            flat.build_filter(doc_filter, fctx, d_out=excl.data_ptr(), stream=stream_ptr)
+        ref32 = [x.clone() for x in lanes[0][0].search(q, topk, lanes[0][2], d_exclude=ex_ptr, threshold=None)]
         torch.cuda.synchronize()
         t1 = time.time()
         flat.set_shadow(True, args.shadow_preselect)
@@ -954,18 +957,20 @@ def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, top
 
         def certify(pend):
             c_l, k_, s_, c_, sp = pend
-            return flat.shadow_certify(q.data_ptr(), batch, topk, k_.data_ptr(), s_.data_ptr(), c_.data_ptr(), c_l, stream=sp)
+            return flat.shadow_certify(q.data_ptr(), batch, topk, k_.data_ptr(), s_.data_ptr(), c_.data_ptr(), c_l, d_exclude=ex_ptr, stream=sp)
 
         def step_shadow(i):
             li = i % len(lanes)
             sh_i, c_l, sp, ts = lanes[li]
             if pending[li] is not None:
                 rer[0] += certify(pending[li])
+            if doc_filter is not None:           # (as step(): the predicate is materialised inside the timed region)
+                flat.build_filter(doc_filter, fctx, d_out=excl.data_ptr(), stream=stream_ptr)
             if ts is None:
-                k_, s_, c_ = sh_i.search(q, topk, sp, d_exclude=None, threshold=None)
+                k_, s_, c_ = sh_i.search(q, topk, sp, d_exclude=ex_ptr, threshold=None)
             else:
                 with torch.cuda.stream(ts):
-                    k_, s_, c_ = sh_i.search(q, topk, sp, d_exclude=None, threshold=None)
+                    k_, s_, c_ = sh_i.search(q, topk, sp, d_exclude=ex_ptr, threshold=None)
             pending[li] = (c_l, k_, s_, c_, sp)
 
         def drain():
@@ -976,7 +981,7 @@ def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, top
         step_shadow(0)
         drain()
         torch.cuda.synchronize()
-        k1, s1, c1 = lanes[0][0].search(q, topk, lanes[0][2], d_exclude=None, threshold=None)
+        k1, s1, c1 = lanes[0][0].search(q, topk, lanes[0][2], d_exclude=ex_ptr, threshold=None)
         parity_rerun = certify((lanes[0][1], k1, s1, c1, lanes[0][2]))
         torch.cuda.synchronize()
         same_ids = int((ref32[0] == k1).all(1).sum().item())

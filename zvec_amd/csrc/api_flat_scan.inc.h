@@ -388,7 +388,9 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     return 0;
   }
   // Sparse keep-set: compact the kept rows and scan those (work ~ kept rows, like the CPU's skip-before-distance)
-  if (d_exclude != nullptr && user_facing && st.n >= 65536) {
+  // (a scan over shadow rows takes the gather variant only: its positions are stored positions, which the fp32 re-scoring needs; the
+  // copying variant numbers the rows of the compacted copy)
+  if (d_exclude != nullptr && profile_it && st.n >= 65536) {
     const uint32_t nchunks_b = (uint32_t)((st.n + 2047) / 2048);
     ZRET(ctx->cmp_cnt.ensure(((size_t)2 * nchunks_b + 8) * sizeof(uint32_t)));
     uint32_t *d_cnt = ctx->cmp_cnt.as<uint32_t>(), *d_off = d_cnt + nchunks_b, *d_total = d_off + nchunks_b;
@@ -402,7 +404,7 @@ int flat_scan_prepared(zvec_hip_ctx_s *ctx, const Store &st, uint32_t count, uin
     // copying the kept rows pays below one half kept; gathering them inside the wide kernel costs ~1.5 % and pays
     // whenever a tenth of the rows can be skipped
     const bool can_gather = !knobs().no_gather && count > 2 * QGROUP && pick_ng(count, topk) == 4 && scan8_lds_bytes(topk) <= LDS_LIMIT - 1024;
-    if ((double)kept <= (can_gather ? 0.9 : 0.5) * (double)st.n) {
+    if ((double)kept <= (can_gather ? 0.9 : 0.5) * (double)st.n && (user_facing || can_gather)) {
       if (kept == 0) {
         ZCHK(hipMemsetAsync(out.counts, 0, sizeof(uint32_t) * count, stream));
         ZCHK(hipMemsetAsync(out.keys, 0xff, sizeof(uint64_t) * (size_t)count * topk, stream));
