@@ -636,6 +636,12 @@ def main():
                 "frac_of_hbm_peak": s_bytes / (s_basis * 1e-3) / 1e9 / HBM_PEAK_GBS if s_basis > 0 else None,
                 "speedup_over_value": None,
             }
+            try:      # the fp16 scan's HBM-side bytes per launch, from separate PMC passes (tools/pmc_shadow_traffic.sh), as roofline.traffic
+                if committed_traffic(args, world, shard_mode)[0] is not None and not args.shadow_preselect:
+                    shadow_leg["traffic"] = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload + "_shadow")
+                    shadow_leg["traffic_source"] = "profiles/r4_ivf10m_shadow_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)"
+            except (OSError, ValueError):
+                pass
             if host_qps is not None and batch > 16:
                 # the boundary's host-pointer entry on the same index: zvec_hip_ivf_search certifies (and re-runs) inside the call
                 host_call()
