@@ -252,7 +252,10 @@ int zvec_hip_ivf_search_probes_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const v
  * zvec_hip_ivf_shadow_certify, which the caller runs on the same context with the same arguments before it reads the results
  * (*rerun = queries re-run; a call with no shadow search pending returns 0 at once).  Unsupported: fp16 / cosine indexes, rows
  * beyond the half range.  enable = 0 frees the copy.  zvec_hip_ivf_shadow_info: state, bytes held, max |b - b16|, max |b16|.
- * Like zvec_hip_ivf_load, zvec_hip_ivf_set_shadow is an index-level operation: not while searches of the index are in flight. */
+ * Like zvec_hip_ivf_load, zvec_hip_ivf_set_shadow is an index-level operation: not while searches of the index are in flight.
+ * Data the twin cannot serve (rows within the fp16 rounding of each other, a few rows of huge norm under inner product) would pay the
+ * fp16 scan AND the fp32 re-run on every search: after four certify steps in a row that re-ran more than half of their queries the
+ * next 64 searches of the index read the fp32 rows directly, then the twin is tried again (same results either way). */
 /* The same for a flat store (FlatSearcher::search_impl / search_bf_impl, flat_searcher.cc:162-211: every row scored in fp32): an fp16
  * twin of the rows present at the call; searches (no radius, k <= 32, any batch size) pre-select on it, re-score in fp32, certify.  A
  * single query's scan is bound by the bytes of the rows (halved), a wide batch's by the fp32 matrix rate (fp16 instead).  ANY later

@@ -138,6 +138,15 @@ def test_uncertifiable_queries_are_rerun_in_fp32(zv):
     assert np.array_equal(k0, k1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and np.array_equal(c0, c1)
     k2, s2, c2 = _search(se, q, k)
     assert np.array_equal(k0, k2) and np.array_equal(s0.view(np.uint32), s2.view(np.uint32))
+    # the governor: four certify steps in a row that re-ran more than half of their queries suspend the shadow route for the next
+    # searches of the index — they read the fp32 lists directly (nothing to certify), same results
+    for _ in range(2):
+        assert _search_dev(zv, se, q, k)[3] == len(q)
+    k3, s3, c3, rerun3 = _search_dev(zv, se, q, k)
+    assert rerun3 == 0
+    assert np.array_equal(k0, k3) and np.array_equal(s0.view(np.uint32), s3.view(np.uint32)) and np.array_equal(c0, c3)
+    se.set_shadow(True)                                   # setting it again lifts the suspension
+    assert _search_dev(zv, se, q, k)[3] == len(q)
 
 
 def test_shadow_with_a_filter_and_short_lists(zv):

@@ -556,7 +556,7 @@ static int flat_search_dev_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, const v
   // query — half the bytes of a small batch's HBM-bound scan, and fp16 matrix work instead of fp32 for a wide one —, those are
   // re-scored on the fp32 rows, the k best certified; zvec_hip_flat_shadow_certify re-runs what fails.
   if (h->shadow_on && h->shadow.base && h->shadow.n == h->st.n && !c->shadow_skip && !(threshold < FLT_MAX) && topk <= 32 &&
-      count <= maxq && h->st.n > 0) {
+      count <= maxq && h->st.n > 0 && h->shadow_gov.allow()) {
     uint32_t kp = h->shadow_kp ? h->shadow_kp : std::max<uint32_t>(32, 3 * topk);
     kp = std::min<uint32_t>(kp, 64);
     if (kp > topk) {
@@ -621,6 +621,7 @@ static int flat_shadow_certify_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, con
   uint32_t nflag = 0;
   ZCHK(hipMemcpyAsync(&nflag, c->sh_flags.as<uint32_t>() + count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   ZCHK(hipStreamSynchronize(s));
+  h->shadow_gov.report(nflag, count);
   if (nflag == 0) return 0;
   std::vector<uint32_t> flags(count);
   ZCHK(hipMemcpyAsync(flags.data(), c->sh_flags.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -690,6 +691,7 @@ int zvec_hip_flat_set_shadow(zvec_hip_flat_t h, int enable, uint32_t preselect) 
   h->shadow_max_err = __builtin_bit_cast(float, f.max_err);
   h->shadow_max_norm = __builtin_bit_cast(float, f.max_norm);
   h->shadow_kp = preselect;
+  h->shadow_gov.reset();
   h->shadow_on = true;
   return 0;
 }

@@ -793,6 +793,7 @@ static int ivf_shadow_certify_locked(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const
   uint32_t nflag = 0;
   ZCHK(hipMemcpyAsync(&nflag, c->sh_flags.as<uint32_t>() + count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   ZCHK(hipStreamSynchronize(s));
+  h->shadow_gov.report(nflag, count);
   if (nflag == 0) return 0;
   std::vector<uint32_t> flags(count);
   ZCHK(hipMemcpyAsync(flags.data(), c->sh_flags.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -845,7 +846,7 @@ int zvec_hip_ivf_set_shadow(zvec_hip_ivf_t h, int enable, uint32_t preselect) {
   if (!h->loaded) return ZVEC_HIP_ERR_NO_INDEX_LOADED;
   if (h->dtype != ZVEC_HIP_DT_FP32 || h->metric == ZVEC_HIP_METRIC_COSINE) return ZVEC_HIP_ERR_UNSUPPORTED;
   if (preselect > 64) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
-  if (h->shadow_on) { h->shadow_kp = preselect; return 0; }
+  if (h->shadow_on) { h->shadow_kp = preselect; h->shadow_gov.reset(); return 0; }
   hipStream_t s = h->defctx->own;
   Store &sh = h->shadow;
   sh = Store();
@@ -871,6 +872,7 @@ int zvec_hip_ivf_set_shadow(zvec_hip_ivf_t h, int enable, uint32_t preselect) {
   h->shadow_max_err = __builtin_bit_cast(float, f.max_err);
   h->shadow_max_norm = __builtin_bit_cast(float, f.max_norm);
   h->shadow_kp = preselect;
+  h->shadow_gov.reset();
   h->shadow_on = true;
   return 0;
 }

@@ -115,6 +115,28 @@ class FairSharedMutex {
   std::shared_mutex rw_;
 };
 
+// When the data does not let the half-width pre-selection certify its results (rows within the fp16 rounding of each other, a few
+// rows of huge norm under inner product) every search pays the fp16 scan AND the fp32 re-run.  The governor watches the certify
+// steps: four in a row that had to re-run more than half of their queries suspend the shadow route for the next 64 searches of the
+// index (they read the fp32 rows directly), after which it is tried again.  Results are the same either way; this only bounds the
+// cost of data the twin cannot serve.
+struct ShadowGovernor {
+  std::atomic<uint32_t> bad{0}, pause{0};
+  bool allow() {                                     // one call per search that could use the shadow rows
+    uint32_t p = pause.load(std::memory_order_relaxed);
+    while (p > 0 && !pause.compare_exchange_weak(p, p - 1, std::memory_order_relaxed)) {}
+    return p == 0;
+  }
+  void report(uint32_t rerun, uint32_t count) {      // one call per certify step
+    if ((uint64_t)rerun * 2 > count) {
+      if (bad.fetch_add(1, std::memory_order_relaxed) + 1 >= 4) { bad.store(0, std::memory_order_relaxed); pause.store(64, std::memory_order_relaxed); }
+    } else {
+      bad.store(0, std::memory_order_relaxed);
+    }
+  }
+  void reset() { bad.store(0, std::memory_order_relaxed); pause.store(0, std::memory_order_relaxed); }
+};
+
 // a blocked, HBM-resident set of rows (flat store, IVF centroids, IVF inverted lists)
 struct Store {
   uint32_t dim_in = 0;   // element dimension at the ABI (cosine: d+1)
@@ -239,6 +261,7 @@ struct zvec_hip_flat_s {
   uint32_t shadow_kp = 0;
   void *d_shadow_facts = nullptr;      // zvk::ShadowFacts
   float shadow_max_err = 0.f, shadow_max_norm = 0.f;
+  ShadowGovernor shadow_gov;
   zvec_hip_ctx_s *defctx = nullptr;
   std::mutex mu;            // serialises the calls that use defctx's workspace (appends, get_vector)
   // The streamer is searched while it grows (flat_streamer_test.cc TestConcurrentAddAndSearch): searches hold `rw`
@@ -295,6 +318,7 @@ struct zvec_hip_ivf_s {
   uint32_t shadow_kp = 0;              // rows pre-selected per query (0: from k)
   void *d_shadow_facts = nullptr;      // zvk::ShadowFacts
   float shadow_max_err = 0.f, shadow_max_norm = 0.f;
+  ShadowGovernor shadow_gov;
   uint64_t count_local = 0, count_global = 0;
   std::vector<uint32_t> h_size, h_size_global, h_tile0;
   std::vector<uint64_t> h_rows_of_largest;   // [i] = rows of the i largest local lists (bound of what i probes can scan)
