@@ -264,3 +264,38 @@ def test_flat_shadow_integer_data_vs_the_oracle_and_mutation(zv, oracle):
     se.set_shadow(True)
     gk, gs, gc = _flat_search(se, q, k)
     tie_tolerant_compare(gk, gs, gc, ok, os_, oc, what="flat shadow after growth")
+
+
+@pytest.mark.parametrize("noise", [1e-3, 1e-2, 0.03, 0.06, 0.1, 0.3])
+def test_certificate_at_the_rounding_scale(zv, oracle, noise):
+    """rows whose mutual distances are small against their norms, down to the ORDER of the fp16 rounding: the fp16 ranking genuinely
+    differs from the true one near the k'-th place, some queries certify and some do not.  The certificate speaks about the TRUE
+    scores — sum((q - b)^2) in fp32, what the reference computes (euclidean_distance_matrix_fp32.cc:229-283) and what both routes
+    report after re-scoring — so the yardstick here is the oracle, with NO selection band: in this regime the fp32 route itself may pick
+    a different row inside its stated band of 4e-6 (|q|^2 + |b|^2) (it selects on |q|^2 + |b|^2 - 2 q.b), the shadow route
+    may not."""
+    rng = np.random.default_rng(int(noise * 1e6))
+    dim, nlist, k, per = 96, 12, 10, 400
+    centres = rng.standard_normal((nlist, dim)).astype(np.float32) * 6
+    base = np.concatenate([c + noise * np.abs(c).mean() * rng.standard_normal((per, dim)).astype(np.float32) for c in centres]).astype(np.float32)
+    q = (centres[rng.integers(0, nlist, 48)] + noise * 6 * rng.standard_normal((48, dim))).astype(np.float32)
+    se, cent, offs, vecs, keys = _index(zv, rng, base, nlist, ratio=0.3)
+    nprobe, max_scan = se.probe_params()
+    ok, os_, _, oc, _ = oracle.ivf_search(cent, offs, vecs, q, k, nprobe, max_scan, keys=keys)
+    cd = np.sort(exact_l2(cent, q), 1)
+    sel = np.nonzero(cd[:, nprobe - 1] != cd[:, nprobe])[0]
+    se.set_shadow(True)
+    k1, s1, c1, rerun = _search_dev(zv, se, q, k)
+    # (queries the certificate refuses are answered by the fp32 route, inside ITS band; a batch that certified everything has none)
+    qn = (q.astype(np.float64) ** 2).sum(1)
+    band = 4e-6 * (2 * qn.max() + 1)
+    tie_tolerant_compare(k1[sel], s1[sel], c1[sel], ok[sel], os_[sel], oc[sel], rtol=2e-6, atol=1e-9, select_band=band if rerun else None,
+                         what="ivf shadow vs oracle, noise %g" % noise)
+    fl = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert fl.load(base) == 0
+    fl.set_shadow(True)
+    fk, fs, fc, frerun = _flat_search_dev(fl, q, k)
+    gk, gs, _, gc = oracle.flat_search(base, q, k)
+    tie_tolerant_compare(fk, fs, fc, gk, gs, gc, rtol=2e-6, atol=1e-9, select_band=band if frerun else None,
+                         what="flat shadow vs oracle, noise %g" % noise)
+    print("noise %g: ivf re-ran %d of 48, flat re-ran %d of 48" % (noise, rerun, frerun))

@@ -12,7 +12,7 @@
 //        L2:  | ‖q − b‖ − ‖q16 − b16‖ |  <=  ‖q − q16‖ + ‖b − b16‖              (triangle inequality; both terms are MEASURED:
 //                                                                                 per query, and as the maximum over the stored rows)
 //        IP:  | q·b − q16·b16 |          <=  ‖q‖ ‖b − b16‖ + ‖q − q16‖ ‖b16‖     (Cauchy-Schwarz)
-//      plus the accumulation error of the fp32 sums (gamma_d = (d + 8) 2^-24 of the operand magnitudes, the textbook bound).
+//      plus the accumulation error of the fp32 sums (gamma_d = (d + 8) 2^-23 of the operand magnitudes: twice the textbook bound).
 //      If the best possible true score of an unseen row is still worse than the k-th re-scored one, the k rows ARE the k best of
 //      the probed lists — what IVFSearcher::search_impl's fp32 scan (ivf_searcher.cc:217-247) keeps.  Otherwise the query is
 //      flagged and the host re-runs it on the fp32 lists (zvec_hip_ivf_shadow_certify).
@@ -176,7 +176,9 @@ __global__ void __launch_bounds__(64) shadow_select_kernel(const ShadowSelectArg
       const float t = a.c_shadow[o + a.kp - 1];       // every row left out has a shadow score >= t
       const f32x2 qi = a.qinfo[q];
       const float eb = __builtin_bit_cast(float, a.facts->max_err), bn = __builtin_bit_cast(float, a.facts->max_norm);
-      const float gamma = (float)(a.dscan + 8) * 5.9604645e-8f;          // (d + 8) 2^-24
+      // (d + 8) 2^-23: twice the textbook bound of a length-d fp32 sum — the matrix cores' internal accumulation of a k-step is not
+      // documented to round to nearest at every addition
+      const float gamma = (float)(a.dscan + 8) * 1.1920929e-7f;
       if (a.metric == METRIC_L2) {
         // shadow score = |q16|^2 + |b16|^2 - 2 q16.b16 in fp32: off the exact ‖q16 − b16‖^2 by <= gamma (|q16|^2 + |b16|^2)
         const float tl = t - gamma * 2.f * (qi.y * qi.y + bn * bn);
