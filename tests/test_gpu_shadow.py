@@ -299,3 +299,27 @@ def test_certificate_at_the_rounding_scale(zv, oracle, noise):
     tie_tolerant_compare(fk, fs, fc, gk, gs, gc, rtol=2e-6, atol=1e-9, select_band=band if frerun else None,
                          what="flat shadow vs oracle, noise %g" % noise)
     print("noise %g: ivf re-ran %d of 48, flat re-ran %d of 48" % (noise, rerun, frerun))
+
+
+def test_queries_beyond_the_half_range_are_rerun(zv):
+    """a query element beyond 65504 has no fp16 image: its shadow scores are infinite — the query must be flagged (never certified,
+    not even by a short pre-selection) and answered by the fp32 rows"""
+    rng = np.random.default_rng(41)
+    n, dim, nlist, k = 6000, 32, 16, 5
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((20, dim)).astype(np.float32)
+    q[3, 5] = 1.0e5
+    q[11, 0] = -2.0e5
+    se, *_ = _index(zv, rng, base, nlist, ratio=0.5)
+    k0, s0, c0 = _search(se, q, k)
+    se.set_shadow(True)
+    k1, s1, c1, rerun = _search_dev(zv, se, q, k)
+    assert rerun >= 2
+    assert np.array_equal(k0, k1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and np.array_equal(c0, c1)
+    fl = zv.HipFlatSearcher(dim, "SquaredEuclidean")
+    assert fl.load(base) == 0
+    f0 = _flat_search(fl, q, k)
+    fl.set_shadow(True)
+    f1 = _flat_search_dev(fl, q, k)
+    assert f1[3] >= 2
+    assert np.array_equal(f0[0], f1[0]) and np.array_equal(f0[1].view(np.uint32), f1[1].view(np.uint32))

@@ -168,13 +168,14 @@ __global__ void __launch_bounds__(64) shadow_select_kernel(const ShadowSelectArg
   }
   // the k-th true score (lane with rank k - 1), wave-uniform
   const unsigned long long kth = __ballot(have && rank + 1 == a.k);
-  bool certified = true;
-  if (c >= a.kp) {                                    // a full pre-selection: rows may have been left out
+  const f32x2 qi = a.qinfo[q];
+  // (a query with an element beyond the half range has infinite / undefined shadow scores: never certified, not even trivially)
+  bool certified = qi.x < 3.0e38f && qi.y < 3.0e38f;
+  if (certified && c >= a.kp) {                       // a full pre-selection: rows may have been left out
     certified = false;
     if (kth) {
       const float sk = bcast_f(s, __builtin_ctzll(kth));
       const float t = a.c_shadow[o + a.kp - 1];       // every row left out has a shadow score >= t
-      const f32x2 qi = a.qinfo[q];
       const float eb = __builtin_bit_cast(float, a.facts->max_err), bn = __builtin_bit_cast(float, a.facts->max_norm);
       // (d + 8) 2^-23: twice the textbook bound of a length-d fp32 sum — the matrix cores' internal accumulation of a k-step is not
       // documented to round to nearest at every addition
