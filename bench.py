@@ -559,6 +559,8 @@ def main():
                 log("shadow lists: %.2f GB in %.2fs; max |b - b16| %.4g, max |b16| %.4g" % (sinfo["bytes"] / 1e9, time.time() - t1,
                                                                                           sinfo["max_row_error"], sinfo["max_row_norm"]))
                 rer = [0]
+                for sh_l, _, _ in lanes:                 # (the lanes certify a step when they come back to it, not inside search())
+                    sh_l.defer_certify = True
 
                 def certify(pend, np_):
                     sh_i, qi, k_, s_, c_, sp = pend
@@ -651,6 +653,8 @@ def main():
                         host_call()
                     shadow_leg["host_pointer_qps"] = 5 * batch / (time.perf_counter() - th)
                 ivf.set_shadow(False)
+                for sh_l, _, _ in lanes:
+                    sh_l.defer_certify = False
                 log("certified half-width scan: %.0f QPS (%.3f ms per step, list scan %.3f ms, %.2f queries re-run per step)" % (
                     shadow_leg["qps"], s_ms, s_kernel_ms, shadow_leg["rerun_queries_per_step"]))
             except Exception as e:      # (the second measurement must never cost the line its first)
@@ -969,6 +973,8 @@ def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, top
                                                                                      sinfo["max_row_error"], sinfo["max_row_norm"]))
             rer = [0]
             pending = [None] * len(lanes)
+            for sh_l, _, _, _ in lanes:                  # (the lanes certify a step when they come back to it, not inside search())
+                sh_l.defer_certify = True
 
             def certify(pend):
                 c_l, k_, s_, c_, sp = pend
@@ -1046,6 +1052,8 @@ def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, top
                 "hbm_gbs": s_by / (s_basis * 1e-3) / 1e9 if s_basis > 0 else None,
             }
             flat.set_shadow(False)
+            for sh_l, _, _, _ in lanes:
+                sh_l.defer_certify = False
             log("certified half-width scan: %.0f QPS (%.3f ms per step, scan %.3f ms, %.2f queries re-run per step)" % (
                 shadow_leg["qps"], s_ms, s_kernel, shadow_leg["rerun_queries_per_step"]))
         except Exception as e:      # (the second measurement must never cost the line its first)

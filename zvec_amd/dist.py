@@ -85,6 +85,11 @@ class _Sharded:
         self.ctx = ctx
         self.rank, self.world, self.group = rank, world, group
         self._buf = {}
+        # An index with shadow rows (zvec_hip_ivf_set_shadow / zvec_hip_flat_set_shadow): the device-pointer search only enqueues, its
+        # result becomes final in the certify step (waits, re-runs uncertified queries on the fp32 rows).  Done inside search() — always
+        # before an exchange; a single-rank caller that pipelines lanes may set defer_certify and call searcher.shadow_certify itself
+        # before it reads a lane's result (bench.py does).
+        self.defer_certify = False
 
     def _buffers(self, count, topk, device):
         key = (count, topk)
@@ -182,7 +187,7 @@ class ShardedIVF(_Sharded):
             rc = self.searcher.search_dev(d_queries.data_ptr(), count, topk, nprobe, max_scan, b["keys"].data_ptr(),
                                           b["scores"].data_ptr(), b["counts"].data_ptr(), self.ctx, stream=stream_ptr)
             _lib.check(rc, "zvec_hip_ivf_search_dev")
-            if self.world > 1:
+            if self.world > 1 or not self.defer_certify:
                 # an index with shadow lists (zvec_hip_ivf_set_shadow): the local lists must be certified (uncertified queries re-run
                 # on the fp32 lists) BEFORE they are exchanged; returns at once when the search did not use the shadow lists
                 self.shadow_reruns += self.searcher.shadow_certify(d_queries.data_ptr(), count, topk, nprobe, max_scan, b["keys"].data_ptr(),
@@ -230,7 +235,7 @@ class ShardedFlat(_Sharded):
         rc = self.searcher.search_dev(d_queries.data_ptr(), count, topk, b["keys"].data_ptr(), b["scores"].data_ptr(),
                                       b["counts"].data_ptr(), self.ctx, d_exclude=d_exclude, stream=stream_ptr, **kw)
         _lib.check(rc, "zvec_hip_flat_search_dev")
-        if self.world > 1:      # a store with shadow rows: certified (uncertified queries re-run in fp32) BEFORE the exchange
+        if self.world > 1 or not self.defer_certify:      # a store with shadow rows: certified (uncertified queries re-run in fp32) BEFORE the exchange
             self.searcher.shadow_certify(d_queries.data_ptr(), count, topk, b["keys"].data_ptr(), b["scores"].data_ptr(),
                                          b["counts"].data_ptr(), self.ctx, d_exclude=d_exclude, stream=stream_ptr)
 
