@@ -629,7 +629,8 @@ def main():
                     "qps": batch * args.steps / el_s, "ms_per_step": s_ms, "unit": "queries/s",
                     "what": "the same steps with zvec_hip_ivf_set_shadow on: list scan over an fp16 twin of the lists for k' rows per query, fp32 "
                             "re-scoring, per-query certificate from the measured rounding, fp32 re-run of uncertified queries inside the timed region",
-                    "preselect": args.shadow_preselect or max(32, 3 * topk), "shadow_bytes": sinfo["bytes"],
+                    "preselect": args.shadow_preselect or "chosen by the index (from max(32, 3k): narrowed after clean certify steps, widened after re-runs)",
+                    "preselect_rows_at_end": ivf.shadow_width(topk), "shadow_bytes": sinfo["bytes"],
                     "max_row_rounding": sinfo["max_row_error"], "max_row_norm": sinfo["max_row_norm"],
                     "rerun_queries_per_step": rer[0] / float(args.steps),
                     "parity_vs_fp32_route": {"queries": total, "identical_key_lists": same_ids, "identical_score_bits": same_bits,
@@ -1042,7 +1043,8 @@ def run_flat(torch, dist, zvec_amd, sharded, flat, fctx, q, n, n_local, dim, top
                 "qps": batch * args.steps / el_s, "ms_per_step": s_ms, "unit": "queries/s", "speedup_over_value": (batch * args.steps / el_s) / (batch * args.steps / elapsed),
                 "what": "the same steps with zvec_hip_flat_set_shadow on: scan over an fp16 twin of the rows for k' rows per query, fp32 re-scoring, "
                         "per-query certificate from the measured rounding, fp32 re-run of uncertified queries inside the timed region",
-                "preselect": args.shadow_preselect or max(32, 3 * topk), "shadow_bytes": sinfo["bytes"], "max_row_rounding": sinfo["max_row_error"],
+                "preselect": args.shadow_preselect or "chosen by the index (from max(32, 3k): narrowed after clean certify steps, widened after re-runs)",
+            "preselect_rows_at_end": flat.shadow_width(topk), "shadow_bytes": sinfo["bytes"], "max_row_rounding": sinfo["max_row_error"],
                 "max_row_norm": sinfo["max_row_norm"], "rerun_queries_per_step": rer[0] / float(args.steps),
                 "parity_vs_fp32_route": {"queries": batch, "identical_key_lists": same_ids, "identical_score_bits": same_bits,
                                          "scores_within_fp32_rounding": close, "rerun_in_fp32": parity_rerun},

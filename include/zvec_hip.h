@@ -244,7 +244,7 @@ int zvec_hip_ivf_search_probes_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const v
  * IVFSearcher::search_impl scores every row of the probed lists in fp32 (ivf_searcher.cc:217-247, ivf_entity.cc:664-717); on the
  * GPU that scan is bound by the bytes of the lists.  zvec_hip_ivf_set_shadow(h, 1, preselect) stores every row a second time rounded
  * to fp16 (HalfFloatConverter's rounding) at the same positions; searches of more than a handful of queries (no radius, k <= 32) then
- * scan the fp16 rows for `preselect` rows per query (0: max(32, 3k); <= 64), re-score those on the fp32 rows with the kernel that
+ * scan the fp16 rows for `preselect` rows per query (0: chosen by the index, from max(32, 3k): zvec_hip_ivf_shadow_width; <= 64), re-score those on the fp32 rows with the kernel that
  * refines the fp32 route's final lists, keep the k best and CERTIFY them: a row that was left out cannot beat the k-th kept one once
  * the measured rounding of the two conversions (max over the stored rows of |b - b16|, per query |q - q16|; triangle inequality for
  * L2, Cauchy-Schwarz for IP) and the accumulation error are allowed for.  Queries that fail the certificate are re-run on the fp32
@@ -263,11 +263,17 @@ int zvec_hip_ivf_search_probes_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const v
  * searches certify inside the call, zvec_hip_flat_search_dev is followed by zvec_hip_flat_shadow_certify. */
 int zvec_hip_flat_set_shadow(zvec_hip_flat_t h, int enable, uint32_t preselect);
 int zvec_hip_flat_shadow_info(zvec_hip_flat_t h, int *enabled, uint64_t *bytes, float *max_row_error, float *max_row_norm);
+int zvec_hip_flat_shadow_width(zvec_hip_flat_t h, uint32_t topk, uint32_t *rows);
 int zvec_hip_flat_shadow_certify(zvec_hip_flat_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,
                                  const uint64_t *d_exclude_bitset, uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts,
                                  void *stream, uint32_t *rerun);
 int zvec_hip_ivf_set_shadow(zvec_hip_ivf_t h, int enable, uint32_t preselect);
 int zvec_hip_ivf_shadow_info(zvec_hip_ivf_t h, int *enabled, uint64_t *bytes, float *max_row_error, float *max_row_norm);
+/* preselect = 0 leaves the width to the index: it starts at max(32, 3k); six certify steps in a row without a re-run narrow it by 8
+ * (a narrower list is cheaper to keep), a step that re-ran more than 1/32 of its queries widens it by 8 and makes the width it failed
+ * at the floor from then on; range max(16, 1.5k rounded up to 8) .. 64.  *rows = the width the next search with this k will use
+ * (0: no twin). */
+int zvec_hip_ivf_shadow_width(zvec_hip_ivf_t h, uint32_t topk, uint32_t *rows);
 int zvec_hip_ivf_shadow_certify(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const void *d_queries, uint32_t count, uint32_t topk,
                                 uint32_t nprobe, uint32_t max_scan_count, const uint64_t *d_exclude_bitset, uint64_t *d_out_keys,
                                 float *d_out_scores, uint32_t *d_out_counts, void *stream, uint32_t *rerun);

@@ -323,3 +323,41 @@ def test_queries_beyond_the_half_range_are_rerun(zv):
     f1 = _flat_search_dev(fl, q, k)
     assert f1[3] >= 2
     assert np.array_equal(f0[0], f1[0]) and np.array_equal(f0[1].view(np.uint32), f1[1].view(np.uint32))
+
+
+def test_the_index_sizes_the_preselection_when_left_open(zv):
+    """preselect = 0: k' starts at max(32, 3k); clean certify steps narrow it (down to 16 for k = 10), steps that re-ran more than 1/32
+    of their queries widen it and pin the floor; an explicit width stays put.  Results never change."""
+    rng = np.random.default_rng(43)
+    n, dim, nlist, nq, k = 20000, 64, 32, 64, 10
+    cl = rng.standard_normal((64, dim)).astype(np.float32) * 3
+    base = (cl[rng.integers(0, 64, n)] + rng.standard_normal((n, dim)).astype(np.float32)).astype(np.float32)
+    q = (cl[rng.integers(0, 64, nq)] + rng.standard_normal((nq, dim)).astype(np.float32)).astype(np.float32)
+    se, *_ = _index(zv, rng, base, nlist)
+    k0, s0, c0 = _search(se, q, k)
+    assert se.shadow_width(k) == 0
+    se.set_shadow(True)
+    assert se.shadow_width(k) == 32 and se.shadow_width(20) == 60 and se.shadow_width(30) == 64
+    widths, clean = [], True
+    for _ in range(14):
+        k1, s1, c1, rerun = _search_dev(zv, se, q, k)
+        clean = clean and rerun == 0
+        assert np.array_equal(k0, k1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and np.array_equal(c0, c1)
+        widths.append(se.shadow_width(k))
+    if clean:
+        assert widths[-1] == 16 and sorted(widths, reverse=True) == widths        # 32 -> 24 -> 16, never below
+    se.set_shadow(True, 40)
+    for _ in range(8):
+        _search_dev(zv, se, q, k)
+    assert se.shadow_width(k) == 40
+    # near-duplicates: every step re-runs everything -> the width climbs to 64 and stays there
+    centres = rng.standard_normal((8, dim)).astype(np.float32) * 4
+    dup = np.concatenate([c + 1e-5 * rng.standard_normal((300, dim)).astype(np.float32) for c in centres]).astype(np.float32)
+    dq = (centres[rng.integers(0, 8, 20)] + 1e-3 * rng.standard_normal((20, dim))).astype(np.float32)
+    du, *_ = _index(zv, rng, dup, 8, ratio=0.5)
+    d0 = _search(du, dq, k)
+    du.set_shadow(True)
+    for _ in range(3):
+        d1 = _search_dev(zv, du, dq, k)
+        assert d1[3] == len(dq) and np.array_equal(d0[0], d1[0]) and np.array_equal(d0[1].view(np.uint32), d1[1].view(np.uint32))
+    assert du.shadow_width(k) == 56

@@ -96,6 +96,8 @@ SYMBOLS = {
     "zvec_hip_flat_shadow_info": (C.c_int, [_h, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "zvec_hip_flat_shadow_certify": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, _u64p, _u64p, _f32p, _u32p, C.c_void_p,
                                                C.POINTER(C.c_uint32)]),
+    "zvec_hip_ivf_shadow_width": (C.c_int, [_h, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "zvec_hip_flat_shadow_width": (C.c_int, [_h, C.c_uint32, C.POINTER(C.c_uint32)]),
     "zvec_hip_ivf_set_shadow": (C.c_int, [_h, C.c_int, C.c_uint32]),
     "zvec_hip_ivf_shadow_info": (C.c_int, [_h, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "zvec_hip_ivf_shadow_certify": (C.c_int, [_h, _h, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _u64p, _f32p,

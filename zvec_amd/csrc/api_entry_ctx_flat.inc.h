@@ -557,7 +557,7 @@ static int flat_search_dev_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, const v
   // re-scored on the fp32 rows, the k best certified; zvec_hip_flat_shadow_certify re-runs what fails.
   if (h->shadow_on && h->shadow.base && h->shadow.n == h->st.n && !c->shadow_skip && !(threshold < FLT_MAX) && topk <= 32 &&
       count <= maxq && h->st.n > 0 && h->shadow_gov.allow()) {
-    uint32_t kp = h->shadow_kp ? h->shadow_kp : std::max<uint32_t>(32, 3 * topk);
+    uint32_t kp = h->shadow_kp ? h->shadow_kp : h->shadow_gov.kp_auto(topk);
     kp = std::min<uint32_t>(kp, 64);
     if (kp > topk) {
       ZRET(prep_queries(c, h->st, d_queries, count, threshold, s));            // fp32 rows for the re-scoring; resets the shared bounds
@@ -622,6 +622,7 @@ static int flat_shadow_certify_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, con
   ZCHK(hipMemcpyAsync(&nflag, c->sh_flags.as<uint32_t>() + count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   ZCHK(hipStreamSynchronize(s));
   h->shadow_gov.report(nflag, count);
+  if (h->shadow_kp == 0) h->shadow_gov.report_width(nflag, count);
   if (nflag == 0) return 0;
   std::vector<uint32_t> flags(count);
   ZCHK(hipMemcpyAsync(flags.data(), c->sh_flags.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -703,6 +704,12 @@ int zvec_hip_flat_shadow_info(zvec_hip_flat_t h, int *enabled, uint64_t *bytes, 
   if (bytes) *bytes = h->shadow_on ? (uint64_t)h->shadow.cap_tiles * TILE_N * (h->shadow.dpad + 1) * sizeof(float) : 0;
   if (max_row_error) *max_row_error = h->shadow_on ? h->shadow_max_err : 0.f;
   if (max_row_norm) *max_row_norm = h->shadow_on ? h->shadow_max_norm : 0.f;
+  return 0;
+}
+
+int zvec_hip_flat_shadow_width(zvec_hip_flat_t h, uint32_t topk, uint32_t *rows) {
+  if (!h || !rows) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  *rows = !h->shadow_on ? 0 : std::min<uint32_t>(64, h->shadow_kp ? h->shadow_kp : h->shadow_gov.kp_auto(topk));
   return 0;
 }
 

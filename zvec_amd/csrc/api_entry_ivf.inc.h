@@ -794,6 +794,7 @@ static int ivf_shadow_certify_locked(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const
   ZCHK(hipMemcpyAsync(&nflag, c->sh_flags.as<uint32_t>() + count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   ZCHK(hipStreamSynchronize(s));
   h->shadow_gov.report(nflag, count);
+  if (h->shadow_kp == 0) h->shadow_gov.report_width(nflag, count);
   if (nflag == 0) return 0;
   std::vector<uint32_t> flags(count);
   ZCHK(hipMemcpyAsync(flags.data(), c->sh_flags.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -884,6 +885,12 @@ int zvec_hip_ivf_shadow_info(zvec_hip_ivf_t h, int *enabled, uint64_t *bytes, fl
   if (bytes) *bytes = h->shadow_on ? (uint64_t)h->shadow.cap_tiles * TILE_N * (h->shadow.dpad + 1) * sizeof(float) : 0;
   if (max_row_error) *max_row_error = h->shadow_on ? h->shadow_max_err : 0.f;
   if (max_row_norm) *max_row_norm = h->shadow_on ? h->shadow_max_norm : 0.f;
+  return 0;
+}
+
+int zvec_hip_ivf_shadow_width(zvec_hip_ivf_t h, uint32_t topk, uint32_t *rows) {
+  if (!h || !rows) return ZVEC_HIP_ERR_INVALID_ARGUMENT;
+  *rows = !h->shadow_on ? 0 : std::min<uint32_t>(64, h->shadow_kp ? h->shadow_kp : h->shadow_gov.kp_auto(topk));
   return 0;
 }
 

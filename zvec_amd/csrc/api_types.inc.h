@@ -120,8 +120,33 @@ class FairSharedMutex {
 // steps: four in a row that had to re-run more than half of their queries suspend the shadow route for the next 64 searches of the
 // index (they read the fp32 rows directly), after which it is tried again.  Results are the same either way; this only bounds the
 // cost of data the twin cannot serve.
+// It also sizes the pre-selection when the caller left it open (preselect = 0): k' starts at max(32, 3k); six certify steps in a row
+// without a single re-run narrow it by 8 (a narrower list is cheaper to keep: flat 1M x 768, batch 256: 194 k QPS at 32, 232 k at 16),
+// a step that had to re-run more than 1/32 of its queries widens it by 8 and fixes the width it failed at as the floor from then on.
+// Range: max(16, 1.5 k rounded up to 8) .. 64.
 struct ShadowGovernor {
-  std::atomic<uint32_t> bad{0}, pause{0};
+  std::atomic<uint32_t> bad{0}, pause{0}, clean{0};
+  std::atomic<int> level{0}, floor_level{-8};
+  uint32_t kp_auto(uint32_t topk) const {
+    const int base = (int)std::max<uint32_t>(32, 3 * topk), lo = (int)std::max<uint32_t>(16, (topk * 3 / 2 + 7) / 8 * 8);
+    return (uint32_t)std::min(64, std::max(lo, base + 8 * level.load(std::memory_order_relaxed)));
+  }
+  void report_width(uint32_t rerun, uint32_t count) {      // one call per certify step of a search whose width was left open
+    if (rerun == 0) {
+      if (clean.fetch_add(1, std::memory_order_relaxed) + 1 >= 6) {
+        clean.store(0, std::memory_order_relaxed);
+        const int l = level.load(std::memory_order_relaxed);
+        if (l > floor_level.load(std::memory_order_relaxed) && l > -4) level.store(l - 1, std::memory_order_relaxed);
+      }
+    } else {
+      clean.store(0, std::memory_order_relaxed);
+      if ((uint64_t)rerun * 32 > count) {
+        const int l = level.load(std::memory_order_relaxed);
+        floor_level.store(std::max(floor_level.load(std::memory_order_relaxed), l + 1), std::memory_order_relaxed);
+        if (l < 4) level.store(l + 1, std::memory_order_relaxed);
+      }
+    }
+  }
   bool allow() {                                     // one call per search that could use the shadow rows
     uint32_t p = pause.load(std::memory_order_relaxed);
     while (p > 0 && !pause.compare_exchange_weak(p, p - 1, std::memory_order_relaxed)) {}
@@ -134,7 +159,10 @@ struct ShadowGovernor {
       bad.store(0, std::memory_order_relaxed);
     }
   }
-  void reset() { bad.store(0, std::memory_order_relaxed); pause.store(0, std::memory_order_relaxed); }
+  void reset() {
+    bad.store(0, std::memory_order_relaxed); pause.store(0, std::memory_order_relaxed); clean.store(0, std::memory_order_relaxed);
+    level.store(0, std::memory_order_relaxed); floor_level.store(-8, std::memory_order_relaxed);
+  }
 };
 
 // a blocked, HBM-resident set of rows (flat store, IVF centroids, IVF inverted lists)

@@ -542,6 +542,12 @@ class _FlatBase:
                    "zvec_hip_flat_shadow_info")
         return {"enabled": bool(on.value), "bytes": int(nbytes.value), "max_row_error": float(err.value), "max_row_norm": float(norm.value)}
 
+    def shadow_width(self, topk):
+        """rows the next search with this k pre-selects per query (zvec_hip_flat_shadow_width; 0: no twin)"""
+        n = C.c_uint32(0)
+        _lib.check(_lib.lib().zvec_hip_flat_shadow_width(self._h, int(topk), C.byref(n)), "zvec_hip_flat_shadow_width")
+        return int(n.value)
+
     def shadow_certify(self, d_queries, count, topk, d_out_keys, d_out_scores, d_out_counts, ctx, d_exclude=None, stream=None):
         """the second half of search_dev on a store with shadow rows: waits, re-runs the uncertified queries on the fp32 rows;
         returns how many were re-run"""
@@ -867,6 +873,12 @@ class HipIVFSearcher:
         _lib.check(_lib.lib().zvec_hip_ivf_shadow_info(self._h, C.byref(on), C.byref(nbytes), C.byref(err), C.byref(norm)),
                    "zvec_hip_ivf_shadow_info")
         return {"enabled": bool(on.value), "bytes": int(nbytes.value), "max_row_error": float(err.value), "max_row_norm": float(norm.value)}
+
+    def shadow_width(self, topk):
+        """rows the next search with this k pre-selects per query (zvec_hip_ivf_shadow_width; 0: no twin)"""
+        n = C.c_uint32(0)
+        _lib.check(_lib.lib().zvec_hip_ivf_shadow_width(self._h, int(topk), C.byref(n)), "zvec_hip_ivf_shadow_width")
+        return int(n.value)
 
     def shadow_certify(self, d_queries, count, topk, nprobe, max_scan, d_out_keys, d_out_scores, d_out_counts, ctx,
                        d_exclude=None, stream=None):
