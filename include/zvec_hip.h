@@ -247,10 +247,11 @@ int zvec_hip_ivf_search_probes_dev(zvec_hip_ivf_t h, zvec_hip_ctx_t ctx, const v
  * scan the fp16 rows for `preselect` rows per query (0: chosen by the index, from max(32, 3k): zvec_hip_ivf_shadow_width; <= 64), re-score those on the fp32 rows with the kernel that
  * refines the fp32 route's final lists, keep the k best and CERTIFY them: a row that was left out cannot beat the k-th kept one once
  * the measured rounding of the two conversions (max over the stored rows of |b - b16|, per query |q - q16|; triangle inequality for
- * L2, Cauchy-Schwarz for IP) and the accumulation error are allowed for.  Queries that fail the certificate are re-run on the fp32
+ * L2, Cauchy-Schwarz for IP) and the accumulation error are allowed for.  Queries that fail the certificate get a second pass over the
+ * fp16 rows at twice the width, and what fails that too is re-run on the fp32
  * lists: by zvec_hip_ivf_search itself (host pointers), or — device pointers, where the search call only enqueues — by
  * zvec_hip_ivf_shadow_certify, which the caller runs on the same context with the same arguments before it reads the results
- * (*rerun = queries re-run; a call with no shadow search pending returns 0 at once).  Unsupported: fp16 / cosine indexes, rows
+ * (*rerun = queries that ended on the fp32 lists; a call with no shadow search pending returns 0 at once).  Unsupported: fp16 / cosine indexes, rows
  * beyond the half range.  enable = 0 frees the copy.  zvec_hip_ivf_shadow_info: state, bytes held, max |b - b16|, max |b16|.
  * Like zvec_hip_ivf_load, zvec_hip_ivf_set_shadow is an index-level operation: not while searches of the index are in flight.
  * Data the twin cannot serve (rows within the fp16 rounding of each other, a few rows of huge norm under inner product) would pay the

@@ -557,7 +557,7 @@ static int flat_search_dev_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, const v
   // re-scored on the fp32 rows, the k best certified; zvec_hip_flat_shadow_certify re-runs what fails.
   if (h->shadow_on && h->shadow.base && h->shadow.n == h->st.n && !c->shadow_skip && !(threshold < FLT_MAX) && topk <= 32 &&
       count <= maxq && h->st.n > 0 && h->shadow_gov.allow()) {
-    uint32_t kp = h->shadow_kp ? h->shadow_kp : h->shadow_gov.kp_auto(topk);
+    uint32_t kp = c->shadow_force_kp ? c->shadow_force_kp : h->shadow_kp ? h->shadow_kp : h->shadow_gov.kp_auto(topk);
     kp = std::min<uint32_t>(kp, 64);
     if (kp > topk) {
       ZRET(prep_queries(c, h->st, d_queries, count, threshold, s));            // fp32 rows for the re-scoring; resets the shared bounds
@@ -598,6 +598,7 @@ static int flat_search_dev_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, const v
       hipLaunchKernelGGL(shadow_select_kernel, dim3(count), dim3(64), 0, s, sa);
       ZCHK(hipGetLastError());
       c->sh_count = count;
+      c->sh_kp = kp;
       return 0;
     }
   }
@@ -621,8 +622,11 @@ static int flat_shadow_certify_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, con
   uint32_t nflag = 0;
   ZCHK(hipMemcpyAsync(&nflag, c->sh_flags.as<uint32_t>() + count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   ZCHK(hipStreamSynchronize(s));
-  h->shadow_gov.report(nflag, count);
-  if (h->shadow_kp == 0) h->shadow_gov.report_width(nflag, count);
+  const uint32_t used_kp = c->sh_kp;
+  if (c->sh_tier == 0) {
+    h->shadow_gov.report(nflag, count);
+    if (h->shadow_kp == 0) h->shadow_gov.report_width(nflag, count);
+  }
   if (nflag == 0) return 0;
   std::vector<uint32_t> flags(count);
   ZCHK(hipMemcpyAsync(flags.data(), c->sh_flags.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -642,10 +646,23 @@ static int flat_shadow_certify_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, con
   ZRET(tc.alloc(m));
   for (uint32_t i = 0; i < m; ++i)
     ZCHK(hipMemcpyAsync(tq.p + (size_t)i * rb, static_cast<const char *>(d_queries) + (size_t)which[i] * rb, rb, hipMemcpyDeviceToDevice, s));
-  const bool old = c->shadow_skip;
-  c->shadow_skip = true;
-  const int rc = flat_search_dev_locked(h, c, tq.p, m, topk, FLT_MAX, d_exclude, tk, ts, tc, s);
-  c->shadow_skip = old;
+  // (as ivf_shadow_certify_locked: a second half-width pass over the flagged queries at the widest pre-selection, then the fp32 rows)
+  uint32_t answered_by_fp32 = m;
+  int rc;
+  if (c->sh_tier == 0 && used_kp < 64 && !c->shadow_skip) {
+    c->sh_tier = 1;
+    c->shadow_force_kp = std::min<uint32_t>(64, std::max<uint32_t>(32, 2 * used_kp));      // (wide lists are dear to keep: twice the first pass)
+    rc = flat_search_dev_locked(h, c, tq.p, m, topk, FLT_MAX, d_exclude, tk, ts, tc, s);
+    c->shadow_force_kp = 0;
+    if (rc == 0 && c->sh_count)
+      rc = flat_shadow_certify_locked(h, c, tq.p, m, topk, d_exclude, tk, ts, tc, s, &answered_by_fp32);
+    c->sh_tier = 0;
+  } else {
+    const bool old = c->shadow_skip;
+    c->shadow_skip = true;
+    rc = flat_search_dev_locked(h, c, tq.p, m, topk, FLT_MAX, d_exclude, tk, ts, tc, s);
+    c->shadow_skip = old;
+  }
   ZRET(rc);
   for (uint32_t i = 0; i < m; ++i) {
     const size_t o = (size_t)which[i] * topk;
@@ -654,7 +671,7 @@ static int flat_shadow_certify_locked(zvec_hip_flat_s *h, zvec_hip_ctx_s *c, con
     ZCHK(hipMemcpyAsync(d_out_counts + which[i], tc.p + i, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
   }
   ZCHK(hipStreamSynchronize(s));
-  if (rerun_out) *rerun_out = m;
+  if (rerun_out) *rerun_out = answered_by_fp32;        // queries that ended on the fp32 rows
   return 0;
 }
 

@@ -793,8 +793,11 @@ static int ivf_shadow_certify_locked(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const
   uint32_t nflag = 0;
   ZCHK(hipMemcpyAsync(&nflag, c->sh_flags.as<uint32_t>() + count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   ZCHK(hipStreamSynchronize(s));
-  h->shadow_gov.report(nflag, count);
-  if (h->shadow_kp == 0) h->shadow_gov.report_width(nflag, count);
+  const uint32_t used_kp = c->sh_kp;
+  if (c->sh_tier == 0) {
+    h->shadow_gov.report(nflag, count);
+    if (h->shadow_kp == 0) h->shadow_gov.report_width(nflag, count);
+  }
   if (nflag == 0) return 0;
   std::vector<uint32_t> flags(count);
   ZCHK(hipMemcpyAsync(flags.data(), c->sh_flags.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -818,11 +821,28 @@ static int ivf_shadow_certify_locked(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const
     if (d_coarse_queries)
       ZCHK(hipMemcpyAsync(tcq.p + (size_t)i * crb, static_cast<const char *>(d_coarse_queries) + (size_t)which[i] * crb, crb, hipMemcpyDeviceToDevice, s));
   }
-  const bool old = c->shadow_skip;
-  c->shadow_skip = true;
-  const int rc = ivf_search_dev_locked(h, c, tq.p, m, topk, FLT_MAX, nprobe, max_scan_count, 0, d_exclude, tk, ts, tc, s,
-                                       d_coarse_queries ? tcq.p : nullptr);
-  c->shadow_skip = old;
+  // A failed certificate first costs a SECOND half-width pass over the flagged queries alone, at twice the pre-selection (32 .. 64 rows:
+  // what separates the k-th row from the rest may simply lie beyond the first k'), and only what that pass cannot certify either is
+  // answered by the fp32 lists.  (A handful of flagged queries take the small-batch route, which reads the fp32 lists anyway.)
+  uint32_t answered_by_fp32 = m;
+  int rc;
+  if (c->sh_tier == 0 && used_kp < 64 && !c->shadow_skip) {
+    c->sh_tier = 1;
+    c->shadow_force_kp = std::min<uint32_t>(64, std::max<uint32_t>(32, 2 * used_kp));      // (wide lists are dear to keep: twice the first pass)
+    rc = ivf_search_dev_locked(h, c, tq.p, m, topk, FLT_MAX, nprobe, max_scan_count, 0, d_exclude, tk, ts, tc, s,
+                               d_coarse_queries ? tcq.p : nullptr);
+    c->shadow_force_kp = 0;
+    if (rc == 0 && c->sh_count)
+      rc = ivf_shadow_certify_locked(h, c, tq.p, m, topk, nprobe, max_scan_count, d_exclude, tk, ts, tc, s,
+                                     d_coarse_queries ? tcq.p : nullptr, &answered_by_fp32);
+    c->sh_tier = 0;
+  } else {
+    const bool old = c->shadow_skip;
+    c->shadow_skip = true;
+    rc = ivf_search_dev_locked(h, c, tq.p, m, topk, FLT_MAX, nprobe, max_scan_count, 0, d_exclude, tk, ts, tc, s,
+                               d_coarse_queries ? tcq.p : nullptr);
+    c->shadow_skip = old;
+  }
   ZRET(rc);
   for (uint32_t i = 0; i < m; ++i) {
     const size_t o = (size_t)which[i] * topk;
@@ -831,7 +851,7 @@ static int ivf_shadow_certify_locked(zvec_hip_ivf_s *h, zvec_hip_ctx_s *c, const
     ZCHK(hipMemcpyAsync(d_out_counts + which[i], tc.p + i, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
   }
   ZCHK(hipStreamSynchronize(s));                       // (the temporaries are freed on return)
-  if (rerun_out) *rerun_out = m;
+  if (rerun_out) *rerun_out = answered_by_fp32;        // queries that ended on the fp32 lists
   return 0;
 }
 

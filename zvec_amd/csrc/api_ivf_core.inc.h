@@ -258,7 +258,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
   // not for search_bf, not on the certify step's own re-run.
   uint32_t kp = 0;
   if (h->shadow_on && h->shadow.base && !ctx->shadow_skip && !brute_force && !(threshold < FLT_MAX) && topk <= 32 && h->shadow_gov.allow()) {
-    kp = h->shadow_kp ? h->shadow_kp : h->shadow_gov.kp_auto(topk);
+    kp = ctx->shadow_force_kp ? ctx->shadow_force_kp : h->shadow_kp ? h->shadow_kp : h->shadow_gov.kp_auto(topk);
     kp = std::min<uint32_t>(kp, 64);                                     // (shadow_select_kernel: one candidate per lane)
     if (kp <= topk || scan_lds_bytes(1, kp, true) > LDS_LIMIT - 1024) kp = 0;
   }
@@ -403,6 +403,7 @@ int ivf_search_core(zvec_hip_ivf_s *h, zvec_hip_ctx_s *ctx, const void *d_querie
     hipLaunchKernelGGL(shadow_select_kernel, dim3(count), dim3(64), 0, stream, sa);
     ZCHK(hipGetLastError());
     ctx->sh_count = count;
+    ctx->sh_kp = kp;
     return 0;
   }
   uint32_t *ridx = out.idx;

@@ -255,6 +255,9 @@ struct zvec_hip_ctx_s {
   DevBuf sh_q16, sh_qn16, sh_qinfo, sh_keys, sh_scores, sh_true, sh_idx, sh_counts, sh_flags;
   uint32_t sh_count = 0;                               // queries of the last search that went through the shadow lists (0: none)
   bool shadow_skip = false;                            // the certify step's re-run: this search must read the fp32 lists
+  uint32_t shadow_force_kp = 0;                        // the certify step's SECOND half-width pass over the flagged queries: this width
+  uint32_t sh_kp = 0;                                  // width the last shadow search on this context used
+  int sh_tier = 0;                                     // 1: inside the second pass (its own flagged queries go to the fp32 rows)
   bool shadow_scan = false;                            // flat_scan_prepared is running over a shadow store: profiled / gated like a user-facing scan
   DevBuf holes_ex;                                     // caller's exclude set OR the store's holes                      // group-by search: per-group bests / lists, group of every position, results
   PinnedBuf pin_in, pin_out;                           // (transfers up to PIN_LIMIT bytes go through pinned memory)
